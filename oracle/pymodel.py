@@ -1,0 +1,747 @@
+"""Independent big-integer model of the anonymous-credit-tokens sigma-protocol hot path.
+
+TEST INFRASTRUCTURE ONLY (oracle).  Nothing in the product path imports this file; it exists so
+that the C oracle (oracle/act_oracle.c) and the HIP engine can be pinned against a second,
+independently written implementation, and to generate the committed fixtures in tests/golden/.
+
+Parity status: the reference crate (Rust, curve25519-dalek 4.1.3 / blake3 1.8.2, neither vendored
+under /root/reference, no Rust toolchain in the image) cannot be run here and ships no golden
+vectors, so byte-parity with the crate itself is "unpinned".  What IS pinned (tests/test_oracle_*.py):
+  * BLAKE3 against the upstream C implementation bundled in LLVM (libclang-cpp's llvm_blake3_*),
+  * Edwards25519 arithmetic against OpenSSL's Ed25519 public-key derivation,
+  * ristretto255 encode/decode/one-way-map against the RFC 9496 vectors recorded in SURVEY.md App. A,
+  * the protocol algebra against the reference's accept/reject behaviour.
+
+Every protocol function below cites the reference lines it restates (paths relative to
+/root/reference).  All arithmetic is Python ints: slow, obviously-correct, no shared code with
+the C oracle or the HIP kernels.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+# --------------------------------------------------------------------------------------------
+# Field GF(2^255-19), scalar field Z_l, curve constants (RFC 9496 section 4.1 / SURVEY.md App. A)
+# --------------------------------------------------------------------------------------------
+P = 2**255 - 19
+ELL = 2**252 + 27742317777372353535851937790883648493
+D = (-121665 * pow(121666, P - 2, P)) % P
+SQRT_M1 = 19681161376707505956807079304988542015446066515923890162744021073123829784752
+SQRT_AD_MINUS_ONE = 25063068953384623474111414158702152701244531502492656460079210482610430750235
+INVSQRT_A_MINUS_D = 54469307008909316920995813868745141605393597292927456921205312896311721017578
+ONE_MINUS_D_SQ = 1159843021668779879193775521855586647937357759715417654439879720876111806838
+D_MINUS_ONE_SQ = 40440834346308536858101042469323190826248399146238708352240133220865137265952
+
+assert D == 37095705934669439343138083508754565189542113879843219016388785533085940283555
+assert SQRT_M1 == pow(2, (P - 1) // 4, P) and SQRT_M1 * SQRT_M1 % P == P - 1
+assert SQRT_AD_MINUS_ONE * SQRT_AD_MINUS_ONE % P == (-D - 1) % P
+assert INVSQRT_A_MINUS_D * INVSQRT_A_MINUS_D * (-1 - D) % P == 1
+assert ONE_MINUS_D_SQ == (1 - D * D) % P and D_MINUS_ONE_SQ == (D - 1) * (D - 1) % P
+
+L_DEFAULT = 128  # src/lib.rs:116
+
+
+def fe_inv(x: int) -> int:
+    return pow(x, P - 2, P)
+
+
+def fe_is_neg(x: int) -> bool:
+    return (x % P) & 1 == 1
+
+
+def fe_abs(x: int) -> int:
+    x %= P
+    return P - x if x & 1 else x
+
+
+def sqrt_ratio_m1(u: int, v: int) -> Tuple[bool, int]:
+    """RFC 9496 section 4.2 SQRT_RATIO_M1."""
+    u %= P
+    v %= P
+    v3 = v * v % P * v % P
+    v7 = v3 * v3 % P * v % P
+    r = u * v3 % P * pow(u * v7 % P, (P - 5) // 8, P) % P
+    check = v * r % P * r % P
+    correct = check == u
+    flipped = check == (-u) % P
+    flipped_i = check == (-u) * SQRT_M1 % P
+    if flipped or flipped_i:
+        r = r * SQRT_M1 % P
+    r = fe_abs(r)
+    return (correct or flipped), r
+
+
+# Edwards points in extended coordinates (X, Y, Z, T), a = -1.
+Point = Tuple[int, int, int, int]
+IDENTITY: Point = (0, 1, 1, 0)
+_BY = 4 * pow(5, P - 2, P) % P
+_ok, _bx = sqrt_ratio_m1((_BY * _BY - 1) % P, (D * _BY * _BY + 1) % P)
+assert _ok
+BASEPOINT: Point = (_bx, _BY, 1, _bx * _BY % P)  # x even ("positive"), RFC 8032 section 5.1
+assert _BY == 46316835694926478169428394003475163141307993866256225615783033603165251855960
+
+
+def pt_add(p: Point, q: Point) -> Point:
+    x1, y1, z1, t1 = p
+    x2, y2, z2, t2 = q
+    a = (y1 - x1) * (y2 - x2) % P
+    b = (y1 + x1) * (y2 + x2) % P
+    c = 2 * D * t1 % P * t2 % P
+    d = 2 * z1 * z2 % P
+    e, f, g, h = b - a, d - c, d + c, b + a
+    return (e * f % P, g * h % P, f * g % P, e * h % P)
+
+
+def pt_neg(p: Point) -> Point:
+    x, y, z, t = p
+    return ((-x) % P, y, z, (-t) % P)
+
+
+def pt_sub(p: Point, q: Point) -> Point:
+    return pt_add(p, pt_neg(q))
+
+
+def pt_double(p: Point) -> Point:
+    return pt_add(p, p)
+
+
+def pt_mul(p: Point, s: int) -> Point:
+    """Plain double-and-add; s is reduced mod l first (group order of the ristretto group)."""
+    s %= ELL
+    acc = IDENTITY
+    for bit in bin(s)[2:] if s else "":
+        acc = pt_add(acc, acc)
+        if bit == "1":
+            acc = pt_add(acc, p)
+    return acc
+
+
+def pt_eq(p: Point, q: Point) -> bool:
+    """ristretto255 equality, RFC 9496 section 4.3.3."""
+    x1, y1, _, _ = p
+    x2, y2, _, _ = q
+    return (x1 * y2 - y1 * x2) % P == 0 or (y1 * y2 - x1 * x2) % P == 0
+
+
+def pt_on_curve(p: Point) -> bool:
+    x, y, z, t = p
+    return (-x * x + y * y - z * z - D * t * t) % P == 0 and (x * y - z * t) % P == 0
+
+
+def ristretto_encode(p: Point) -> bytes:
+    """RFC 9496 section 4.3.2; used at src/transcript.rs:106 and src/cbor.rs:53."""
+    x0, y0, z0, t0 = p
+    u1 = (z0 + y0) * (z0 - y0) % P
+    u2 = x0 * y0 % P
+    _, invsqrt = sqrt_ratio_m1(1, u1 * u2 % P * u2 % P)
+    den1 = invsqrt * u1 % P
+    den2 = invsqrt * u2 % P
+    z_inv = den1 * den2 % P * t0 % P
+    ix0 = x0 * SQRT_M1 % P
+    iy0 = y0 * SQRT_M1 % P
+    enchanted = den1 * INVSQRT_A_MINUS_D % P
+    if fe_is_neg(t0 * z_inv):
+        x, y, den_inv = iy0, ix0, enchanted
+    else:
+        x, y, den_inv = x0, y0, den2
+    if fe_is_neg(x * z_inv):
+        y = (-y) % P
+    s = fe_abs(den_inv * (z0 - y) % P)
+    return s.to_bytes(32, "little")
+
+
+def ristretto_decode(b: bytes) -> Optional[Point]:
+    """RFC 9496 section 4.3.1 (the check done by src/cbor.rs:62-77 on every wire point)."""
+    assert len(b) == 32
+    s = int.from_bytes(b, "little")
+    if s >= P or s & 1:
+        return None
+    ss = s * s % P
+    u1 = (1 - ss) % P
+    u2 = (1 + ss) % P
+    u2s = u2 * u2 % P
+    v = (-(D * u1 % P * u1) - u2s) % P
+    was_square, invsqrt = sqrt_ratio_m1(1, v * u2s % P)
+    den_x = invsqrt * u2 % P
+    den_y = invsqrt * den_x % P * v % P
+    x = fe_abs(2 * s * den_x % P)
+    y = u1 * den_y % P
+    t = x * y % P
+    if (not was_square) or fe_is_neg(t) or y == 0:
+        return None
+    return (x, y, 1, t)
+
+
+def ristretto_map(t: int) -> Point:
+    """RFC 9496 section 4.3.4 MAP (Elligator)."""
+    r = SQRT_M1 * t % P * t % P
+    u = (r + 1) * ONE_MINUS_D_SQ % P
+    v = (-1 - r * D) % P * ((r + D) % P) % P
+    was_square, s = sqrt_ratio_m1(u, v)
+    s_prime = (-fe_abs(s * t % P)) % P
+    if not was_square:
+        s = s_prime
+        c = r
+    else:
+        c = P - 1
+    n = (c * (r - 1) % P * D_MINUS_ONE_SQ - v) % P
+    w0 = 2 * s * v % P
+    w1 = n * SQRT_AD_MINUS_ONE % P
+    w2 = (1 - s * s) % P
+    w3 = (1 + s * s) % P
+    return (w0 * w3 % P, w2 * w1 % P, w1 * w3 % P, w0 * w2 % P)
+
+
+def ristretto_from_uniform_bytes(b: bytes) -> Point:
+    """RistrettoPoint::from_uniform_bytes (src/lib.rs:353, :261-263): two MAPs added.
+    Each 32-byte half is read little-endian with bit 255 masked, then reduced mod p."""
+    assert len(b) == 64
+    r0 = (int.from_bytes(b[:32], "little") & ((1 << 255) - 1)) % P
+    r1 = (int.from_bytes(b[32:], "little") & ((1 << 255) - 1)) % P
+    return pt_add(ristretto_map(r0), ristretto_map(r1))
+
+
+# Scalars ---------------------------------------------------------------------------------------
+def sc_from_wide(b: bytes) -> int:
+    """Scalar::from_bytes_mod_order_wide (src/transcript.rs:153; inside every Scalar::random)."""
+    assert len(b) == 64
+    return int.from_bytes(b, "little") % ELL
+
+
+def sc_bytes(s: int) -> bytes:
+    return (s % ELL).to_bytes(32, "little")
+
+
+def sc_from_bytes_mod_order(b: bytes) -> int:
+    return int.from_bytes(b, "little") % ELL
+
+
+def sc_inv(s: int) -> int:
+    return pow(s, ELL - 2, ELL)
+
+
+# --------------------------------------------------------------------------------------------
+# BLAKE3 (hash mode only; finalize / finalize_xof), written from the BLAKE3 specification.
+# --------------------------------------------------------------------------------------------
+_IV = (0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19)
+_PERM = (2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8)
+_CHUNK_START, _CHUNK_END, _PARENT, _ROOT = 1, 2, 4, 8
+_M32 = 0xFFFFFFFF
+
+
+def _rotr(x, n):
+    return ((x >> n) | (x << (32 - n))) & _M32
+
+
+def _g(v, a, b, c, d, mx, my):
+    v[a] = (v[a] + v[b] + mx) & _M32
+    v[d] = _rotr(v[d] ^ v[a], 16)
+    v[c] = (v[c] + v[d]) & _M32
+    v[b] = _rotr(v[b] ^ v[c], 12)
+    v[a] = (v[a] + v[b] + my) & _M32
+    v[d] = _rotr(v[d] ^ v[a], 8)
+    v[c] = (v[c] + v[d]) & _M32
+    v[b] = _rotr(v[b] ^ v[c], 7)
+
+
+def _compress(cv, block_words, counter, block_len, flags):
+    v = list(cv) + list(_IV[:4]) + [counter & _M32, (counter >> 32) & _M32, block_len, flags]
+    m = list(block_words)
+    for r in range(7):
+        _g(v, 0, 4, 8, 12, m[0], m[1])
+        _g(v, 1, 5, 9, 13, m[2], m[3])
+        _g(v, 2, 6, 10, 14, m[4], m[5])
+        _g(v, 3, 7, 11, 15, m[6], m[7])
+        _g(v, 0, 5, 10, 15, m[8], m[9])
+        _g(v, 1, 6, 11, 12, m[10], m[11])
+        _g(v, 2, 7, 8, 13, m[12], m[13])
+        _g(v, 3, 4, 9, 14, m[14], m[15])
+        if r < 6:
+            m = [m[i] for i in _PERM]
+    for i in range(8):
+        v[i] ^= v[i + 8]
+        v[i + 8] ^= cv[i]
+    return v
+
+
+def _words(block: bytes):
+    block = block + b"\x00" * (64 - len(block))
+    return struct.unpack("<16I", block)
+
+
+def _chunk_output(chunk: bytes, counter: int):
+    """Returns (cv, words, counter, block_len, flags) of the chunk's LAST block, un-finalised."""
+    cv = list(_IV)
+    blocks = [chunk[i:i + 64] for i in range(0, len(chunk), 64)] or [b""]
+    for i, blk in enumerate(blocks):
+        flags = (_CHUNK_START if i == 0 else 0)
+        if i == len(blocks) - 1:
+            return (cv, _words(blk), counter, len(blk), flags | _CHUNK_END)
+        cv = _compress(cv, _words(blk), counter, 64, flags)[:8]
+
+
+def _output_cv(out):
+    cv, w, ctr, bl, fl = out
+    return _compress(cv, w, ctr, bl, fl)[:8]
+
+
+def _parent_output(left_cv, right_cv):
+    return (list(_IV), list(left_cv) + list(right_cv), 0, 64, _PARENT)
+
+
+def _subtree(data: bytes, first_chunk: int):
+    """Un-finalised output node for `data` laid out as a left-heavy BLAKE3 tree."""
+    if len(data) <= 1024:
+        return _chunk_output(data, first_chunk)
+    nchunks = (len(data) + 1023) // 1024
+    left_chunks = 1 << ((nchunks - 1).bit_length() - 1)  # largest power of two < nchunks
+    left = _subtree(data[: left_chunks * 1024], first_chunk)
+    right = _subtree(data[left_chunks * 1024:], first_chunk + left_chunks)
+    return _parent_output(_output_cv(left), _output_cv(right))
+
+
+def blake3(data: bytes, out_len: int = 32) -> bytes:
+    cv, w, _ctr, bl, fl = _subtree(bytes(data), 0)
+    out = b""
+    block = 0
+    while len(out) < out_len:
+        v = _compress(cv, w, block, bl, fl | _ROOT)
+        out += struct.pack("<16I", *v)
+        block += 1
+    return out[:out_len]
+
+
+# --------------------------------------------------------------------------------------------
+# Deterministic byte-stream RNG standing in for `impl CryptoRngCore`.
+# --------------------------------------------------------------------------------------------
+class ByteRng:
+    def __init__(self, data: bytes):
+        self.data = bytes(data)
+        self.pos = 0
+
+    def take(self, n: int) -> bytes:
+        assert self.pos + n <= len(self.data), "rng stream exhausted"
+        out = self.data[self.pos:self.pos + n]
+        self.pos += n
+        return out
+
+    def scalar(self) -> int:
+        """Scalar::random: one 64-byte fill_bytes then wide reduction."""
+        return sc_from_wide(self.take(64))
+
+
+# --------------------------------------------------------------------------------------------
+# Protocol: Params, Transcript, request / issue / prove_spend / refund and the client verifiers
+# --------------------------------------------------------------------------------------------
+PROTOCOL_VERSION = b"curve25519-ristretto anonymous-credits v1.0"  # src/transcript.rs:29
+
+ERR_OK = 0
+ERR_INVALID_ISSUANCE_REQUEST_PROOF = 1   # src/lib.rs:103
+ERR_INVALID_ISSUANCE_RESPONSE_PROOF = 2  # :104
+ERR_DOUBLE_SPEND = 3
+ERR_INVALID_REFUND_PROOF = 4             # :106
+ERR_INVALID_REFUND_RESPONSE_PROOF = 5
+ERR_IDENTITY_POINT = 6                   # :108
+ERR_INVALID_CLIENT_SPEND_PROOF = 7       # :109
+ERR_AMOUNT_TOO_BIG = 8
+ERR_SCALAR_OUT_OF_RANGE = 9
+ERR_UNDECODABLE = 255
+
+
+class ActError(Exception):
+    def __init__(self, code: int):
+        super().__init__(f"act error {code}")
+        self.code = code
+
+
+@dataclass
+class Params:
+    h1: Point
+    h2: Point
+    h3: Point
+
+    @staticmethod
+    def new(organization: str, service: str, deployment_id: str, version: str) -> "Params":
+        """src/lib.rs:291-315."""
+        ds = f"ACT-v1:{organization}:{service}:{deployment_id}:{version}".encode()
+        seed = blake3(struct.pack(">Q", len(ds)) + ds, 32)
+        return Params(*(Params._hash_to_ristretto(ds, seed, i) for i in range(3)))
+
+    @staticmethod
+    def _hash_to_ristretto(ds: bytes, seed: bytes, counter: int) -> Point:
+        """src/lib.rs:332-354."""
+        msg = struct.pack(">Q", len(ds)) + ds + struct.pack(">Q", len(seed)) + seed
+        msg += struct.pack(">Q", 4) + struct.pack("<I", counter)
+        return ristretto_from_uniform_bytes(blake3(msg, 64))
+
+    @staticmethod
+    def random(rng: ByteRng) -> "Params":
+        """src/lib.rs:259-265 (RistrettoPoint::random = 64-byte fill + from_uniform_bytes)."""
+        return Params(*(ristretto_from_uniform_bytes(rng.take(64)) for _ in range(3)))
+
+    def encoded(self) -> bytes:
+        return ristretto_encode(self.h1) + ristretto_encode(self.h2) + ristretto_encode(self.h3)
+
+
+def _lp(b: bytes) -> bytes:
+    return struct.pack(">Q", len(b)) + b
+
+
+def transcript_preimage(params: Params, label: bytes, items: Sequence[bytes]) -> bytes:
+    """Byte string hashed by Transcript (src/transcript.rs:54-74, :95-98); items are the 32-byte
+    encodings of scalars (as_bytes) or points (compress) in the order they are added."""
+    out = _lp(PROTOCOL_VERSION)
+    for h in (params.h1, params.h2, params.h3):
+        out += _lp(ristretto_encode(h))
+    out += _lp(label)
+    for it in items:
+        out += _lp(it)
+    return out
+
+
+def transcript_challenge(params: Params, label: bytes, items: Sequence[bytes]) -> int:
+    """Transcript::with(...).challenge(): 64 XOF bytes -> scalar mod l (src/transcript.rs:149-154)."""
+    return sc_from_wide(blake3(transcript_preimage(params, label, items), 64))
+
+
+E = ristretto_encode
+G = BASEPOINT
+
+
+@dataclass
+class PrivateKey:
+    x: int
+    w: Point
+
+    @staticmethod
+    def random(rng: ByteRng) -> "PrivateKey":
+        x = rng.scalar()                      # src/lib.rs:189
+        return PrivateKey(x, pt_mul(G, x))    # :191
+
+    def record(self) -> bytes:                # CBOR order x, w (src/cbor.rs:477-480)
+        return sc_bytes(self.x) + E(self.w)
+
+
+@dataclass
+class PreIssuance:
+    r: int
+    k: int
+
+    @staticmethod
+    def random(rng: ByteRng) -> "PreIssuance":
+        r = rng.scalar()                      # src/lib.rs:434
+        k = rng.scalar()                      # :435
+        return PreIssuance(r, k)
+
+    def record(self) -> bytes:                # r, k (src/cbor.rs:546-549)
+        return sc_bytes(self.r) + sc_bytes(self.k)
+
+
+@dataclass
+class IssuanceRequest:
+    big_k: Point
+    gamma: int
+    k_bar: int
+    r_bar: int
+
+    def record(self) -> bytes:                # K, gamma, k_bar, r_bar (src/cbor.rs:105-110)
+        return E(self.big_k) + sc_bytes(self.gamma) + sc_bytes(self.k_bar) + sc_bytes(self.r_bar)
+
+
+@dataclass
+class IssuanceResponse:
+    a: Point
+    e: int
+    gamma: int
+    z: int
+    c: int
+
+    def record(self) -> bytes:                # A, e, gamma, z, c (src/cbor.rs:163-169)
+        return E(self.a) + b"".join(sc_bytes(v) for v in (self.e, self.gamma, self.z, self.c))
+
+
+@dataclass
+class CreditToken:
+    a: Point
+    e: int
+    k: int
+    r: int
+    c: int
+
+    def record(self) -> bytes:                # a, e, k, r, c (src/cbor.rs:596-602)
+        return E(self.a) + b"".join(sc_bytes(v) for v in (self.e, self.k, self.r, self.c))
+
+
+@dataclass
+class SpendProof:
+    k: int
+    s: int
+    a_prime: Point
+    b_bar: Point
+    com: List[Point]
+    gamma: int
+    e_bar: int
+    r2_bar: int
+    r3_bar: int
+    c_bar: int
+    r_bar: int
+    w00: int
+    w01: int
+    gamma0: List[int]
+    z: List[Tuple[int, int]]
+    k_bar: int
+    s_bar: int
+
+    def record(self) -> bytes:
+        """k,s,A',B_bar,Com[L],gamma,e_bar,r2_bar,r3_bar,c_bar,r_bar,w00,w01,gamma0[L],z[L][2],
+        k_bar,s_bar (src/cbor.rs:250-268): 32*(14+4L) bytes."""
+        out = sc_bytes(self.k) + sc_bytes(self.s) + E(self.a_prime) + E(self.b_bar)
+        out += b"".join(E(c) for c in self.com)
+        for v in (self.gamma, self.e_bar, self.r2_bar, self.r3_bar, self.c_bar, self.r_bar, self.w00, self.w01):
+            out += sc_bytes(v)
+        out += b"".join(sc_bytes(g) for g in self.gamma0)
+        out += b"".join(sc_bytes(z0) + sc_bytes(z1) for z0, z1 in self.z)
+        return out + sc_bytes(self.k_bar) + sc_bytes(self.s_bar)
+
+
+@dataclass
+class PreRefund:
+    r: int
+    k: int
+    m: int
+
+    def record(self) -> bytes:                # r, k, m (src/cbor.rs:656-660)
+        return sc_bytes(self.r) + sc_bytes(self.k) + sc_bytes(self.m)
+
+
+@dataclass
+class Refund:
+    a: Point
+    e: int
+    gamma: int
+    z: int
+
+    def record(self) -> bytes:                # A*, e, gamma, z (src/cbor.rs:422-427)
+        return E(self.a) + sc_bytes(self.e) + sc_bytes(self.gamma) + sc_bytes(self.z)
+
+
+def request(pre: PreIssuance, params: Params, rng: ByteRng) -> IssuanceRequest:
+    """PreIssuance::request, src/lib.rs:463-487."""
+    big_k = pt_add(pt_mul(params.h2, pre.k), pt_mul(params.h3, pre.r))           # :465
+    k_prime = rng.scalar()                                                        # :468
+    r_prime = rng.scalar()                                                        # :469
+    k1 = pt_add(pt_mul(params.h2, k_prime), pt_mul(params.h3, r_prime))           # :470
+    gamma = transcript_challenge(params, b"request", [E(big_k), E(k1)])           # :473-475
+    k_bar = (k_prime + pre.k * gamma) % ELL                                       # :478
+    r_bar = (r_prime + pre.r * gamma) % ELL                                       # :479
+    return IssuanceRequest(big_k, gamma, k_bar, r_bar)
+
+
+def issue(sk: PrivateKey, params: Params, req: IssuanceRequest, c: int, rng: ByteRng) -> IssuanceResponse:
+    """PrivateKey::issue, src/lib.rs:621-663.  RNG is drawn only after the PoK verifies."""
+    k1 = pt_sub(pt_add(pt_mul(params.h2, req.k_bar), pt_mul(params.h3, req.r_bar)),
+                pt_mul(req.big_k, req.gamma))                                     # :629-630
+    gamma = transcript_challenge(params, b"request", [E(req.big_k), E(k1)])       # :633-635
+    if gamma != req.gamma:                                                        # :638
+        raise ActError(ERR_INVALID_ISSUANCE_REQUEST_PROOF)
+    e = rng.scalar()                                                              # :643
+    x_a = pt_add(pt_add(G, pt_mul(params.h1, c)), req.big_k)                      # :644
+    a = pt_mul(x_a, sc_inv((e + sk.x) % ELL))                                     # :645
+    x_g = pt_add(pt_mul(G, e), sk.w)                                              # :646
+    alpha = rng.scalar()                                                          # :649
+    y_a = pt_mul(a, alpha)                                                        # :650
+    y_g = pt_mul(G, alpha)                                                        # :651
+    gamma = transcript_challenge(params, b"respond",
+                                 [sc_bytes(c), sc_bytes(e), E(a), E(x_a), E(x_g), E(y_a), E(y_g)])  # :654-657
+    z = (gamma * (sk.x + e) + alpha) % ELL                                        # :660
+    return IssuanceResponse(a, e, gamma, z, c % ELL)
+
+
+def issuance_to_credit_token(pre: PreIssuance, params: Params, w: Point, req: IssuanceRequest,
+                             resp: IssuanceResponse) -> CreditToken:
+    """PreIssuance::to_credit_token, src/lib.rs:528-562."""
+    x_a = pt_add(pt_add(G, pt_mul(params.h1, resp.c)), req.big_k)                 # :536
+    x_g = pt_add(pt_mul(G, resp.e), w)                                            # :537
+    ng = (-resp.gamma) % ELL
+    y_a = pt_add(pt_mul(resp.a, resp.z), pt_mul(x_a, ng))                         # :540
+    y_g = pt_add(pt_mul(G, resp.z), pt_mul(x_g, ng))                              # :541
+    gamma = transcript_challenge(params, b"respond",
+                                 [sc_bytes(resp.c), sc_bytes(resp.e), E(resp.a), E(x_a), E(x_g), E(y_a), E(y_g)])
+    if gamma != resp.gamma:                                                       # :550
+        raise ActError(ERR_INVALID_ISSUANCE_RESPONSE_PROOF)
+    return CreditToken(resp.a, resp.e, pre.k, pre.r, resp.c)
+
+
+def bits_of(s: int, nbits: int) -> List[int]:
+    """src/lib.rs:902-915: low `L` bits of the canonical little-endian encoding."""
+    b = sc_bytes(s)
+    return [(b[i // 8] >> (i % 8)) & 1 for i in range(nbits)]
+
+
+def prove_spend(tok: CreditToken, params: Params, s: int, rng: ByteRng, nbits: int = L_DEFAULT
+                ) -> Tuple[SpendProof, PreRefund]:
+    """CreditToken::prove_spend, src/lib.rs:972-1152 (RNG draw order: SURVEY.md App. B)."""
+    h1, h2, h3 = params.h1, params.h2, params.h3
+    r1 = rng.scalar(); r2 = rng.scalar(); c_prime = rng.scalar(); r_prime = rng.scalar()   # :978-981
+    e_prime = rng.scalar(); r2_prime = rng.scalar(); r3_prime = rng.scalar()                # :982-984
+    b = pt_add(pt_add(pt_add(G, pt_mul(h1, tok.c)), pt_mul(h2, tok.k)), pt_mul(h3, tok.r))  # :986-989
+    a_prime = pt_mul(tok.a, r1 * r2 % ELL)                                                  # :990
+    b_bar = pt_mul(b, r1)                                                                   # :991
+    r3 = sc_inv(r1)                                                                         # :992
+    a1 = pt_add(pt_mul(a_prime, e_prime), pt_mul(b_bar, r2_prime))                          # :993
+    a2 = pt_add(pt_add(pt_mul(b_bar, r3_prime), pt_mul(h1, c_prime)), pt_mul(h3, r_prime))  # :994
+    i = bits_of((tok.c - s) % ELL, nbits)                                                   # :996
+    k_star = rng.scalar()                                                                   # :998
+    s_i = [rng.scalar() for _ in range(nbits)]                                              # :999
+    com = [None] * nbits
+    com[0] = pt_add(pt_add(pt_mul(h1, i[0]), pt_mul(h2, k_star)), pt_mul(h3, s_i[0]))       # :1001
+    for j in range(1, nbits):
+        com[j] = pt_add(pt_mul(h1, i[j]), pt_mul(h3, s_i[j]))                               # :1003
+    k0_prime = rng.scalar()                                                                 # :1010
+    s_i_prime = [rng.scalar() for _ in range(nbits)]                                        # :1012-1014
+    gamma_i = [rng.scalar() for _ in range(nbits)]                                          # :1016-1018
+    w0 = rng.scalar()                                                                       # :1019
+    z = [rng.scalar() for _ in range(nbits)]                                                # :1021-1023
+    big_c_prime = [[None, None] for _ in range(nbits)]
+    c00 = com[0]
+    c01 = pt_sub(com[0], h1)                                                                # :1008
+    sim0 = lambda base: pt_sub(pt_add(pt_mul(h2, w0), pt_mul(h3, z[0])), pt_mul(base, gamma_i[0]))
+    real0 = pt_add(pt_mul(h2, k0_prime), pt_mul(h3, s_i_prime[0]))
+    # conditional_select(a, b, choice) returns b when choice is true (subtle semantics)
+    big_c_prime[0][0] = real0 if i[0] == 0 else sim0(c00)                                   # :1025-1029
+    big_c_prime[0][1] = sim0(c01) if i[0] == 0 else real0                                   # :1031-1035
+    for j in range(1, nbits):
+        cj0 = com[j]
+        cj1 = pt_sub(com[j], h1)                                                            # :1039
+        real = pt_mul(h3, s_i_prime[j])
+        sim = lambda base, j=j: pt_sub(pt_mul(h3, z[j]), pt_mul(base, gamma_i[j]))
+        big_c_prime[j][0] = real if i[j] == 0 else sim(cj0)                                 # :1041-1045
+        big_c_prime[j][1] = sim(cj1) if i[j] == 0 else real                                 # :1046-1050
+    r_star = sum(si << idx for idx, si in enumerate(s_i)) % ELL                             # :1052-1056
+    k_prime = rng.scalar()                                                                  # :1057
+    s_prime = rng.scalar()                                                                  # :1058
+    c_ = pt_add(pt_add(pt_mul(h1, (-c_prime) % ELL), pt_mul(h2, k_prime)), pt_mul(h3, s_prime))  # :1059
+    items = [sc_bytes(tok.k), E(a_prime), E(b_bar), E(a1), E(a2)] + [E(c) for c in com]
+    for cp in big_c_prime:
+        items += [E(cp[0]), E(cp[1])]
+    items.append(E(c_))
+    gamma = transcript_challenge(params, b"spend", items)                                   # :1061-1070
+    ng = (-gamma) % ELL
+    e_bar = (ng * tok.e + e_prime) % ELL                                                    # :1072
+    r2_bar = (gamma * r2 + r2_prime) % ELL                                                  # :1073
+    r3_bar = (gamma * r3 + r3_prime) % ELL                                                  # :1074
+    c_bar = (ng * tok.c + c_prime) % ELL                                                    # :1075
+    r_bar = (ng * tok.r + r_prime) % ELL                                                    # :1076
+    gamma00 = [0] * nbits
+    zz = [(0, 0)] * nbits
+    for j in range(nbits):
+        gamma00[j] = (gamma - gamma_i[j]) % ELL if i[j] == 0 else gamma_i[j]                # :1078-1082, :1105-1109
+        z0 = (gamma00[j] * s_i[j] + s_i_prime[j]) % ELL if i[j] == 0 else z[j]              # :1094-1098, :1110-1114
+        z1 = z[j] if i[j] == 0 else ((gamma - gamma00[j]) * s_i[j] + s_i_prime[j]) % ELL    # :1099-1103, :1115-1119
+        zz[j] = (z0, z1)
+    w00 = (gamma00[0] * k_star + k0_prime) % ELL if i[0] == 0 else w0                       # :1083-1087
+    w01 = w0 if i[0] == 0 else ((gamma - gamma00[0]) * k_star + k0_prime) % ELL             # :1088-1092
+    k_bar = (gamma * k_star + k_prime) % ELL                                                # :1121
+    s_bar = (gamma * r_star + s_prime) % ELL                                                # :1122
+    proof = SpendProof(tok.k, s % ELL, a_prime, b_bar, com, gamma, e_bar, r2_bar, r3_bar, c_bar, r_bar,
+                       w00, w01, gamma00, zz, k_bar, s_bar)
+    return proof, PreRefund(r_star, k_star, (tok.c - s) % ELL)                              # :1124-1128
+
+
+def spend_verify_challenge(sk_x: int, params: Params, pr: SpendProof) -> Tuple[int, Point]:
+    """src/lib.rs:791-840: recompute every commitment and the challenge; returns (gamma', K')."""
+    h1, h2, h3 = params.h1, params.h2, params.h3
+    nbits = len(pr.com)
+    ng = (-pr.gamma) % ELL
+    a_bar = pt_mul(pr.a_prime, sk_x)                                                        # :791
+    big_h1 = pt_add(G, pt_mul(h2, pr.k))                                                    # :792
+    a1 = pt_add(pt_add(pt_mul(pr.a_prime, pr.e_bar), pt_mul(pr.b_bar, pr.r2_bar)), pt_mul(a_bar, ng))   # :793-795
+    a2 = pt_add(pt_add(pt_add(pt_mul(pr.b_bar, pr.r3_bar), pt_mul(h1, pr.c_bar)), pt_mul(h3, pr.r_bar)),
+                pt_mul(big_h1, ng))                                                         # :796-799
+    cps = []
+    for j in range(nbits):
+        g0 = pr.gamma0[j]
+        g1 = (pr.gamma - g0) % ELL                                                          # :801, :811
+        cj0 = pr.com[j]
+        cj1 = pt_sub(pr.com[j], h1)                                                         # :804, :813
+        p0 = pt_sub(pt_mul(h3, pr.z[j][0]), pt_mul(cj0, g0))
+        p1 = pt_sub(pt_mul(h3, pr.z[j][1]), pt_mul(cj1, g1))
+        if j == 0:
+            p0 = pt_add(pt_mul(h2, pr.w00), p0)                                             # :806-807
+            p1 = pt_add(pt_mul(h2, pr.w01), p1)                                             # :808-809
+        cps += [p0, p1]
+    k_prime = IDENTITY
+    for idx, c in enumerate(pr.com):                                                        # :819-824
+        k_prime = pt_add(k_prime, pt_mul(c, 1 << idx))
+    com_ = pt_add(pt_mul(h1, pr.s), k_prime)                                                # :825
+    big_c = pt_sub(pt_add(pt_add(pt_mul(h1, (-pr.c_bar) % ELL), pt_mul(h2, pr.k_bar)), pt_mul(h3, pr.s_bar)),
+                   pt_mul(com_, pr.gamma))                                                  # :826-829
+    items = [sc_bytes(pr.k), E(pr.a_prime), E(pr.b_bar), E(a1), E(a2)] + [E(c) for c in pr.com]
+    items += [E(p) for p in cps]
+    items.append(E(big_c))
+    return transcript_challenge(params, b"spend", items), k_prime                           # :831-840
+
+
+def refund(sk: PrivateKey, params: Params, pr: SpendProof, rng: ByteRng) -> Refund:
+    """PrivateKey::refund, src/lib.rs:781-869.  RNG is drawn only after the proof verifies."""
+    if pt_eq(pr.a_prime, IDENTITY):                                                         # :787
+        raise ActError(ERR_IDENTITY_POINT)
+    gamma, k_prime = spend_verify_challenge(sk.x, params, pr)
+    if gamma != pr.gamma:                                                                   # :842
+        raise ActError(ERR_INVALID_CLIENT_SPEND_PROOF)
+    e = rng.scalar()                                                                        # :846
+    x_a = pt_add(G, k_prime)                                                                # :848
+    a = pt_mul(x_a, sc_inv((e + sk.x) % ELL))                                               # :849
+    x_g = pt_add(pt_mul(G, e), sk.w)                                                        # :851
+    alpha = rng.scalar()                                                                    # :852
+    y_a = pt_mul(a, alpha)                                                                  # :853
+    y_g = pt_mul(G, alpha)                                                                  # :854
+    rg = transcript_challenge(params, b"refund", [sc_bytes(e), E(a), E(x_a), E(x_g), E(y_a), E(y_g)])  # :856-859
+    z = (rg * (sk.x + e) + alpha) % ELL                                                     # :861
+    return Refund(a, e, rg, z)
+
+
+def refund_to_credit_token(pre: PreRefund, params: Params, pr: SpendProof, rf: Refund, w: Point) -> CreditToken:
+    """PreRefund::to_credit_token, src/lib.rs:1217-1253."""
+    k_prime = IDENTITY
+    for idx, c in enumerate(pr.com):
+        k_prime = pt_add(k_prime, pt_mul(c, 1 << idx))
+    x_a = pt_add(G, k_prime)                                                                # :1224-1230
+    x_g = pt_add(pt_mul(G, rf.e), w)                                                        # :1232
+    ng = (-rf.gamma) % ELL
+    y_a = pt_add(pt_mul(rf.a, rf.z), pt_mul(x_a, ng))                                       # :1233
+    y_g = pt_add(pt_mul(G, rf.z), pt_mul(x_g, ng))                                          # :1234
+    gamma = transcript_challenge(params, b"refund", [sc_bytes(rf.e), E(rf.a), E(x_a), E(x_g), E(y_a), E(y_g)])
+    if gamma != rf.gamma:                                                                   # :1241
+        raise ActError(ERR_INVALID_REFUND_PROOF)
+    return CreditToken(rf.a, rf.e, pre.k, pre.r, pre.m)
+
+
+# Record parsers (raw 32-byte-field layouts) -------------------------------------
+def _pt(b: bytes) -> Point:
+    p = ristretto_decode(b)
+    if p is None:
+        raise ActError(ERR_UNDECODABLE)
+    return p
+
+
+def _sc(b: bytes) -> int:
+    return int.from_bytes(b, "little")
+
+
+def parse_spend_proof(rec: bytes, nbits: int = L_DEFAULT) -> SpendProof:
+    assert len(rec) == 32 * (14 + 4 * nbits)
+    f = [rec[i:i + 32] for i in range(0, len(rec), 32)]
+    o = 4
+    com = [_pt(f[o + j]) for j in range(nbits)]
+    o += nbits
+    sc8 = [_sc(f[o + i]) for i in range(8)]
+    o += 8
+    gamma0 = [_sc(f[o + j]) for j in range(nbits)]
+    o += nbits
+    z = [(_sc(f[o + 2 * j]), _sc(f[o + 2 * j + 1])) for j in range(nbits)]
+    o += 2 * nbits
+    return SpendProof(_sc(f[0]), _sc(f[1]), _pt(f[2]), _pt(f[3]), com, *sc8[:6], sc8[6], sc8[7], gamma0, z,
+                      _sc(f[o]), _sc(f[o + 1]))
