@@ -1,0 +1,251 @@
+"""Host-side mirror of the reference crate's public interface (/root/reference/src/lib.rs) over the
+C ABI: same type names, method names, argument meaning and error behaviour, with `*_batch`
+siblings that take lists.  Every method is one (batched) call into the HIP engine; nothing here
+computes curve or scalar arithmetic.  Values are held as the raw records of include/act_mi355x.h.
+
+    params = Params.new("org", "svc", "prod", "2024-01-15")                 # src/lib.rs:291
+    sk = PrivateKey.random(OsRng())                                            # :188
+    pre = PreIssuance.random(rng); req = pre.request(params, rng)              # :432, :463
+    resp = sk.issue(params, req, 20, rng)                                      # :621  (raises Error)
+    tok = pre.to_credit_token(params, sk.public(), req, resp)                  # :528
+    proof, prerefund = tok.prove_spend(params, 5, rng)                         # :972
+    refund = sk.refund(params, proof, rng)                                     # :781  (raises Error)
+    tok2 = prerefund.to_credit_token(params, proof, refund, sk.public())       # :1217
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+from . import capi
+
+L = 128  # src/lib.rs:116
+
+_ELL = 2**252 + 27742317777372353535851937790883648493
+
+
+class Error(Exception):
+    """Mirror of `enum Error` (src/lib.rs:102-112); `code` = 1 + discriminant, 255 = undecodable point."""
+    NAMES = {1: "InvalidIssuanceRequestProof", 2: "InvalidIssuanceResponseProof", 3: "DoubleSpendError",
+             4: "InvalidRefundProof", 5: "InvalidRefundResponseProof", 6: "IdentityPointError",
+             7: "InvalidClientSpendProof", 8: "AmountTooBigError", 9: "ScalarOutOfRangeError", 255: "UndecodablePoint"}
+
+    def __init__(self, code: int):
+        super().__init__(self.NAMES.get(code, f"status {code}"))
+        self.code = code
+        self.name = self.NAMES.get(code, str(code))
+
+
+class OsRng:
+    """CryptoRngCore stand-in backed by os.urandom."""
+
+    def fill_bytes(self, n: int) -> bytes:
+        return os.urandom(n)
+
+
+class ByteStreamRng:
+    """Deterministic CryptoRngCore stand-in replaying a byte string (tests; parity runs)."""
+
+    def __init__(self, data: bytes):
+        self.data, self.pos = bytes(data), 0
+
+    def fill_bytes(self, n: int) -> bytes:
+        if self.pos + n > len(self.data):
+            raise ValueError("rng stream exhausted")
+        out = self.data[self.pos:self.pos + n]
+        self.pos += n
+        return out
+
+    def peek(self, n: int) -> bytes:
+        return self.data[self.pos:self.pos + n].ljust(n, b"\0")
+
+    def advance(self, n: int):
+        self.pos += n
+
+
+def scalar(v) -> bytes:
+    """Scalar::from(u128) / canonical 32-byte little-endian scalar."""
+    if isinstance(v, (bytes, bytearray)):
+        assert len(v) == 32
+        return bytes(v)
+    return (int(v) % _ELL).to_bytes(32, "little")
+
+
+def scalar_to_u128(s: bytes):
+    """src/lib.rs:146-153: Some(value) iff the high 16 bytes are zero."""
+    return int.from_bytes(s[:16], "little") if not any(s[16:]) else None
+
+
+def _draw_accepting(rng, n_lanes: int, run):
+    """issue/refund draw 128 rng bytes per ACCEPTED lane, in lane order (src/lib.rs:638-643, 842-846).
+    With a peekable rng the unused bytes stay in the stream, like a sequential loop over one generator."""
+    if hasattr(rng, "peek"):
+        st, out = run(rng.peek(128 * n_lanes), capi.RNG_SEQUENTIAL)
+        rng.advance(128 * sum(1 for s in st if s == 0))
+    else:
+        st, out = run(rng.fill_bytes(128 * n_lanes), capi.RNG_SEQUENTIAL)
+    return st, out
+
+
+class Params:
+    _engines: dict = {}
+
+    def __init__(self, h: bytes, device: int = 0):
+        self.h, self.device = bytes(h), device
+
+    @staticmethod
+    def new(organization: str, service: str, deployment_id: str, version: str, device: int = 0) -> "Params":
+        return Params(capi.params_new(organization, service, deployment_id, version, device), device)
+
+    @staticmethod
+    def random(rng, device: int = 0) -> "Params":
+        return Params(capi.params_random(rng.fill_bytes(192), device), device)
+
+    def engine(self, nbits: int = L) -> capi.Engine:
+        key = (self.h, nbits, self.device)
+        if key not in Params._engines:
+            mode = capi.TRANSCRIPT_DEVICE if os.environ.get("ACT_TRANSCRIPT", "host") == "device" else capi.TRANSCRIPT_HOST
+            Params._engines[key] = capi.Engine(self.h, nbits, self.device, transcript=mode)
+        return Params._engines[key]
+
+    def __eq__(self, other):
+        # the reference compares self.h3 with other.h2 (src/lib.rs:233); mirrored, quirk included
+        return self.h[0:32] == other.h[0:32] and self.h[32:64] == other.h[32:64] and self.h[64:96] == other.h[32:64]
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
+class PublicKey:
+    def __init__(self, w: bytes):
+        self.w = bytes(w)
+
+
+class PrivateKey:
+    def __init__(self, record: bytes):
+        assert len(record) == 64
+        self.record = bytes(record)
+
+    @staticmethod
+    def random(rng, params: Params = None) -> "PrivateKey":
+        params = params or Params.new("act", "keygen", "default", "1970-01-01")
+        return PrivateKey(params.engine().private_key_random(rng.fill_bytes(64)))
+
+    def public(self) -> PublicKey:
+        return PublicKey(self.record[32:])
+
+    def issue(self, params: Params, request: "IssuanceRequest", c, rng) -> "IssuanceResponse":
+        return self.issue_batch(params, [request], [c], rng)[0]
+
+    def issue_batch(self, params: Params, requests: Sequence["IssuanceRequest"], cs: Sequence, rng) -> List["IssuanceResponse"]:
+        e = params.engine()
+        req = b"".join(r.record for r in requests); cc = b"".join(scalar(c) for c in cs)
+        st, out = _draw_accepting(rng, len(requests), lambda rb, mode: e.issue(self.record, req, cc, rb, mode))
+        res = [IssuanceResponse(out[160 * i:160 * i + 160]) if st[i] == 0 else Error(st[i]) for i in range(len(requests))]
+        if len(res) == 1 and isinstance(res[0], Error):
+            raise res[0]
+        return res
+
+    def refund(self, params: Params, spend_proof: "SpendProof", rng) -> "Refund":
+        return self.refund_batch(params, [spend_proof], rng)[0]
+
+    def refund_batch(self, params: Params, proofs: Sequence["SpendProof"], rng) -> List["Refund"]:
+        nbits = proofs[0].nbits if proofs else L
+        e = params.engine(nbits)
+        pb = b"".join(p.record for p in proofs)
+        st, out = _draw_accepting(rng, len(proofs), lambda rb, mode: e.refund(self.record, pb, rb, mode))
+        res = [Refund(out[128 * i:128 * i + 128]) if st[i] == 0 else Error(st[i]) for i in range(len(proofs))]
+        if len(res) == 1 and isinstance(res[0], Error):
+            raise res[0]
+        return res
+
+    def verify_spend_batch(self, params: Params, proofs: Sequence["SpendProof"]) -> bytes:
+        nbits = proofs[0].nbits if proofs else L
+        return params.engine(nbits).verify_spend(self.record, b"".join(p.record for p in proofs))
+
+
+class PreIssuance:
+    def __init__(self, record: bytes):
+        assert len(record) == 64
+        self.record = bytes(record)   # r | k
+
+    @staticmethod
+    def random(rng, params: Params = None) -> "PreIssuance":
+        params = params or Params.new("act", "keygen", "default", "1970-01-01")
+        return PreIssuance(params.engine().pre_issuance_random(rng.fill_bytes(128)))
+
+    def request(self, params: Params, rng) -> "IssuanceRequest":
+        return IssuanceRequest(params.engine().request(self.record, rng.fill_bytes(128)))
+
+    def to_credit_token(self, params: Params, public: PublicKey, request: "IssuanceRequest", response: "IssuanceResponse") -> "CreditToken":
+        st, out = params.engine().issuance_to_credit_token(self.record, public.w, request.record, response.record)
+        if st[0]:
+            raise Error(st[0])
+        return CreditToken(out)
+
+
+class IssuanceRequest:
+    def __init__(self, record: bytes):
+        assert len(record) == 128
+        self.record = bytes(record)   # K | gamma | k_bar | r_bar
+
+
+class IssuanceResponse:
+    def __init__(self, record: bytes):
+        assert len(record) == 160
+        self.record = bytes(record)   # A | e | gamma | z | c
+
+
+class CreditToken:
+    def __init__(self, record: bytes):
+        assert len(record) == 160
+        self.record = bytes(record)   # a | e | k | r | c
+
+    def nullifier(self) -> bytes:
+        return self.record[64:96]
+
+    def credits(self) -> bytes:
+        return self.record[128:160]
+
+    def prove_spend(self, params: Params, s, rng, nbits: int = L) -> Tuple["SpendProof", "PreRefund"]:
+        e = params.engine(nbits)
+        st, proof, pre = e.prove_spend(self.record, scalar(s), rng.fill_bytes(e.prove_rng_bytes))
+        if st[0]:
+            raise Error(st[0])
+        return SpendProof(proof, nbits), PreRefund(pre)
+
+    def __eq__(self, other):
+        return self.record == other.record
+
+
+class SpendProof:
+    def __init__(self, record: bytes, nbits: int = L):
+        assert len(record) == 32 * (14 + 4 * nbits)
+        self.record, self.nbits = bytes(record), nbits
+
+    def nullifier(self) -> bytes:
+        return self.record[0:32]
+
+    def charge(self) -> bytes:
+        return self.record[32:64]
+
+
+class PreRefund:
+    def __init__(self, record: bytes):
+        assert len(record) == 96
+        self.record = bytes(record)   # r | k | m
+
+    def to_credit_token(self, params: Params, spend_proof: SpendProof, refund: "Refund", public_key: PublicKey) -> CreditToken:
+        st, out = params.engine(spend_proof.nbits).refund_to_credit_token(self.record, spend_proof.record, refund.record, public_key.w)
+        if st[0]:
+            raise Error(st[0])
+        return CreditToken(out)
+
+
+class Refund:
+    def __init__(self, record: bytes):
+        assert len(record) == 128
+        self.record = bytes(record)   # A* | e | gamma | z
+
+    def __eq__(self, other):
+        return self.record == other.record

@@ -1,0 +1,241 @@
+"""ctypes binding of libact_mi355x.so (C ABI: include/act_mi355x.h).  Host side only moves bytes."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libact_mi355x.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+RNG_PER_LANE, RNG_SEQUENTIAL = 0, 1
+TRANSCRIPT_HOST, TRANSCRIPT_DEVICE = 0, 1
+_ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO_DEVICE"}
+
+EXPORTS = [
+    "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
+    "act_ctx_set_host_threads", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
+    "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
+    "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_prof_enable",
+    "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get",
+]
+
+
+class ActError(RuntimeError):
+    pass
+
+
+def build(jobs: int = 8) -> str:
+    """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}", "-s"], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ActError(f"{LIB_PATH} is missing: build it with act_amd.build() / make -C anonymous-credit-tokens_amd/csrc "
+                       "(the HIP engine is the only implementation; there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, i32, u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
+    lib.act_params_new.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, u8p]
+    lib.act_params_random.argtypes = [i32, u8p, u8p]
+    lib.act_ctx_create.argtypes = [u8p, i32, i32, sz, C.POINTER(vp)]
+    lib.act_ctx_destroy.argtypes = [vp]
+    lib.act_ctx_destroy.restype = None
+    lib.act_ctx_set_transcript_mode.argtypes = [vp, i32]
+    lib.act_ctx_set_host_threads.argtypes = [vp, i32]
+    lib.act_last_error.argtypes = [vp]
+    lib.act_last_error.restype = C.c_char_p
+    for f in ("act_spend_proof_bytes", "act_prove_rng_bytes", "act_spend_transcript_bytes"):
+        getattr(lib, f).argtypes = [vp]
+        getattr(lib, f).restype = sz
+    lib.act_private_key_random.argtypes = [vp, u8p, u8p]
+    lib.act_pre_issuance_random_batch.argtypes = [vp, sz, i32, u8p, u8p]
+    lib.act_request_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p]
+    lib.act_issue_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_issuance_to_credit_token_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
+    lib.act_prove_spend_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
+    lib.act_verify_spend_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p]
+    lib.act_refund_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_refund_to_credit_token_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
+    lib.act_debug_last_spend_transcripts.argtypes = [vp, sz, u8p, C.POINTER(sz)]
+    lib.act_prof_enable.argtypes = [vp, i32]
+    lib.act_prof_reset.argtypes = [vp]
+    lib.act_prof_kernel_count.argtypes = [vp]
+    lib.act_prof_kernel_name.argtypes = [vp, i32]
+    lib.act_prof_kernel_name.restype = C.c_char_p
+    lib.act_prof_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    _lib = lib
+    return lib
+
+
+def _in(x, nbytes=None):
+    """bytes / numpy uint8 -> (ctypes pointer value, keep-alive object)."""
+    if x is None:
+        return None, None
+    a = np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray, memoryview)) else np.ascontiguousarray(x, dtype=np.uint8)
+    if nbytes is not None and a.size != nbytes:
+        raise ValueError(f"expected {nbytes} bytes, got {a.size}")
+    return a.ctypes.data, a
+
+
+def params_new(org: str, svc: str, dep: str, ver: str, device: int = 0) -> bytes:
+    out = np.zeros(96, np.uint8)
+    rc = load().act_params_new(device, org.encode(), svc.encode(), dep.encode(), ver.encode(), out.ctypes.data)
+    if rc:
+        raise ActError(f"act_params_new failed: {_ERRS.get(rc, rc)}")
+    return out.tobytes()
+
+
+def params_random(rng: bytes, device: int = 0) -> bytes:
+    out = np.zeros(96, np.uint8)
+    p, keep = _in(rng, 192)
+    rc = load().act_params_random(device, p, out.ctypes.data)
+    if rc:
+        raise ActError(f"act_params_random failed: {_ERRS.get(rc, rc)}")
+    return out.tobytes()
+
+
+class Engine:
+    """One context: Params (enc(h1)|enc(h2)|enc(h3)) + range width L + one GPU.
+    Host-memory methods take/return bytes; the *_dev methods take raw device pointers (ints)."""
+
+    def __init__(self, h: bytes, L: int = 128, device: int = 0, max_batch: int = 0,
+                 transcript: int = TRANSCRIPT_HOST, host_threads: int = 0):
+        self.lib = load()
+        self.h, self.L, self.device = bytes(h), L, device
+        ctx = C.c_void_p()
+        p, keep = _in(h, 96)
+        rc = self.lib.act_ctx_create(p, L, device, max_batch, C.byref(ctx))
+        if rc:
+            msg = self.lib.act_last_error(ctx).decode() if ctx else ""
+            if ctx:
+                self.lib.act_ctx_destroy(ctx)
+            raise ActError(f"act_ctx_create failed: {_ERRS.get(rc, rc)} {msg}")
+        self.ctx = ctx
+        self.proof_bytes = self.lib.act_spend_proof_bytes(ctx)
+        self.prove_rng_bytes = self.lib.act_prove_rng_bytes(ctx)
+        self.transcript_bytes = self.lib.act_spend_transcript_bytes(ctx)
+        self.set_transcript_mode(transcript)
+        if host_threads:
+            self._ck(self.lib.act_ctx_set_host_threads(ctx, host_threads))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.act_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise ActError(f"{_ERRS.get(rc, rc)}: {self.lib.act_last_error(self.ctx).decode()}")
+
+    def set_transcript_mode(self, mode: int):
+        self._ck(self.lib.act_ctx_set_transcript_mode(self.ctx, mode))
+
+    # ---- host-memory batch calls ----------------------------------------------------------------
+    def private_key_random(self, rng: bytes) -> bytes:
+        out = np.zeros(64, np.uint8); p, k = _in(rng, 64)
+        self._ck(self.lib.act_private_key_random(self.ctx, p, out.ctypes.data)); return out.tobytes()
+
+    def pre_issuance_random(self, rng: bytes) -> bytes:
+        n = len(rng) // 128; out = np.zeros(64 * n, np.uint8); p, k = _in(rng, 128 * n)
+        self._ck(self.lib.act_pre_issuance_random_batch(self.ctx, n, MEM_HOST, p, out.ctypes.data)); return out.tobytes()
+
+    def request(self, pre: bytes, rng: bytes) -> bytes:
+        n = len(pre) // 64; out = np.zeros(128 * n, np.uint8)
+        p0, k0 = _in(pre, 64 * n); p1, k1 = _in(rng, 128 * n)
+        self._ck(self.lib.act_request_batch(self.ctx, n, MEM_HOST, p0, p1, out.ctypes.data)); return out.tobytes()
+
+    def issue(self, sk: bytes, req: bytes, c: bytes, rng: bytes, rng_mode: int = RNG_PER_LANE):
+        n = len(req) // 128; out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(req, 128 * n); p1, k1 = _in(c, 32 * n); p2, k2 = _in(rng)
+        self._ck(self.lib.act_issue_batch(self.ctx, n, MEM_HOST, ps, p0, p1, p2, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def issuance_to_credit_token(self, pre: bytes, w: bytes, req: bytes, resp: bytes):
+        n = len(pre) // 64; out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(pre, 64 * n); pw, kw = _in(w, 32); p1, k1 = _in(req, 128 * n); p2, k2 = _in(resp, 160 * n)
+        self._ck(self.lib.act_issuance_to_credit_token_batch(self.ctx, n, MEM_HOST, p0, pw, p1, p2, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def prove_spend(self, tok: bytes, s: bytes, rng: bytes):
+        n = len(tok) // 160; out = np.zeros(self.proof_bytes * n, np.uint8); pr = np.zeros(96 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(tok, 160 * n); p1, k1 = _in(s, 32 * n); p2, k2 = _in(rng, self.prove_rng_bytes * n)
+        self._ck(self.lib.act_prove_spend_batch(self.ctx, n, MEM_HOST, p0, p1, p2, out.ctypes.data, pr.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes(), pr.tobytes()
+
+    def verify_spend(self, sk: bytes, proofs: bytes, want_kprime: bool = False):
+        n = len(proofs) // self.proof_bytes; st = np.zeros(n, np.uint8)
+        kp = np.zeros(32 * n, np.uint8) if want_kprime else None
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n)
+        self._ck(self.lib.act_verify_spend_batch(self.ctx, n, MEM_HOST, ps, p0, st.ctypes.data, kp.ctypes.data if want_kprime else None))
+        return (st.tobytes(), kp.tobytes()) if want_kprime else st.tobytes()
+
+    def refund(self, sk: bytes, proofs: bytes, rng: bytes, rng_mode: int = RNG_PER_LANE):
+        n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
+        self._ck(self.lib.act_refund_batch(self.ctx, n, MEM_HOST, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def refund_to_credit_token(self, prerefund: bytes, proofs: bytes, refund: bytes, w: bytes):
+        n = len(prerefund) // 96; out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(prerefund, 96 * n); p1, k1 = _in(proofs, self.proof_bytes * n); p2, k2 = _in(refund, 128 * n); pw, kw = _in(w, 32)
+        self._ck(self.lib.act_refund_to_credit_token_batch(self.ctx, n, MEM_HOST, p0, p1, p2, pw, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def last_spend_transcripts(self, max_lanes: int) -> list:
+        out = np.zeros(max_lanes * self.transcript_bytes, np.uint8); n = C.c_size_t(0)
+        self._ck(self.lib.act_debug_last_spend_transcripts(self.ctx, max_lanes, out.ctypes.data, C.byref(n)))
+        b = out.tobytes()
+        return [b[i * self.transcript_bytes:(i + 1) * self.transcript_bytes] for i in range(n.value)]
+
+    # ---- device-memory batch calls (raw device pointers) -----------------------------------------
+    def verify_spend_dev(self, sk: bytes, n: int, d_proofs: int, d_status: int, d_kprime: int = 0):
+        ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_verify_spend_batch(self.ctx, n, MEM_DEVICE, ps, d_proofs, d_status, d_kprime or None))
+
+    def refund_dev(self, sk: bytes, n: int, d_proofs: int, d_rng: int, rng_mode: int, d_out: int, d_status: int):
+        ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_refund_batch(self.ctx, n, MEM_DEVICE, ps, d_proofs, d_rng, rng_mode, d_out, d_status))
+
+    def prove_spend_dev(self, n: int, d_tok: int, d_s: int, d_rng: int, d_proof: int, d_prerefund: int, d_status: int):
+        self._ck(self.lib.act_prove_spend_batch(self.ctx, n, MEM_DEVICE, d_tok, d_s, d_rng, d_proof, d_prerefund, d_status))
+
+    def issue_dev(self, sk: bytes, n: int, d_req: int, d_c: int, d_rng: int, rng_mode: int, d_out: int, d_status: int):
+        ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_issue_batch(self.ctx, n, MEM_DEVICE, ps, d_req, d_c, d_rng, rng_mode, d_out, d_status))
+
+    def request_dev(self, n: int, d_pre: int, d_rng: int, d_out: int):
+        self._ck(self.lib.act_request_batch(self.ctx, n, MEM_DEVICE, d_pre, d_rng, d_out))
+
+    # ---- profiling ---------------------------------------------------------------------------------
+    def prof_enable(self, on: bool = True):
+        self._ck(self.lib.act_prof_enable(self.ctx, 1 if on else 0))
+
+    def prof_reset(self):
+        self._ck(self.lib.act_prof_reset(self.ctx))
+
+    def prof(self) -> dict:
+        out = {}
+        for i in range(self.lib.act_prof_kernel_count(self.ctx)):
+            ms, la, ln = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+            self._ck(self.lib.act_prof_get(self.ctx, i, C.byref(ms), C.byref(la), C.byref(ln)))
+            if la.value:
+                out[self.lib.act_prof_kernel_name(self.ctx, i).decode()] = {"ms": ms.value, "launches": la.value, "lanes": ln.value}
+        return out

@@ -1,0 +1,185 @@
+// ge25519.h — twisted-Edwards (a = -1) extended-coordinate group law and ristretto255
+// encode / decode / one-way map (RFC 9496) for gfx950 lanes, one point per lane.
+// Restates what the reference takes from curve25519-dalek's RistrettoPoint (call sites
+// /root/reference/src/lib.rs:465-1239; compress at src/transcript.rs:106).
+// How a group element is computed does not change its canonical 32-byte encoding, so the
+// kernels are free to use different addition chains than the reference.
+//
+// Operand-size discipline of fe25519.h is annotated per formula: [g] = fits the 19x-premultiplied
+// operand (<= 1.68*2^27), [f] = needs the wide operand slot (<= 1.5*2^28).
+#pragma once
+#include "fe25519.h"
+#include "sc25519.h"
+
+namespace act {
+
+struct ge { fe X, Y, Z, T; };                 // extended; all coordinates tight
+struct ge_cached { fe YpX, YmX, Z, T2d; };    // "projective Niels": YpX, YmX loose [g]; Z, T2d tight
+struct ge_niels { fe ypx, ymx, xy2d; };       // affine Niels (Z = 1); tight
+
+ACT_HD ge ge_identity() { ge p; p.X = fe_zero(); p.Y = fe_one(); p.Z = fe_one(); p.T = fe_zero(); return p; }
+ACT_HD ge ge_basepoint() { ge p; p.X = fe_base_x(); p.Y = fe_base_y(); p.Z = fe_one(); p.T = fe_base_t(); return p; }
+ACT_HD ge_niels ge_niels_identity() { ge_niels n; n.ypx = fe_one(); n.ymx = fe_one(); n.xy2d = fe_zero(); return n; }
+ACT_HD ge ge_neg(const ge& p) { ge r; r.X = fe_carry(fe_neg(p.X)); r.Y = p.Y; r.Z = p.Z; r.T = fe_carry(fe_neg(p.T)); return r; }
+
+ACT_HD ge_cached ge_to_cached(const ge& p) {
+  ge_cached c;
+  c.YpX = fe_add(p.Y, p.X);          // <= 2^27            [g]
+  c.YmX = fe_sub(p.Y, p.X);          // <= 1.5 * 2^27      [g]
+  c.Z = p.Z;
+  c.T2d = fe_mul(p.T, fe_d2());
+  return c;
+}
+// per-lane conditional negation of a cached point: swap Y+X / Y-X, negate 2dT
+ACT_HD ge_cached ge_cached_cneg(const ge_cached& c, bool neg) {
+  ge_cached r = c;
+  fe_cswap(r.YpX, r.YmX, neg);
+  r.T2d = fe_select(c.T2d, fe_neg(c.T2d), neg);   // <= 2^27 [g]
+  return r;
+}
+ACT_HD ge_niels ge_niels_cneg(const ge_niels& c, bool neg) {
+  ge_niels r = c;
+  fe_cswap(r.ypx, r.ymx, neg);
+  r.xy2d = fe_select(c.xy2d, fe_neg(c.xy2d), neg);
+  return r;
+}
+
+// completed point (cx : cz) x (cy : ct) -> extended.  Operand classes: cx [g], cy [g], cz [g], ct [f]
+template <bool WITH_T = true>
+ACT_HD ge ge_from_completed(const fe& cx, const fe& cy, const fe& cz, const fe& ct) {
+  ge r;
+  r.X = fe_mul(ct, cx);
+  r.Y = fe_mul(cz, cy);
+  r.Z = fe_mul(ct, cz);
+  if (WITH_T) r.T = fe_mul(cx, cy); else r.T = fe_zero();
+  return r;
+}
+
+// p + q, q cached.  8M.
+template <bool WITH_T = true>
+ACT_HD ge ge_add_cached(const ge& p, const ge_cached& q) {
+  fe ypx = fe_add(p.Y, p.X);                 // [g] 2^27
+  fe ymx = fe_sub(p.Y, p.X);                 // [g] 1.5*2^27
+  fe pp = fe_mul(ypx, q.YpX);
+  fe mm = fe_mul(ymx, q.YmX);
+  fe tt2d = fe_mul(p.T, q.T2d);
+  fe zz2 = fe_dbl(fe_mul(p.Z, q.Z));         // 2^27
+  fe cx = fe_sub(pp, mm);                    // [g] 1.5*2^27
+  fe cy = fe_add(pp, mm);                    // [g] 2^27
+  fe cz = fe_add(zz2, tt2d);                 // [g] 1.5*2^27
+  fe ct = fe_sub(zz2, tt2d);                 // [f] 2^28
+  return ge_from_completed<WITH_T>(cx, cy, cz, ct);
+}
+// p + q, q affine Niels.  7M.
+template <bool WITH_T = true>
+ACT_HD ge ge_madd(const ge& p, const ge_niels& q) {
+  fe ypx = fe_add(p.Y, p.X);
+  fe ymx = fe_sub(p.Y, p.X);
+  fe pp = fe_mul(ypx, q.ypx);
+  fe mm = fe_mul(ymx, q.ymx);
+  fe tt2d = fe_mul(p.T, q.xy2d);
+  fe zz2 = fe_dbl(p.Z);
+  fe cx = fe_sub(pp, mm);
+  fe cy = fe_add(pp, mm);
+  fe cz = fe_add(zz2, tt2d);
+  fe ct = fe_sub(zz2, tt2d);
+  return ge_from_completed<WITH_T>(cx, cy, cz, ct);
+}
+ACT_HD ge ge_add(const ge& p, const ge& q) { return ge_add_cached(p, ge_to_cached(q)); }
+ACT_HD ge ge_sub(const ge& p, const ge& q) { return ge_add_cached(p, ge_cached_cneg(ge_to_cached(q), true)); }
+
+// 2p.  4S + 4M (3M without T).  Input T unused.
+template <bool WITH_T = true>
+ACT_HD ge ge_double(const ge& p) {
+  fe xx = fe_sq(p.X), yy = fe_sq(p.Y);
+  fe zz2 = fe_dbl(fe_sq(p.Z));               // 2^27
+  fe xpy2 = fe_sq(fe_add(p.X, p.Y));         // sq operand 2^27 [g]
+  fe yypxx = fe_add(yy, xx);                 // cy [g] 2^27
+  fe yymxx = fe_sub(yy, xx);                 // cz [g] 1.5*2^27
+  fe cx = fe_carry(fe_sub4(xpy2, yypxx));    // tight
+  fe ct = fe_sub4(zz2, yymxx);               // [f] 1.5*2^28
+  return ge_from_completed<WITH_T>(cx, yypxx, yymxx, ct);
+}
+
+// ---- ristretto255 ----------------------------------------------------------------------------
+// RFC 9496 4.3.2; output = canonical little-endian words of s
+ACT_HD void ristretto_encode(uint32_t out[8], const ge& p) {
+  fe u1 = fe_mul(fe_add(p.Z, p.Y), fe_sub(p.Z, p.Y));
+  fe u2 = fe_mul(p.X, p.Y);
+  fe inv;
+  fe_invsqrt(inv, fe_mul(u1, fe_sq(u2)));
+  fe d1 = fe_mul(inv, u1), d2 = fe_mul(inv, u2);
+  fe zinv = fe_mul(fe_mul(d1, d2), p.T);
+  fe ix = fe_mul(p.X, fe_sqrt_m1()), iy = fe_mul(p.Y, fe_sqrt_m1());
+  fe ench = fe_mul(d1, fe_invsqrt_a_minus_d());
+  bool rotate = fe_is_negative(fe_mul(p.T, zinv));
+  fe x = fe_select(p.X, iy, rotate);
+  fe y = fe_select(p.Y, ix, rotate);
+  fe den = fe_select(d2, ench, rotate);
+  y = fe_cneg(y, fe_is_negative(fe_mul(x, zinv)));          // <= 2^27
+  fe s = fe_mul(fe_sub4(p.Z, y), den);                       // f = Z - y (<= 1.25*2^28)
+  fe_to_words(out, fe_abs(s));
+}
+// RFC 9496 4.3.1; returns false for non-canonical / negative / non-square / t negative / y == 0
+ACT_HD bool ristretto_decode(ge& p, const uint32_t in[8]) {
+  fe s = fe_from_words(in);
+  uint32_t chk[8]; fe_to_words(chk, s);
+  bool canonical = true;
+  for (int i = 0; i < 8; i++) canonical = canonical && (chk[i] == in[i]);
+  bool ok = canonical && !(in[0] & 1u);
+  fe ss = fe_sq(s);
+  fe u1 = fe_sub(fe_one(), ss);                              // [g] 2^27
+  fe u2 = fe_add(fe_one(), ss);                              // [g]
+  fe u2s = fe_sq(u2);
+  fe du1s = fe_mul(fe_sq(u1), fe_d());
+  fe v = fe_sub(fe_neg(du1s), u2s);                          // [f] 2^28 : -(d*u1^2) - u2^2
+  fe inv;
+  bool was_square = fe_invsqrt(inv, fe_mul(v, u2s));
+  fe dx = fe_mul(inv, u2);
+  fe dy = fe_mul(v, fe_mul(inv, dx));
+  fe x = fe_carry(fe_abs(fe_mul(fe_add(s, s), dx)));
+  fe y = fe_mul(u1, dy);
+  fe t = fe_mul(x, y);
+  ok = ok && was_square && !fe_is_negative(t) && !fe_is_zero(y);
+  p.X = x; p.Y = y; p.Z = fe_one(); p.T = t;
+  return ok;
+}
+// RFC 9496 4.3.3
+ACT_HD bool ristretto_equal(const ge& a, const ge& b) {
+  bool e1 = fe_equal(fe_mul(a.X, b.Y), fe_mul(a.Y, b.X));
+  bool e2 = fe_equal(fe_mul(a.Y, b.Y), fe_mul(a.X, b.X));
+  return e1 || e2;
+}
+ACT_HD bool ristretto_is_identity(const ge& a) {   // == identity (0,1,1,0): X*1 == Y*0  or  Y*1 == X*0
+  return fe_is_zero(a.X) || fe_is_zero(a.Y);
+}
+// RFC 9496 4.3.4 MAP; t tight
+ACT_HD ge ristretto_map(const fe& t0) {
+  fe one = fe_one();
+  fe r = fe_mul(fe_sq(t0), fe_sqrt_m1());
+  fe u = fe_mul(fe_add(r, one), fe_one_minus_d_sq());
+  fe m1 = fe_carry(fe_neg(one));                                   // -1
+  fe v = fe_mul(fe_sub(m1, fe_mul(r, fe_d())), fe_add(r, fe_d()));  // (-1 - r d)(r + d)
+  fe s;
+  bool was_square = fe_sqrt_ratio_m1(s, u, v);
+  fe sp = fe_carry(fe_neg(fe_carry(fe_abs(fe_mul(s, t0)))));
+  s = fe_select(s, sp, !was_square);
+  fe c = fe_select(m1, r, !was_square);
+  fe n = fe_carry(fe_sub(fe_mul(fe_mul(c, fe_carry(fe_sub(r, one))), fe_d_minus_one_sq()), v));
+  fe w0 = fe_carry(fe_dbl(fe_mul(s, v)));
+  fe w1 = fe_mul(n, fe_sqrt_ad_minus_one());
+  fe s2 = fe_sq(s);
+  fe w2 = fe_carry(fe_sub(one, s2));
+  fe w3 = fe_carry(fe_add(one, s2));
+  ge p;
+  p.X = fe_mul(w0, w3); p.Y = fe_mul(w2, w1); p.Z = fe_mul(w1, w3); p.T = fe_mul(w0, w2);
+  return p;
+}
+// RistrettoPoint::from_uniform_bytes: 16 little-endian words
+ACT_HD ge ristretto_from_uniform(const uint32_t w[16]) {
+  ge p0 = ristretto_map(fe_carry(fe_from_words(w)));
+  ge p1 = ristretto_map(fe_carry(fe_from_words(w + 8)));
+  return ge_add(p0, p1);
+}
+
+}  // namespace act

@@ -1,0 +1,90 @@
+// k_misc.hip — set-up kernels (fixed-base tables, point decoding, Params one-way map, key
+// generation) and the device BLAKE3 transcript kernel.
+#include "kernels.h"
+
+namespace act {
+
+// T[pos][e] = e * 256^pos * B as affine Niels (msm.h).  lane = (pos, e): 8*pos doublings of B, an
+// 8-bit double-and-add, one inversion.  Runs once per context (cf. RistrettoBasepointTable::create,
+// /root/reference/src/lib.rs:311-313).
+__global__ void __launch_bounds__(256) k_build_table(const uint32_t* base_ext, uint32_t* table) {
+  uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (uint32_t)(FB_WINDOWS * FB_ENTRIES)) return;
+  uint32_t pos = gid / FB_ENTRIES, e = gid % FB_ENTRIES;
+  ge b = ge_load(base_ext);
+  for (uint32_t i = 0; i < 8 * pos; i++) b = ge_double(b);
+  ge acc = ge_identity();
+  ge_cached bc = ge_to_cached(b);
+  for (int bit = 7; bit >= 0; bit--) {
+    acc = ge_double(acc);
+    if ((e >> bit) & 1u) acc = ge_add_cached(acc, bc);
+  }
+  fe zi = fe_invert(acc.Z);
+  ge af; af.X = fe_mul(acc.X, zi); af.Y = fe_mul(acc.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
+  niels_store(table + (size_t)gid * NIELS_WORDS, niels_from_affine(af));
+}
+void launch_build_table(const uint32_t* base_ext, uint32_t* table, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_table, dim3(FB_WINDOWS * FB_ENTRIES / 256), dim3(256), 0, s, base_ext, table);
+}
+
+__global__ void __launch_bounds__(64) k_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8]; load8(w, enc + (size_t)i * 32);
+  ge p; bool good = ristretto_decode(p, w);
+  ge_store(out_ext + (size_t)i * GE_WORDS, p);
+  ok[i] = good ? 1u : 0u;
+}
+void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_decode_points, dim3((n + 63) / 64), dim3(64), 0, s, enc, n, out_ext, ok);
+}
+
+// RistrettoPoint::from_uniform_bytes (src/lib.rs:353, :261-263)
+__global__ void __launch_bounds__(64) k_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[16]; load8(w, in64 + (size_t)i * 64); load8(w + 8, in64 + (size_t)i * 64 + 32);
+  ge p = ristretto_from_uniform(w);
+  uint32_t e[8]; ristretto_encode(e, p); store8(out_enc + (size_t)i * 32, e);
+}
+void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_from_uniform, dim3((n + 63) / 64), dim3(64), 0, s, in64, n, out_enc);
+}
+
+// PrivateKey::random (src/lib.rs:188-194): x <- 64 rng bytes; w = x * g
+__global__ void __launch_bounds__(64) k_keygen(DevParams P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  sc x = load_wide(rng64 + (size_t)i * 64);
+  ge w = fixed_base_acc(ge_identity(), P.tab[BASE_G], x);
+  uint32_t e[8]; ristretto_encode(e, w);
+  store_sc(out_sk + (size_t)i * 64, x); store8(out_sk + (size_t)i * 64 + 32, e);
+}
+void launch_keygen(const DevParams& P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_keygen, dim3((n + 63) / 64), dim3(64), 0, s, P, rng64, n, out_sk);
+}
+// PreIssuance::random (src/lib.rs:432-437): r then k, record r | k
+__global__ void __launch_bounds__(256) k_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  store_sc(out + (size_t)i * 64, load_wide(rng + (size_t)i * 128));
+  store_sc(out + (size_t)i * 64 + 32, load_wide(rng + (size_t)i * 128 + 64));
+}
+void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_pre_issuance_random, dim3((n + 255) / 256), dim3(256), 0, s, rng, n, out);
+}
+
+// Transcript::challenge's hash (src/transcript.rs:149-152): lane = message, 64 XOF bytes out.
+__global__ void __launch_bounds__(64) k_hash_xof(HashArgs a) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  uint32_t o[16];
+  uint32_t len = a.len_per_lane ? a.len_per_lane[i] : a.len;
+  b3_hash_xof64(o, reinterpret_cast<const uint32_t*>(a.msg + (size_t)i * a.stride), len);
+  uint4* q = reinterpret_cast<uint4*>(a.xof + (size_t)i * 16);
+  q[0] = make_uint4(o[0], o[1], o[2], o[3]); q[1] = make_uint4(o[4], o[5], o[6], o[7]);
+  q[2] = make_uint4(o[8], o[9], o[10], o[11]); q[3] = make_uint4(o[12], o[13], o[14], o[15]);
+}
+void launch_hash(const HashArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_hash_xof, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
+
+}  // namespace act

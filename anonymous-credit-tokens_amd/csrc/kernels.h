@@ -1,0 +1,174 @@
+// kernels.h — argument blocks and launchers shared by the HIP kernels and the host engine.
+// One lane = one proof (head / tail / sign kernels) or one (proof, bit) pair (range-proof kernels).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "msm.h"
+#include "blake3_hd.h"
+
+namespace act {
+
+enum { LABEL_REQUEST = 0, LABEL_RESPOND = 1, LABEL_SPEND = 2, LABEL_REFUND = 3 };
+enum { BASE_G = 0, BASE_H1 = 1, BASE_H2 = 2, BASE_H3 = 3 };
+enum : uint32_t { FLAG_UNDECODABLE = 1u, FLAG_IDENTITY = 2u, FLAG_MISMATCH = 4u };
+
+constexpr int PREFIX_WORDS = 48;          // transcript prefixes are 184..186 bytes (src/transcript.rs:54-74)
+constexpr int SMALL_TR_STRIDE = 512;      // request 266 B, respond 466 B, refund 425 B
+
+// Params-dependent constants, by value in every launch (~1 KiB of kernarg, read through the scalar cache)
+struct DevParams {
+  const uint32_t* tab[4];                 // position-specific fixed-base tables of g, h1, h2, h3 (msm.h)
+  uint32_t prefix[4][PREFIX_WORDS];       // Transcript::new(params, label) bytes, zero padded
+  uint32_t prefix_len[4];
+  int L;                                  // range-proof width (src/lib.rs:116)
+};
+struct DevKey { sc x; ge w; };            // PrivateKey (src/lib.rs:161-167), w decoded
+
+// ---- SpendProof record field indices (32-byte fields; src/cbor.rs:250-268) ----
+struct ProofLayout {
+  int L;
+  __host__ __device__ int k() const { return 0; }
+  __host__ __device__ int s() const { return 1; }
+  __host__ __device__ int a_prime() const { return 2; }
+  __host__ __device__ int b_bar() const { return 3; }
+  __host__ __device__ int com(int j) const { return 4 + j; }
+  __host__ __device__ int gamma() const { return 4 + L; }
+  __host__ __device__ int e_bar() const { return 5 + L; }
+  __host__ __device__ int r2_bar() const { return 6 + L; }
+  __host__ __device__ int r3_bar() const { return 7 + L; }
+  __host__ __device__ int c_bar() const { return 8 + L; }
+  __host__ __device__ int r_bar() const { return 9 + L; }
+  __host__ __device__ int w00() const { return 10 + L; }
+  __host__ __device__ int w01() const { return 11 + L; }
+  __host__ __device__ int gamma0(int j) const { return 12 + L + j; }
+  __host__ __device__ int z(int j, int b) const { return 12 + 2 * L + 2 * j + b; }
+  __host__ __device__ int k_bar() const { return 12 + 4 * L; }
+  __host__ __device__ int s_bar() const { return 13 + 4 * L; }
+  __host__ __device__ size_t bytes() const { return 32u * (14u + 4u * (size_t)L); }
+};
+// "spend" transcript element slots (40 bytes each after the prefix; src/lib.rs:831-840)
+struct SpendTranscript {
+  int L;
+  __host__ __device__ int el_k() const { return 0; }
+  __host__ __device__ int el_a_prime() const { return 1; }
+  __host__ __device__ int el_b_bar() const { return 2; }
+  __host__ __device__ int el_a1() const { return 3; }
+  __host__ __device__ int el_a2() const { return 4; }
+  __host__ __device__ int el_com(int j) const { return 5 + j; }
+  __host__ __device__ int el_cprime(int j, int b) const { return 5 + L + 2 * j + b; }
+  __host__ __device__ int el_c() const { return 5 + 3 * L; }
+  __host__ __device__ size_t bytes() const { return 184u + 40u * (6u + 3u * (size_t)L); }
+  __host__ __device__ size_t stride() const { return (bytes() + 15u) & ~(size_t)15u; }
+};
+
+struct SpendArgs {
+  DevParams P;
+  DevKey K;
+  const uint8_t* proofs;     // n records
+  uint32_t n;
+  uint8_t* tr;               // n * tr_stride bytes: "spend" transcript pre-images
+  uint32_t tr_stride;
+  uint32_t* coords;          // n * L * NIELS_WORDS : affine Niels of every decoded Com_j
+  uint32_t* d01;             // n * 2 * GE_WORDS    : w00*h2, w01*h2
+  uint32_t* xa;              // n * GE_WORDS        : X_A = g + K'
+  uint32_t* flags;           // n
+  const uint32_t* xof;       // n * 16              : BLAKE3 XOF words of the transcript
+  uint8_t* status;           // n
+  uint8_t* kprime_enc;       // n * 32 or null
+};
+
+struct SignArgs {
+  DevParams P;
+  DevKey K;
+  uint32_t n;
+  int label;                 // LABEL_RESPOND (issue) or LABEL_REFUND (refund)
+  const uint32_t* xa;        // n * GE_WORDS
+  const uint8_t* status;     // n: lanes with status != 0 produce an all-zero record
+  const uint32_t* rng_slot;  // n: index of the lane's 128-byte rng slice
+  const uint8_t* rng;
+  const uint8_t* c_amount;   // n * 32 (issue) or null
+  uint8_t* trs;              // n * SMALL_TR_STRIDE small transcripts
+  uint32_t* state;           // n * 24 words: e | alpha | enc(A)
+  const uint32_t* xof;
+  uint8_t* out;              // n * 128 (refund) or n * 160 (issue)
+};
+
+struct IssueArgs {
+  DevParams P;
+  uint32_t n;
+  const uint8_t* req;        // n * 128
+  const uint8_t* c_amount;   // n * 32
+  uint8_t* trs;
+  uint32_t* xa;
+  uint32_t* flags;
+  const uint32_t* xof;
+  uint8_t* status;
+};
+
+struct RequestArgs {
+  DevParams P;
+  uint32_t n;
+  const uint8_t* pre;        // n * 64  (r | k)
+  const uint8_t* rng;        // n * 128
+  uint8_t* trs;
+  const uint32_t* xof;
+  uint8_t* out;              // n * 128
+};
+
+struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n; uint32_t* xof; const uint32_t* len_per_lane; };
+
+// launchers (defined in the .hip files)
+void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, hipStream_t s);
+void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s);
+void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s);
+void launch_keygen(const DevParams& P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk, hipStream_t s);
+void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hipStream_t s);
+void launch_hash(const HashArgs& a, hipStream_t s);
+void launch_spend_prep(const SpendArgs& a, hipStream_t s);
+void launch_spend_bits(const SpendArgs& a, hipStream_t s);
+void launch_spend_tail(const SpendArgs& a, hipStream_t s);
+void launch_spend_finish(const SpendArgs& a, hipStream_t s);
+void launch_sign_a(const SignArgs& a, hipStream_t s);
+void launch_sign_b(const SignArgs& a, hipStream_t s);
+void launch_issue_a(const IssueArgs& a, hipStream_t s);
+void launch_issue_check(const IssueArgs& a, hipStream_t s);
+void launch_request_a(const RequestArgs& a, hipStream_t s);
+void launch_request_b(const RequestArgs& a, hipStream_t s);
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+// ---- device helpers ----
+__device__ __forceinline__ void load8(uint32_t w[8], const uint8_t* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void store8(uint8_t* p, const uint32_t w[8]) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void zero8(uint8_t* p) { uint4* q = reinterpret_cast<uint4*>(p); q[0] = make_uint4(0, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0); }
+__device__ __forceinline__ sc load_sc(const uint8_t* p) { uint32_t w[8]; load8(w, p); return sc_from_words(w); }
+__device__ __forceinline__ sc load_wide(const uint8_t* p) {   // Scalar::random: 64 rng bytes -> mod l
+  uint32_t w[16]; load8(w, p); load8(w + 8, p + 32); return sc_from_wide_words(w);
+}
+__device__ __forceinline__ void store_sc(uint8_t* p, const sc& s) { store8(p, s.v); }
+// one transcript element = u64_be(32) | 32 payload bytes (src/transcript.rs:95-98); `slot` 8-byte aligned
+__device__ __forceinline__ void tr_put_aligned(uint8_t* slot, const uint32_t w[8]) {
+  uint2* q = reinterpret_cast<uint2*>(slot);
+  q[0] = make_uint2(0u, 0x20000000u);
+  q[1] = make_uint2(w[0], w[1]); q[2] = make_uint2(w[2], w[3]); q[3] = make_uint2(w[4], w[5]); q[4] = make_uint2(w[6], w[7]);
+}
+// same at an arbitrary byte offset (the small transcripts have 185/186-byte prefixes)
+__device__ __forceinline__ void tr_put_bytes(uint8_t* slot, const uint32_t w[8]) {
+  for (int i = 0; i < 7; i++) slot[i] = 0;
+  slot[7] = 0x20;
+  for (int i = 0; i < 8; i++) { uint32_t v = w[i]; slot[8 + 4 * i] = (uint8_t)v; slot[9 + 4 * i] = (uint8_t)(v >> 8); slot[10 + 4 * i] = (uint8_t)(v >> 16); slot[11 + 4 * i] = (uint8_t)(v >> 24); }
+}
+__device__ __forceinline__ void tr_put_prefix(uint8_t* tr, const DevParams& P, int label) {
+  uint32_t* q = reinterpret_cast<uint32_t*>(tr);
+  for (int i = 0; i < PREFIX_WORDS; i++) if (4u * i < P.prefix_len[label]) q[i] = P.prefix[label][i];
+}
+#endif
+
+}  // namespace act

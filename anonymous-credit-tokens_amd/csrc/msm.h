@@ -1,0 +1,123 @@
+// msm.h — the two scalar-multiplication shapes every kernel of the engine is built from.
+//
+// 1. chain<NACC>: variable-base, right-to-left, radix 4, NACC accumulators sharing ONE doubling
+//    chain.  For acc_a += s_a * N the lane walks P = 4^i N; per step it has P and 2P in cached form
+//    and adds +-P or 2P (signed digit in {-1,0,1,2}) to each accumulator.  No per-lane table (the
+//    reference's 8-entry table per `point * scalar` — dalek variable_base — would be 1 KiB per lane,
+//    which neither LDS at 2 waves/SIMD nor VGPRs can hold), and the doublings are paid once for all
+//    NACC scalars on the same base: the verifier's C'_j0 / C'_j1 share Com_j
+//    (/root/reference/src/lib.rs:814-816), A1/A2 share B_bar (:793-797), A*/Y_A share X_A (:849-853).
+//    Every lane of a wavefront executes the same schedule (a digit-0 lane only sits out an add), so
+//    there is no vartime-wNAF divergence to lose on a 64-wide SIMD.
+// 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as 32 mixed
+//    additions, one per scalar byte, from position-specific affine-Niels tables
+//    T[pos][byte] = byte * 256^pos * B resident in L2 (built once per context by k_build_table).
+#pragma once
+#include "ge25519.h"
+
+namespace act {
+
+// ---- fixed-base tables -------------------------------------------------------------------------
+constexpr int FB_WINDOWS = 32;          // one per scalar byte
+constexpr int FB_ENTRIES = 256;
+constexpr int NIELS_WORDS = 32;         // 30 used (ypx, ymx, xy2d), padded to 128 B = one L2 line
+constexpr int FB_TABLE_WORDS = FB_WINDOWS * FB_ENTRIES * NIELS_WORDS;   // 1 MiB per base
+
+ACT_HD ge_niels niels_load(const uint32_t* p) {
+  ge_niels n;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7];
+  n.ypx.v[0] = a0.x; n.ypx.v[1] = a0.y; n.ypx.v[2] = a0.z; n.ypx.v[3] = a0.w;
+  n.ypx.v[4] = a1.x; n.ypx.v[5] = a1.y; n.ypx.v[6] = a1.z; n.ypx.v[7] = a1.w;
+  n.ypx.v[8] = a2.x; n.ypx.v[9] = a2.y; n.ymx.v[0] = a2.z; n.ymx.v[1] = a2.w;
+  n.ymx.v[2] = a3.x; n.ymx.v[3] = a3.y; n.ymx.v[4] = a3.z; n.ymx.v[5] = a3.w;
+  n.ymx.v[6] = a4.x; n.ymx.v[7] = a4.y; n.ymx.v[8] = a4.z; n.ymx.v[9] = a4.w;
+  n.xy2d.v[0] = a5.x; n.xy2d.v[1] = a5.y; n.xy2d.v[2] = a5.z; n.xy2d.v[3] = a5.w;
+  n.xy2d.v[4] = a6.x; n.xy2d.v[5] = a6.y; n.xy2d.v[6] = a6.z; n.xy2d.v[7] = a6.w;
+  n.xy2d.v[8] = a7.x; n.xy2d.v[9] = a7.y;
+#else
+  for (int i = 0; i < 10; i++) { n.ypx.v[i] = p[i]; n.ymx.v[i] = p[10 + i]; n.xy2d.v[i] = p[20 + i]; }
+#endif
+  return n;
+}
+ACT_HD void niels_store(uint32_t* p, const ge_niels& n) {
+  for (int i = 0; i < 10; i++) { p[i] = n.ypx.v[i]; p[10 + i] = n.ymx.v[i]; p[20 + i] = n.xy2d.v[i]; }
+  p[30] = 0; p[31] = 0;
+}
+// affine Niels form of an extended point with Z == 1 (x, y, t = xy all tight)
+ACT_HD ge_niels niels_from_affine(const ge& p) {
+  ge_niels n;
+  n.ypx = fe_carry(fe_add(p.Y, p.X));
+  n.ymx = fe_carry(fe_sub(p.Y, p.X));
+  n.xy2d = fe_mul(p.T, fe_d2());
+  return n;
+}
+ACT_HD void ge_store(uint32_t* p, const ge& g) {
+  for (int i = 0; i < 10; i++) { p[i] = g.X.v[i]; p[10 + i] = g.Y.v[i]; p[20 + i] = g.Z.v[i]; p[30 + i] = g.T.v[i]; }
+}
+ACT_HD ge ge_load(const uint32_t* p) {
+  ge g;
+  for (int i = 0; i < 10; i++) { g.X.v[i] = p[i]; g.Y.v[i] = p[10 + i]; g.Z.v[i] = p[20 + i]; g.T.v[i] = p[30 + i]; }
+  return g;
+}
+constexpr int GE_WORDS = 40;
+
+// acc += s * B using B's table; s canonical (< l).  32 mixed additions.
+ACT_HD ge fixed_base_acc(ge acc, const uint32_t* table, const sc& s) {
+  uint32_t w[8];
+  for (int i = 0; i < 8; i++) w[i] = s.v[i];
+  for (int pos = 0; pos < FB_WINDOWS; pos++) {
+    uint32_t byte = w[0] & 0xffu;
+    // shift the scalar down one byte (static indices only: a runtime-indexed limb array would live in scratch)
+    for (int i = 0; i < 7; i++) w[i] = (w[i] >> 8) | (w[i + 1] << 24);
+    w[7] >>= 8;
+    ge_niels n = niels_load(table + ((size_t)pos * FB_ENTRIES + byte) * NIELS_WORDS);
+    acc = ge_madd(acc, n);
+  }
+  return acc;
+}
+
+// ---- shared-doubling variable-base chain ---------------------------------------------------------
+// radix-4 digit extraction with carry: v = (low 2 bits) + carry in 0..4 -> digit in {0,1,2,-1,0}
+struct digit4 { bool nonzero, two, neg; };
+ACT_HD digit4 next_digit4(uint32_t w[8], uint32_t& carry) {
+  uint32_t v = (w[0] & 3u) + carry;
+  for (int i = 0; i < 7; i++) w[i] = (w[i] >> 2) | (w[i + 1] << 30);
+  w[7] >>= 2;
+  digit4 d;
+  carry = v >= 3u ? 1u : 0u;
+  d.nonzero = (v != 0u) && (v != 4u);
+  d.two = (v == 2u);
+  d.neg = (v == 3u);
+  return d;
+}
+ACT_HD ge chain_step_add(const ge& acc, const ge_cached& c1, const ge_cached& c2, const digit4& d) {
+  ge_cached q;
+  q.YpX = fe_select(c1.YpX, c2.YpX, d.two);
+  q.YmX = fe_select(c1.YmX, c2.YmX, d.two);
+  q.Z = fe_select(c1.Z, c2.Z, d.two);
+  q.T2d = fe_select(c1.T2d, c2.T2d, d.two);
+  q = ge_cached_cneg(q, d.neg);
+  return ge_add_cached(acc, q);
+}
+// acc[a] += s[a] * N for a < NACC; scalars canonical (< l < 2^253): 127 radix-4 digits
+template <int NACC>
+ACT_HD void chain(ge* acc, const ge& N, const sc* s) {
+  uint32_t w[NACC][8], carry[NACC];
+  for (int a = 0; a < NACC; a++) { carry[a] = 0; for (int i = 0; i < 8; i++) w[a][i] = s[a].v[i]; }
+  ge P = N;
+  for (int step = 0; step < 127; step++) {
+    ge_cached c1 = ge_to_cached(P);
+    ge Q = ge_double(P);
+    ge_cached c2 = ge_to_cached(Q);
+    if (step < 126) P = ge_double(Q);
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+      digit4 d = next_digit4(w[a], carry[a]);
+      if (d.nonzero) acc[a] = chain_step_add(acc[a], c1, c2, d);
+    }
+  }
+}
+
+}  // namespace act

@@ -1,0 +1,147 @@
+/* act_mi355x.h — C ABI of libact_mi355x.so: the MI355X (gfx950) batch engine for the sigma-protocol
+ * hot path of anonymous-credit-tokens v0.2.1.
+ *
+ * The reference crate has no FFI of its own; the drop-in boundary is its public Rust API
+ * (/root/reference/src/lib.rs).  Each *_batch entry point below is what a `mod mi355x` inside the
+ * crate binds for the corresponding method (INTEGRATION.md shows the Rust side), lane i of a batch
+ * being one call of the method:
+ *
+ *   act_params_new                      <-> Params::new                  src/lib.rs:291-315
+ *   act_request_batch                   <-> PreIssuance::request         src/lib.rs:463-487
+ *   act_issue_batch                     <-> PrivateKey::issue            src/lib.rs:621-663
+ *   act_prove_spend_batch               <-> CreditToken::prove_spend     src/lib.rs:972-1152
+ *   act_refund_batch                    <-> PrivateKey::refund           src/lib.rs:781-869
+ *   act_verify_spend_batch              <-> PrivateKey::refund up to the challenge check (:787-844)
+ *   act_issuance_to_credit_token_batch  <-> PreIssuance::to_credit_token src/lib.rs:528-562
+ *   act_refund_to_credit_token_batch    <-> PreRefund::to_credit_token   src/lib.rs:1217-1253
+ *
+ * Records are the crate's structs as consecutive 32-byte fields in CBOR key order
+ * (src/cbor.rs:105-110, 163-169, 250-268, 422-427, 477-480, 546-549, 596-602, 656-660) with the CBOR
+ * framing stripped; scalars little-endian (Scalar::as_bytes), points compressed Ristretto:
+ *   PrivateKey        x | w                                                              64 B
+ *   PreIssuance       r | k                                                              64 B
+ *   IssuanceRequest   K | gamma | k_bar | r_bar                                         128 B
+ *   IssuanceResponse  A | e | gamma | z | c                                             160 B
+ *   CreditToken       a | e | k | r | c                                                 160 B
+ *   SpendProof        k | s | A' | B_bar | Com[L] | gamma | e_bar | r2_bar | r3_bar | c_bar | r_bar |
+ *                     w00 | w01 | gamma0[L] | z[L][2] | k_bar | s_bar                 32*(14+4L) B
+ *   PreRefund         r | k | m                                                          96 B
+ *   Refund            A* | e | gamma | z                                               128 B
+ *
+ * RNG: where the crate takes `impl CryptoRngCore`, the ABI takes the bytes that generator would
+ * have produced; every Scalar::random is one 64-byte draw reduced mod l (draw order per function:
+ * src/lib.rs:468-469, 643/649, 846/852, 978-1058).  issue/refund draw only for accepted lanes
+ * (src/lib.rs:638-643, 842-846): ACT_RNG_PER_LANE gives lane i the slice rng[128*i..], and
+ * ACT_RNG_SEQUENTIAL hands consecutive 128-byte slices to the accepted lanes in lane order — the
+ * byte-for-byte equivalent of a sequential loop sharing one generator.
+ *
+ * Errors: the function result reports infrastructure failures only.  Per-lane results are
+ * status[i] = 0 for Ok, else 1 + the discriminant of the crate's `Error` (src/lib.rs:102-112);
+ * 255 = a point field that is not a canonical Ristretto encoding (the crate rejects those while
+ * decoding, src/cbor.rs:62-77, before any of these methods can run).  The output record of a
+ * failed lane is all zero.  Scalar fields are reduced mod l on input (src/cbor.rs:85).
+ *
+ * Memory: every bulk pointer of one call is either host memory (ACT_MEM_HOST) or memory of the
+ * context's GPU (ACT_MEM_DEVICE); `sk` is always host memory.  A context is bound to one GPU,
+ * owns its streams and workspace, and may be used by one host thread at a time; contexts on
+ * different GPUs run concurrently (batches shard across GPUs with no collective).
+ * There is no CPU fallback: without a HIP device every entry point fails.
+ */
+#ifndef ACT_MI355X_H
+#define ACT_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACT_OK 0
+#define ACT_ERR_ARG 1        /* null pointer, bad L, bad mode */
+#define ACT_ERR_HIP 2        /* a HIP runtime call failed; act_last_error() has the text */
+#define ACT_ERR_PARAMS 3     /* h1/h2/h3 or the public key is not a canonical Ristretto encoding */
+#define ACT_ERR_NO_DEVICE 4
+
+#define ACT_MEM_HOST 0
+#define ACT_MEM_DEVICE 1
+
+#define ACT_RNG_PER_LANE 0
+#define ACT_RNG_SEQUENTIAL 1
+
+#define ACT_TRANSCRIPT_HOST 0    /* BLAKE3 of every transcript on host threads (src/transcript.rs stays on the host) */
+#define ACT_TRANSCRIPT_DEVICE 1  /* the same bytes hashed by the device BLAKE3 kernel; no D2H/H2D inside a batch */
+
+/* per-lane status = 1 + discriminant of reference `Error`, src/lib.rs:102-112 */
+#define ACT_STATUS_OK 0
+#define ACT_STATUS_INVALID_ISSUANCE_REQUEST_PROOF 1
+#define ACT_STATUS_INVALID_ISSUANCE_RESPONSE_PROOF 2
+#define ACT_STATUS_DOUBLE_SPEND 3
+#define ACT_STATUS_INVALID_REFUND_PROOF 4
+#define ACT_STATUS_INVALID_REFUND_RESPONSE_PROOF 5
+#define ACT_STATUS_IDENTITY_POINT 6
+#define ACT_STATUS_INVALID_CLIENT_SPEND_PROOF 7
+#define ACT_STATUS_AMOUNT_TOO_BIG 8
+#define ACT_STATUS_SCALAR_OUT_OF_RANGE 9
+#define ACT_STATUS_UNDECODABLE 255
+
+typedef struct act_ctx act_ctx;
+
+/* Params::new (src/lib.rs:291-315): out_h = enc(h1) | enc(h2) | enc(h3).  Runs on `device`. */
+int act_params_new(int device, const char *organization, const char *service, const char *deployment_id,
+                   const char *version, uint8_t out_h[96]);
+/* Params::random (src/lib.rs:259-265): rng = 192 bytes (three RistrettoPoint::random draws). */
+int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
+
+/* A context = Params (h1,h2,h3 with their device-resident fixed-base tables, cf. the three
+ * RistrettoBasepointTables of src/lib.rs:222-229) + the range-proof width L (src/lib.rs:116; 128 is the
+ * crate's value, 1..128 accepted) + one GPU.  max_batch (0 = default) bounds the lanes per
+ * internal launch and thereby the workspace. */
+int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act_ctx **out);
+void act_ctx_destroy(act_ctx *ctx);
+int act_ctx_set_transcript_mode(act_ctx *ctx, int mode);    /* default ACT_TRANSCRIPT_HOST */
+int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);   /* host BLAKE3 workers; 0 = hardware concurrency */
+const char *act_last_error(const act_ctx *ctx);
+size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
+size_t act_prove_rng_bytes(const act_ctx *ctx);             /* 64*(4L+12) */
+size_t act_spend_transcript_bytes(const act_ctx *ctx);      /* pre-image of the "spend" challenge */
+
+/* PrivateKey::random (src/lib.rs:188-194): rng 64 B -> x | w.  PreIssuance::random (:432-437): rng 128 B -> r | k. */
+int act_private_key_random(act_ctx *ctx, const uint8_t rng[64], uint8_t out_sk[64]);
+int act_pre_issuance_random_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *rng, uint8_t *out_pre);
+
+/* PreIssuance::request: pre n*64, rng n*128 -> req n*128 */
+int act_request_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *pre, const uint8_t *rng, uint8_t *out_req);
+/* PrivateKey::issue: req n*128, c n*32, rng (n or #accepted)*128 -> resp n*160, status n */
+int act_issue_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *req, const uint8_t *c,
+                    const uint8_t *rng, int rng_mode, uint8_t *out_resp, uint8_t *status);
+/* PreIssuance::to_credit_token: pre n*64, w 32 (host), req n*128, resp n*160 -> token n*160, status n */
+int act_issuance_to_credit_token_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *pre, const uint8_t w[32],
+                                       const uint8_t *req, const uint8_t *resp, uint8_t *out_token, uint8_t *status);
+/* CreditToken::prove_spend: token n*160, s n*32, rng n*act_prove_rng_bytes -> proof n*act_spend_proof_bytes, prerefund n*96 */
+int act_prove_spend_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *token, const uint8_t *s, const uint8_t *rng,
+                          uint8_t *out_proof, uint8_t *out_prerefund, uint8_t *status);
+/* spend-proof verification only (src/lib.rs:787-844): proof -> status n; out_kprime (nullable) n*32 = enc(K') */
+int act_verify_spend_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof,
+                           uint8_t *status, uint8_t *out_kprime);
+/* PrivateKey::refund: proof, rng (n or #accepted)*128 -> refund n*128, status n */
+int act_refund_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof, const uint8_t *rng,
+                     int rng_mode, uint8_t *out_refund, uint8_t *status);
+/* PreRefund::to_credit_token: prerefund n*96, proof, refund n*128, w 32 (host) -> token n*160, status n */
+int act_refund_to_credit_token_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *prerefund, const uint8_t *proof,
+                                     const uint8_t *refund, const uint8_t w[32], uint8_t *out_token, uint8_t *status);
+
+/* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
+ * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
+int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *out, size_t *n_copied);
+
+/* Kernel timing (HIP events on the context's own stream, which torch.cuda.Event cannot see):
+ * enable, run batches, then read per-kernel totals.  names: act_prof_kernel_name(i), i < act_prof_kernel_count(). */
+int act_prof_enable(act_ctx *ctx, int on);
+int act_prof_reset(act_ctx *ctx);
+int act_prof_kernel_count(const act_ctx *ctx);
+const char *act_prof_kernel_name(const act_ctx *ctx, int i);
+int act_prof_get(act_ctx *ctx, int i, double *ms_total, uint64_t *launches, uint64_t *lanes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,100 @@
+// hostcheck.cpp — TEST-ONLY host build of the device arithmetic headers (csrc/fe25519.h,
+// sc25519.h, ge25519.h, msm.h, blake3_hd.h) so `pytest -m "not gpu"` can check the formulas,
+// the limb-size discipline (ACT_FE_BOUNDS) and the BLAKE3 code against the oracle without a GPU.
+// Never linked into libact_mi355x.so; the product has no CPU compute path.
+#include <cstring>
+#include <vector>
+#define ACT_FE_BOUNDS 1
+#include "../../anonymous-credit-tokens_amd/csrc/msm.h"
+#include "../../anonymous-credit-tokens_amd/csrc/blake3_hd.h"
+
+namespace act { fe_bounds_t fe_bounds = {0, 0, 0, 0, 0, 0}; }
+using namespace act;
+
+static void ld(uint32_t w[8], const uint8_t* b) { memcpy(w, b, 32); }
+static void st(uint8_t* b, const uint32_t w[8]) { memcpy(b, w, 32); }
+static fe fe_in(const uint8_t* b) { uint32_t w[8]; ld(w, b); return fe_from_words(w); }
+static void fe_out(uint8_t* b, const fe& f) { uint32_t w[8]; fe_to_words(w, f); st(b, w); }
+static sc sc_in(const uint8_t* b) { uint32_t w[8]; ld(w, b); return sc_from_words(w); }
+static void sc_out(uint8_t* b, const sc& s) { memcpy(b, s.v, 32); }
+
+extern "C" {
+void hc_bounds(uint64_t out[6]) { memcpy(out, &fe_bounds, sizeof(fe_bounds)); }
+void hc_bounds_reset() { memset(&fe_bounds, 0, sizeof(fe_bounds)); }
+
+void hc_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t* o) { fe_out(o, fe_mul(fe_in(a), fe_in(b))); }
+void hc_fe_sq(const uint8_t* a, uint8_t* o) { fe_out(o, fe_sq(fe_in(a))); }
+void hc_fe_add(const uint8_t* a, const uint8_t* b, uint8_t* o) { fe_out(o, fe_add(fe_in(a), fe_in(b))); }
+void hc_fe_sub(const uint8_t* a, const uint8_t* b, uint8_t* o) { fe_out(o, fe_sub(fe_in(a), fe_in(b))); }
+void hc_fe_invert(const uint8_t* a, uint8_t* o) { fe_out(o, fe_invert(fe_in(a))); }
+int hc_fe_invsqrt(const uint8_t* a, uint8_t* o) { fe r; bool ok = fe_invsqrt(r, fe_in(a)); fe_out(o, r); return ok; }
+int hc_fe_sqrt_ratio(const uint8_t* u, const uint8_t* v, uint8_t* o) { fe r; bool ok = fe_sqrt_ratio_m1(r, fe_in(u), fe_in(v)); fe_out(o, r); return ok; }
+// stress: a chain of lazily-reduced operations at the extreme of the allowed operand classes
+void hc_fe_stress(const uint8_t* a, const uint8_t* b, uint8_t* o) {
+  fe x = fe_in(a), y = fe_in(b);
+  fe s = fe_sub(x, y), t = fe_add(x, y);                // [g]-class operands
+  fe f = fe_sub4(fe_dbl(x), fe_sub(y, x));              // [f]-class: 2x - (y - x)
+  fe r = fe_mul(f, s);                                  // (3x - y)(x - y)
+  r = fe_mul(fe_sub(fe_dbl(r), t), fe_sq(s));           // (2r - (x+y)) (x-y)^2
+  fe_out(o, r);
+}
+
+void hc_sc_reduce_wide(const uint8_t* a, uint8_t* o) { uint32_t w[16]; memcpy(w, a, 64); sc_out(o, sc_from_wide_words(w)); }
+void hc_sc_from_bytes(const uint8_t* a, uint8_t* o) { sc_out(o, sc_in(a)); }
+void hc_sc_muladd(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* o) { sc_out(o, sc_muladd(sc_in(a), sc_in(b), sc_in(c))); }
+void hc_sc_sub(const uint8_t* a, const uint8_t* b, uint8_t* o) { sc_out(o, sc_sub(sc_in(a), sc_in(b))); }
+void hc_sc_neg(const uint8_t* a, uint8_t* o) { sc_out(o, sc_neg(sc_in(a))); }
+void hc_sc_invert(const uint8_t* a, uint8_t* o) { sc_out(o, sc_invert(sc_in(a))); }
+
+int hc_decode_encode(const uint8_t* a, uint8_t* o) {
+  uint32_t w[8], r[8]; ld(w, a); ge p; bool ok = ristretto_decode(p, w);
+  if (ok) { ristretto_encode(r, p); st(o, r); } else memset(o, 0, 32);
+  return ok;
+}
+void hc_from_uniform(const uint8_t* a, uint8_t* o) { uint32_t w[16], r[8]; memcpy(w, a, 64); ge p = ristretto_from_uniform(w); ristretto_encode(r, p); st(o, r); }
+// out = s0*P (chain<1>), and (s0*P, s1*P) via chain<2>; also s0*P + s1*Q through add/sub/double mixes
+int hc_chain2(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
+  uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
+  ge acc[2] = {ge_identity(), ge_identity()}; sc s[2] = {sc_in(s0), sc_in(s1)};
+  chain<2>(acc, p, s);
+  ristretto_encode(r, acc[0]); st(o0, r); ristretto_encode(r, acc[1]); st(o1, r);
+  return 1;
+}
+int hc_chain1(const uint8_t* pt, const uint8_t* s0, uint8_t* o0) {
+  uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
+  ge acc[1] = {ge_identity()}; sc s[1] = {sc_in(s0)};
+  chain<1>(acc, p, s);
+  ristretto_encode(r, acc[0]); st(o0, r);
+  return 1;
+}
+// builds the position-specific table of `pt` on the host (same recurrence as k_build_table) and evaluates s*pt
+int hc_fixed_base(const uint8_t* pt, const uint8_t* s, uint8_t* o) {
+  uint32_t w[8], r[8]; ld(w, pt); ge b; if (!ristretto_decode(b, w)) return 0;
+  std::vector<uint32_t> tab((size_t)FB_TABLE_WORDS);
+  ge base = b;
+  for (int pos = 0; pos < FB_WINDOWS; pos++) {
+    ge acc = ge_identity();
+    for (int e = 0; e < FB_ENTRIES; e++) {
+      // affine-normalise acc
+      fe zi = fe_invert(acc.Z); ge a; a.X = fe_mul(acc.X, zi); a.Y = fe_mul(acc.Y, zi); a.Z = fe_one(); a.T = fe_mul(a.X, a.Y);
+      niels_store(&tab[((size_t)pos * FB_ENTRIES + e) * NIELS_WORDS], niels_from_affine(a));
+      acc = ge_add(acc, base);
+    }
+    base = acc;   // 256 * base
+  }
+  ge acc = fixed_base_acc(ge_identity(), tab.data(), sc_in(s));
+  ristretto_encode(r, acc); st(o, r);
+  return 1;
+}
+int hc_add_sub_dbl(const uint8_t* a, const uint8_t* b, uint8_t* o_add, uint8_t* o_sub, uint8_t* o_dbl) {
+  uint32_t w[8], r[8]; ge p, q; ld(w, a); if (!ristretto_decode(p, w)) return 0; ld(w, b); if (!ristretto_decode(q, w)) return 0;
+  ristretto_encode(r, ge_add(p, q)); st(o_add, r);
+  ristretto_encode(r, ge_sub(p, q)); st(o_sub, r);
+  ristretto_encode(r, ge_double(p)); st(o_dbl, r);
+  return 1;
+}
+void hc_blake3_xof64(const uint8_t* msg, uint32_t len, uint8_t* out) {
+  std::vector<uint32_t> w((len + 3) / 4 + 1, 0u); if (len) memcpy(w.data(), msg, len);
+  uint32_t o[16]; b3_hash_xof64(o, w.data(), len); memcpy(out, o, 64);
+}
+}
