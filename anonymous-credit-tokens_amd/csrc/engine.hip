@@ -202,7 +202,7 @@ int workspace_alloc(act_ctx* c) {
   size_t B = c->max_batch;
   HIPCK(c, hipMalloc(&c->d_tr, B * st.stride()));
   HIPCK(c, hipMalloc(&c->d_coords, B * (size_t)c->L * NIELS_WORDS * 4));
-  HIPCK(c, hipMalloc(&c->d_d01, B * 2 * GE_WORDS * 4));
+  HIPCK(c, hipMalloc(&c->d_d01, B * 3 * GE_WORDS * 4));
   HIPCK(c, hipMalloc(&c->d_xa, B * GE_WORDS * 4));
   HIPCK(c, hipMalloc(&c->d_flags, B * 4));
   HIPCK(c, hipMalloc(&c->d_xof, B * 64));
@@ -476,6 +476,91 @@ int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const 
     if ((rc = prof_collect(c))) return rc;
   }
   return ACT_OK;
+}
+
+int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng,
+                          uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
+  if (!c || (n && (!token || !s || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+  HIPCK(c, hipSetDevice(c->device));
+  const size_t pb = ProofLayout{c->L}.bytes(), rb = act_prove_rng_bytes(c);
+  const SpendTranscript st{c->L};
+  for (size_t off = 0; off < n; off += c->max_batch) {
+    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    ProveArgs a{}; a.P = c->P; a.n = m; a.tr = c->d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = c->d_d01; a.state = c->d_state;
+    a.flags = c->d_flags; a.xof = c->d_xof; a.status = c->d_status;
+    int rc;
+    if ((rc = dev_in(c, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
+    if ((rc = dev_in(c, 1, mem, s + off * 32, (size_t)m * 32, &a.s))) return rc;
+    if ((rc = dev_in(c, 3, mem, rng + off * rb, (size_t)m * rb, &a.rng))) return rc;
+    if ((rc = dev_out_begin(c, 2, mem, out_proof + off * pb, (size_t)m * pb, &a.proof))) return rc;
+    if ((rc = dev_out_begin(c, 4, mem, out_prerefund + off * 96, (size_t)m * 96, &a.prerefund))) return rc;
+    if ((rc = prof_launch(c, PK_PROVE_HEAD, m, [&] { launch_prove_head(a, c->stream); }))) return rc;
+    if ((rc = prof_launch(c, PK_PROVE_BITS, (uint64_t)m * c->L, [&] { launch_prove_bits(a, c->stream); }))) return rc;
+    if ((rc = prof_launch(c, PK_PROVE_TAIL, m, [&] { launch_prove_tail(a, c->stream); }))) return rc;
+    if ((rc = hash_step(c, PK_HASH_SPEND, c->d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
+    if ((rc = prof_launch(c, PK_PROVE_RESP, (uint64_t)m * c->L, [&] { launch_prove_resp(a, c->stream); }))) return rc;
+    if ((rc = dev_out_end(c, mem, out_proof + off * pb, a.proof, (size_t)m * pb))) return rc;
+    if ((rc = dev_out_end(c, mem, out_prerefund + off * 96, a.prerefund, (size_t)m * 96))) return rc;
+    HIPCK(c, hipMemcpyAsync(status + off, c->d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if ((rc = prof_collect(c))) return rc;
+  }
+  return ACT_OK;
+}
+
+static int set_pubkey(act_ctx* c, const uint8_t w[32]) {
+  if (c->w_valid && memcmp(c->w_cached, w, 32) == 0) return ACT_OK;
+  int rc = stage_reserve(c, 5, 32 + GE_WORDS * 4 + 16); if (rc) return rc;
+  uint8_t* d = c->d_stage[5];
+  HIPCK(c, hipMemcpyAsync(d, w, 32, hipMemcpyHostToDevice, c->stream));
+  launch_decode_points(d, 1, reinterpret_cast<uint32_t*>(d + 32), reinterpret_cast<uint32_t*>(d + 32 + GE_WORDS * 4), c->stream);
+  uint32_t host[GE_WORDS + 1];
+  HIPCK(c, hipMemcpyAsync(host, d + 32, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipStreamSynchronize(c->stream));
+  if (!host[GE_WORDS]) { c->err = "public key w is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
+  c->w_pub = ge_load(host); memcpy(c->w_cached, w, 32); c->w_valid = true;
+  return ACT_OK;
+}
+
+static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
+                        const uint8_t* resp, const uint8_t* proofs, uint8_t* out_token, uint8_t* status) {
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = set_pubkey(c, w); if (rc) return rc;
+  const bool issuance = label == LABEL_RESPOND;
+  const size_t pre_b = issuance ? 64 : 96, resp_b = issuance ? 160 : 128, pb = ProofLayout{c->L}.bytes();
+  for (size_t off = 0; off < n; off += c->max_batch) {
+    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = c->d_coords; a.trs = c->d_trs; a.flags = c->d_flags;
+    a.xof = c->d_xof; a.status = c->d_status;
+    if ((rc = dev_in(c, 0, mem, pre + off * pre_b, (size_t)m * pre_b, &a.pre))) return rc;
+    if ((rc = dev_in(c, 1, mem, resp + off * resp_b, (size_t)m * resp_b, &a.resp))) return rc;
+    if (issuance) { if ((rc = dev_in(c, 3, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc; }
+    else { if ((rc = dev_in(c, 3, mem, proofs + off * pb, (size_t)m * pb, &a.proofs))) return rc; }
+    if ((rc = dev_out_begin(c, 2, mem, out_token + off * 160, (size_t)m * 160, &a.out_token))) return rc;
+    if (!issuance) {
+      HIPCK(c, hipMemsetAsync(c->d_flags, 0, (size_t)m * 4, c->stream));
+      if ((rc = prof_launch(c, PK_CLIENT, (uint64_t)m * c->L, [&] { launch_client_decode_com(a, c->stream); }))) return rc;
+    }
+    if ((rc = prof_launch(c, PK_CLIENT, m, [&] { launch_client_a(a, c->stream); }))) return rc;
+    uint32_t len = c->P.prefix_len[label] + 40u * (issuance ? 7u : 6u);
+    if ((rc = hash_step(c, PK_HASH_SMALL, c->d_trs, SMALL_TR_STRIDE, len, m))) return rc;
+    if ((rc = prof_launch(c, PK_CLIENT, m, [&] { launch_client_b(a, c->stream); }))) return rc;
+    if ((rc = dev_out_end(c, mem, out_token + off * 160, a.out_token, (size_t)m * 160))) return rc;
+    HIPCK(c, hipMemcpyAsync(status + off, c->d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if ((rc = prof_collect(c))) return rc;
+  }
+  return ACT_OK;
+}
+int act_issuance_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
+                                       const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
+  if (!c || !w || (n && (!pre || !req || !resp || !out_token || !status))) return ACT_ERR_ARG;
+  return client_batch(c, n, mem, LABEL_RESPOND, pre, w, req, resp, nullptr, out_token, status);
+}
+int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_t* prerefund, const uint8_t* proof, const uint8_t* refund,
+                                     const uint8_t w[32], uint8_t* out_token, uint8_t* status) {
+  if (!c || !w || (n && (!prerefund || !proof || !refund || !out_token || !status))) return ACT_ERR_ARG;
+  return client_batch(c, n, mem, LABEL_REFUND, prerefund, w, nullptr, refund, proof, out_token, status);
 }
 
 int act_debug_last_spend_transcripts(act_ctx* c, size_t max_lanes, uint8_t* out, size_t* n_copied) {

@@ -1,4 +1,98 @@
-// placeholder until the client-verifier kernels land (this round)
-#include "../../include/act_mi355x.h"
-extern "C" int act_issuance_to_credit_token_batch(act_ctx*, size_t, int, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*) { return ACT_ERR_ARG; }
-extern "C" int act_refund_to_credit_token_batch(act_ctx*, size_t, int, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, uint8_t*, uint8_t*) { return ACT_ERR_ARG; }
+// k_client.hip — the client-side verifiers that close the lifecycle ("next" #1):
+// PreIssuance::to_credit_token (/root/reference/src/lib.rs:528-562) and PreRefund::to_credit_token
+// (:1217-1253).  Both check the issuer's DLEQ proof:
+//   X_g = e g + w;  Y_A = z A - gamma X_A;  Y_g = z g - gamma X_g = (z - gamma e) g - gamma w
+// with X_A = g + c h1 + K (issuance) or g + K', K' = sum 2^j Com_j (refund).
+#include "kernels.h"
+
+namespace act {
+
+// refund only: decode every Com_j of the spend proof (lane = (proof, bit))
+__global__ void __launch_bounds__(256) k_client_decode_com(ClientArgs a) {
+  const int L = a.P.L;
+  uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  uint32_t p = gid / (uint32_t)L, j = gid % (uint32_t)L;
+  if (p >= a.n) return;
+  const ProofLayout pl{L};
+  uint32_t wc[8]; load8(wc, a.proofs + (size_t)p * pl.bytes() + 32 * pl.com(j));
+  ge C;
+  if (!ristretto_decode(C, wc)) atomicOr(a.flags + p, FLAG_UNDECODABLE);
+  niels_store(a.coords + ((size_t)p * L + j) * NIELS_WORDS, niels_from_affine(C));
+}
+
+__global__ void __launch_bounds__(64, 2) k_client_a(ClientArgs a) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= a.n) return;
+  const int L = a.P.L;
+  const bool issuance = a.label == LABEL_RESPOND;
+  const uint8_t* resp = a.resp + (size_t)p * (issuance ? 160 : 128);
+  uint32_t flags = issuance ? 0u : a.flags[p];
+  uint32_t wa[8]; load8(wa, resp);
+  ge A; if (!ristretto_decode(A, wa)) flags |= FLAG_UNDECODABLE;
+  sc e = load_sc(resp + 32), gamma = load_sc(resp + 64), z = load_sc(resp + 96);
+  ge xa; sc c = sc_zero();
+  if (issuance) {
+    uint32_t wk[8]; load8(wk, a.req + (size_t)p * 128);
+    ge K; if (!ristretto_decode(K, wk)) flags |= FLAG_UNDECODABLE;
+    c = load_sc(resp + 128);
+    xa = ge_add(fixed_base_acc(ge_basepoint(), a.P.tab[BASE_H1], c), K);                   // :536
+  } else {
+    ge kp = ge_identity();                                                                 // :1224-1230 by Horner
+    for (int j = L - 1; j >= 0; j--) { kp = ge_double(kp); kp = ge_madd(kp, niels_load(a.coords + ((size_t)p * L + j) * NIELS_WORDS)); }
+    xa = ge_add(kp, ge_basepoint());
+  }
+  sc ng = sc_neg(gamma);
+  ge xg = ge_add(fixed_base_acc(ge_identity(), a.P.tab[BASE_G], e), a.w);                  // :537 / :1232
+  ge acc[2];
+  acc[0] = ge_identity();                                                                  // Y_A
+  acc[1] = fixed_base_acc(ge_identity(), a.P.tab[BASE_G], sc_sub(z, sc_mul(gamma, e)));   // Y_g
+  sc s1[1] = {z}; chain<1>(acc, A, s1);                                                    // z A
+  sc s2[1] = {ng}; chain<1>(acc, xa, s2);                                                  // - gamma X_A   (:540 / :1233)
+  ge yg[1] = {acc[1]}; chain<1>(yg, a.w, s2);                                              // - gamma w     (:541 / :1234)
+  uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
+  tr_put_prefix(tr, a.P, a.label);
+  uint8_t* el = tr + a.P.prefix_len[a.label];
+  if (issuance) { tr_put_bytes(el, c.v); el += 40; }
+  tr_put_bytes(el, e.v); el += 40;
+  uint32_t enc[8];
+  tr_put_bytes(el, wa); el += 40;
+  ristretto_encode(enc, xa); tr_put_bytes(el, enc); el += 40;
+  ristretto_encode(enc, xg); tr_put_bytes(el, enc); el += 40;
+  ristretto_encode(enc, acc[0]); tr_put_bytes(el, enc); el += 40;
+  ristretto_encode(enc, yg[0]); tr_put_bytes(el, enc);
+  a.flags[p] = flags;
+}
+
+__global__ void __launch_bounds__(256) k_client_b(ClientArgs a) {
+  uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n) return;
+  const bool issuance = a.label == LABEL_RESPOND;
+  const uint8_t* resp = a.resp + (size_t)p * (issuance ? 160 : 128);
+  uint32_t w[16];
+  for (int i = 0; i < 16; i++) w[i] = a.xof[(size_t)p * 16 + i];
+  sc gamma = load_sc(resp + 64);
+  uint8_t stt = 0;
+  if (a.flags[p] & FLAG_UNDECODABLE) stt = 255;
+  else if (!sc_equal(sc_from_wide_words(w), gamma)) stt = issuance ? 2 : 4;   // InvalidIssuanceResponseProof / InvalidRefundProof
+  a.status[p] = stt;
+  uint8_t* out = a.out_token + (size_t)p * 160;
+  if (stt) { for (int i = 0; i < 160; i += 32) zero8(out + i); return; }
+  // CreditToken { a, e, k, r, c } (:554-560 / :1246-1252); pre record is r | k (| m)
+  const uint8_t* pre = a.pre + (size_t)p * (issuance ? 64 : 96);
+  uint32_t t[8];
+  load8(t, resp); store8(out, t);
+  store_sc(out + 32, load_sc(resp + 32));
+  store_sc(out + 64, load_sc(pre + 32));
+  store_sc(out + 96, load_sc(pre));
+  store_sc(out + 128, issuance ? load_sc(resp + 128) : load_sc(pre + 64));
+}
+
+void launch_client_decode_com(const ClientArgs& a, hipStream_t s) {
+  if (!a.n) return;
+  size_t lanes = (size_t)a.n * a.P.L;
+  hipLaunchKernelGGL(k_client_decode_com, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_client_a(const ClientArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_client_a, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
+void launch_client_b(const ClientArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_client_b, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
+
+}  // namespace act

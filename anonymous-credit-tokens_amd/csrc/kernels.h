@@ -116,6 +116,40 @@ struct RequestArgs {
   uint8_t* out;              // n * 128
 };
 
+// CreditToken::prove_spend (src/lib.rs:972-1152)
+struct ProveArgs {
+  DevParams P;
+  uint32_t n;
+  const uint8_t* tok;        // n * 160  (a | e | k | r | c)
+  const uint8_t* s;          // n * 32
+  const uint8_t* rng;        // n * 64*(4L+12), draw order of SURVEY.md Appendix B
+  uint8_t* tr; uint32_t tr_stride;
+  uint32_t* d3;              // n * 3 * GE_WORDS : k* h2, k0' h2, (w0 - gamma_0 k*) h2
+  uint32_t* state;           // n * 24 words: r3 | r*
+  uint32_t* flags;
+  const uint32_t* xof;
+  uint8_t* proof;            // n * 32*(14+4L)
+  uint8_t* prerefund;        // n * 96
+  uint8_t* status;
+};
+// PreIssuance::to_credit_token (src/lib.rs:528-562) / PreRefund::to_credit_token (:1217-1253)
+struct ClientArgs {
+  DevParams P;
+  ge w;                      // issuer public key, decoded
+  uint32_t n;
+  int label;                 // LABEL_RESPOND or LABEL_REFUND
+  const uint8_t* pre;        // n * 64 (r|k)  or  n * 96 (r|k|m)
+  const uint8_t* req;        // n * 128 (issuance) or null
+  const uint8_t* resp;       // n * 160 (IssuanceResponse) or n * 128 (Refund)
+  const uint8_t* proofs;     // refund: n spend proofs
+  uint32_t* coords;          // refund: decoded Com_j
+  uint8_t* trs;
+  uint32_t* flags;
+  const uint32_t* xof;
+  uint8_t* out_token;        // n * 160
+  uint8_t* status;
+};
+
 struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n; uint32_t* xof; const uint32_t* len_per_lane; };
 
 // launchers (defined in the .hip files)
@@ -135,6 +169,13 @@ void launch_issue_a(const IssueArgs& a, hipStream_t s);
 void launch_issue_check(const IssueArgs& a, hipStream_t s);
 void launch_request_a(const RequestArgs& a, hipStream_t s);
 void launch_request_b(const RequestArgs& a, hipStream_t s);
+void launch_prove_head(const ProveArgs& a, hipStream_t s);
+void launch_prove_bits(const ProveArgs& a, hipStream_t s);
+void launch_prove_tail(const ProveArgs& a, hipStream_t s);
+void launch_prove_resp(const ProveArgs& a, hipStream_t s);
+void launch_client_decode_com(const ClientArgs& a, hipStream_t s);
+void launch_client_a(const ClientArgs& a, hipStream_t s);
+void launch_client_b(const ClientArgs& a, hipStream_t s);
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 // ---- device helpers ----
