@@ -67,7 +67,7 @@ ACT_HD uint32_t b3_load_block(uint32_t m[16], const uint32_t* msg, uint32_t len,
 // 64 bytes of root output (finalize_xof().fill(&mut [0u8; 64]), src/transcript.rs:150-152)
 ACT_HD void b3_hash_xof64(uint32_t out[16], const uint32_t* msg, uint32_t len) {
   uint32_t nchunks = len ? (len + 1023u) >> 10 : 1u;
-  uint32_t stack[5][8];      // enough for 2^5 chunks per subtree path: messages up to 64 KiB here
+  uint32_t stack[8][8];      // one entry per level: enough for 2^8 chunks = messages up to 256 KiB (ours are <= 16 KiB)
   int sp = 0;
   uint32_t cv[8], m[16], o[16];
   // every chunk but the last is finished into a chaining value and merged into the stack

@@ -1,0 +1,133 @@
+"""The reference's own behavioural tests (/root/reference/src/tests.rs), restated against the API mirror
+(act_amd.api: same type and method names) running on the HIP engine."""
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from act_amd import api
+    params = api.Params.new("test-org", "test-service", "test", "2024-01-01")
+    rng = api.OsRng()
+    sk = api.PrivateKey.random(rng, params)
+    return api, params, rng, sk
+
+
+def issue_token(api, params, rng, sk, c):
+    pre = api.PreIssuance.random(rng, params)
+    req = pre.request(params, rng)
+    resp = sk.issue(params, req, c, rng)
+    return pre.to_credit_token(params, sk.public(), req, resp)
+
+
+def test_issuance(env):                                   # src/tests.rs:52-77
+    api, params, rng, sk = env
+    for _ in range(5):
+        tok = issue_token(api, params, rng, sk, 20)
+        assert api.scalar_to_u128(tok.credits()) == 20
+
+
+def test_full_cycle_and_sequential_spends(env):           # :79-125, :259-337
+    api, params, rng, sk = env
+    tok = issue_token(api, params, rng, sk, 40)
+    seen = set()
+    for charge, remaining in ((20, 20), (5, 15), (15, 0)):
+        proof, prerefund = tok.prove_spend(params, charge, rng)
+        assert api.scalar_to_u128(proof.charge()) == charge
+        assert proof.nullifier() == tok.nullifier() and proof.nullifier() not in seen
+        seen.add(proof.nullifier())
+        refund = sk.refund(params, proof, rng)
+        tok = prerefund.to_credit_token(params, proof, refund, sk.public())
+        assert api.scalar_to_u128(tok.credits()) == remaining
+
+
+def test_zero_spend_and_zero_credit(env):                 # :377-426, :875-914
+    api, params, rng, sk = env
+    tok = issue_token(api, params, rng, sk, 0)
+    proof, prerefund = tok.prove_spend(params, 0, rng)
+    tok2 = prerefund.to_credit_token(params, proof, sk.refund(params, proof, rng), sk.public())
+    assert api.scalar_to_u128(tok2.credits()) == 0
+
+
+def test_large_amounts(env):                              # :641-689, :1007-1059
+    api, params, rng, sk = env
+    top = 2**128 - 1
+    tok = issue_token(api, params, rng, sk, top)
+    proof, prerefund = tok.prove_spend(params, 1, rng)
+    tok2 = prerefund.to_credit_token(params, proof, sk.refund(params, proof, rng), sk.public())
+    assert api.scalar_to_u128(tok2.credits()) == top - 1
+
+
+def test_overspend_is_rejected(env):                      # :339-375
+    api, params, rng, sk = env
+    tok = issue_token(api, params, rng, sk, 10)
+    proof, _ = tok.prove_spend(params, 11, rng)          # the prover still emits a proof
+    with pytest.raises(api.Error) as e:
+        sk.refund(params, proof, rng)
+    assert e.value.name == "InvalidClientSpendProof"
+
+
+def test_invalid_proofs_and_requests(env):                # :570-639, :850-873
+    api, params, rng, sk = env
+    pre = api.PreIssuance.random(rng, params)
+    req = pre.request(params, rng)
+    bad = bytearray(req.record); bad[64] ^= 1
+    with pytest.raises(api.Error) as e:
+        sk.issue(params, api.IssuanceRequest(bytes(bad)), 20, rng)
+    assert e.value.name == "InvalidIssuanceRequestProof"
+    tok = issue_token(api, params, rng, sk, 20)
+    proof, _ = tok.prove_spend(params, 5, rng)
+    bad = bytearray(proof.record); bad[32] ^= 1
+    with pytest.raises(api.Error) as e:
+        sk.refund(params, api.SpendProof(bytes(bad)), rng)
+    assert e.value.name == "InvalidClientSpendProof"
+    bad = bytearray(proof.record); bad[64:96] = bytes(32)
+    with pytest.raises(api.Error) as e:
+        sk.refund(params, api.SpendProof(bytes(bad)), rng)
+    assert e.value.name == "IdentityPointError"
+
+
+def test_client_rejects_tampered_responses(env):          # :691-720, :780-848
+    api, params, rng, sk = env
+    pre = api.PreIssuance.random(rng, params)
+    req = pre.request(params, rng)
+    resp = sk.issue(params, req, 20, rng)
+    for off in (32, 64, 96):
+        bad = bytearray(resp.record); bad[off] ^= 1
+        with pytest.raises(api.Error) as e:
+            pre.to_credit_token(params, sk.public(), req, api.IssuanceResponse(bytes(bad)))
+        assert e.value.name == "InvalidIssuanceResponseProof"
+    tok = pre.to_credit_token(params, sk.public(), req, resp)
+    proof, prerefund = tok.prove_spend(params, 3, rng)
+    refund = sk.refund(params, proof, rng)
+    for off in (32, 64, 96):
+        bad = bytearray(refund.record); bad[off] ^= 1
+        with pytest.raises(api.Error) as e:
+            prerefund.to_credit_token(params, proof, api.Refund(bytes(bad)), sk.public())
+        assert e.value.name == "InvalidRefundProof"
+
+
+def test_multiple_issuers_are_independent(env):           # :1997
+    api, params, rng, sk = env
+    sk2 = api.PrivateKey.random(rng, params)
+    tok = issue_token(api, params, rng, sk, 30)
+    proof, _ = tok.prove_spend(params, 4, rng)
+    with pytest.raises(api.Error):
+        sk2.refund(params, proof, rng)
+    sk.refund(params, proof, rng)
+
+
+def test_sequential_rng_is_consumed_only_by_accepted_lanes(env):   # src/lib.rs:638-643, :842-846
+    api, params, _, sk = env
+    stream = api.ByteStreamRng(os.urandom(128 * 4 + 64 * 600 * 3))
+    pres = [api.PreIssuance.random(stream, params) for _ in range(3)]
+    reqs = [p.request(params, stream) for p in pres]
+    bad = bytearray(reqs[1].record); bad[70] ^= 1
+    reqs[1] = api.IssuanceRequest(bytes(bad))
+    pos = stream.pos
+    out = sk.issue_batch(params, reqs, [5, 6, 7], stream)
+    assert isinstance(out[1], api.Error) and not isinstance(out[0], api.Error)
+    assert stream.pos == pos + 2 * 128                     # two accepted lanes drew 2 scalars each

@@ -1,0 +1,182 @@
+"""Parity tests proper: the HIP engine, called through the C ABI, against the committed golden fixtures and
+against the C oracle on the same seeded inputs.  Bit-exact (integer / byte work): every record, every status."""
+import pytest
+
+from conftest import load_golden, shake, scb
+
+pytestmark = pytest.mark.gpu
+
+MODES = [0, 1]   # ACT_TRANSCRIPT_HOST, ACT_TRANSCRIPT_DEVICE
+
+
+def test_params_new_matches_golden():
+    from act_amd import capi
+    for v in load_golden("primitives.json")["params"]:
+        assert capi.params_new(*v["args"]).hex() == v["h"]
+    u = shake("params-random", 192)
+    import pymodel as m
+    assert capi.params_random(u) == m.Params.random(m.ByteRng(u)).encoded()
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["lifecycle_L128.json", "lifecycle_L64.json"])
+def test_golden_lifecycle(engine_factory, name, mode):
+    g = load_golden(name)
+    L = g["L"]
+    eng = engine_factory(bytes.fromhex(g["params"]), L, max_batch=4, transcript=mode)
+    sk, sk2 = bytes.fromhex(g["sk"]), bytes.fromhex(g["sk_other"])
+    assert eng.private_key_random(shake("golden-sk", 64)) == sk
+    cases = g["cases"]
+    n = len(cases)
+    tag = lambda i: "L%d-case%d" % (L, i)
+    cat = lambda f: b"".join(f(i) for i in range(n))
+    pre = eng.pre_issuance_random(cat(lambda i: shake(tag(i) + "-pre", 128)))
+    assert pre == cat(lambda i: bytes.fromhex(cases[i]["pre"]))
+    req = eng.request(pre, cat(lambda i: shake(tag(i) + "-request", 128)))
+    assert req == cat(lambda i: bytes.fromhex(cases[i]["request"]))
+    st, resp = eng.issue(sk, req, cat(lambda i: scb(int(cases[i]["c"]))), cat(lambda i: shake(tag(i) + "-issue", 128)))
+    assert st == bytes(n) and resp == cat(lambda i: bytes.fromhex(cases[i]["response"]))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    assert st == bytes(n) and tok == cat(lambda i: bytes.fromhex(cases[i]["token"]))
+    st, proofs, prer = eng.prove_spend(tok, cat(lambda i: scb(int(cases[i]["s"]))), cat(lambda i: shake(tag(i) + "-prove", eng.prove_rng_bytes)))
+    assert st == bytes(n) and prer == cat(lambda i: bytes.fromhex(cases[i]["prerefund"]))
+    pb = eng.proof_bytes
+    for i, c in enumerate(cases):
+        if c["tamper"] is None:
+            assert proofs[pb * i:pb * i + pb].hex() == c["proof"], i
+    proofs = cat(lambda i: bytes.fromhex(cases[i]["proof"]))
+    st, kp = eng.verify_spend(sk, proofs, True)
+    assert list(st) == [c["status"] for c in cases]
+    for i, c in enumerate(cases):
+        if "kprime" in c:
+            assert kp[32 * i:32 * i + 32].hex() == c["kprime"]
+    st, rf = eng.refund(sk, proofs, cat(lambda i: shake(tag(i) + "-refund", 128)))
+    assert list(st) == [c["status"] for c in cases]
+    assert rf == cat(lambda i: bytes.fromhex(cases[i]["refund"]))
+    st2, tok2 = eng.refund_to_credit_token(prer, proofs, rf, sk[32:])
+    for i, c in enumerate(cases):
+        if c["status"] == 0:
+            assert st2[i] == 0 and tok2[160 * i:160 * i + 160].hex() == c["token2"]
+        else:
+            assert st2[i] != 0 and tok2[160 * i:160 * i + 160] == bytes(160)
+    assert list(eng.verify_spend(sk2, proofs)) == [c["status_other_issuer"] for c in cases]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("L", [128, 64, 8])
+def test_random_batches_against_oracle(engine_factory, oracle, bench_params, L, mode):
+    """Seeded random batch with tampered / undecodable / identity / overspend lanes, ragged chunks (max_batch = 7)."""
+    octx = oracle.ctx(bench_params, L)
+    eng = engine_factory(bench_params, L, max_batch=7, transcript=mode)
+    N = 23
+    sk = octx.private_key_random(shake("pk-%d" % L, 64))
+    pre = b"".join(octx.pre_issuance_random(shake("pre-%d-%d" % (L, i), 128)) for i in range(N))
+    rq = shake("rq-%d" % L, 128 * N)
+    req = eng.request(pre, rq)
+    assert req == octx.request_batch(pre, rq, 8)
+    bad_req = bytearray(req)
+    bad_req[128 * 2 + 70] ^= 1          # k_bar
+    bad_req[128 * 5 + 3] ^= 0x08        # K (almost surely undecodable)
+    bad_req[128 * 9 + 40] ^= 1          # gamma
+    bad_req = bytes(bad_req)
+    cam = b"".join(scb((1 << min(L, 60)) // (i + 1) + i) for i in range(N))
+    irng = shake("ir-%d" % L, 128 * N)
+    for rng_mode in (0, 1):
+        st, resp = eng.issue(sk, bad_req, cam, irng, rng_mode)
+        cur = 0
+        for i in range(N):
+            slot = i if rng_mode == 0 else cur
+            so, ro = octx.issue(sk, bad_req[128 * i:128 * i + 128], cam[32 * i:32 * i + 32], irng[128 * slot:128 * slot + 128])
+            assert so == st[i] and ro == resp[160 * i:160 * i + 160], (rng_mode, i)
+            cur += so == 0
+    st, resp = eng.issue(sk, req, cam, irng)
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    assert st == bytes(N)
+    amounts = [(1 << min(L, 60)) // (i + 1) + i for i in range(N)]
+    spend = [a // 3 for a in amounts]
+    spend[4] = amounts[4] + 1           # overspend
+    spend[6] = amounts[6]               # spend everything
+    spend[7] = 0
+    s_b = b"".join(scb(v) for v in spend)
+    prng = shake("pr-%d" % L, octx.prove_rng_bytes * N)
+    st, proofs, prer = eng.prove_spend(tok, s_b, prng)
+    po, pro = octx.prove_spend_batch(tok, s_b, prng, 8)
+    assert st == bytes(N) and proofs == po and prer == pro
+    pb = octx.proof_bytes
+    t = bytearray(proofs)
+    t[pb * 1 + 33] ^= 2                             # s
+    t[pb * 3 + 64:pb * 3 + 96] = bytes(32)          # A' = identity
+    t[pb * 8 + 32 * (4 + (L - 1)) + 9] ^= 0x40      # last Com
+    t[pb * 10 + 32 * (12 + L) + 5] ^= 1             # gamma0[0]
+    t[pb * 11 + 32 * (13 + 4 * L)] ^= 1             # s_bar
+    t[pb * 12 + 96 + 1] ^= 0x20                     # B_bar
+    t = bytes(t)
+    rrng = shake("rr-%d" % L, 128 * N)
+    st_o = octx.verify_spend_batch(sk, t, 8)
+    st, kp = eng.verify_spend(sk, t, True)
+    assert st == st_o
+    assert {0, 6, 7, 255} <= set(st) or L == 8
+    trs = eng.last_spend_transcripts(7)            # last chunk: lanes 21, 22
+    for k, i in enumerate(range(21, N)):
+        so, kpo, tro = octx.verify_spend(sk, t[pb * i:pb * i + pb], True)
+        assert trs[k] == tro and kp[32 * i:32 * i + 32] == kpo
+    for rng_mode in (0, 1):
+        st, rf = eng.refund(sk, t, rrng, rng_mode)
+        cur = 0
+        for i in range(N):
+            slot = i if rng_mode == 0 else cur
+            so, ro = octx.refund(sk, t[pb * i:pb * i + pb], rrng[128 * slot:128 * slot + 128])
+            assert so == st[i] and ro == rf[128 * i:128 * i + 128], (rng_mode, i)
+            cur += so == 0
+    st, rf = eng.refund(sk, proofs, rrng)
+    st_c, tok2 = eng.refund_to_credit_token(prer, proofs, rf, sk[32:])
+    for i in range(N):
+        so, to = octx.refund_to_credit_token(prer[96 * i:96 * i + 96], proofs[pb * i:pb * i + pb], rf[128 * i:128 * i + 128], sk[32:])
+        assert so == st_c[i] and to == tok2[160 * i:160 * i + 160]
+
+
+def test_empty_and_single_lane_batches(engine_factory, bench_params):
+    eng = engine_factory(bench_params, 128, max_batch=7)
+    sk = eng.private_key_random(shake("sk-empty", 64))
+    assert eng.request(b"", b"") == b""
+    assert eng.verify_spend(sk, b"") == b""
+    assert eng.refund(sk, b"", b"") == (b"", b"")
+    assert eng.issue(sk, b"", b"", b"") == (b"", b"")
+    assert eng.prove_spend(b"", b"", b"") == (b"", b"", b"")
+
+
+def test_device_memory_path_and_full_size_properties(engine_factory, bench_params):
+    """BASELINE sizes through size-independent properties: 2^16 (config 2 count) and 2^20 (metric batch) tiled proofs
+    resident in HBM; every valid lane accepted, every tampered lane (1 in 1024) rejected with the right code, and the
+    result is independent of chunking."""
+    import numpy as np
+    import torch
+    from act_amd import capi
+    L, D = 128, 512
+    eng = engine_factory(bench_params, L, max_batch=16384, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("sk-big", 64))
+    pre = eng.pre_issuance_random(shake("pre-big", 128 * D))
+    req = eng.request(pre, shake("rq-big", 128 * D))
+    cam = b"".join(scb(10 + (i * 7919) % 990) for i in range(D))
+    st, resp = eng.issue(sk, req, cam, shake("ir-big", 128 * D))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    s_b = b"".join(scb(1 + (i * 31) % (10 + (i * 7919) % 990 - 1)) for i in range(D))
+    st, proofs, _ = eng.prove_spend(tok, s_b, shake("pr-big", eng.prove_rng_bytes * D))
+    assert st == bytes(D)
+    pb = eng.proof_bytes
+    host = np.frombuffer(proofs, np.uint8).reshape(D, pb)
+    for n_total in (1 << 16, 1 << 20):
+        reps = n_total // D
+        dev = torch.from_numpy(host.copy()).cuda().repeat(reps, 1).contiguous()
+        # tamper 1 lane in 1024: flip a bit of s (-> 7), or zero A' (-> 6)
+        idx = torch.arange(513, n_total, 1024, device="cuda")
+        dev[idx[0::2], 32] ^= 1
+        dev[idx[1::2], 64:96] = 0
+        status = torch.full((n_total,), 99, dtype=torch.uint8, device="cuda")
+        eng.verify_spend_dev(sk, n_total, dev.data_ptr(), status.data_ptr())
+        torch.cuda.synchronize()
+        exp = torch.zeros(n_total, dtype=torch.uint8, device="cuda")
+        exp[idx[0::2]] = 7
+        exp[idx[1::2]] = 6
+        assert torch.equal(status, exp), n_total
+        del dev

@@ -1,0 +1,110 @@
+"""The device arithmetic headers (csrc/*.h), compiled for the host by tests/hostcheck/hostcheck.cpp, against
+the Python model: field / scalar / ristretto255 / shared-doubling chain / fixed-base windows / BLAKE3, plus the
+limb-size discipline the lazily-reduced field code relies on.  CPU-only unit tests of kernel math; the product
+has no CPU path."""
+import ctypes as C
+
+import pymodel as m
+from conftest import load_golden, shake
+
+P = m.P
+
+
+def call(hc, fn, *ins, nout=1, outlen=32):
+    outs = [C.create_string_buffer(outlen) for _ in range(nout)]
+    r = getattr(hc, fn)(*ins, *outs)
+    return (r, *[o.raw for o in outs])
+
+
+def le(x):
+    return x.to_bytes(32, "little")
+
+
+def test_field(hostcheck):
+    hc = hostcheck
+    edge = [0, 1, 2, 19, P - 1, P - 2, P - 19, 2**255 - 20, 2**254, (1 << 26) - 1, (1 << 51) - 1, 2**128, 2**255 - 1]
+    vals = edge + [int.from_bytes(shake("f%d" % i, 32), "little") % 2**255 for i in range(200)]
+    for i, a in enumerate(vals):
+        b = vals[(i * 7 + 3) % len(vals)]
+        fi = lambda x: int.from_bytes(x, "little")
+        assert fi(call(hc, "hc_fe_mul", le(a), le(b))[1]) == a * b % P
+        assert fi(call(hc, "hc_fe_sq", le(a))[1]) == a * a % P
+        assert fi(call(hc, "hc_fe_add", le(a), le(b))[1]) == (a + b) % P
+        assert fi(call(hc, "hc_fe_sub", le(a), le(b))[1]) == (a - b) % P
+        x, y = a % P, b % P
+        exp = ((3 * x - y) * (x - y)) % P
+        exp = ((2 * exp - (x + y)) * (x - y) ** 2) % P
+        assert fi(call(hc, "hc_fe_stress", le(a), le(b))[1]) == exp
+        if i < 40 and a % P:
+            assert fi(call(hc, "hc_fe_invert", le(a))[1]) == pow(a, P - 2, P)
+            ok, r = call(hc, "hc_fe_invsqrt", le(a))
+            ok2, r2 = m.sqrt_ratio_m1(1, a)
+            assert bool(ok) == ok2 and fi(r) == r2
+
+
+def test_scalars(hostcheck):
+    hc = hostcheck
+    for v in load_golden("primitives.json")["sc_from_wide"]:
+        assert call(hc, "hc_sc_reduce_wide", bytes.fromhex(v["in"]))[1].hex() == v["out"]
+    for i in range(100):
+        a, b, c = (shake("%s%d" % (t, i), 32) for t in "abc")
+        if i == 0:
+            a = b"\xff" * 32
+        ai, bi, ci = (int.from_bytes(x, "little") for x in (a, b, c))
+        assert call(hc, "hc_sc_from_bytes", a)[1] == m.sc_bytes(ai)
+        assert call(hc, "hc_sc_muladd", a, b, c)[1] == m.sc_bytes(ai * bi + ci)
+        assert call(hc, "hc_sc_sub", a, b)[1] == m.sc_bytes(ai - bi)
+        assert call(hc, "hc_sc_neg", a)[1] == m.sc_bytes(-ai)
+        if i < 5:
+            assert call(hc, "hc_sc_invert", a)[1] == m.sc_bytes(m.sc_inv(ai % m.ELL))
+
+
+def test_blake3_against_upstream_vectors(hostcheck):
+    for v in load_golden("blake3_llvm.json")["vectors"]:
+        if v["len"] > 200000:
+            continue
+        data = bytes(i % 251 for i in range(v["len"]))
+        out = C.create_string_buffer(64)
+        hostcheck.hc_blake3_xof64(data, v["len"], out)
+        assert out.raw.hex() == v["xof"][:128], v["len"]
+
+
+def test_group_and_msm_shapes(hostcheck):
+    hc = hostcheck
+    g = load_golden("primitives.json")
+    for v in g["decode_validity"]:
+        ok, _ = call(hc, "hc_decode_encode", bytes.fromhex(v["bytes"]))
+        assert bool(ok) == v["valid"], v["bytes"]
+    for i, v in enumerate(g["from_uniform_bytes"]):
+        e = bytes.fromhex(v["encoding"])
+        assert call(hc, "hc_from_uniform", bytes.fromhex(v["uniform"]))[1] == e
+        ok, r = call(hc, "hc_decode_encode", e)
+        assert ok and r == e
+        s = bytes.fromhex(v["scalar"])
+        ok, o0 = call(hc, "hc_chain1", e, s)
+        assert ok and o0.hex() == v["mul"]
+        s1 = m.sc_from_wide(shake("hc-s1-%d" % i, 64))
+        pm = m.ristretto_decode(e)
+        ok, o0, o1 = call(hc, "hc_chain2", e, s, m.sc_bytes(s1), nout=2)
+        assert o0.hex() == v["mul"] and o1 == m.ristretto_encode(m.pt_mul(pm, s1))
+        if i < 4:
+            ok, o = call(hc, "hc_fixed_base", e, s)
+            assert o.hex() == v["mul"]
+    # digit-recoding corner cases of the radix-4 chain
+    e = bytes.fromhex(g["generator_multiples"][1])
+    for s in (0, 1, 2, 3, 4, m.ELL - 1, (1 << 252) + 5, (1 << 252) - 1, int("3" * 60, 16) % m.ELL, int("2" * 63, 16) % m.ELL):
+        ok, o0, o1 = call(hc, "hc_chain2", e, m.sc_bytes(s), m.sc_bytes(m.ELL - 1 - s), nout=2)
+        assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, s)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, m.ELL - 1 - s))
+    ok, o0, o1 = call(hc, "hc_chain2", bytes(32), m.sc_bytes(5), m.sc_bytes(7), nout=2)   # identity base
+    assert o0 == bytes(32) and o1 == bytes(32)
+
+
+def test_limb_bounds_hold(hostcheck):
+    """Every operand recorded by the instrumented host build stays inside its class (fe25519.h header comment)."""
+    test_field(hostcheck)
+    test_group_and_msm_shapes(hostcheck)
+    bd = (C.c_uint64 * 6)()
+    hostcheck.hc_bounds(bd)
+    lim = [1.68 * 2**27, 1.68 * 2**26, 1.5 * 2**28, 1.5 * 2**27, 2**27 - 38, 2**26 - 2]
+    for v, l in zip(bd, lim):
+        assert 0 < v <= l
