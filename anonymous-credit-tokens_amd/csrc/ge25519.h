@@ -33,14 +33,16 @@ ACT_HD ge_cached ge_to_cached(const ge& p) {
 // per-lane conditional negation of a cached point: swap Y+X / Y-X, negate 2dT
 ACT_HD ge_cached ge_cached_cneg(const ge_cached& c, bool neg) {
   ge_cached r = c;
-  fe_cswap(r.YpX, r.YmX, neg);
-  r.T2d = fe_select(c.T2d, fe_neg(c.T2d), neg);   // <= 2^27 [g]
+  uint32_t m = fe_mask(neg);
+  fe_cswap_m(r.YpX, r.YmX, m);
+  r.T2d = fe_select_m(c.T2d, fe_neg(c.T2d), m);   // <= 2^27 [g]
   return r;
 }
 ACT_HD ge_niels ge_niels_cneg(const ge_niels& c, bool neg) {
   ge_niels r = c;
-  fe_cswap(r.ypx, r.ymx, neg);
-  r.xy2d = fe_select(c.xy2d, fe_neg(c.xy2d), neg);
+  uint32_t m = fe_mask(neg);
+  fe_cswap_m(r.ypx, r.ymx, m);
+  r.xy2d = fe_select_m(c.xy2d, fe_neg(c.xy2d), m);
   return r;
 }
 

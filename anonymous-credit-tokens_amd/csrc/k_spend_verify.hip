@@ -94,20 +94,22 @@ __global__ void __launch_bounds__(256, 2) k_spend_bits(SpendArgs a) {
   sc g1 = sc_sub(gamma, g0);                                                  // src/lib.rs:801, 811
   sc z0 = load_sc(rec + 32 * pl.z(j, 0)), z1 = load_sc(rec + 32 * pl.z(j, 1));
 
-  ge acc[2];
-  acc[0] = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
-  acc[1] = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z1);
-  acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_H1], g1);
-  if (j == 0) {                                                               // + w00 h2 / + w01 h2 (:806, :808)
-    acc[0] = ge_add(acc[0], ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));
-    acc[1] = ge_add(acc[1], ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));
-  }
-  sc s[2] = {g0, g1};
-  chain<2>(acc, ge_neg(C), s);                                                // - gamma_j0 Com_j, - gamma_j1 Com_j
+  // C'_j0 = z_j0 h3 + D,  C'_j1 = z_j1 h3 + gamma_j1 h1 + G - D  with D = gamma_j0 N, G = gamma N, N = -Com_j
+  // (gamma_j1 = gamma - gamma_j0).  G's scalar is the proof-wide gamma: uniform NAF digits per wavefront (msm.h chain2u).
+  ge acc_u = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z1);
+  acc_u = fixed_base_acc(acc_u, a.P.tab[BASE_H1], g1);
+  if (j == 0) acc_u = ge_add(acc_u, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));      // + w01 h2 (:808)
+  ge acc_l = ge_identity();
+  chain2u(acc_l, acc_u, ge_neg(C), g0, gamma);
+  ge f0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
+  if (j == 0) f0 = ge_add(f0, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));                        // + w00 h2 (:806)
+  ge_cached dl = ge_to_cached(acc_l);
+  ge c0 = ge_add_cached(f0, dl);
+  ge c1 = ge_add_cached(acc_u, ge_cached_cneg(dl, true));
 
   uint32_t enc[8];
-  ristretto_encode(enc, acc[0]); tr_put_aligned(el + 40 * st.el_cprime(j, 0), enc);
-  ristretto_encode(enc, acc[1]); tr_put_aligned(el + 40 * st.el_cprime(j, 1), enc);
+  ristretto_encode(enc, c0); tr_put_aligned(el + 40 * st.el_cprime(j, 0), enc);
+  ristretto_encode(enc, c1); tr_put_aligned(el + 40 * st.el_cprime(j, 1), enc);
 }
 
 __global__ void __launch_bounds__(64, 2) k_spend_tail(SpendArgs a) {

@@ -94,10 +94,11 @@ ACT_HD digit4 next_digit4(uint32_t w[8], uint32_t& carry) {
 }
 ACT_HD ge chain_step_add(const ge& acc, const ge_cached& c1, const ge_cached& c2, const digit4& d) {
   ge_cached q;
-  q.YpX = fe_select(c1.YpX, c2.YpX, d.two);
-  q.YmX = fe_select(c1.YmX, c2.YmX, d.two);
-  q.Z = fe_select(c1.Z, c2.Z, d.two);
-  q.T2d = fe_select(c1.T2d, c2.T2d, d.two);
+  uint32_t m2 = fe_mask(d.two);
+  q.YpX = fe_select_m(c1.YpX, c2.YpX, m2);
+  q.YmX = fe_select_m(c1.YmX, c2.YmX, m2);
+  q.Z = fe_select_m(c1.Z, c2.Z, m2);
+  q.T2d = fe_select_m(c1.T2d, c2.T2d, m2);
   q = ge_cached_cneg(q, d.neg);
   return ge_add_cached(acc, q);
 }
@@ -118,6 +119,50 @@ ACT_HD void chain(ge* acc, const ge& N, const sc* s) {
       if (d.nonzero) acc[a] = chain_step_add(acc[a], c1, c2, d);
     }
   }
+}
+
+// ---- chain2u: acc_l += s_l * N (per-lane scalar, radix-4 digits) and acc_u += s_u * N where s_u is the SAME
+// scalar in every lane of the wavefront (the proof-wide challenge gamma: a wavefront holds 64 bits of one proof
+// when L >= 64).  s_u is recoded in non-adjacent form over the single-doubling positions of the same chain;
+// a zero digit is zero in every lane, so the wavefront skips that addition entirely (no exec-mask loss):
+// ~84 additions instead of 127.  With mixed proofs per wavefront (L < 64) the digits differ per lane and the
+// branch merely diverges; the result is the same.
+struct naf_state { uint32_t w[9]; };     // scalar + carry headroom
+ACT_HD naf_state naf_init(const sc& s) { naf_state n; for (int i = 0; i < 8; i++) n.w[i] = s.v[i]; n.w[8] = 0; return n; }
+// returns digit in {-1, 0, +1} for the current bit and advances one bit: standard NAF (k odd -> d = 2 - (k mod 4))
+ACT_HD int naf_next(naf_state& n) {
+  int d = 0;
+  if (n.w[0] & 1u) {
+    d = 2 - (int)(n.w[0] & 3u);          // +1 or -1
+    if (d < 0) {                         // k += 1
+      uint64_t c = 1;
+      for (int i = 0; i < 9; i++) { c += n.w[i]; n.w[i] = (uint32_t)c; c >>= 32; }
+    } else {
+      n.w[0] &= ~1u;                     // k -= 1
+    }
+  }
+  for (int i = 0; i < 8; i++) n.w[i] = (n.w[i] >> 1) | (n.w[i + 1] << 31);
+  n.w[8] >>= 1;
+  return d;
+}
+ACT_HD void chain2u(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& s_u) {
+  uint32_t w[8], carry = 0;
+  for (int i = 0; i < 8; i++) w[i] = s_l.v[i];
+  naf_state nu = naf_init(s_u);
+  ge P = N;
+  for (int step = 0; step < 127; step++) {
+    ge_cached c1 = ge_to_cached(P);
+    ge Q = ge_double(P);
+    ge_cached c2 = ge_to_cached(Q);
+    if (step < 126) P = ge_double(Q);
+    digit4 d = next_digit4(w, carry);
+    if (d.nonzero) acc_l = chain_step_add(acc_l, c1, c2, d);
+    int u0 = naf_next(nu);
+    if (u0 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(c1, u0 < 0));
+    int u1 = naf_next(nu);
+    if (u1 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(c2, u1 < 0));
+  }
+  // s_u < l < 2^253 has at most 254 NAF digits (positions 0..253): all consumed by the 127 steps above
 }
 
 }  // namespace act

@@ -64,9 +64,9 @@ ACT_HD void sc_cond_sub_l(uint32_t* r, int times) {
   for (int i = 0; i < 8; i++) l[i] = sc_l_word(i);
   for (int t = 0; t < times; t++) {
     uint32_t d[8];
-    uint32_t borrow = bn_sub<8>(d, r, l);
+    uint32_t keep = fe_mask(bn_sub<8>(d, r, l) != 0u);   // borrow: r < l, keep r
 #pragma unroll
-    for (int i = 0; i < 8; i++) r[i] = borrow ? r[i] : d[i];
+    for (int i = 0; i < 8; i++) r[i] = sel32(d[i], r[i], keep);
   }
 }
 // 512-bit little-endian words -> scalar mod l

@@ -98,3 +98,10 @@ void hc_blake3_xof64(const uint8_t* msg, uint32_t len, uint8_t* out) {
   uint32_t o[16]; b3_hash_xof64(o, w.data(), len); memcpy(out, o, 64);
 }
 }
+extern "C" int hc_chain2u(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
+  uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
+  ge al = ge_identity(), au = ge_identity();
+  chain2u(al, au, p, sc_in(s0), sc_in(s1));
+  ristretto_encode(r, al); st(o0, r); ristretto_encode(r, au); st(o1, r);
+  return 1;
+}

@@ -18,16 +18,17 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 
-constexpr int ITER = 2048;
+constexpr int ITER = 16384;
 
 enum Op { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, ADD_U32, ADDC_CHAIN,
           FMA_F64, MUL_F64, ADD_F64, FMA_F32, PK_FMA_F32, LSHL_ADD, ALIGNBIT, CNDMASK, MAD_I64_I32,
-          MAD_MIX_ADDC, DOT4_U8, DOT2_U16, ADD3_U32, LSHLREV_B64, NOPS };
+          MAD_MIX_ADDC, DOT4_U8, DOT2_U16, ADD3_U32, LSHLREV_B64, CNDMASK_SGPR, BFI, AND_B32, SUB_U32, XOR_B32, LSHL_ADD_U64, LSHRREV_B64, LSHRREV_B32, CNDMASK_VCC_SET, NOPS };
 
 static const char* op_name[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
   "v_add_u32", "v_add_co+v_addc_co (pair)", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_fma_f32", "v_pk_fma_f32",
   "v_lshl_add_u32", "v_alignbit_b32", "v_cndmask_b32", "v_mad_i64_i32", "v_mad_u64_u32+v_addc (pair)",
-  "v_dot4_u32_u8", "v_dot2_u32_u16", "v_add3_u32", "v_lshlrev_b64"};
+  "v_dot4_u32_u8", "v_dot2_u32_u16", "v_add3_u32", "v_lshlrev_b64", "v_cndmask_b32 (sgpr mask)", "v_bfi_b32", "v_and_b32", "v_sub_u32", "v_xor_b32",
+  "v_lshl_add_u64", "v_lshrrev_b64", "v_lshrrev_b32", "v_cndmask_b32 (vcc set by v_cmp)"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_rate(uint32_t* out, unsigned long long* cyc, uint32_t seed) {
@@ -44,6 +45,9 @@ __global__ void __launch_bounds__(256) k_rate(uint32_t* out, unsigned long long*
 #pragma unroll
   for (int i = 0; i < 8; i++) { pf[i].x = f[i]; pf[i].y = f[i] + 0.5f; }
   v2f pfa = {fa, fa}, pfb = {fb, fb};
+  unsigned long long smask = __ballot((threadIdx.x & 3) != 0);
+  uint64_t ab64 = ((uint64_t)a << 32) | b;
+  if constexpr (OP == CNDMASK_VCC_SET) asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a), "v"(b) : "vcc");
   unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int it = 0; it < ITER; it++) {
 #pragma unroll
@@ -70,6 +74,15 @@ __global__ void __launch_bounds__(256) k_rate(uint32_t* out, unsigned long long*
       else if constexpr (OP == DOT4_U8) { asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(lo) : "v"(a), "v"(b)); r[i] = lo; }
       else if constexpr (OP == DOT2_U16) { asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(lo) : "v"(a), "v"(b)); r[i] = lo; }
       else if constexpr (OP == LSHLREV_B64) { asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(r[i])); }
+      else if constexpr (OP == CNDMASK_SGPR) { asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(lo) : "v"(a), "s"(smask)); r[i] = lo; }
+      else if constexpr (OP == CNDMASK_VCC_SET) { asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(lo) : "v"(a) : ); r[i] = lo; }
+      else if constexpr (OP == BFI) { asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(lo) : "v"(a), "v"(b)); r[i] = lo; }
+      else if constexpr (OP == AND_B32) { asm volatile("v_and_b32 %0, %0, %1" : "+v"(lo) : "v"(a)); r[i] = lo; }
+      else if constexpr (OP == SUB_U32) { asm volatile("v_sub_u32 %0, %0, %1" : "+v"(lo) : "v"(a)); r[i] = lo; }
+      else if constexpr (OP == XOR_B32) { asm volatile("v_xor_b32 %0, %0, %1" : "+v"(lo) : "v"(a)); r[i] = lo; }
+      else if constexpr (OP == LSHL_ADD_U64) { asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(r[i]) : "v"(ab64)); }
+      else if constexpr (OP == LSHRREV_B64) { asm volatile("v_lshrrev_b64 %0, 3, %0" : "+v"(r[i])); }
+      else if constexpr (OP == LSHRREV_B32) { asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(lo)); r[i] = lo + a; }
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -127,6 +140,15 @@ int main() {
   run<MAD_MIX_ADDC>(out, cyc, ncu);
   run<DOT4_U8>(out, cyc, ncu);
   run<DOT2_U16>(out, cyc, ncu);
+  run<CNDMASK_SGPR>(out, cyc, ncu);
+  run<CNDMASK_VCC_SET>(out, cyc, ncu);
+  run<BFI>(out, cyc, ncu);
+  run<AND_B32>(out, cyc, ncu);
+  run<SUB_U32>(out, cyc, ncu);
+  run<XOR_B32>(out, cyc, ncu);
+  run<LSHL_ADD_U64>(out, cyc, ncu);
+  run<LSHRREV_B64>(out, cyc, ncu);
+  run<LSHRREV_B32>(out, cyc, ncu);
   run<FMA_F64>(out, cyc, ncu);
   run<MUL_F64>(out, cyc, ncu);
   run<ADD_F64>(out, cyc, ncu);
