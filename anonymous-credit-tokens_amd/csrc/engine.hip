@@ -44,7 +44,7 @@ struct act_ctx {
   std::string err;
   // device workspace (sized for max_batch lanes)
   uint8_t *d_tr = nullptr, *d_trs = nullptr, *d_status = nullptr;
-  uint32_t *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr;
+  uint32_t *d_buckets = nullptr, *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr;
   uint32_t* d_tables = nullptr;
   // staging for host-memory callers: grow-only device buffers
   uint8_t* d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -203,6 +203,7 @@ int workspace_alloc(act_ctx* c) {
   HIPCK(c, hipMalloc(&c->d_tr, B * st.stride()));
   HIPCK(c, hipMalloc(&c->d_coords, B * (size_t)c->L * NIELS_WORDS * 4));
   HIPCK(c, hipMalloc(&c->d_d01, B * 3 * GE_WORDS * 4));
+  HIPCK(c, hipMalloc(&c->d_buckets, B * (size_t)c->L * BUCKET_WORDS * 4));
   HIPCK(c, hipMalloc(&c->d_xa, B * GE_WORDS * 4));
   HIPCK(c, hipMalloc(&c->d_flags, B * 4));
   HIPCK(c, hipMalloc(&c->d_xof, B * 64));
@@ -297,7 +298,7 @@ void act_ctx_destroy(act_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->d_tr, c->d_trs, c->d_status, c->d_coords, c->d_d01, c->d_xa, c->d_flags, c->d_xof, c->d_state, c->d_slot, c->d_tables};
+  void* ptrs[] = {c->d_buckets, c->d_tr, c->d_trs, c->d_status, c->d_coords, c->d_d01, c->d_xa, c->d_flags, c->d_xof, c->d_state, c->d_slot, c->d_tables};
   for (void* p : ptrs) if (p) hipFree(p);
   for (int i = 0; i < 6; i++) if (c->d_stage[i]) { hipMemset(c->d_stage[i], 0, c->d_stage_cap[i]); hipFree(c->d_stage[i]); }   // staging may hold secrets
   if (c->h_tr) hipHostFree(c->h_tr);
@@ -424,7 +425,7 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
 static int verify_chunk(act_ctx* c, uint32_t m, const uint8_t* d_proofs, uint8_t* d_kprime) {
   const SpendTranscript st{c->L};
   SpendArgs a{}; a.P = c->P; a.K = c->key; a.proofs = d_proofs; a.n = m; a.tr = c->d_tr; a.tr_stride = (uint32_t)st.stride();
-  a.coords = c->d_coords; a.d01 = c->d_d01; a.xa = c->d_xa; a.flags = c->d_flags; a.xof = c->d_xof; a.status = c->d_status; a.kprime_enc = d_kprime;
+  a.coords = c->d_coords; a.d01 = c->d_d01; a.buckets = c->d_buckets; a.xa = c->d_xa; a.flags = c->d_flags; a.xof = c->d_xof; a.status = c->d_status; a.kprime_enc = d_kprime;
   int rc;
   if ((rc = prof_launch(c, PK_SPEND_PREP, m, [&] { launch_spend_prep(a, c->stream); }))) return rc;
   if ((rc = prof_launch(c, PK_SPEND_BITS, (uint64_t)m * c->L, [&] { launch_spend_bits(a, c->stream); }))) return rc;

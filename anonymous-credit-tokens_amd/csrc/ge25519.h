@@ -90,6 +90,23 @@ ACT_HD ge ge_madd(const ge& p, const ge_niels& q) {
 ACT_HD ge ge_add(const ge& p, const ge& q) { return ge_add_cached(p, ge_to_cached(q)); }
 ACT_HD ge ge_sub(const ge& p, const ge& q) { return ge_add_cached(p, ge_cached_cneg(ge_to_cached(q), true)); }
 
+// 2p with the T coordinate computed only when `with_t` (a wave-uniform flag): 4S + 3M or 4S + 4M
+ACT_HD ge ge_double_opt(const ge& p, bool with_t) {
+  fe xx = fe_sq(p.X), yy = fe_sq(p.Y);
+  fe zz2 = fe_dbl(fe_sq(p.Z));
+  fe xpy2 = fe_sq(fe_add(p.X, p.Y));
+  fe yypxx = fe_add(yy, xx);
+  fe yymxx = fe_sub(yy, xx);
+  fe cx = fe_carry(fe_sub4(xpy2, yypxx));
+  fe ct = fe_sub4(zz2, yymxx);
+  ge r;
+  r.X = fe_mul(ct, cx);
+  r.Y = fe_mul(yymxx, yypxx);
+  r.Z = fe_mul(ct, yymxx);
+  r.T = fe_zero();
+  if (with_t) r.T = fe_mul(cx, yypxx);
+  return r;
+}
 // 2p.  4S + 4M (3M without T).  Input T unused.
 template <bool WITH_T = true>
 ACT_HD ge ge_double(const ge& p) {

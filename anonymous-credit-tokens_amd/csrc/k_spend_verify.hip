@@ -95,12 +95,12 @@ __global__ void __launch_bounds__(256, 2) k_spend_bits(SpendArgs a) {
   sc z0 = load_sc(rec + 32 * pl.z(j, 0)), z1 = load_sc(rec + 32 * pl.z(j, 1));
 
   // C'_j0 = z_j0 h3 + D,  C'_j1 = z_j1 h3 + gamma_j1 h1 + G - D  with D = gamma_j0 N, G = gamma N, N = -Com_j
-  // (gamma_j1 = gamma - gamma_j0).  G's scalar is the proof-wide gamma: uniform NAF digits per wavefront (msm.h chain2u).
+  // (gamma_j1 = gamma - gamma_j0).  G's scalar is the proof-wide gamma: uniform NAF digits per wavefront; D's digits go through per-lane buckets (msm.h chain_bu).
   ge acc_u = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z1);
   acc_u = fixed_base_acc(acc_u, a.P.tab[BASE_H1], g1);
   if (j == 0) acc_u = ge_add(acc_u, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));      // + w01 h2 (:808)
   ge acc_l = ge_identity();
-  chain2u(acc_l, acc_u, ge_neg(C), g0, gamma);
+  chain_bu(acc_l, acc_u, ge_neg(C), g0, gamma, a.buckets + (size_t)gid * BUCKET_WORDS);
   ge f0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
   if (j == 0) f0 = ge_add(f0, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));                        // + w00 h2 (:806)
   ge_cached dl = ge_to_cached(acc_l);

@@ -71,6 +71,7 @@ struct SpendArgs {
   uint32_t tr_stride;
   uint32_t* coords;          // n * L * NIELS_WORDS : affine Niels of every decoded Com_j
   uint32_t* d01;             // n * 2 * GE_WORDS    : w00*h2, w01*h2
+  uint32_t* buckets;         // n * L * BUCKET_WORDS: per-lane Pippenger buckets of k_spend_bits (msm.h chain_bu)
   uint32_t* xa;              // n * GE_WORDS        : X_A = g + K'
   uint32_t* flags;           // n
   const uint32_t* xof;       // n * 16              : BLAKE3 XOF words of the transcript

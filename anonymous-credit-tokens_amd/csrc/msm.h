@@ -165,4 +165,87 @@ ACT_HD void chain2u(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& 
   // s_u < l < 2^253 has at most 254 NAF digits (positions 0..253): all consumed by the 127 steps above
 }
 
+// ---- chain_bu: bucketed per-lane accumulator + wave-uniform NAF accumulator on one doubling chain ----------
+// acc_u += s_u * N as in chain2u.  The per-lane scalar s_l is recoded in signed radix 16 (digits in [-8, 8]) and
+// handled Pippenger-style: every fourth chain point P_i = 16^i N is added, with the digit's sign, into bucket
+// |digit| of the lane (9 extended points per lane in global memory, AoS so a lane's bucket is 160 contiguous
+// bytes; bucket 0 absorbs the zero digits so no lane ever sits out or selects).  Afterwards
+// s_l * N = sum_v v * B_v by running sums: 64 + 14 additions instead of 127, one cached conversion per four
+// doublings instead of four, and T is computed only for chain points that are actually added (the NAF
+// positions are wave-uniform, so that is a uniform branch).  Working set: 1440 B per lane, re-touched every
+// step -> served by L2 / Infinity Cache.
+constexpr int BUCKETS = 9;
+constexpr int BUCKET_WORDS = BUCKETS * GE_WORDS;     // 360 words = 1440 B per lane
+
+ACT_HD ge bucket_load(const uint32_t* p) {
+  ge g;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a[10];
+  for (int i = 0; i < 10; i++) a[i] = q[i];
+  uint32_t w[40];
+  for (int i = 0; i < 10; i++) { w[4 * i] = a[i].x; w[4 * i + 1] = a[i].y; w[4 * i + 2] = a[i].z; w[4 * i + 3] = a[i].w; }
+  for (int i = 0; i < 10; i++) { g.X.v[i] = w[i]; g.Y.v[i] = w[10 + i]; g.Z.v[i] = w[20 + i]; g.T.v[i] = w[30 + i]; }
+#else
+  g = ge_load(p);
+#endif
+  return g;
+}
+ACT_HD void bucket_store(uint32_t* p, const ge& g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t w[40];
+  for (int i = 0; i < 10; i++) { w[i] = g.X.v[i]; w[10 + i] = g.Y.v[i]; w[20 + i] = g.Z.v[i]; w[30 + i] = g.T.v[i]; }
+  uint4* q = reinterpret_cast<uint4*>(p);
+  for (int i = 0; i < 10; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+#else
+  ge_store(p, g);
+#endif
+}
+// `bk`: this lane's BUCKET_WORDS words.  Returns s_l * N in acc_l (overwritten), adds s_u * N to acc_u.
+ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& s_u, uint32_t* bk) {
+  const ge id = ge_identity();
+  for (int b = 0; b < BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);
+  uint32_t w[8], carry = 0;
+  for (int i = 0; i < 8; i++) w[i] = s_l.v[i];
+  naf_state nu = naf_init(s_u);
+  ge P = N;                                    // position 0, T valid
+  for (int step = 0; step < 64; step++) {
+    // per-lane signed radix-16 digit
+    uint32_t v = (w[0] & 15u) + carry;
+    for (int i = 0; i < 7; i++) w[i] = (w[i] >> 4) | (w[i + 1] << 28);
+    w[7] >>= 4;
+    carry = v > 8u ? 1u : 0u;
+    bool neg = v > 8u;
+    uint32_t mag = neg ? 16u - v : v;          // 0..8
+    ge_cached c = ge_to_cached(P);
+    uint32_t* slot = bk + mag * GE_WORDS;
+    ge B = bucket_load(slot);
+    B = ge_add_cached(B, ge_cached_cneg(c, neg));
+    bucket_store(slot, B);
+    int u = naf_next(nu);
+    if (u != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(c, u < 0));
+    // three intermediate positions: only the uniform accumulator may use them
+    int u1 = naf_next(nu), u2 = naf_next(nu), u3 = naf_next(nu);
+    if (step == 63) {                          // positions 253 (u1) is the last possible NAF digit; 254, 255 are zero
+      if (u1 != 0) { P = ge_double_opt(P, true); acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u1 < 0)); }
+      break;
+    }
+    P = ge_double_opt(P, u1 != 0);
+    if (u1 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u1 < 0));
+    P = ge_double_opt(P, u2 != 0);
+    if (u2 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u2 < 0));
+    P = ge_double_opt(P, u3 != 0);
+    if (u3 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u3 < 0));
+    P = ge_double_opt(P, true);                // next step's bucket point needs T
+  }
+  // sum_v v * B_v = running sums: S = B8 + ... + Bv, R accumulates S
+  ge S = bucket_load(bk + 8 * GE_WORDS);
+  ge R = S;
+  for (int vv = 7; vv >= 1; vv--) {
+    S = ge_add_cached(S, ge_to_cached(bucket_load(bk + vv * GE_WORDS)));
+    R = ge_add_cached(R, ge_to_cached(S));
+  }
+  acc_l = R;
+}
+
 }  // namespace act

@@ -105,3 +105,11 @@ extern "C" int hc_chain2u(const uint8_t* pt, const uint8_t* s0, const uint8_t* s
   ristretto_encode(r, al); st(o0, r); ristretto_encode(r, au); st(o1, r);
   return 1;
 }
+extern "C" int hc_chain_bu(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
+  uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
+  ge al = ge_identity(), au = ge_identity();
+  std::vector<uint32_t> bk(BUCKET_WORDS);
+  chain_bu(al, au, p, sc_in(s0), sc_in(s1), bk.data());
+  ristretto_encode(r, al); st(o0, r); ristretto_encode(r, au); st(o1, r);
+  return 1;
+}
