@@ -33,33 +33,37 @@ struct PendingProf { int id; hipEvent_t e0, e1; uint64_t lanes; };
 
 }  // namespace
 
+// One workspace slot: a stream plus every per-chunk device buffer.  Two slots let chunk i+1's kernels (and the
+// host-side hashing of chunk i in host-transcript mode) overlap chunk i's low-occupancy head/tail kernels.
+struct Slot {
+  hipStream_t stream = nullptr;
+  uint8_t *d_tr = nullptr, *d_trs = nullptr, *d_status = nullptr;
+  uint32_t *d_buckets = nullptr, *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr;
+  uint8_t* d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // staging for host-memory callers (grow-only)
+  size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
+  uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
+  uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
+  std::vector<PendingProf> pending;
+  size_t last_spend_lanes = 0;
+};
+
 struct act_ctx {
   int device = 0, L = 128;
   size_t max_batch = 0;
-  hipStream_t stream = nullptr;
   DevParams P{};
   uint8_t henc[96]{};
   int tr_mode = ACT_TRANSCRIPT_HOST;
   int host_threads = 0;
   std::string err;
-  // device workspace (sized for max_batch lanes)
-  uint8_t *d_tr = nullptr, *d_trs = nullptr, *d_status = nullptr;
-  uint32_t *d_buckets = nullptr, *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr;
+  Slot slots[2];
   uint32_t* d_tables = nullptr;
-  // staging for host-memory callers: grow-only device buffers
-  uint8_t* d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
-  // pinned host buffers for the host-transcript mode
-  uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;
-  uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
   // key cache
   uint8_t sk_cached[64]{}; bool sk_valid = false; DevKey key{};
   uint8_t w_cached[32]{}; bool w_valid = false; ge w_pub{};
   // profiling
   bool prof_on = false;
   double prof_ms[PK_COUNT]{}; uint64_t prof_launches[PK_COUNT]{}; uint64_t prof_lanes[PK_COUNT]{};
-  std::vector<PendingProf> pending;
-  size_t last_spend_lanes = 0;
+  int last_spend_slot = 0;
 };
 
 namespace {
@@ -74,52 +78,57 @@ namespace {
   } while (0)
 
 template <class F>
-int prof_launch(act_ctx* c, int id, uint64_t lanes, F&& f) {
+int prof_launch(act_ctx* c, Slot& sl, int id, uint64_t lanes, F&& f) {
   if (!c->prof_on) { f(); return ACT_OK; }
   PendingProf p{id, nullptr, nullptr, lanes};
   HIPCK(c, hipEventCreate(&p.e0)); HIPCK(c, hipEventCreate(&p.e1));
-  HIPCK(c, hipEventRecord(p.e0, c->stream));
+  HIPCK(c, hipEventRecord(p.e0, sl.stream));
   f();
-  HIPCK(c, hipEventRecord(p.e1, c->stream));
-  c->pending.push_back(p);
+  HIPCK(c, hipEventRecord(p.e1, sl.stream));
+  sl.pending.push_back(p);
   return ACT_OK;
 }
-int prof_collect(act_ctx* c) {
-  for (auto& p : c->pending) {
+int prof_collect(act_ctx* c, Slot& sl) {
+  for (auto& p : sl.pending) {
     HIPCK(c, hipEventSynchronize(p.e1));
     float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, p.e0, p.e1));
     c->prof_ms[p.id] += ms; c->prof_launches[p.id]++; c->prof_lanes[p.id] += p.lanes;
     hipEventDestroy(p.e0); hipEventDestroy(p.e1);
   }
-  c->pending.clear();
+  sl.pending.clear();
   return ACT_OK;
 }
 
-int stage_reserve(act_ctx* c, int slot, size_t bytes) {
-  if (bytes <= c->d_stage_cap[slot]) return ACT_OK;
-  if (c->d_stage[slot]) HIPCK(c, hipFree(c->d_stage[slot]));
-  c->d_stage[slot] = nullptr; c->d_stage_cap[slot] = 0;
-  HIPCK(c, hipMalloc(&c->d_stage[slot], bytes));
-  c->d_stage_cap[slot] = bytes;
+int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
+  if (bytes <= sl.d_stage_cap[slot]) return ACT_OK;
+  HIPCK(c, hipStreamSynchronize(sl.stream));
+  if (sl.d_stage[slot]) HIPCK(c, hipFree(sl.d_stage[slot]));
+  sl.d_stage[slot] = nullptr; sl.d_stage_cap[slot] = 0;
+  HIPCK(c, hipMalloc(&sl.d_stage[slot], bytes));
+  sl.d_stage_cap[slot] = bytes;
   return ACT_OK;
 }
 // device view of `bytes` of caller memory: the pointer itself (device memory) or a staged H2D copy
-int dev_in(act_ctx* c, int slot, int mem, const uint8_t* p, size_t bytes, const uint8_t** out) {
+int dev_in(act_ctx* c, Slot& sl, int slot, int mem, const uint8_t* p, size_t bytes, const uint8_t** out) {
   if (mem == ACT_MEM_DEVICE || bytes == 0) { *out = p; return ACT_OK; }
-  int rc = stage_reserve(c, slot, bytes); if (rc) return rc;
-  HIPCK(c, hipMemcpyAsync(c->d_stage[slot], p, bytes, hipMemcpyHostToDevice, c->stream));
-  *out = c->d_stage[slot];
+  int rc = stage_reserve(c, sl, slot, bytes); if (rc) return rc;
+  HIPCK(c, hipMemcpyAsync(sl.d_stage[slot], p, bytes, hipMemcpyHostToDevice, sl.stream));
+  *out = sl.d_stage[slot];
   return ACT_OK;
 }
-int dev_out_begin(act_ctx* c, int slot, int mem, uint8_t* p, size_t bytes, uint8_t** out) {
+int dev_out_begin(act_ctx* c, Slot& sl, int slot, int mem, uint8_t* p, size_t bytes, uint8_t** out) {
   if (mem == ACT_MEM_DEVICE || bytes == 0) { *out = p; return ACT_OK; }
-  int rc = stage_reserve(c, slot, bytes); if (rc) return rc;
-  *out = c->d_stage[slot];
+  int rc = stage_reserve(c, sl, slot, bytes); if (rc) return rc;
+  *out = sl.d_stage[slot];
   return ACT_OK;
 }
-int dev_out_end(act_ctx* c, int mem, uint8_t* host_p, const uint8_t* dev_p, size_t bytes) {
+int dev_out_end(act_ctx* c, Slot& sl, int mem, uint8_t* host_p, const uint8_t* dev_p, size_t bytes) {
   if (mem == ACT_MEM_DEVICE || bytes == 0) return ACT_OK;
-  HIPCK(c, hipMemcpyAsync(host_p, dev_p, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(c, hipMemcpyAsync(host_p, dev_p, bytes, hipMemcpyDeviceToHost, sl.stream));
+  return ACT_OK;
+}
+int copy_status_out(act_ctx* c, Slot& sl, int mem, uint8_t* dst, uint32_t m) {
+  HIPCK(c, hipMemcpyAsync(dst, sl.d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, sl.stream));
   return ACT_OK;
 }
 
@@ -157,67 +166,99 @@ void host_hash_many(const act_ctx* c, const uint8_t* msgs, size_t stride, uint32
 }
 
 // transcript hashing step: device kernel, or D2H -> host threads -> H2D
-int hash_step(act_ctx* c, int prof_id, const uint8_t* d_msgs, uint32_t stride, uint32_t len, uint32_t n) {
+// transcript hashing step, split so that callers can overlap the host part with other slots' GPU work:
+//   hash_begin : device mode -> launch k_hash_xof;  host mode -> enqueue the D2H copy of the pre-images
+//   hash_end   : device mode -> nothing;            host mode -> wait for the copy, hash on host threads, enqueue H2D of the XOF words
+int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_t stride, uint32_t len, uint32_t n) {
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) {
-    HashArgs h{d_msgs, stride, len, n, c->d_xof, nullptr};
-    return prof_launch(c, prof_id, n, [&] { launch_hash(h, c->stream); });
+    HashArgs h{d_msgs, stride, len, n, sl.d_xof, nullptr};
+    return prof_launch(c, sl, prof_id, n, [&] { launch_hash(h, sl.stream); });
   }
   size_t bytes = (size_t)n * stride;
-  if (bytes > c->h_tr_cap) {
-    if (c->h_tr) HIPCK(c, hipHostFree(c->h_tr));
-    c->h_tr = nullptr; c->h_tr_cap = 0;
-    HIPCK(c, hipHostMalloc(&c->h_tr, bytes, hipHostMallocDefault)); c->h_tr_cap = bytes;
+  if (bytes > sl.h_tr_cap) {
+    HIPCK(c, hipStreamSynchronize(sl.stream));
+    if (sl.h_tr) HIPCK(c, hipHostFree(sl.h_tr));
+    sl.h_tr = nullptr; sl.h_tr_cap = 0;
+    HIPCK(c, hipHostMalloc(&sl.h_tr, bytes, hipHostMallocDefault)); sl.h_tr_cap = bytes;
   }
-  if ((size_t)n * 64 > c->h_xof_cap) {
-    if (c->h_xof) HIPCK(c, hipHostFree(c->h_xof));
-    c->h_xof = nullptr; c->h_xof_cap = 0;
-    HIPCK(c, hipHostMalloc(&c->h_xof, (size_t)n * 64, hipHostMallocDefault)); c->h_xof_cap = (size_t)n * 64;
+  if ((size_t)n * 64 > sl.h_xof_cap) {
+    HIPCK(c, hipStreamSynchronize(sl.stream));
+    if (sl.h_xof) HIPCK(c, hipHostFree(sl.h_xof));
+    sl.h_xof = nullptr; sl.h_xof_cap = 0;
+    HIPCK(c, hipHostMalloc(&sl.h_xof, (size_t)n * 64, hipHostMallocDefault)); sl.h_xof_cap = (size_t)n * 64;
   }
-  HIPCK(c, hipMemcpyAsync(c->h_tr, d_msgs, bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(c, hipStreamSynchronize(c->stream));
-  host_hash_many(c, c->h_tr, stride, len, n, c->h_xof);
-  HIPCK(c, hipMemcpyAsync(c->d_xof, c->h_xof, (size_t)n * 64, hipMemcpyHostToDevice, c->stream));
+  HIPCK(c, hipMemcpyAsync(sl.h_tr, d_msgs, bytes, hipMemcpyDeviceToHost, sl.stream));
   return ACT_OK;
 }
+int hash_end(act_ctx* c, Slot& sl, uint32_t stride, uint32_t len, uint32_t n) {
+  if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) return ACT_OK;
+  HIPCK(c, hipStreamSynchronize(sl.stream));
+  host_hash_many(c, sl.h_tr, stride, len, n, sl.h_xof);
+  HIPCK(c, hipMemcpyAsync(sl.d_xof, sl.h_xof, (size_t)n * 64, hipMemcpyHostToDevice, sl.stream));
+  return ACT_OK;
+}
+int hash_step(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_t stride, uint32_t len, uint32_t n) {
+  int rc = hash_begin(c, sl, prof_id, d_msgs, stride, len, n); if (rc) return rc;
+  return hash_end(c, sl, stride, len, n);
+}
 
+// decode one point on the device (public keys): returns ACT_ERR_PARAMS if it is not a canonical encoding
+int decode_one(act_ctx* c, const uint8_t enc[32], ge* out) {
+  Slot& sl = c->slots[0];
+  int rc = stage_reserve(c, sl, 5, 32 + GE_WORDS * 4 + 16); if (rc) return rc;
+  uint8_t* d = sl.d_stage[5];
+  HIPCK(c, hipMemcpyAsync(d, enc, 32, hipMemcpyHostToDevice, sl.stream));
+  launch_decode_points(d, 1, reinterpret_cast<uint32_t*>(d + 32), reinterpret_cast<uint32_t*>(d + 32 + GE_WORDS * 4), sl.stream);
+  uint32_t host[GE_WORDS + 1];
+  HIPCK(c, hipMemcpyAsync(host, d + 32, sizeof(host), hipMemcpyDeviceToHost, sl.stream));
+  HIPCK(c, hipStreamSynchronize(sl.stream));
+  if (!host[GE_WORDS]) { c->err = "public key w is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
+  *out = ge_load(host);
+  return ACT_OK;
+}
 int set_key(act_ctx* c, const uint8_t sk[64]) {
   if (c->sk_valid && memcmp(c->sk_cached, sk, 64) == 0) return ACT_OK;
   uint32_t w[8]; memcpy(w, sk, 32);
   c->key.x = sc_from_words(w);
-  int rc = stage_reserve(c, 5, 32 + GE_WORDS * 4 + 16); if (rc) return rc;
-  uint8_t* d = c->d_stage[5];
-  HIPCK(c, hipMemcpyAsync(d, sk + 32, 32, hipMemcpyHostToDevice, c->stream));
-  launch_decode_points(d, 1, reinterpret_cast<uint32_t*>(d + 32), reinterpret_cast<uint32_t*>(d + 32 + GE_WORDS * 4), c->stream);
-  uint32_t host[GE_WORDS + 1];
-  HIPCK(c, hipMemcpyAsync(host, d + 32, sizeof(host), hipMemcpyDeviceToHost, c->stream));
-  HIPCK(c, hipStreamSynchronize(c->stream));
-  if (!host[GE_WORDS]) { c->err = "public key w is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
-  c->key.w = ge_load(host);
+  int rc = decode_one(c, sk + 32, &c->key.w); if (rc) return rc;
   memcpy(c->sk_cached, sk, 64); c->sk_valid = true;
+  return ACT_OK;
+}
+int set_pubkey(act_ctx* c, const uint8_t w[32]) {
+  if (c->w_valid && memcmp(c->w_cached, w, 32) == 0) return ACT_OK;
+  int rc = decode_one(c, w, &c->w_pub); if (rc) return rc;
+  memcpy(c->w_cached, w, 32); c->w_valid = true;
   return ACT_OK;
 }
 
 int workspace_alloc(act_ctx* c) {
   const SpendTranscript st{c->L};
   size_t B = c->max_batch;
-  HIPCK(c, hipMalloc(&c->d_tr, B * st.stride()));
-  HIPCK(c, hipMalloc(&c->d_coords, B * (size_t)c->L * NIELS_WORDS * 4));
-  HIPCK(c, hipMalloc(&c->d_d01, B * 3 * GE_WORDS * 4));
-  HIPCK(c, hipMalloc(&c->d_buckets, B * (size_t)c->L * BUCKET_WORDS * 4));
-  HIPCK(c, hipMalloc(&c->d_xa, B * GE_WORDS * 4));
-  HIPCK(c, hipMalloc(&c->d_flags, B * 4));
-  HIPCK(c, hipMalloc(&c->d_xof, B * 64));
-  HIPCK(c, hipMalloc(&c->d_status, B));
-  HIPCK(c, hipMalloc(&c->d_trs, B * SMALL_TR_STRIDE));
-  HIPCK(c, hipMalloc(&c->d_state, B * 24 * 4));
-  HIPCK(c, hipMalloc(&c->d_slot, B * 4));
-  HIPCK(c, hipMemsetAsync(c->d_trs, 0, B * SMALL_TR_STRIDE, c->stream));
+  for (Slot& sl : c->slots) {
+    HIPCK(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+    HIPCK(c, hipMalloc(&sl.d_tr, B * st.stride()));
+    HIPCK(c, hipMalloc(&sl.d_coords, B * (size_t)c->L * NIELS_WORDS * 4));
+    HIPCK(c, hipMalloc(&sl.d_d01, B * 3 * GE_WORDS * 4));
+    HIPCK(c, hipMalloc(&sl.d_buckets, B * (size_t)c->L * BUCKET_WORDS * 4));
+    HIPCK(c, hipMalloc(&sl.d_xa, B * GE_WORDS * 4));
+    HIPCK(c, hipMalloc(&sl.d_flags, B * 4));
+    HIPCK(c, hipMalloc(&sl.d_xof, B * 64));
+    HIPCK(c, hipMalloc(&sl.d_status, B));
+    HIPCK(c, hipMalloc(&sl.d_trs, B * SMALL_TR_STRIDE));
+    HIPCK(c, hipMalloc(&sl.d_state, B * 24 * 4));
+    HIPCK(c, hipMalloc(&sl.d_slot, B * 4));
+    HIPCK(c, hipMemsetAsync(sl.d_trs, 0, B * SMALL_TR_STRIDE, sl.stream));
+  }
+  return ACT_OK;
+}
+int sync_all(act_ctx* c) {
+  for (Slot& sl : c->slots) { HIPCK(c, hipStreamSynchronize(sl.stream)); int rc = prof_collect(c, sl); if (rc) return rc; }
   return ACT_OK;
 }
 
-int from_uniform_on_device(int device, const uint8_t* in64, int n, uint8_t* out_enc, std::string* err) {
+int from_uniform_on_device(int device, const uint8_t* in64, int n, uint8_t* out_enc) {
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { if (err) *err = "no HIP device"; return ACT_ERR_NO_DEVICE; }
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
   if (hipSetDevice(device) != hipSuccess) return ACT_ERR_HIP;
   uint8_t* d = nullptr;
   if (hipMalloc(&d, (size_t)n * 96) != hipSuccess) return ACT_ERR_HIP;
@@ -225,8 +266,68 @@ int from_uniform_on_device(int device, const uint8_t* in64, int n, uint8_t* out_
   if (hipMemcpy(d, in64, (size_t)n * 64, hipMemcpyHostToDevice) != hipSuccess) rc = ACT_ERR_HIP;
   if (!rc) { launch_from_uniform(d, (uint32_t)n, d + (size_t)n * 64, nullptr); if (hipDeviceSynchronize() != hipSuccess) rc = ACT_ERR_HIP; }
   if (!rc && hipMemcpy(out_enc, d + (size_t)n * 64, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = ACT_ERR_HIP;
-  hipFree(d);
+  (void)hipFree(d);
   return rc;
+}
+
+// rng slices for the signing phase of issue / refund.  PER_LANE needs no knowledge of the statuses; SEQUENTIAL hands
+// consecutive 128-byte slices to the accepted lanes in lane order, so it must read the chunk's statuses back first.
+int prepare_rng_slots(act_ctx* c, Slot& sl, uint32_t m, size_t off, int mem, const uint8_t* rng, int rng_mode, size_t* seq_cursor,
+                      const uint8_t** d_rng) {
+  std::vector<uint32_t> slot(m);
+  if (rng_mode == ACT_RNG_PER_LANE) {
+    if (mem == ACT_MEM_DEVICE) { for (uint32_t i = 0; i < m; i++) slot[i] = (uint32_t)(off + i); *d_rng = rng; }
+    else { for (uint32_t i = 0; i < m; i++) slot[i] = i; int rc = dev_in(c, sl, 3, mem, rng + off * 128, (size_t)m * 128, d_rng); if (rc) return rc; }
+  } else {
+    std::vector<uint8_t> st(m);
+    HIPCK(c, hipMemcpyAsync(st.data(), sl.d_status, m, hipMemcpyDeviceToHost, sl.stream));
+    HIPCK(c, hipStreamSynchronize(sl.stream));
+    size_t cur = *seq_cursor, base = cur;
+    for (uint32_t i = 0; i < m; i++) { slot[i] = (uint32_t)(mem == ACT_MEM_DEVICE ? cur : cur - base); if (st[i] == 0) cur++; }
+    *seq_cursor = cur;
+    if (mem == ACT_MEM_DEVICE) *d_rng = rng;
+    else if (cur > base) { int rc = dev_in(c, sl, 3, mem, rng + base * 128, (cur - base) * 128, d_rng); if (rc) return rc; }
+    else *d_rng = reinterpret_cast<const uint8_t*>(sl.d_slot);   // no accepted lane reads it
+  }
+  HIPCK(c, hipMemcpyAsync(sl.d_slot, slot.data(), (size_t)m * 4, hipMemcpyHostToDevice, sl.stream));
+  HIPCK(c, hipStreamSynchronize(sl.stream));   // `slot` is a stack-lifetime host buffer
+  return ACT_OK;
+}
+
+int sign_phase(act_ctx* c, Slot& sl, uint32_t m, int label, const uint8_t* d_rng, const uint8_t* d_camount, uint8_t* d_out) {
+  SignArgs s{}; s.P = c->P; s.K = c->key; s.n = m; s.label = label; s.xa = sl.d_xa; s.status = sl.d_status; s.rng_slot = sl.d_slot;
+  s.rng = d_rng; s.c_amount = d_camount; s.trs = sl.d_trs; s.state = sl.d_state; s.xof = sl.d_xof; s.out = d_out;
+  int rc;
+  if ((rc = prof_launch(c, sl, PK_SIGN_A, m, [&] { launch_sign_a(s, sl.stream); }))) return rc;
+  uint32_t len = c->P.prefix_len[label] + 40u * (label == LABEL_RESPOND ? 7u : 6u);
+  if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, len, m))) return rc;
+  return prof_launch(c, sl, PK_SIGN_B, m, [&] { launch_sign_b(s, sl.stream); });
+}
+
+// ---- spend verification, pipelined over two slots ----------------------------------------------------------
+struct SpendChunk { uint32_t m = 0; size_t off = 0; const uint8_t* d_proofs = nullptr; uint8_t* d_kprime = nullptr; uint8_t* d_out = nullptr; SpendArgs a{}; };
+
+// stage 1: everything up to (and including the start of) the transcript hash
+int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
+  const SpendTranscript st{c->L};
+  SpendArgs& a = ch.a;
+  a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = ch.d_proofs; a.n = ch.m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride();
+  a.coords = sl.d_coords; a.d01 = sl.d_d01; a.buckets = sl.d_buckets; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
+  a.kprime_enc = ch.d_kprime;
+  int rc;
+  if ((rc = prof_launch(c, sl, PK_SPEND_PREP, ch.m, [&] { launch_spend_prep(a, sl.stream); }))) return rc;
+  if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)ch.m * c->L, [&] { launch_spend_bits(a, sl.stream); }))) return rc;
+  if ((rc = prof_launch(c, sl, PK_SPEND_TAIL, ch.m, [&] { launch_spend_tail(a, sl.stream); }))) return rc;
+  if ((rc = hash_begin(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), ch.m))) return rc;
+  sl.last_spend_lanes = ch.m;
+  return ACT_OK;
+}
+// stage 2: finish the hash (host mode blocks on this slot only) and set the statuses
+int spend_stage2(act_ctx* c, Slot& sl, SpendChunk& ch) {
+  const SpendTranscript st{c->L};
+  int rc;
+  if ((rc = hash_end(c, sl, (uint32_t)st.stride(), (uint32_t)st.bytes(), ch.m))) return rc;
+  return prof_launch(c, sl, PK_SPEND_FINISH, ch.m, [&] { launch_spend_finish(ch.a, sl.stream); });
 }
 
 }  // namespace
@@ -245,11 +346,11 @@ int act_params_new(int device, const char* org, const char* svc, const char* dep
     uint8_t cb[4] = {(uint8_t)ctr, 0, 0, 0}; put_lp(msg, cb, 4);
     host_xof64(msg, uni + 64 * ctr);
   }
-  return from_uniform_on_device(device, uni, 3, out_h, nullptr);  // src/lib.rs:353
+  return from_uniform_on_device(device, uni, 3, out_h);         // src/lib.rs:353
 }
 int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]) {
   if (!rng || !out_h) return ACT_ERR_ARG;
-  return from_uniform_on_device(device, rng, 3, out_h, nullptr);
+  return from_uniform_on_device(device, rng, 3, out_h);
 }
 
 int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act_ctx** out) {
@@ -259,26 +360,27 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   if (device < 0 || device >= ndev) return ACT_ERR_ARG;
   act_ctx* c = new act_ctx();
   *out = c;
-  c->device = device; c->L = L; c->max_batch = max_batch ? max_batch : 16384;
+  c->device = device; c->L = L; c->max_batch = max_batch ? max_batch : 8192;
   memcpy(c->henc, h, 96);
   HIPCK(c, hipSetDevice(device));
-  HIPCK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  int rc = workspace_alloc(c); if (rc) return rc;
+  hipStream_t s0 = c->slots[0].stream;
   // decode g, h1, h2, h3 and build their fixed-base tables
   uint8_t enc[128]; memcpy(enc, kGeneratorEnc, 32); memcpy(enc + 32, h, 96);
   uint8_t* d_enc = nullptr; uint32_t *d_ext = nullptr, *d_ok = nullptr;
   HIPCK(c, hipMalloc(&d_enc, 128)); HIPCK(c, hipMalloc(&d_ext, 4 * GE_WORDS * 4)); HIPCK(c, hipMalloc(&d_ok, 16));
-  HIPCK(c, hipMemcpyAsync(d_enc, enc, 128, hipMemcpyHostToDevice, c->stream));
-  launch_decode_points(d_enc, 4, d_ext, d_ok, c->stream);
+  HIPCK(c, hipMemcpyAsync(d_enc, enc, 128, hipMemcpyHostToDevice, s0));
+  launch_decode_points(d_enc, 4, d_ext, d_ok, s0);
   uint32_t ok[4];
-  HIPCK(c, hipMemcpyAsync(ok, d_ok, 16, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipMemcpyAsync(ok, d_ok, 16, hipMemcpyDeviceToHost, s0));
+  HIPCK(c, hipStreamSynchronize(s0));
   if (!(ok[0] && ok[1] && ok[2] && ok[3])) { c->err = "h1/h2/h3 is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
   HIPCK(c, hipMalloc(&c->d_tables, (size_t)4 * FB_TABLE_WORDS * 4));
   for (int b = 0; b < 4; b++) {
-    launch_build_table(d_ext + b * GE_WORDS, c->d_tables + (size_t)b * FB_TABLE_WORDS, c->stream);
+    launch_build_table(d_ext + b * GE_WORDS, c->d_tables + (size_t)b * FB_TABLE_WORDS, s0);
     c->P.tab[b] = c->d_tables + (size_t)b * FB_TABLE_WORDS;
   }
-  HIPCK(c, hipStreamSynchronize(c->stream));
+  HIPCK(c, hipStreamSynchronize(s0));
   HIPCK(c, hipFree(d_enc)); HIPCK(c, hipFree(d_ext)); HIPCK(c, hipFree(d_ok));
   // Transcript::new(params, label) prefixes, src/transcript.rs:54-74
   for (int l = 0; l < 4; l++) {
@@ -291,19 +393,22 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
     memcpy(c->P.prefix[l], p.data(), PREFIX_WORDS * 4);
   }
   c->P.L = L;
-  return workspace_alloc(c);
+  return ACT_OK;
 }
 
 void act_ctx_destroy(act_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->d_buckets, c->d_tr, c->d_trs, c->d_status, c->d_coords, c->d_d01, c->d_xa, c->d_flags, c->d_xof, c->d_state, c->d_slot, c->d_tables};
-  for (void* p : ptrs) if (p) hipFree(p);
-  for (int i = 0; i < 6; i++) if (c->d_stage[i]) { hipMemset(c->d_stage[i], 0, c->d_stage_cap[i]); hipFree(c->d_stage[i]); }   // staging may hold secrets
-  if (c->h_tr) hipHostFree(c->h_tr);
-  if (c->h_xof) hipHostFree(c->h_xof);
-  if (c->stream) hipStreamDestroy(c->stream);
+  (void)hipSetDevice(c->device);
+  for (Slot& sl : c->slots) {
+    if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    void* ptrs[] = {sl.d_buckets, sl.d_tr, sl.d_trs, sl.d_status, sl.d_coords, sl.d_d01, sl.d_xa, sl.d_flags, sl.d_xof, sl.d_state, sl.d_slot};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int i = 0; i < 6; i++) if (sl.d_stage[i]) { (void)hipMemset(sl.d_stage[i], 0, sl.d_stage_cap[i]); (void)hipFree(sl.d_stage[i]); }   // staging may hold secrets
+    if (sl.h_tr) (void)hipHostFree(sl.h_tr);
+    if (sl.h_xof) (void)hipHostFree(sl.h_xof);
+    if (sl.stream) (void)hipStreamDestroy(sl.stream);
+  }
+  if (c->d_tables) (void)hipFree(c->d_tables);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
   delete c;
 }
@@ -320,24 +425,26 @@ size_t act_spend_transcript_bytes(const act_ctx* c) { return SpendTranscript{c->
 int act_private_key_random(act_ctx* c, const uint8_t rng[64], uint8_t out_sk[64]) {
   if (!c || !rng || !out_sk) return ACT_ERR_ARG;
   HIPCK(c, hipSetDevice(c->device));
-  int rc = stage_reserve(c, 0, 128); if (rc) return rc;
-  HIPCK(c, hipMemcpyAsync(c->d_stage[0], rng, 64, hipMemcpyHostToDevice, c->stream));
-  launch_keygen(c->P, c->d_stage[0], 1, c->d_stage[0] + 64, c->stream);
-  HIPCK(c, hipMemcpyAsync(out_sk, c->d_stage[0] + 64, 64, hipMemcpyDeviceToHost, c->stream));
-  HIPCK(c, hipStreamSynchronize(c->stream));
+  Slot& sl = c->slots[0];
+  int rc = stage_reserve(c, sl, 0, 128); if (rc) return rc;
+  HIPCK(c, hipMemcpyAsync(sl.d_stage[0], rng, 64, hipMemcpyHostToDevice, sl.stream));
+  launch_keygen(c->P, sl.d_stage[0], 1, sl.d_stage[0] + 64, sl.stream);
+  HIPCK(c, hipMemcpyAsync(out_sk, sl.d_stage[0] + 64, 64, hipMemcpyDeviceToHost, sl.stream));
+  HIPCK(c, hipStreamSynchronize(sl.stream));
   return ACT_OK;
 }
 int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* rng, uint8_t* out_pre) {
   if (!c || (n && (!rng || !out_pre))) return ACT_ERR_ARG;
   HIPCK(c, hipSetDevice(c->device));
+  Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
     const uint8_t* d_rng; uint8_t* d_out; int rc;
-    if ((rc = dev_in(c, 0, mem, rng + off * 128, (size_t)m * 128, &d_rng))) return rc;
-    if ((rc = dev_out_begin(c, 1, mem, out_pre + off * 64, (size_t)m * 64, &d_out))) return rc;
-    launch_pre_issuance_random(d_rng, m, d_out, c->stream);
-    if ((rc = dev_out_end(c, mem, out_pre + off * 64, d_out, (size_t)m * 64))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
+    if ((rc = dev_in(c, sl, 0, mem, rng + off * 128, (size_t)m * 128, &d_rng))) return rc;
+    if ((rc = dev_out_begin(c, sl, 1, mem, out_pre + off * 64, (size_t)m * 64, &d_out))) return rc;
+    launch_pre_issuance_random(d_rng, m, d_out, sl.stream);
+    if ((rc = dev_out_end(c, sl, mem, out_pre + off * 64, d_out, (size_t)m * 64))) return rc;
+    HIPCK(c, hipStreamSynchronize(sl.stream));
   }
   return ACT_OK;
 }
@@ -345,52 +452,20 @@ int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* 
 int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
   if (!c || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
   HIPCK(c, hipSetDevice(c->device));
+  Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    RequestArgs a{}; a.P = c->P; a.n = m; a.trs = c->d_trs; a.xof = c->d_xof; int rc;
-    if ((rc = dev_in(c, 0, mem, pre + off * 64, (size_t)m * 64, &a.pre))) return rc;
-    if ((rc = dev_in(c, 1, mem, rng + off * 128, (size_t)m * 128, &a.rng))) return rc;
-    if ((rc = dev_out_begin(c, 2, mem, out_req + off * 128, (size_t)m * 128, &a.out))) return rc;
-    if ((rc = prof_launch(c, PK_REQUEST_A, m, [&] { launch_request_a(a, c->stream); }))) return rc;
-    if ((rc = hash_step(c, PK_HASH_SMALL, c->d_trs, SMALL_TR_STRIDE, c->P.prefix_len[LABEL_REQUEST] + 80, m))) return rc;
-    if ((rc = prof_launch(c, PK_REQUEST_B, m, [&] { launch_request_b(a, c->stream); }))) return rc;
-    if ((rc = dev_out_end(c, mem, out_req + off * 128, a.out, (size_t)m * 128))) return rc;
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    if ((rc = prof_collect(c))) return rc;
+    RequestArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xof = sl.d_xof; int rc;
+    if ((rc = dev_in(c, sl, 0, mem, pre + off * 64, (size_t)m * 64, &a.pre))) return rc;
+    if ((rc = dev_in(c, sl, 1, mem, rng + off * 128, (size_t)m * 128, &a.rng))) return rc;
+    if ((rc = dev_out_begin(c, sl, 2, mem, out_req + off * 128, (size_t)m * 128, &a.out))) return rc;
+    if ((rc = prof_launch(c, sl, PK_REQUEST_A, m, [&] { launch_request_a(a, sl.stream); }))) return rc;
+    if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, c->P.prefix_len[LABEL_REQUEST] + 80, m))) return rc;
+    if ((rc = prof_launch(c, sl, PK_REQUEST_B, m, [&] { launch_request_b(a, sl.stream); }))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_req + off * 128, a.out, (size_t)m * 128))) return rc;
+    if ((rc = sync_all(c))) return rc;
   }
   return ACT_OK;
-}
-
-// rng slots for the signing phase of issue / refund.  Returns the device rng base through *d_rng.
-static int prepare_rng_slots(act_ctx* c, uint32_t m, size_t off, int mem, const uint8_t* rng, int rng_mode, size_t* seq_cursor,
-                             const uint8_t** d_rng) {
-  std::vector<uint32_t> slot(m);
-  if (rng_mode == ACT_RNG_PER_LANE) {
-    if (mem == ACT_MEM_DEVICE) { for (uint32_t i = 0; i < m; i++) slot[i] = (uint32_t)(off + i); *d_rng = rng; }
-    else { for (uint32_t i = 0; i < m; i++) slot[i] = i; int rc = dev_in(c, 3, mem, rng + off * 128, (size_t)m * 128, d_rng); if (rc) return rc; }
-  } else {
-    std::vector<uint8_t> st(m);
-    HIPCK(c, hipMemcpyAsync(st.data(), c->d_status, m, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    size_t cur = *seq_cursor, base = cur;
-    for (uint32_t i = 0; i < m; i++) { slot[i] = (uint32_t)(mem == ACT_MEM_DEVICE ? cur : cur - base); if (st[i] == 0) cur++; }
-    *seq_cursor = cur;
-    if (mem == ACT_MEM_DEVICE) *d_rng = rng;
-    else { int rc = dev_in(c, 3, mem, rng + base * 128, (cur - base) * 128, d_rng); if (rc) return rc; if (cur == base) *d_rng = c->d_stage[3]; }
-  }
-  HIPCK(c, hipMemcpyAsync(c->d_slot, slot.data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
-  HIPCK(c, hipStreamSynchronize(c->stream));   // `slot` is a stack-lifetime host buffer
-  return ACT_OK;
-}
-
-static int sign_phase(act_ctx* c, uint32_t m, int label, const uint8_t* d_rng, const uint8_t* d_camount, uint8_t* d_out) {
-  SignArgs s{}; s.P = c->P; s.K = c->key; s.n = m; s.label = label; s.xa = c->d_xa; s.status = c->d_status; s.rng_slot = c->d_slot;
-  s.rng = d_rng; s.c_amount = d_camount; s.trs = c->d_trs; s.state = c->d_state; s.xof = c->d_xof; s.out = d_out;
-  int rc;
-  if ((rc = prof_launch(c, PK_SIGN_A, m, [&] { launch_sign_a(s, c->stream); }))) return rc;
-  uint32_t len = c->P.prefix_len[label] + 40u * (label == LABEL_RESPOND ? 7u : 6u);
-  if ((rc = hash_step(c, PK_HASH_SMALL, c->d_trs, SMALL_TR_STRIDE, len, m))) return rc;
-  return prof_launch(c, PK_SIGN_B, m, [&] { launch_sign_b(s, c->stream); });
 }
 
 int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
@@ -399,84 +474,80 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
+  Slot& sl = c->slots[0];
   size_t cursor = 0;
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    IssueArgs a{}; a.P = c->P; a.n = m; a.trs = c->d_trs; a.xa = c->d_xa; a.flags = c->d_flags; a.xof = c->d_xof; a.status = c->d_status;
-    if ((rc = dev_in(c, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
-    if ((rc = dev_in(c, 1, mem, camt + off * 32, (size_t)m * 32, &a.c_amount))) return rc;
+    IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
+    if ((rc = dev_in(c, sl, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
+    if ((rc = dev_in(c, sl, 1, mem, camt + off * 32, (size_t)m * 32, &a.c_amount))) return rc;
     uint8_t* d_out;
-    if ((rc = dev_out_begin(c, 2, mem, out_resp + off * 160, (size_t)m * 160, &d_out))) return rc;
-    if ((rc = prof_launch(c, PK_ISSUE_A, m, [&] { launch_issue_a(a, c->stream); }))) return rc;
-    if ((rc = hash_step(c, PK_HASH_SMALL, c->d_trs, SMALL_TR_STRIDE, c->P.prefix_len[LABEL_REQUEST] + 80, m))) return rc;
-    if ((rc = prof_launch(c, PK_ISSUE_CHECK, m, [&] { launch_issue_check(a, c->stream); }))) return rc;
+    if ((rc = dev_out_begin(c, sl, 2, mem, out_resp + off * 160, (size_t)m * 160, &d_out))) return rc;
+    if ((rc = prof_launch(c, sl, PK_ISSUE_A, m, [&] { launch_issue_a(a, sl.stream); }))) return rc;
+    if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, c->P.prefix_len[LABEL_REQUEST] + 80, m))) return rc;
+    if ((rc = prof_launch(c, sl, PK_ISSUE_CHECK, m, [&] { launch_issue_check(a, sl.stream); }))) return rc;
     const uint8_t* d_rng;
-    if ((rc = prepare_rng_slots(c, m, off, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
-    if ((rc = sign_phase(c, m, LABEL_RESPOND, d_rng, a.c_amount, d_out))) return rc;
-    if ((rc = dev_out_end(c, mem, out_resp + off * 160, d_out, (size_t)m * 160))) return rc;
-    HIPCK(c, hipMemcpyAsync(status + off, c->d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    if ((rc = prof_collect(c))) return rc;
+    if ((rc = prepare_rng_slots(c, sl, m, off, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
+    if ((rc = sign_phase(c, sl, m, LABEL_RESPOND, d_rng, a.c_amount, d_out))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_resp + off * 160, d_out, (size_t)m * 160))) return rc;
+    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
+    if ((rc = sync_all(c))) return rc;
   }
   return ACT_OK;
 }
 
-// spend verification of one chunk; leaves status in d_status and X_A in d_xa
-static int verify_chunk(act_ctx* c, uint32_t m, const uint8_t* d_proofs, uint8_t* d_kprime) {
-  const SpendTranscript st{c->L};
-  SpendArgs a{}; a.P = c->P; a.K = c->key; a.proofs = d_proofs; a.n = m; a.tr = c->d_tr; a.tr_stride = (uint32_t)st.stride();
-  a.coords = c->d_coords; a.d01 = c->d_d01; a.buckets = c->d_buckets; a.xa = c->d_xa; a.flags = c->d_flags; a.xof = c->d_xof; a.status = c->d_status; a.kprime_enc = d_kprime;
-  int rc;
-  if ((rc = prof_launch(c, PK_SPEND_PREP, m, [&] { launch_spend_prep(a, c->stream); }))) return rc;
-  if ((rc = prof_launch(c, PK_SPEND_BITS, (uint64_t)m * c->L, [&] { launch_spend_bits(a, c->stream); }))) return rc;
-  if ((rc = prof_launch(c, PK_SPEND_TAIL, m, [&] { launch_spend_tail(a, c->stream); }))) return rc;
-  if ((rc = hash_step(c, PK_HASH_SPEND, c->d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
-  if ((rc = prof_launch(c, PK_SPEND_FINISH, m, [&] { launch_spend_finish(a, c->stream); }))) return rc;
-  c->last_spend_lanes = m;
-  return ACT_OK;
+// verify (sign == false) or refund (sign == true), two-slot software pipeline: stage 1 of chunk i+1 is enqueued before
+// the host touches chunk i again.
+static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
+                       int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime) {
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = set_key(c, sk); if (rc) return rc;
+  const size_t pb = ProofLayout{c->L}.bytes();
+  const size_t nchunks = (n + c->max_batch - 1) / c->max_batch;
+  SpendChunk chunks[2];
+  size_t cursor = 0;
+  auto stage1 = [&](size_t i) -> int {
+    Slot& sl = c->slots[i & 1]; SpendChunk& ch = chunks[i & 1];
+    ch = SpendChunk{}; ch.off = i * c->max_batch; ch.m = (uint32_t)std::min(c->max_batch, n - ch.off);
+    int r;
+    if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
+    if (out_kprime && (r = dev_out_begin(c, sl, 2, mem, out_kprime + ch.off * 32, (size_t)ch.m * 32, &ch.d_kprime))) return r;
+    if (sign && (r = dev_out_begin(c, sl, 4, mem, out_refund + ch.off * 128, (size_t)ch.m * 128, &ch.d_out))) return r;
+    return spend_stage1(c, sl, ch);
+  };
+  auto stage2 = [&](size_t i) -> int {
+    Slot& sl = c->slots[i & 1]; SpendChunk& ch = chunks[i & 1];
+    int r;
+    if ((r = spend_stage2(c, sl, ch))) return r;
+    if (out_kprime && (r = dev_out_end(c, sl, mem, out_kprime + ch.off * 32, ch.d_kprime, (size_t)ch.m * 32))) return r;
+    if (sign) {
+      const uint8_t* d_rng;
+      if ((r = prepare_rng_slots(c, sl, ch.m, ch.off, mem, rng, rng_mode, &cursor, &d_rng))) return r;
+      if ((r = sign_phase(c, sl, ch.m, LABEL_REFUND, d_rng, nullptr, ch.d_out))) return r;
+      if ((r = dev_out_end(c, sl, mem, out_refund + ch.off * 128, ch.d_out, (size_t)ch.m * 128))) return r;
+    }
+    c->last_spend_slot = (int)(i & 1);
+    return copy_status_out(c, sl, mem, status + ch.off, ch.m);
+  };
+  for (size_t i = 0; i < nchunks; i++) {
+    // slot reuse: chunk i-2's copies out of this slot must have completed before its staging buffers are overwritten
+    if (i >= 2) { HIPCK(c, hipStreamSynchronize(c->slots[i & 1].stream)); }
+    if ((rc = stage1(i))) return rc;
+    if (i >= 1 && (rc = stage2(i - 1))) return rc;
+  }
+  if (nchunks && (rc = stage2(nchunks - 1))) return rc;
+  return sync_all(c);
 }
 
 int act_verify_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!c || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
-  HIPCK(c, hipSetDevice(c->device));
-  int rc = set_key(c, sk); if (rc) return rc;
-  const size_t pb = ProofLayout{c->L}.bytes();
-  for (size_t off = 0; off < n; off += c->max_batch) {
-    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    const uint8_t* d_proofs; uint8_t* d_kp = nullptr;
-    if ((rc = dev_in(c, 0, mem, proof + off * pb, (size_t)m * pb, &d_proofs))) return rc;
-    if (out_kprime && (rc = dev_out_begin(c, 2, mem, out_kprime + off * 32, (size_t)m * 32, &d_kp))) return rc;
-    if ((rc = verify_chunk(c, m, d_proofs, d_kp))) return rc;
-    if (out_kprime && (rc = dev_out_end(c, mem, out_kprime + off * 32, d_kp, (size_t)m * 32))) return rc;
-    HIPCK(c, hipMemcpyAsync(status + off, c->d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    if ((rc = prof_collect(c))) return rc;
-  }
-  return ACT_OK;
+  return spend_batch(c, n, mem, sk, proof, false, nullptr, ACT_RNG_PER_LANE, nullptr, status, out_kprime);
 }
-
 int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
                      uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  HIPCK(c, hipSetDevice(c->device));
-  int rc = set_key(c, sk); if (rc) return rc;
-  const size_t pb = ProofLayout{c->L}.bytes();
-  size_t cursor = 0;
-  for (size_t off = 0; off < n; off += c->max_batch) {
-    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    const uint8_t *d_proofs, *d_rng; uint8_t* d_out;
-    if ((rc = dev_in(c, 0, mem, proof + off * pb, (size_t)m * pb, &d_proofs))) return rc;
-    if ((rc = dev_out_begin(c, 2, mem, out_refund + off * 128, (size_t)m * 128, &d_out))) return rc;
-    if ((rc = verify_chunk(c, m, d_proofs, nullptr))) return rc;
-    if ((rc = prepare_rng_slots(c, m, off, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
-    if ((rc = sign_phase(c, m, LABEL_REFUND, d_rng, nullptr, d_out))) return rc;
-    if ((rc = dev_out_end(c, mem, out_refund + off * 128, d_out, (size_t)m * 128))) return rc;
-    HIPCK(c, hipMemcpyAsync(status + off, c->d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    if ((rc = prof_collect(c))) return rc;
-  }
-  return ACT_OK;
+  return spend_batch(c, n, mem, sk, proof, true, rng, rng_mode, out_refund, status, nullptr);
 }
 
 int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng,
@@ -485,41 +556,27 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
   HIPCK(c, hipSetDevice(c->device));
   const size_t pb = ProofLayout{c->L}.bytes(), rb = act_prove_rng_bytes(c);
   const SpendTranscript st{c->L};
+  Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    ProveArgs a{}; a.P = c->P; a.n = m; a.tr = c->d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = c->d_d01; a.state = c->d_state;
-    a.flags = c->d_flags; a.xof = c->d_xof; a.status = c->d_status;
+    ProveArgs a{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.state = sl.d_state;
+    a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
     int rc;
-    if ((rc = dev_in(c, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
-    if ((rc = dev_in(c, 1, mem, s + off * 32, (size_t)m * 32, &a.s))) return rc;
-    if ((rc = dev_in(c, 3, mem, rng + off * rb, (size_t)m * rb, &a.rng))) return rc;
-    if ((rc = dev_out_begin(c, 2, mem, out_proof + off * pb, (size_t)m * pb, &a.proof))) return rc;
-    if ((rc = dev_out_begin(c, 4, mem, out_prerefund + off * 96, (size_t)m * 96, &a.prerefund))) return rc;
-    if ((rc = prof_launch(c, PK_PROVE_HEAD, m, [&] { launch_prove_head(a, c->stream); }))) return rc;
-    if ((rc = prof_launch(c, PK_PROVE_BITS, (uint64_t)m * c->L, [&] { launch_prove_bits(a, c->stream); }))) return rc;
-    if ((rc = prof_launch(c, PK_PROVE_TAIL, m, [&] { launch_prove_tail(a, c->stream); }))) return rc;
-    if ((rc = hash_step(c, PK_HASH_SPEND, c->d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
-    if ((rc = prof_launch(c, PK_PROVE_RESP, (uint64_t)m * c->L, [&] { launch_prove_resp(a, c->stream); }))) return rc;
-    if ((rc = dev_out_end(c, mem, out_proof + off * pb, a.proof, (size_t)m * pb))) return rc;
-    if ((rc = dev_out_end(c, mem, out_prerefund + off * 96, a.prerefund, (size_t)m * 96))) return rc;
-    HIPCK(c, hipMemcpyAsync(status + off, c->d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    if ((rc = prof_collect(c))) return rc;
+    if ((rc = dev_in(c, sl, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
+    if ((rc = dev_in(c, sl, 1, mem, s + off * 32, (size_t)m * 32, &a.s))) return rc;
+    if ((rc = dev_in(c, sl, 3, mem, rng + off * rb, (size_t)m * rb, &a.rng))) return rc;
+    if ((rc = dev_out_begin(c, sl, 2, mem, out_proof + off * pb, (size_t)m * pb, &a.proof))) return rc;
+    if ((rc = dev_out_begin(c, sl, 4, mem, out_prerefund + off * 96, (size_t)m * 96, &a.prerefund))) return rc;
+    if ((rc = prof_launch(c, sl, PK_PROVE_HEAD, m, [&] { launch_prove_head(a, sl.stream); }))) return rc;
+    if ((rc = prof_launch(c, sl, PK_PROVE_BITS, (uint64_t)m * c->L, [&] { launch_prove_bits(a, sl.stream); }))) return rc;
+    if ((rc = prof_launch(c, sl, PK_PROVE_TAIL, m, [&] { launch_prove_tail(a, sl.stream); }))) return rc;
+    if ((rc = hash_step(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
+    if ((rc = prof_launch(c, sl, PK_PROVE_RESP, (uint64_t)m * c->L, [&] { launch_prove_resp(a, sl.stream); }))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_proof + off * pb, a.proof, (size_t)m * pb))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_prerefund + off * 96, a.prerefund, (size_t)m * 96))) return rc;
+    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
+    if ((rc = sync_all(c))) return rc;
   }
-  return ACT_OK;
-}
-
-static int set_pubkey(act_ctx* c, const uint8_t w[32]) {
-  if (c->w_valid && memcmp(c->w_cached, w, 32) == 0) return ACT_OK;
-  int rc = stage_reserve(c, 5, 32 + GE_WORDS * 4 + 16); if (rc) return rc;
-  uint8_t* d = c->d_stage[5];
-  HIPCK(c, hipMemcpyAsync(d, w, 32, hipMemcpyHostToDevice, c->stream));
-  launch_decode_points(d, 1, reinterpret_cast<uint32_t*>(d + 32), reinterpret_cast<uint32_t*>(d + 32 + GE_WORDS * 4), c->stream);
-  uint32_t host[GE_WORDS + 1];
-  HIPCK(c, hipMemcpyAsync(host, d + 32, sizeof(host), hipMemcpyDeviceToHost, c->stream));
-  HIPCK(c, hipStreamSynchronize(c->stream));
-  if (!host[GE_WORDS]) { c->err = "public key w is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
-  c->w_pub = ge_load(host); memcpy(c->w_cached, w, 32); c->w_valid = true;
   return ACT_OK;
 }
 
@@ -529,27 +586,27 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
   int rc = set_pubkey(c, w); if (rc) return rc;
   const bool issuance = label == LABEL_RESPOND;
   const size_t pre_b = issuance ? 64 : 96, resp_b = issuance ? 160 : 128, pb = ProofLayout{c->L}.bytes();
+  Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = c->d_coords; a.trs = c->d_trs; a.flags = c->d_flags;
-    a.xof = c->d_xof; a.status = c->d_status;
-    if ((rc = dev_in(c, 0, mem, pre + off * pre_b, (size_t)m * pre_b, &a.pre))) return rc;
-    if ((rc = dev_in(c, 1, mem, resp + off * resp_b, (size_t)m * resp_b, &a.resp))) return rc;
-    if (issuance) { if ((rc = dev_in(c, 3, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc; }
-    else { if ((rc = dev_in(c, 3, mem, proofs + off * pb, (size_t)m * pb, &a.proofs))) return rc; }
-    if ((rc = dev_out_begin(c, 2, mem, out_token + off * 160, (size_t)m * 160, &a.out_token))) return rc;
+    ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = sl.d_coords; a.trs = sl.d_trs; a.flags = sl.d_flags;
+    a.xof = sl.d_xof; a.status = sl.d_status;
+    if ((rc = dev_in(c, sl, 0, mem, pre + off * pre_b, (size_t)m * pre_b, &a.pre))) return rc;
+    if ((rc = dev_in(c, sl, 1, mem, resp + off * resp_b, (size_t)m * resp_b, &a.resp))) return rc;
+    if (issuance) { if ((rc = dev_in(c, sl, 3, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc; }
+    else { if ((rc = dev_in(c, sl, 3, mem, proofs + off * pb, (size_t)m * pb, &a.proofs))) return rc; }
+    if ((rc = dev_out_begin(c, sl, 2, mem, out_token + off * 160, (size_t)m * 160, &a.out_token))) return rc;
     if (!issuance) {
-      HIPCK(c, hipMemsetAsync(c->d_flags, 0, (size_t)m * 4, c->stream));
-      if ((rc = prof_launch(c, PK_CLIENT, (uint64_t)m * c->L, [&] { launch_client_decode_com(a, c->stream); }))) return rc;
+      HIPCK(c, hipMemsetAsync(sl.d_flags, 0, (size_t)m * 4, sl.stream));
+      if ((rc = prof_launch(c, sl, PK_CLIENT, (uint64_t)m * c->L, [&] { launch_client_decode_com(a, sl.stream); }))) return rc;
     }
-    if ((rc = prof_launch(c, PK_CLIENT, m, [&] { launch_client_a(a, c->stream); }))) return rc;
+    if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_a(a, sl.stream); }))) return rc;
     uint32_t len = c->P.prefix_len[label] + 40u * (issuance ? 7u : 6u);
-    if ((rc = hash_step(c, PK_HASH_SMALL, c->d_trs, SMALL_TR_STRIDE, len, m))) return rc;
-    if ((rc = prof_launch(c, PK_CLIENT, m, [&] { launch_client_b(a, c->stream); }))) return rc;
-    if ((rc = dev_out_end(c, mem, out_token + off * 160, a.out_token, (size_t)m * 160))) return rc;
-    HIPCK(c, hipMemcpyAsync(status + off, c->d_status, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    if ((rc = prof_collect(c))) return rc;
+    if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, len, m))) return rc;
+    if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_b(a, sl.stream); }))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_token + off * 160, a.out_token, (size_t)m * 160))) return rc;
+    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
+    if ((rc = sync_all(c))) return rc;
   }
   return ACT_OK;
 }
@@ -568,9 +625,10 @@ int act_debug_last_spend_transcripts(act_ctx* c, size_t max_lanes, uint8_t* out,
   if (!c || !out || !n_copied) return ACT_ERR_ARG;
   HIPCK(c, hipSetDevice(c->device));
   const SpendTranscript st{c->L};
-  size_t m = std::min(max_lanes, c->last_spend_lanes);
+  Slot& sl = c->slots[c->last_spend_slot];
+  size_t m = std::min(max_lanes, sl.last_spend_lanes);
   std::vector<uint8_t> tmp(m * st.stride());
-  HIPCK(c, hipMemcpy(tmp.data(), c->d_tr, tmp.size(), hipMemcpyDeviceToHost));
+  HIPCK(c, hipMemcpy(tmp.data(), sl.d_tr, tmp.size(), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < m; i++) memcpy(out + i * st.bytes(), tmp.data() + i * st.stride(), st.bytes());
   *n_copied = m;
   return ACT_OK;

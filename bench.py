@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--distinct", type=int, default=4096)
-    ap.add_argument("--max-batch", type=int, default=32768)
+    ap.add_argument("--max-batch", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
