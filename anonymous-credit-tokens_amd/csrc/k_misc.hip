@@ -4,18 +4,18 @@
 
 namespace act {
 
-// T[pos][e] = e * 256^pos * B as affine Niels (msm.h).  lane = (pos, e): 8*pos doublings of B, an
-// 8-bit double-and-add, one inversion.  Runs once per context (cf. RistrettoBasepointTable::create,
+// T[pos][e] = e * 2^(w*pos) * B as affine Niels (msm.h).  lane = (pos, e): w*pos doublings of B, a
+// w-bit double-and-add, one inversion.  Runs once per context (cf. RistrettoBasepointTable::create,
 // /root/reference/src/lib.rs:311-313).
 __global__ void __launch_bounds__(256) k_build_table(const uint32_t* base_ext, uint32_t* table) {
   uint32_t gid = blockIdx.x * 256 + threadIdx.x;
   if (gid >= (uint32_t)(FB_WINDOWS * FB_ENTRIES)) return;
   uint32_t pos = gid / FB_ENTRIES, e = gid % FB_ENTRIES;
   ge b = ge_load(base_ext);
-  for (uint32_t i = 0; i < 8 * pos; i++) b = ge_double(b);
+  for (uint32_t i = 0; i < (uint32_t)FB_WBITS * pos; i++) b = ge_double(b);
   ge acc = ge_identity();
   ge_cached bc = ge_to_cached(b);
-  for (int bit = 7; bit >= 0; bit--) {
+  for (int bit = FB_WBITS - 1; bit >= 0; bit--) {
     acc = ge_double(acc);
     if ((e >> bit) & 1u) acc = ge_add_cached(acc, bc);
   }
@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_build_table(const uint32_t* base_ext, u
   niels_store(table + (size_t)gid * NIELS_WORDS, niels_from_affine(af));
 }
 void launch_build_table(const uint32_t* base_ext, uint32_t* table, hipStream_t s) {
-  hipLaunchKernelGGL(k_build_table, dim3(FB_WINDOWS * FB_ENTRIES / 256), dim3(256), 0, s, base_ext, table);
+  hipLaunchKernelGGL(k_build_table, dim3((FB_WINDOWS * FB_ENTRIES + 255) / 256), dim3(256), 0, s, base_ext, table);
 }
 
 __global__ void __launch_bounds__(64) k_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok) {

@@ -9,19 +9,24 @@
 //    (/root/reference/src/lib.rs:814-816), A1/A2 share B_bar (:793-797), A*/Y_A share X_A (:849-853).
 //    Every lane of a wavefront executes the same schedule (a digit-0 lane only sits out an add), so
 //    there is no vartime-wNAF divergence to lose on a 64-wide SIMD.
-// 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as 32 mixed
-//    additions, one per scalar byte, from position-specific affine-Niels tables
-//    T[pos][byte] = byte * 256^pos * B resident in L2 (built once per context by k_build_table).
+// 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as 22 mixed
+//    additions, one per scalar window, from position-specific affine-Niels tables
+//    T[pos][d] = d * 2^(w*pos) * B, w = FB_WBITS = 12 (22 windows x 4096 entries x 128 B = 11 MiB per base,
+//    resident in the 256 MiB Infinity Cache; built once per context by k_build_table).
 #pragma once
 #include "ge25519.h"
 
 namespace act {
 
 // ---- fixed-base tables -------------------------------------------------------------------------
-constexpr int FB_WINDOWS = 32;          // one per scalar byte
-constexpr int FB_ENTRIES = 256;
+#ifndef ACT_FB_WBITS
+#define ACT_FB_WBITS 12
+#endif
+constexpr int FB_WBITS = ACT_FB_WBITS;                      // window width in bits
+constexpr int FB_WINDOWS = (253 + FB_WBITS - 1) / FB_WBITS;  // scalars are canonical: < l < 2^253
+constexpr int FB_ENTRIES = 1 << FB_WBITS;
 constexpr int NIELS_WORDS = 32;         // 30 used (ypx, ymx, xy2d), padded to 128 B = one L2 line
-constexpr int FB_TABLE_WORDS = FB_WINDOWS * FB_ENTRIES * NIELS_WORDS;   // 1 MiB per base
+constexpr size_t FB_TABLE_WORDS = (size_t)FB_WINDOWS * FB_ENTRIES * NIELS_WORDS;   // 11 MiB per base at 12 bits
 
 ACT_HD ge_niels niels_load(const uint32_t* p) {
   ge_niels n;
@@ -63,19 +68,25 @@ ACT_HD ge ge_load(const uint32_t* p) {
 }
 constexpr int GE_WORDS = 40;
 
-// acc += s * B using B's table; s canonical (< l).  32 mixed additions.
+// acc += s * B using B's table; s canonical (< l).  FB_WINDOWS mixed additions, no doublings.  The entry of window
+// pos+1 is loaded before the addition of window pos (the tables live in L2 / Infinity Cache: ~550-cycle loads).
+ACT_HD uint32_t fb_next_digit(uint32_t w[8]) {
+  uint32_t digit = w[0] & (uint32_t)(FB_ENTRIES - 1);
+  // shift the scalar down one window (static indices only: a runtime-indexed limb array would live in scratch)
+  for (int i = 0; i < 7; i++) w[i] = (w[i] >> FB_WBITS) | (w[i + 1] << (32 - FB_WBITS));
+  w[7] >>= FB_WBITS;
+  return digit;
+}
 ACT_HD ge fixed_base_acc(ge acc, const uint32_t* table, const sc& s) {
   uint32_t w[8];
   for (int i = 0; i < 8; i++) w[i] = s.v[i];
-  for (int pos = 0; pos < FB_WINDOWS; pos++) {
-    uint32_t byte = w[0] & 0xffu;
-    // shift the scalar down one byte (static indices only: a runtime-indexed limb array would live in scratch)
-    for (int i = 0; i < 7; i++) w[i] = (w[i] >> 8) | (w[i + 1] << 24);
-    w[7] >>= 8;
-    ge_niels n = niels_load(table + ((size_t)pos * FB_ENTRIES + byte) * NIELS_WORDS);
-    acc = ge_madd(acc, n);
+  ge_niels cur = niels_load(table + (size_t)fb_next_digit(w) * NIELS_WORDS);
+  for (int pos = 1; pos < FB_WINDOWS; pos++) {
+    ge_niels nxt = niels_load(table + ((size_t)pos * FB_ENTRIES + fb_next_digit(w)) * NIELS_WORDS);
+    acc = ge_madd(acc, cur);
+    cur = nxt;
   }
-  return acc;
+  return ge_madd(acc, cur);
 }
 
 // ---- shared-doubling variable-base chain ---------------------------------------------------------

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 #define ACT_FE_BOUNDS 1
+#define ACT_FB_WBITS 6   /* host test of the window logic: small tables (43 windows x 64 entries) */
 #include "../../anonymous-credit-tokens_amd/csrc/msm.h"
 #include "../../anonymous-credit-tokens_amd/csrc/blake3_hd.h"
 
@@ -80,7 +81,7 @@ int hc_fixed_base(const uint8_t* pt, const uint8_t* s, uint8_t* o) {
       niels_store(&tab[((size_t)pos * FB_ENTRIES + e) * NIELS_WORDS], niels_from_affine(a));
       acc = ge_add(acc, base);
     }
-    base = acc;   // 256 * base
+    base = acc;   // 2^w * base
   }
   ge acc = fixed_base_acc(ge_identity(), tab.data(), sc_in(s));
   ristretto_encode(r, acc); st(o, r);
