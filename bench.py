@@ -164,6 +164,15 @@ def main():
         proofs_per_launch = bits["lanes"] / max(1, bits["launches"]) / L
         achieved = ALGO_BYTES_PER_VERIFY * proofs_per_launch / launch_s / 1e9 if launch_s else 0.0
         kernel_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
+        # PMC counters cannot be collected inside this process, so the figure is read from profiles/ when its launch size matches
+        traffic = None
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")))
+            if int(t["proofs_per_launch"]) == int(proofs_per_launch):
+                traffic = t["hbm_bytes_per_launch_fetch_x2"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "spend-proof verifies/sec (whole node), batch=2^20", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -173,10 +182,11 @@ def main():
             "config": {"workload": "configs[1] scaled to the metric batch: 2^%d spend-proof verifies per GPU, L=128 (the crate's width), inputs resident in HBM"
                                    % args.batch_log2,
                        "batch_per_gpu": n, "range_bits": L, "lanes_per_launch": args.max_batch, "transcript": "device BLAKE3", "sharding": "independent batches per rank, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "k_spend_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
                          "algorithmic_bytes_per_verify": ALGO_BYTES_PER_VERIFY,
-                         "note": "the path is integer-VALU bound, not HBM bound (DESIGN.md): ~0.6 M field multiplications per verify"},
+                         "concurrent_launches": 2,
+                         "note": "integer-VALU-issue bound, not HBM bound (DESIGN.md 6): ~0.78 M VALU instructions per wavefront-lane; two chunks' launches overlap on two streams, so avg_launch_ms is per overlapped launch; traffic (bytes, PMC) is dominated by the per-lane Pippenger buckets cycling through L2/Infinity Cache"},
             "kernel_ms_per_step": kernel_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
