@@ -359,7 +359,9 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev) return ACT_ERR_ARG;
   act_ctx* c = new act_ctx();
-  *out = c;
+  *out = c;   // returned even on failure so that act_last_error() can be read; the caller destroys it
+  // lanes per launch = max_batch * L must stay below 2^31 (kernels index lanes with 32-bit integers)
+  if (max_batch > ((size_t)1 << 22)) max_batch = (size_t)1 << 22;
   c->device = device; c->L = L; c->max_batch = max_batch ? max_batch : 8192;
   memcpy(c->henc, h, 96);
   HIPCK(c, hipSetDevice(device));
@@ -556,10 +558,14 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
   HIPCK(c, hipSetDevice(c->device));
   const size_t pb = ProofLayout{c->L}.bytes(), rb = act_prove_rng_bytes(c);
   const SpendTranscript st{c->L};
-  Slot& sl = c->slots[0];
-  for (size_t off = 0; off < n; off += c->max_batch) {
-    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    ProveArgs a{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.state = sl.d_state;
+  const size_t nchunks = (n + c->max_batch - 1) / c->max_batch;
+  ProveArgs args[2]; uint32_t ms[2] = {0, 0}; size_t offs[2] = {0, 0};
+  // two-slot pipeline like spend_batch: head/bits/tail + hash start of chunk i+1 are enqueued before chunk i is finished
+  auto stage1 = [&](size_t i) -> int {
+    Slot& sl = c->slots[i & 1]; ProveArgs& a = args[i & 1];
+    size_t off = i * c->max_batch; uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    ms[i & 1] = m; offs[i & 1] = off;
+    a = ProveArgs{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.state = sl.d_state;
     a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
     int rc;
     if ((rc = dev_in(c, sl, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
@@ -570,14 +576,26 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
     if ((rc = prof_launch(c, sl, PK_PROVE_HEAD, m, [&] { launch_prove_head(a, sl.stream); }))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_BITS, (uint64_t)m * c->L, [&] { launch_prove_bits(a, sl.stream); }))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_TAIL, m, [&] { launch_prove_tail(a, sl.stream); }))) return rc;
-    if ((rc = hash_step(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
+    return hash_begin(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m);
+  };
+  auto stage2 = [&](size_t i) -> int {
+    Slot& sl = c->slots[i & 1]; ProveArgs& a = args[i & 1];
+    uint32_t m = ms[i & 1]; size_t off = offs[i & 1];
+    int rc;
+    if ((rc = hash_end(c, sl, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_RESP, (uint64_t)m * c->L, [&] { launch_prove_resp(a, sl.stream); }))) return rc;
     if ((rc = dev_out_end(c, sl, mem, out_proof + off * pb, a.proof, (size_t)m * pb))) return rc;
     if ((rc = dev_out_end(c, sl, mem, out_prerefund + off * 96, a.prerefund, (size_t)m * 96))) return rc;
-    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
-    if ((rc = sync_all(c))) return rc;
+    return copy_status_out(c, sl, mem, status + off, m);
+  };
+  int rc;
+  for (size_t i = 0; i < nchunks; i++) {
+    if (i >= 2) { HIPCK(c, hipStreamSynchronize(c->slots[i & 1].stream)); }
+    if ((rc = stage1(i))) return rc;
+    if (i >= 1 && (rc = stage2(i - 1))) return rc;
   }
-  return ACT_OK;
+  if (nchunks && (rc = stage2(nchunks - 1))) return rc;
+  return sync_all(c);
 }
 
 static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
