@@ -45,6 +45,13 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ActError(f"{LIB_PATH} is missing: build it with act_amd.build() / make -C anonymous-credit-tokens_amd/csrc "
                        "(the HIP engine is the only implementation; there is no CPU fallback)")
+    # PyTorch ships its own libamdhip64; if this library initialises HIP first (binding /opt/rocm's copy) a later
+    # `import torch` in the same process reports "No HIP GPUs are available".  Loading torch's runtime first makes
+    # both use one copy, whichever order the caller imports things in.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, sz, i32, u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
     lib.act_params_new.argtypes = [i32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, u8p]

@@ -14,6 +14,8 @@
 
 using namespace act;
 
+extern "C" void act_host_b3_xof64_x16(const uint8_t* msgs, size_t stride, uint32_t len, uint32_t* xof);   // host_hash.cpp
+
 namespace {
 
 const char* const kLabels[4] = {"request", "respond", "spend", "refund"};
@@ -147,16 +149,18 @@ int n_host_threads(const act_ctx* c) {
   int t = c->host_threads > 0 ? c->host_threads : (int)std::thread::hardware_concurrency();
   return t < 1 ? 1 : t;
 }
-// hash n messages of `len` bytes at `stride` (host memory) into xof[n][16] on host threads
+// hash n messages of `len` bytes at `stride` (host memory) into xof[n][16] on host threads: groups of sixteen through
+// the SIMD routine of host_hash.cpp (one message per 32-bit lane), the remainder through the scalar routine
 void host_hash_many(const act_ctx* c, const uint8_t* msgs, size_t stride, uint32_t len, size_t n, uint32_t* xof) {
-  int nt = (int)std::min<size_t>((size_t)n_host_threads(c), n ? n : 1);
+  int nt = (int)std::min<size_t>((size_t)n_host_threads(c), n ? (n + 63) / 64 : 1);
   std::atomic<size_t> next{0};
   auto work = [&]() {
     for (;;) {
       size_t i0 = next.fetch_add(64);
       if (i0 >= n) break;
-      size_t i1 = std::min(n, i0 + 64);
-      for (size_t i = i0; i < i1; i++) b3_hash_xof64(xof + i * 16, reinterpret_cast<const uint32_t*>(msgs + i * stride), len);
+      size_t i1 = std::min(n, i0 + 64), i = i0;
+      for (; i + 16 <= i1; i += 16) act_host_b3_xof64_x16(msgs + i * stride, stride, len, xof + i * 16);
+      for (; i < i1; i++) b3_hash_xof64(xof + i * 16, reinterpret_cast<const uint32_t*>(msgs + i * stride), len);
     }
   };
   if (nt <= 1) { work(); return; }
@@ -165,7 +169,6 @@ void host_hash_many(const act_ctx* c, const uint8_t* msgs, size_t stride, uint32
   for (auto& t : th) t.join();
 }
 
-// transcript hashing step: device kernel, or D2H -> host threads -> H2D
 // transcript hashing step, split so that callers can overlap the host part with other slots' GPU work:
 //   hash_begin : device mode -> launch k_hash_xof;  host mode -> enqueue the D2H copy of the pre-images
 //   hash_end   : device mode -> nothing;            host mode -> wait for the copy, hash on host threads, enqueue H2D of the XOF words

@@ -56,3 +56,30 @@ def test_product_does_not_link_the_oracle(lib):
             assert "oracle" not in open(os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc", f)).read().lower().replace("oracle-independent", ""), f
     for f in ("capi.py", "api.py", "__init__.py"):
         assert "oracle" not in open(os.path.join(ROOT, "anonymous-credit-tokens_amd", f)).read().lower(), f
+
+
+def test_simd_host_blake3_matches_upstream_vectors(lib):
+    """The 16-lane host hasher of the host-transcript mode (csrc/host_hash.cpp) against the LLVM-BLAKE3 fixtures:
+    sixteen copies of each message, each lane must give the upstream XOF bytes.  Hashing only; no GPU involved."""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "blake3_llvm.json")))
+    lib.act_host_b3_xof64_x16.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+    for v in g["vectors"]:
+        n = v["len"]
+        if n > 200000:
+            continue
+        stride = (n + 64 + 15) & ~15
+        buf = bytearray(stride * 16)
+        for i in range(16):
+            buf[i * stride:i * stride + n] = bytes((j + 0) % 251 for j in range(n))
+        if n:                                  # make lane 5 differ to catch lane mix-ups
+            buf[5 * stride] ^= 0xFF
+        arr = (C.c_uint8 * len(buf)).from_buffer(buf)
+        out = (C.c_uint32 * 256)()
+        lib.act_host_b3_xof64_x16(arr, stride, n, out)
+        raw = bytes(out)
+        for i in range(16):
+            if i == 5 and n:
+                assert raw[64 * i:64 * i + 64].hex() != v["xof"][:128]
+            else:
+                assert raw[64 * i:64 * i + 64].hex() == v["xof"][:128], (n, i)

@@ -180,3 +180,24 @@ def test_device_memory_path_and_full_size_properties(engine_factory, bench_param
         exp[idx[1::2]] = 6
         assert torch.equal(status, exp), n_total
         del dev
+
+
+def test_simd_host_hash_on_this_cpu_matches_scalar_and_device(engine_factory, bench_params):
+    """Host-transcript mode on the GPU box's CPU (AVX-512 / AVX2 clone of csrc/host_hash.cpp) must give the same
+    statuses and refunds as the device-transcript mode on a batch large enough to use the 16-lane groups."""
+    from act_amd import capi
+    eng = engine_factory(bench_params, 128, max_batch=64)
+    sk = eng.private_key_random(shake("sk-simd", 64))
+    n = 83                                    # 5 SIMD groups + 3 scalar leftovers, two chunks
+    pre = eng.pre_issuance_random(shake("pre-simd", 128 * n))
+    req = eng.request(pre, shake("rq-simd", 128 * n))
+    st, resp = eng.issue(sk, req, scb(900) * n, shake("ir-simd", 128 * n))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i) for i in range(n)), shake("pr-simd", eng.prove_rng_bytes * n))
+    bad = bytearray(proofs); bad[eng.proof_bytes * 40 + 33] ^= 1
+    out = {}
+    for mode in (capi.TRANSCRIPT_HOST, capi.TRANSCRIPT_DEVICE):
+        eng.set_transcript_mode(mode)
+        out[mode] = eng.refund(sk, bytes(bad), shake("rr-simd", 128 * n))
+    assert out[capi.TRANSCRIPT_HOST] == out[capi.TRANSCRIPT_DEVICE]
+    assert list(out[0][0]) == [7 if i == 40 else 0 for i in range(n)]
