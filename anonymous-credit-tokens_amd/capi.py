@@ -22,7 +22,10 @@ EXPORTS = [
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_prof_enable",
     "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get",
+    "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch",
 ]
+CBOR_TYPES = {"IssuanceRequest": 1, "IssuanceResponse": 2, "SpendProof": 3, "Refund": 4, "PrivateKey": 5, "PublicKey": 6,
+              "PreIssuance": 7, "CreditToken": 8, "PreRefund": 9}
 
 
 class ActError(RuntimeError):
@@ -76,6 +79,11 @@ def load() -> C.CDLL:
     lib.act_refund_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_refund_to_credit_token_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
     lib.act_debug_last_spend_transcripts.argtypes = [vp, sz, u8p, C.POINTER(sz)]
+    for f in ("act_cbor_size", "act_cbor_record_bytes"):
+        getattr(lib, f).argtypes = [vp, i32]
+        getattr(lib, f).restype = sz
+    lib.act_cbor_encode_batch.argtypes = [vp, i32, sz, i32, u8p, u8p]
+    lib.act_cbor_decode_batch.argtypes = [vp, i32, sz, i32, u8p, vp, u8p, u8p]
     lib.act_prof_enable.argtypes = [vp, i32]
     lib.act_prof_reset.argtypes = [vp]
     lib.act_prof_kernel_count.argtypes = [vp]
@@ -211,6 +219,26 @@ class Engine:
         self._ck(self.lib.act_debug_last_spend_transcripts(self.ctx, max_lanes, out.ctypes.data, C.byref(n)))
         b = out.tobytes()
         return [b[i * self.transcript_bytes:(i + 1) * self.transcript_bytes] for i in range(n.value)]
+
+    # ---- CBOR wire codec (src/cbor.rs) -----------------------------------------------------------------
+    def cbor_size(self, type_name: str) -> int:
+        return self.lib.act_cbor_size(self.ctx, CBOR_TYPES[type_name])
+
+    def cbor_encode(self, type_name: str, records: bytes) -> list:
+        t = CBOR_TYPES[type_name]; rb = self.lib.act_cbor_record_bytes(self.ctx, t); ml = self.lib.act_cbor_size(self.ctx, t)
+        n = len(records) // rb; out = np.zeros(ml * n, np.uint8); p0, k0 = _in(records, rb * n)
+        self._ck(self.lib.act_cbor_encode_batch(self.ctx, t, n, MEM_HOST, p0, out.ctypes.data))
+        b = out.tobytes()
+        return [b[i * ml:(i + 1) * ml] for i in range(n)]
+
+    def cbor_decode(self, type_name: str, messages: list):
+        """messages: list of byte strings (any lengths).  Returns (status bytes, records bytes)."""
+        t = CBOR_TYPES[type_name]; rb = self.lib.act_cbor_record_bytes(self.ctx, t); n = len(messages)
+        offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(m) for m in messages], dtype=np.uint64)
+        blob = b"".join(messages) + b"\0"
+        out = np.zeros(rb * n, np.uint8); st = np.zeros(n, np.uint8); p0, k0 = _in(blob)
+        self._ck(self.lib.act_cbor_decode_batch(self.ctx, t, n, MEM_HOST, p0, offs.ctypes.data, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
 
     # ---- device-memory batch calls (raw device pointers) -----------------------------------------
     def verify_spend_dev(self, sk: bytes, n: int, d_proofs: int, d_status: int, d_kprime: int = 0):

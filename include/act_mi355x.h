@@ -129,6 +129,30 @@ int act_refund_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], cons
 int act_refund_to_credit_token_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *prerefund, const uint8_t *proof,
                                      const uint8_t *refund, const uint8_t w[32], uint8_t *out_token, uint8_t *status);
 
+/* Batch CBOR codec (src/cbor.rs: to_cbor / from_cbor of the nine wire and state types; deterministic RFC 8949
+ * encoding, int-keyed maps, 32-byte byte strings).  `type` selects the struct; records are the raw layouts above.
+ * Encoding writes n canonical messages of act_cbor_size(ctx, type) bytes each, back to back.  Decoding takes n
+ * messages delimited by offsets[0..n] (byte offsets into `cbor`, host memory; NULL = n canonical-size messages back to
+ * back) and accepts whatever ciborium accepts (any well-formed CBOR map; unknown keys ignored; the last duplicate
+ * wins; bytes after the first item ignored).  Scalars come out reduced mod l (decode_scalar, src/cbor.rs:80-91).
+ * status[i]: 0 ok, 1 malformed CBOR (CborError::Ciborium), 2 CborError::InvalidStructure, 3 CborError::InvalidValue
+ * (a point that is not a canonical Ristretto encoding, src/cbor.rs:59-78); the record of a failed message is zero.
+ * Canonical messages are framed / unframed on the GPU (one lane per 32-byte field); others take a host reader. */
+#define ACT_CBOR_ISSUANCE_REQUEST 1
+#define ACT_CBOR_ISSUANCE_RESPONSE 2
+#define ACT_CBOR_SPEND_PROOF 3
+#define ACT_CBOR_REFUND 4
+#define ACT_CBOR_PRIVATE_KEY 5
+#define ACT_CBOR_PUBLIC_KEY 6
+#define ACT_CBOR_PRE_ISSUANCE 7
+#define ACT_CBOR_CREDIT_TOKEN 8
+#define ACT_CBOR_PRE_REFUND 9
+size_t act_cbor_size(const act_ctx *ctx, int type);
+size_t act_cbor_record_bytes(const act_ctx *ctx, int type);
+int act_cbor_encode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8_t *records, uint8_t *out_cbor);
+int act_cbor_decode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8_t *cbor, const uint64_t *offsets,
+                          uint8_t *out_records, uint8_t *status);
+
 /* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
 int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *out, size_t *n_copied);

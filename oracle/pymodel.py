@@ -745,3 +745,200 @@ def parse_spend_proof(rec: bytes, nbits: int = L_DEFAULT) -> SpendProof:
     o += 2 * nbits
     return SpendProof(_sc(f[0]), _sc(f[1]), _pt(f[2]), _pt(f[3]), com, *sc8[:6], sc8[6], sc8[7], gamma0, z,
                       _sc(f[o]), _sc(f[o + 1]))
+
+
+# --------------------------------------------------------------------------------------------
+# CBOR wire codec (restates /root/reference/src/cbor.rs; ciborium 0.2.2 does the RFC 8949 parsing there)
+# --------------------------------------------------------------------------------------------
+# type -> list of (key, kind 'S'/'P', shape 0 single / 1 array[L] / 2 array[L] of pairs); PublicKey is a bare bstr
+CBOR_TYPES = {
+    "IssuanceRequest": [(1, "P", 0), (2, "S", 0), (3, "S", 0), (4, "S", 0)],                       # src/cbor.rs:105-110
+    "IssuanceResponse": [(1, "P", 0), (2, "S", 0), (3, "S", 0), (4, "S", 0), (5, "S", 0)],         # :163-169
+    "SpendProof": [(1, "S", 0), (2, "S", 0), (3, "P", 0), (4, "P", 0), (5, "P", 1), (6, "S", 0), (7, "S", 0), (8, "S", 0), (9, "S", 0),
+                   (10, "S", 0), (11, "S", 0), (12, "S", 0), (13, "S", 0), (14, "S", 1), (15, "S", 2), (16, "S", 0), (17, "S", 0)],  # :250-268
+    "Refund": [(1, "P", 0), (2, "S", 0), (3, "S", 0), (4, "S", 0)],                                 # :422-427
+    "PrivateKey": [(1, "S", 0), (2, "P", 0)],                                                       # :477-480
+    "PublicKey": None,                                                                              # :522-526
+    "PreIssuance": [(1, "S", 0), (2, "S", 0)],                                                      # :546-549
+    "CreditToken": [(1, "P", 0), (2, "S", 0), (3, "S", 0), (4, "S", 0), (5, "S", 0)],               # :596-602
+    "PreRefund": [(1, "S", 0), (2, "S", 0), (3, "S", 0)],                                           # :656-660
+}
+CBOR_OK, CBOR_ERR_PARSE, CBOR_ERR_STRUCTURE, CBOR_ERR_VALUE = 0, 1, 2, 3
+
+
+def _cbor_head(major: int, n: int) -> bytes:
+    if n < 24:
+        return bytes([major << 5 | n])
+    if n < 256:
+        return bytes([major << 5 | 24, n])
+    return bytes([major << 5 | 25, n >> 8, n & 255])
+
+
+def cbor_encode(type_name: str, record: bytes, nbits: int = L_DEFAULT) -> bytes:
+    """to_cbor: deterministic encoding of a raw record."""
+    f = [record[i:i + 32] for i in range(0, len(record), 32)]
+    bstr = lambda b: _cbor_head(2, 32) + b
+    spec = CBOR_TYPES[type_name]
+    if spec is None:
+        return bstr(f[0])
+    out = _cbor_head(5, len(spec))
+    i = 0
+    for key, _kind, shape in spec:
+        out += _cbor_head(0, key)
+        if shape == 0:
+            out += bstr(f[i]); i += 1
+        elif shape == 1:
+            out += _cbor_head(4, nbits) + b"".join(bstr(f[i + j]) for j in range(nbits)); i += nbits
+        else:
+            out += _cbor_head(4, nbits) + b"".join(_cbor_head(4, 2) + bstr(f[i + 2 * j]) + bstr(f[i + 2 * j + 1]) for j in range(nbits)); i += 2 * nbits
+    assert i == len(f)
+    return out
+
+
+class _CborParseError(Exception):
+    pass
+
+
+def _cbor_parse(b: bytes, pos: int, depth: int = 0):
+    """One RFC 8949 data item -> (value, new_pos).  Values: ('int', n) | ('bytes', b) | ('text', b) | ('array', [..]) |
+    ('map', [(k, v)..]) | ('tag', n, v) | ('other',)."""
+    if depth > 256 or pos >= len(b):
+        raise _CborParseError
+    ib = b[pos]; pos += 1
+    major, ai = ib >> 5, ib & 31
+    ind = False
+    if ai < 24:
+        val = ai
+    elif ai == 31:
+        if major in (0, 1, 6):
+            raise _CborParseError
+        ind, val = True, 0
+    elif ai <= 27:
+        ln = 1 << (ai - 24)
+        if pos + ln > len(b):
+            raise _CborParseError
+        val = int.from_bytes(b[pos:pos + ln], "big"); pos += ln
+    else:
+        raise _CborParseError
+    if major == 0:
+        return ("int", val), pos
+    if major == 1:
+        return ("int", -1 - val), pos
+    if major in (2, 3):
+        if not ind:
+            if pos + val > len(b):
+                raise _CborParseError
+            return (("bytes" if major == 2 else "text"), b[pos:pos + val]), pos + val
+        acc = b""
+        while True:
+            if pos >= len(b):
+                raise _CborParseError
+            if b[pos] == 0xFF:
+                return (("bytes" if major == 2 else "text"), acc), pos + 1
+            (kind, chunk), pos = _cbor_parse(b, pos, depth + 1)
+            if kind != ("bytes" if major == 2 else "text"):
+                raise _CborParseError
+            acc += chunk
+    if major in (4, 5):
+        items = []
+        per = 2 if major == 5 else 1
+        if ind:
+            while True:
+                if pos >= len(b):
+                    raise _CborParseError
+                if b[pos] == 0xFF:
+                    pos += 1
+                    break
+                group = []
+                for _ in range(per):
+                    v, pos = _cbor_parse(b, pos, depth + 1); group.append(v)
+                items.append(tuple(group) if per == 2 else group[0])
+        else:
+            if val > len(b) - pos:
+                raise _CborParseError
+            for _ in range(val):
+                group = []
+                for _ in range(per):
+                    v, pos = _cbor_parse(b, pos, depth + 1); group.append(v)
+                items.append(tuple(group) if per == 2 else group[0])
+        return (("map" if major == 5 else "array"), items), pos
+    if major == 6:
+        v, pos = _cbor_parse(b, pos, depth + 1)
+        return ("tag", val, v), pos
+    if ind:
+        raise _CborParseError     # stray break
+    return ("other",), pos
+
+
+def cbor_decode(type_name: str, msg: bytes, nbits: int = L_DEFAULT):
+    """from_cbor -> (status, record).  Status 1 malformed CBOR, 2 InvalidStructure, 3 InvalidValue; record zero on failure.
+    (When a message is broken in more than one way the reference reports the first problem in map order; this model
+    reports structure problems before invalid points.  Either way the message is rejected.)"""
+    spec = CBOR_TYPES[type_name]
+    nf = 1 if spec is None else sum(1 if s == 0 else nbits if s == 1 else 2 * nbits for _, _, s in spec)
+    fail = lambda code: (code, bytes(32 * nf))
+    try:
+        value, _ = _cbor_parse(msg, 0)            # trailing bytes are not read
+    except _CborParseError:
+        return fail(CBOR_ERR_PARSE)
+
+    def b32(v):
+        return v[1] if v[0] == "bytes" and len(v[1]) == 32 else None
+
+    fields = [None] * nf
+    kinds = []
+    if spec is None:
+        kinds = ["P"]
+        x = b32(value)
+        if x is None:
+            return fail(CBOR_ERR_STRUCTURE)
+        fields[0] = x
+    else:
+        if value[0] != "map":
+            return fail(CBOR_ERR_STRUCTURE)
+        first, i = {}, 0
+        for key, kind, shape in spec:
+            first[key] = (i, kind, shape)
+            cnt = 1 if shape == 0 else nbits if shape == 1 else 2 * nbits
+            kinds += [kind] * cnt; i += cnt
+        present = set()
+        for k, v in value[1]:
+            if k[0] != "int" or k[1] not in first:
+                continue
+            i, kind, shape = first[k[1]]
+            if shape == 0:
+                x = b32(v)
+                if x is None:
+                    return fail(CBOR_ERR_STRUCTURE)
+                fields[i] = x; present.add(k[1])
+            else:
+                if v[0] != "array":
+                    continue                       # silently not set (src/cbor.rs:306, :331, :347)
+                elems = []
+                for el in v[1]:
+                    if shape == 1:
+                        x = b32(el)
+                        if x is None:
+                            return fail(CBOR_ERR_STRUCTURE)
+                        elems.append(x)
+                    else:
+                        if el[0] != "array" or len(el[1]) != 2:
+                            return fail(CBOR_ERR_STRUCTURE)
+                        x0, x1 = b32(el[1][0]), b32(el[1][1])
+                        if x0 is None or x1 is None:
+                            return fail(CBOR_ERR_STRUCTURE)
+                        elems += [x0, x1]
+                if len(v[1]) != nbits:
+                    return fail(CBOR_ERR_STRUCTURE)
+                fields[i:i + len(elems)] = elems; present.add(k[1])
+        if len(present) != len(spec):
+            return fail(CBOR_ERR_STRUCTURE)
+    out = b""
+    for kind, x in zip(kinds, fields):
+        if kind == "S":
+            out += sc_bytes(sc_from_bytes_mod_order(x))      # decode_scalar, src/cbor.rs:80-91
+        else:
+            if ristretto_decode(x) is None:                  # decode_point, src/cbor.rs:59-78
+                return fail(CBOR_ERR_VALUE)
+            out += x
+    return CBOR_OK, out
