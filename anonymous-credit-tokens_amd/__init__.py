@@ -5,6 +5,6 @@ types and method names over it.  The HIP library is mandatory: importing `capi.l
 libact_mi355x.so is missing, and every call fails without a GPU — there is no CPU fallback.
 """
 from . import capi  # noqa: F401
-from .capi import Engine, ActError, load, build, LIB_PATH  # noqa: F401
+from .capi import Engine, NullifierSet, ActError, load, build, LIB_PATH  # noqa: F401
 from .api import (Params, PrivateKey, PublicKey, PreIssuance, IssuanceRequest, IssuanceResponse,  # noqa: F401
                   CreditToken, SpendProof, PreRefund, Refund, Error, L)

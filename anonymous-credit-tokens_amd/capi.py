@@ -23,6 +23,8 @@ EXPORTS = [
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_prof_enable",
     "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch",
+    "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
+    "act_nullifier_check_and_insert_batch",
 ]
 CBOR_TYPES = {"IssuanceRequest": 1, "IssuanceResponse": 2, "SpendProof": 3, "Refund": 4, "PrivateKey": 5, "PublicKey": 6,
               "PreIssuance": 7, "CreditToken": 8, "PreRefund": 9}
@@ -84,6 +86,14 @@ def load() -> C.CDLL:
         getattr(lib, f).restype = sz
     lib.act_cbor_encode_batch.argtypes = [vp, i32, sz, i32, u8p, u8p]
     lib.act_cbor_decode_batch.argtypes = [vp, i32, sz, i32, u8p, vp, u8p, u8p]
+    lib.act_nullifier_set_create.argtypes = [i32, sz, u8p, C.POINTER(vp)]
+    lib.act_nullifier_set_destroy.argtypes = [vp]
+    lib.act_nullifier_set_destroy.restype = None
+    lib.act_nullifier_set_len.argtypes = [vp]
+    lib.act_nullifier_set_len.restype = sz
+    lib.act_nullifier_set_last_error.argtypes = [vp]
+    lib.act_nullifier_set_last_error.restype = C.c_char_p
+    lib.act_nullifier_check_and_insert_batch.argtypes = [vp, sz, i32, u8p, sz, u8p, u8p]
     lib.act_prof_enable.argtypes = [vp, i32]
     lib.act_prof_reset.argtypes = [vp]
     lib.act_prof_kernel_count.argtypes = [vp]
@@ -274,3 +284,44 @@ class Engine:
             if la.value:
                 out[self.lib.act_prof_kernel_name(self.ctx, i).decode()] = {"ms": ms.value, "launches": la.value, "lanes": ln.value}
         return out
+
+
+class NullifierSet:
+    """GPU double-spend set with the sequential meaning of the reference tests' NullifierDb (src/tests.rs:29-50)."""
+
+    def __init__(self, capacity: int, device: int = 0, salt: bytes = None):
+        self.lib = load()
+        h = C.c_void_p()
+        p, keep = _in(salt, 16) if salt else (None, None)
+        rc = self.lib.act_nullifier_set_create(device, capacity, p, C.byref(h))
+        if rc:
+            raise ActError(f"act_nullifier_set_create failed: {_ERRS.get(rc, rc)}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.act_nullifier_set_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.lib.act_nullifier_set_len(self.h)
+
+    def _ck(self, rc):
+        if rc:
+            raise ActError(f"{_ERRS.get(rc, rc)}: {self.lib.act_nullifier_set_last_error(self.h).decode()}")
+
+    def check_and_insert(self, nullifiers: bytes, stride: int = 32, skip_mask: bytes = None) -> bytes:
+        n = (len(nullifiers) + stride - 32) // stride if nullifiers else 0
+        out = np.zeros(n, np.uint8)
+        p0, k0 = _in(nullifiers); pm, km = _in(skip_mask, n) if skip_mask is not None else (None, None)
+        self._ck(self.lib.act_nullifier_check_and_insert_batch(self.h, n, MEM_HOST, p0, stride, pm, out.ctypes.data))
+        return out.tobytes()
+
+    def check_and_insert_dev(self, n: int, d_nullifiers: int, stride: int, d_skip_mask: int, d_out_spent: int):
+        self._ck(self.lib.act_nullifier_check_and_insert_batch(self.h, n, MEM_DEVICE, d_nullifiers, stride, d_skip_mask or None, d_out_spent))

@@ -674,3 +674,4 @@ int act_prof_get(act_ctx* c, int i, double* ms_total, uint64_t* launches, uint64
 }  // extern "C"
 
 #include "cbor_impl.inc"
+#include "nullifier_impl.inc"

@@ -153,6 +153,23 @@ int act_cbor_encode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8
 int act_cbor_decode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8_t *cbor, const uint64_t *offsets,
                           uint8_t *out_records, uint8_t *status);
 
+/* Nullifier set: the double-spend database the crate leaves to the caller (src/lib.rs:741-745; `HashSet<Scalar>` with
+ * "is_spent? reject : insert" per spend in src/tests.rs:29-50, examples/act.rs:10-30), as a hash set in one GPU's HBM.
+ * act_nullifier_check_and_insert_batch has the meaning of that loop run over the batch in lane order: out_spent[i] = 1
+ * iff nullifier i is already in the set or equals the nullifier of an earlier lane of this batch; fresh nullifiers are
+ * inserted.  Nullifier i is the 32 bytes at nullifiers + i*stride (stride = act_spend_proof_bytes reads the `k` field
+ * straight out of SpendProof records).  skip_mask (nullable): lanes with a non-zero byte (e.g. the status of a rejected
+ * proof) are neither checked nor inserted and report 0.  capacity = the number of nullifiers the set must hold; `salt`
+ * (nullable, 16 bytes) keys the slot hash.  Multi-GPU deployments shard the key space (owner = hash mod N) — the one
+ * step of this repo that would need an exchange between GPUs. */
+typedef struct act_nullifier_set act_nullifier_set;
+int act_nullifier_set_create(int device, size_t capacity, const uint8_t salt[16], act_nullifier_set **out);
+void act_nullifier_set_destroy(act_nullifier_set *set);
+size_t act_nullifier_set_len(const act_nullifier_set *set);
+const char *act_nullifier_set_last_error(const act_nullifier_set *set);
+int act_nullifier_check_and_insert_batch(act_nullifier_set *set, size_t n, int mem, const uint8_t *nullifiers, size_t stride,
+                                         const uint8_t *skip_mask, uint8_t *out_spent);
+
 /* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
 int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *out, size_t *n_copied);
