@@ -406,6 +406,9 @@ void act_ctx_destroy(act_ctx* c) {
   (void)hipSetDevice(c->device);
   for (Slot& sl : c->slots) {
     if (sl.stream) (void)hipStreamSynchronize(sl.stream);
+    // d_state held the signing nonces (e, alpha) / the prover's r3, r*; d_d01 the prover's k* h2 terms: wipe before freeing
+    if (sl.d_state) (void)hipMemset(sl.d_state, 0, c->max_batch * 24 * 4);
+    if (sl.d_d01) (void)hipMemset(sl.d_d01, 0, c->max_batch * 3 * GE_WORDS * 4);
     void* ptrs[] = {sl.d_buckets, sl.d_tr, sl.d_trs, sl.d_status, sl.d_coords, sl.d_d01, sl.d_xa, sl.d_flags, sl.d_xof, sl.d_state, sl.d_slot};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 6; i++) if (sl.d_stage[i]) { (void)hipMemset(sl.d_stage[i], 0, sl.d_stage_cap[i]); (void)hipFree(sl.d_stage[i]); }   // staging may hold secrets

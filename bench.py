@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=4096)
     ap.add_argument("--max-batch", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # test hooks: exercise the N>1 control path on a box with one GPU (RCCL refuses two ranks on one device)
+    ap.add_argument("--dist-backend", default="nccl")
+    ap.add_argument("--force-device", type=int, default=-1)
     args = ap.parse_args()
 
     import numpy as np
@@ -110,10 +113,15 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
+    if args.force_device >= 0:
+        local = args.force_device
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from act_amd import capi
     n = 1 << args.batch_log2
@@ -151,7 +159,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.prof_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.equal(status, expect), "verification statuses wrong"
@@ -167,6 +175,19 @@ def main():
         # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
         # PMC counters cannot be collected inside this process, so the figure is read from profiles/ when its launch size matches
         traffic = None
+        valu = None
+        try:
+            v = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_valu.json")))
+            # the roofline that actually binds: SIMD issue slots.  A wavefront of k_spend_bits is v instructions at c cycles
+            # each with two waves per SIMD; at the measured clock the chip's 1024 SIMDs cannot exceed this many verifies/s.
+            per_wave, cyc, clk = v["valu_instructions_per_wave"], v["cycles_per_valu_instruction_per_simd_2waves"], v["effective_clock_ghz"] * 1e9
+            waves_per_proof = L / 64.0
+            bound = 1024 * clk / (waves_per_proof * per_wave * cyc)
+            valu = {"valu_instructions_per_wave": per_wave, "cycles_per_instruction": cyc, "clock_ghz": v["effective_clock_ghz"],
+                    "issue_bound_verifies_per_s_per_gpu": bound, "frac_of_issue_bound": (value / world) / bound,
+                    "source": "profiles/r01_c_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE)"}
+        except (OSError, KeyError, ValueError):
+            pass
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")))
             if int(t["proofs_per_launch"]) == int(proofs_per_launch):
@@ -185,7 +206,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "k_spend_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
                          "algorithmic_bytes_per_verify": ALGO_BYTES_PER_VERIFY,
-                         "concurrent_launches": 2,
+                         "concurrent_launches": 2, "valu_issue": valu,
                          "note": "integer-VALU-issue bound, not HBM bound (DESIGN.md 6): ~0.78 M VALU instructions per wavefront-lane; two chunks' launches overlap on two streams, so avg_launch_ms is per overlapped launch; traffic (bytes, PMC) is dominated by the per-lane Pippenger buckets cycling through L2/Infinity Cache"},
             "kernel_ms_per_step": kernel_ms,
         }
