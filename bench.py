@@ -148,6 +148,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()      # the engine runs on its own streams: inputs written by torch must be complete first
     for _ in range(args.warmup):
         step()
     eng.prof_reset(); eng.prof_enable(True)        # HIP events on the engine's own stream (torch events cannot see it)

@@ -42,7 +42,9 @@
  * failed lane is all zero.  Scalar fields are reduced mod l on input (src/cbor.rs:85).
  *
  * Memory: every bulk pointer of one call is either host memory (ACT_MEM_HOST) or memory of the
- * context's GPU (ACT_MEM_DEVICE); `sk` is always host memory.  A context is bound to one GPU,
+ * context's GPU (ACT_MEM_DEVICE); `sk` is always host memory.  The engine works on its own HIP streams:
+ * device-memory inputs must be complete (the producing stream synchronised) before a call, and outputs are
+ * complete when the call returns.  A context is bound to one GPU,
  * owns its streams and workspace, and may be used by one host thread at a time; contexts on
  * different GPUs run concurrently (batches shard across GPUs with no collective).
  * There is no CPU fallback: without a HIP device every entry point fails.

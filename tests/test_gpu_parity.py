@@ -173,6 +173,7 @@ def test_device_memory_path_and_full_size_properties(engine_factory, bench_param
         dev[idx[0::2], 32] ^= 1
         dev[idx[1::2], 64:96] = 0
         status = torch.full((n_total,), 99, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()          # the engine uses its own streams: torch's writes must have landed
         eng.verify_spend_dev(sk, n_total, dev.data_ptr(), status.data_ptr())
         torch.cuda.synchronize()
         exp = torch.zeros(n_total, dtype=torch.uint8, device="cuda")

@@ -76,6 +76,7 @@ def test_million_keys_on_device():
     keys[n // 2:] = keys[: n // 2]                   # second half repeats the first half
     spent = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
     ns = capi.NullifierSet(capacity=2 * n)
+    torch.cuda.synchronize()                         # inputs written on torch's stream must be complete before the call
     ns.check_and_insert_dev(n, keys.data_ptr(), 32, 0, spent.data_ptr())
     torch.cuda.synchronize()
     assert int(spent[: n // 2].sum()) == 0 and int(spent[n // 2:].sum()) == n // 2 and len(ns) == n // 2

@@ -18,6 +18,7 @@ def dev_bytes(b, rows):
 
 
 def timed(fn, reps=2):
+    torch.cuda.synchronize()          # inputs produced on torch's stream must be complete: the engine uses its own streams
     fn(); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(reps):
@@ -31,6 +32,7 @@ def main():
     ap.add_argument("--prove-log2", type=int, default=18)
     ap.add_argument("--issue-log2", type=int, default=19)
     ap.add_argument("--refund-log2", type=int, default=18)
+    ap.add_argument("--lifecycle-log2", type=int, default=18)
     ap.add_argument("--max-batch", type=int, default=16384)
     a = ap.parse_args()
     out = {}
@@ -65,6 +67,7 @@ def main():
         out["config3_prove_spend_L128_2^%d" % a.prove_log2] = {"proofs_per_s": n / dt, "ms": 1e3 * dt}
         # the fresh proofs verify
         nv = min(n, 1 << 16); status = torch.zeros(nv, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         eng.verify_spend_dev(sk, nv, d_proof.data_ptr(), status.data_ptr()); torch.cuda.synchronize()
         assert int((status == 0).sum()) == nv, "GPU-made proofs must verify"
         del d_rng, d_tok, d_s
@@ -86,6 +89,57 @@ def main():
         d_pre = dev_bytes(pre, D).repeat(n // D, 1).contiguous(); d_out = torch.empty((n, 128), dtype=torch.uint8, device="cuda")
         dt = timed(lambda: eng.request_dev(n, d_pre.data_ptr(), d_ir.data_ptr(), d_out.data_ptr()), 2)
         out["request_2^%d" % a.issue_log2] = {"requests_per_s": n / dt, "ms": 1e3 * dt}
+        del d_req, d_c, d_ir, d_resp, d_pre, d_out
+        print("configs 2-4 done", out, file=sys.stderr, flush=True)
+        # config 5: full lifecycles request -> issue -> token -> prove_spend -> refund -> token, everything resident in HBM,
+        # streamed in chunks of 2^16 lanes (device RNG bytes stand in for the callers' generators)
+        nl, chunk = 1 << a.lifecycle_log2, 1 << 16
+        w = sk[32:]
+        u8 = lambda *shape: torch.empty(shape, dtype=torch.uint8, device="cuda")
+        rnd = lambda *shape: torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda")
+        b = {k: u8(chunk, v) for k, v in dict(pre=64, req=128, resp=160, tok=160, proof=pb, prer=96, rf=128, tok2=160).items()}
+        stt = u8(chunk); d_c = dev_bytes(b"".join(scb(c) for c in cs), D).repeat(chunk // D, 1).contiguous()
+        d_s = dev_bytes(b"".join(scb(s) for s in ss), D).repeat(chunk // D, 1).contiguous()
+        r_pre, r_rq, r_ir, r_pr, r_rr = rnd(chunk, 128), rnd(chunk, 128), rnd(chunk, 128), rnd(chunk, eng.prove_rng_bytes), rnd(chunk, 128)
+        lib, ctx = eng.lib, eng.ctx
+        import ctypes as C
+        wbuf = (C.c_uint8 * 32).from_buffer_copy(w); skbuf = (C.c_uint8 * 64).from_buffer_copy(sk)
+        def lifecycle_chunk():
+            ck = eng._ck
+            ck(lib.act_pre_issuance_random_batch(ctx, chunk, 1, r_pre.data_ptr(), b["pre"].data_ptr()))
+            ck(lib.act_request_batch(ctx, chunk, 1, b["pre"].data_ptr(), r_rq.data_ptr(), b["req"].data_ptr()))
+            ck(lib.act_issue_batch(ctx, chunk, 1, skbuf, b["req"].data_ptr(), d_c.data_ptr(), r_ir.data_ptr(), 0, b["resp"].data_ptr(), stt.data_ptr()))
+            ck(lib.act_issuance_to_credit_token_batch(ctx, chunk, 1, b["pre"].data_ptr(), wbuf, b["req"].data_ptr(), b["resp"].data_ptr(), b["tok"].data_ptr(), stt.data_ptr()))
+            ck(lib.act_prove_spend_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), r_pr.data_ptr(), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr()))
+            ck(lib.act_refund_batch(ctx, chunk, 1, skbuf, b["proof"].data_ptr(), r_rr.data_ptr(), 0, b["rf"].data_ptr(), stt.data_ptr()))
+            ck(lib.act_refund_to_credit_token_batch(ctx, chunk, 1, b["prer"].data_ptr(), b["proof"].data_ptr(), b["rf"].data_ptr(), wbuf, b["tok2"].data_ptr(), stt.data_ptr()))
+        torch.cuda.synchronize(); lifecycle_chunk(); torch.cuda.synchronize()
+        assert int((stt == 0).sum()) == chunk, "every lifecycle must close"
+        t = time.perf_counter()
+        for _ in range(nl // chunk):
+            lifecycle_chunk()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        print("lifecycle done", file=sys.stderr, flush=True)
+        out["config5_lifecycles_L128_2^%d" % a.lifecycle_log2] = {"lifecycles_per_s": nl / dt, "ms": 1e3 * dt}
+        # wire codec and nullifier set
+        nc = 1 << 15
+        recs = np.frombuffer(proofs, np.uint8).reshape(D, pb)
+        host_recs = np.tile(recs, (nc // D, 1)).tobytes()
+        t = time.perf_counter(); enc = eng.cbor_encode("SpendProof", host_recs); dt_e = time.perf_counter() - t
+        t = time.perf_counter(); st_c, back = eng.cbor_decode("SpendProof", enc); dt_d = time.perf_counter() - t
+        assert st_c == bytes(nc) and back == host_recs
+        print("cbor done", file=sys.stderr, flush=True)
+        out["cbor_spend_proof_2^15_host_memory"] = {"encode_msgs_per_s": nc / dt_e, "decode_msgs_per_s": nc / dt_d, "wire_bytes": len(enc[0])}
+        nn = 1 << 22
+        keys = torch.randint(0, 256, (nn, 32), dtype=torch.uint8, device="cuda"); spent = torch.zeros(nn, dtype=torch.uint8, device="cuda")
+        ns = capi.NullifierSet(capacity=4 * nn)
+        torch.cuda.synchronize()
+        ns.check_and_insert_dev(nn, keys.data_ptr(), 32, 0, spent.data_ptr()); torch.cuda.synchronize()
+        keys2 = torch.randint(0, 256, (nn, 32), dtype=torch.uint8, device="cuda"); keys2[::2] = keys[::2]
+        torch.cuda.synchronize()
+        t = time.perf_counter(); ns.check_and_insert_dev(nn, keys2.data_ptr(), 32, 0, spent.data_ptr()); torch.cuda.synchronize(); dt = time.perf_counter() - t
+        assert int(spent.sum()) == nn // 2
+        out["nullifier_set_check_insert_2^22"] = {"nullifiers_per_s": nn / dt, "ms": 1e3 * dt}
     print(json.dumps(out))
 
 

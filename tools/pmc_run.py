@@ -17,6 +17,7 @@ st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
 st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i % 90) for i in range(D)), sh("pr", eng.prove_rng_bytes * D))
 dev = torch.from_numpy(np.frombuffer(proofs, np.uint8).copy().reshape(D, -1)).cuda().repeat(NB // D, 1).contiguous()
 status = torch.zeros(NB, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
 for _ in range(int(os.environ.get("REPS", "2"))):
     eng.verify_spend_dev(sk, NB, dev.data_ptr(), status.data_ptr())
 torch.cuda.synchronize()

@@ -25,6 +25,7 @@ host = np.frombuffer(proofs, np.uint8)
 dev = torch.from_numpy(np.tile(host, NB // D)).cuda()
 status = torch.zeros(NB, dtype=torch.uint8, device="cuda")
 eng = capi.Engine(hp, L, max_batch=MB, transcript=capi.TRANSCRIPT_DEVICE)
+torch.cuda.synchronize()
 eng.prof_enable(True)
 for mode, name in ((capi.TRANSCRIPT_DEVICE, "device-transcript"), (capi.TRANSCRIPT_HOST, "host-transcript")):
     eng.set_transcript_mode(mode)
