@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libact_mi355x.so")
+LIB_PATH = os.environ.get("ACT_LIB_PATH") or os.path.join(_HERE, "libact_mi355x.so")   # override: tuning A/B runs only
 
 MEM_HOST, MEM_DEVICE = 0, 1
 RNG_PER_LANE, RNG_SEQUENTIAL = 0, 1

@@ -71,9 +71,12 @@ __global__ void __launch_bounds__(64, 2) k_spend_prep(SpendArgs a) {
   a.flags[p] = flags;     // bits kernel ORs its decode failures in afterwards (same stream)
 }
 
-__global__ void __launch_bounds__(256, 2) k_spend_bits(SpendArgs a) {
+#ifndef ACT_BITS_BLOCK
+#define ACT_BITS_BLOCK 256
+#endif
+__global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
   const int L = a.P.L;
-  uint32_t gid = blockIdx.x * 256 + threadIdx.x;
+  uint32_t gid = blockIdx.x * ACT_BITS_BLOCK + threadIdx.x;
   uint32_t p = gid / (uint32_t)L, j = gid % (uint32_t)L;
   if (p >= a.n) return;
   const ProofLayout pl{L};
@@ -165,7 +168,7 @@ void launch_spend_prep(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKe
 void launch_spend_bits(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t lanes = (size_t)a.n * a.P.L;
-  hipLaunchKernelGGL(k_spend_bits, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_spend_bits, dim3((unsigned)((lanes + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK)), dim3(ACT_BITS_BLOCK), 0, s, a);
 }
 void launch_spend_tail(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
 void launch_spend_finish(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_finish, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
