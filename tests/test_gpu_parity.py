@@ -110,6 +110,9 @@ def test_random_batches_against_oracle(engine_factory, oracle, bench_params, L, 
     t[pb * 10 + 32 * (12 + L) + 5] ^= 1             # gamma0[0]
     t[pb * 11 + 32 * (13 + 4 * L)] ^= 1             # s_bar
     t[pb * 12 + 96 + 1] ^= 0x20                     # B_bar
+    t[pb * 13 + 32 * (4 + 2):pb * 13 + 32 * (4 + 3)] = bytes(32)      # Com_2 = identity: a valid point, the proof is just wrong
+    t[pb * 14 + 96:pb * 14 + 128] = bytes(32)                         # B_bar = identity (the reference only checks A')
+    t[pb * 15 + 32 * (12 + 2 * L):pb * 15 + 32 * (13 + 2 * L)] = b"\xff" * 32   # z[0][0] not canonical: reduced mod l on input
     t = bytes(t)
     rrng = shake("rr-%d" % L, 128 * N)
     st_o = octx.verify_spend_batch(sk, t, 8)

@@ -97,8 +97,9 @@ def test_group_and_msm_shapes(hostcheck):
         for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu"):      # radix-4 / radix-4, radix-4 / NAF, buckets / NAF
             ok, o0, o1 = call(hc, fn, e, m.sc_bytes(s), m.sc_bytes(m.ELL - 1 - s), nout=2)
             assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, s)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, m.ELL - 1 - s)), (fn, s)
-    ok, o0, o1 = call(hc, "hc_chain2", bytes(32), m.sc_bytes(5), m.sc_bytes(7), nout=2)   # identity base
-    assert o0 == bytes(32) and o1 == bytes(32)
+    for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu"):                                     # identity base
+        ok, o0, o1 = call(hc, fn, bytes(32), m.sc_bytes(5), m.sc_bytes(m.ELL - 7), nout=2)
+        assert o0 == bytes(32) and o1 == bytes(32), fn
 
 
 def test_limb_bounds_hold(hostcheck):
