@@ -103,7 +103,8 @@ __global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
   acc_u = fixed_base_acc(acc_u, a.P.tab[BASE_H1], g1);
   if (j == 0) acc_u = ge_add(acc_u, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));      // + w01 h2 (:808)
   ge acc_l = ge_identity();
-  chain_bu(acc_l, acc_u, ge_neg(C), g0, gamma, a.buckets + (size_t)gid * BUCKET_WORDS);
+  __shared__ uint32_t u_lds[(ACT_BITS_BLOCK / 64) * 2 * GE_LDS_WORDS_PER_WAVE];            // 20 KiB per wavefront
+  chain_bu(acc_l, acc_u, ge_neg(C), g0, gamma, a.buckets + (size_t)gid * BUCKET_WORDS, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
   ge f0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
   if (j == 0) f0 = ge_add(f0, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));                        // + w00 h2 (:806)
   ge_cached dl = ge_to_cached(acc_l);

@@ -156,6 +156,22 @@ ACT_HD int naf_next(naf_state& n) {
   n.w[8] >>= 1;
   return d;
 }
+// width-3 NAF (digits 0, +-1, +-3; a nonzero digit is followed by at least two zeros, density 1/4): k odd -> d = k mods 8
+ACT_HD int naf3_next(naf_state& n) {
+  int d = 0;
+  if (n.w[0] & 1u) {
+    const uint32_t m = n.w[0] & 7u;
+    d = m < 4u ? (int)m : (int)m - 8;
+    n.w[0] &= ~7u;                       // k -= m
+    if (d < 0) {                         // ... += 8
+      uint64_t c = 8;
+      for (int i = 0; i < 9; i++) { c += n.w[i]; n.w[i] = (uint32_t)c; c >>= 32; }
+    }
+  }
+  for (int i = 0; i < 8; i++) n.w[i] = (n.w[i] >> 1) | (n.w[i + 1] << 31);
+  n.w[8] >>= 1;
+  return d;
+}
 ACT_HD void chain2u(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& s_u) {
   uint32_t w[8], carry = 0;
   for (int i = 0; i < 8; i++) w[i] = s_l.v[i];
@@ -213,12 +229,56 @@ ACT_HD void bucket_store(uint32_t* p, const ge& g) {
 #endif
 }
 // `bk`: this lane's BUCKET_WORDS words.  Returns s_l * N in acc_l (overwritten), adds s_u * N to acc_u.
-ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& s_u, uint32_t* bk) {
+constexpr int GE_LDS_WORDS_PER_WAVE = 10 * 64 * 4;   // one extended point per lane of a wavefront
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// home of an extended point in LDS: [piece][lane][4 words], so the ds_read/write_b128 are conflict-free
+__device__ __forceinline__ void ge_to_lds(uint32_t* lds_wave, const ge& g) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t w[40];
+  for (int i = 0; i < 10; i++) { w[i] = g.X.v[i]; w[10 + i] = g.Y.v[i]; w[20 + i] = g.Z.v[i]; w[30 + i] = g.T.v[i]; }
+  for (int k = 0; k < 10; k++)
+    *reinterpret_cast<uint4*>(lds_wave + (k * 64 + lane) * 4) = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+__device__ __forceinline__ ge ge_from_lds(const uint32_t* lds_wave) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t w[40];
+  for (int k = 0; k < 10; k++) {
+    const uint4 q = *reinterpret_cast<const uint4*>(lds_wave + (k * 64 + lane) * 4);
+    w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
+  }
+  ge g;
+  for (int i = 0; i < 10; i++) { g.X.v[i] = w[i]; g.Y.v[i] = w[10 + i]; g.Z.v[i] = w[20 + i]; g.T.v[i] = w[30 + i]; }
+  return g;
+}
+#endif
+
+// `bk`: this lane's BUCKET_WORDS words.  Returns s_l * N in acc_l (overwritten), adds s_u * N to acc_u.
+// `lds_wave` (device): 2 * GE_LDS_WORDS_PER_WAVE words of LDS owned by the calling wavefront; unused on the host.
+// The wave-uniform scalar is recoded in width-3 NAF with two accumulators, U1 for digits +-1 and U3 for digits +-3
+// (acc_u += U1 + U3 + 2*U3 at the end: ~63 + 3 additions instead of ~84 with plain NAF).  On the device both live in
+// LDS between their additions -- one addition site per position, its operand picked by address -- which also takes
+// the 40 accumulator registers out of the loop's live set.
+ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& s_u, uint32_t* bk, uint32_t* lds_wave = nullptr) {
   const ge id = ge_identity();
   for (int b = 0; b < BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);
   uint32_t w[8], carry = 0;
   for (int i = 0; i < 8; i++) w[i] = s_l.v[i];
   naf_state nu = naf_init(s_u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  ge_to_lds(lds_wave, id);
+  ge_to_lds(lds_wave + GE_LDS_WORDS_PER_WAVE, id);
+  auto add_u = [&](const ge_cached& q, int d) {
+    uint32_t* home = lds_wave + ((d == 3 || d == -3) ? GE_LDS_WORDS_PER_WAVE : 0);
+    ge_to_lds(home, ge_add_cached(ge_from_lds(home), ge_cached_cneg(q, d < 0)));
+  };
+#else
+  ge U[2] = {id, id};
+  auto add_u = [&](const ge_cached& q, int d) {
+    ge& t = U[(d == 3 || d == -3) ? 1 : 0];
+    t = ge_add_cached(t, ge_cached_cneg(q, d < 0));
+  };
+#endif
   ge P = N;                                    // position 0, T valid
   for (int step = 0; step < 64; step++) {
     // per-lane signed radix-16 digit
@@ -233,21 +293,31 @@ ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc&
     ge B = bucket_load(slot);
     B = ge_add_cached(B, ge_cached_cneg(c, neg));
     bucket_store(slot, B);
-    int u = naf_next(nu);
-    if (u != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(c, u < 0));
-    // three intermediate positions: only the uniform accumulator may use them
-    int u1 = naf_next(nu), u2 = naf_next(nu), u3 = naf_next(nu);
-    if (step == 63) {                          // positions 253 (u1) is the last possible NAF digit; 254, 255 are zero
-      if (u1 != 0) { P = ge_double_opt(P, true); acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u1 < 0)); }
+    int u = naf3_next(nu);
+    if (u != 0) add_u(c, u);
+    // three intermediate positions: only the uniform accumulators may use them
+    int u1 = naf3_next(nu), u2 = naf3_next(nu), u3 = naf3_next(nu);
+    if (step == 63) {                          // position 253 (u1) is the last possible digit of a scalar < 2^253; 254, 255 are zero
+      if (u1 != 0) { P = ge_double_opt(P, true); add_u(ge_to_cached(P), u1); }
       break;
     }
     P = ge_double_opt(P, u1 != 0);
-    if (u1 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u1 < 0));
+    if (u1 != 0) add_u(ge_to_cached(P), u1);
     P = ge_double_opt(P, u2 != 0);
-    if (u2 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u2 < 0));
+    if (u2 != 0) add_u(ge_to_cached(P), u2);
     P = ge_double_opt(P, u3 != 0);
-    if (u3 != 0) acc_u = ge_add_cached(acc_u, ge_cached_cneg(ge_to_cached(P), u3 < 0));
+    if (u3 != 0) add_u(ge_to_cached(P), u3);
     P = ge_double_opt(P, true);                // next step's bucket point needs T
+  }
+  {                                            // acc_u += U1 + 3 * U3
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ge U1 = ge_from_lds(lds_wave), U3 = ge_from_lds(lds_wave + GE_LDS_WORDS_PER_WAVE);
+#else
+    const ge U1 = U[0], U3 = U[1];
+#endif
+    acc_u = ge_add_cached(acc_u, ge_to_cached(U1));
+    acc_u = ge_add_cached(acc_u, ge_to_cached(U3));
+    acc_u = ge_add_cached(acc_u, ge_to_cached(ge_double_opt(U3, true)));
   }
   // sum_v v * B_v = running sums: S = B8 + ... + Bv, R accumulates S
   ge S = bucket_load(bk + 8 * GE_WORDS);
