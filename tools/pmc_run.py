@@ -7,7 +7,7 @@ from act_amd import capi
 sh = lambda l, n: hashlib.shake_256(l.encode()).digest(n)
 ELL = 2**252 + 27742317777372353535851937790883648493
 scb = lambda v: (v % ELL).to_bytes(32, "little")
-L = 128; NB = int(os.environ.get("NB", "16384")); D = 256
+L = 128; NB = int(os.environ.get("NB", "65536")); D = 256
 h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
 eng = capi.Engine(h, L, max_batch=NB, transcript=capi.TRANSCRIPT_DEVICE)
 sk = eng.private_key_random(sh("sk", 64))
