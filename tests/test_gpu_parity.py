@@ -2,7 +2,7 @@
 against the C oracle on the same seeded inputs.  Bit-exact (integer / byte work): every record, every status."""
 import pytest
 
-from conftest import load_golden, shake, scb
+from conftest import ELL, load_golden, shake, scb
 
 pytestmark = pytest.mark.gpu
 
@@ -136,6 +136,43 @@ def test_random_batches_against_oracle(engine_factory, oracle, bench_params, L, 
     for i in range(N):
         so, to = octx.refund_to_credit_token(prer[96 * i:96 * i + 96], proofs[pb * i:pb * i + pb], rf[128 * i:128 * i + 128], sk[32:])
         assert so == st_c[i] and to == tok2[160 * i:160 * i + 160]
+
+
+@pytest.mark.parametrize("L", [128, 64])
+def test_crafted_scalars_reproduce_the_oracle_transcript(engine_factory, oracle, bench_params, L):
+    """Recoding corner cases on the device: gamma (wave-uniform width-3 NAF) and gamma0_j / z_j* (per-lane radix-16 buckets,
+    fixed-base windows) set to runs of ones, alternating digits, l-1, 0 and non-canonical values.  The proofs are
+    invalid by construction (status 7 / 3), but every commitment the verifier recomputes (src/lib.rs:790-829) is in
+    the transcript, which must equal the oracle's byte for byte."""
+    octx = oracle.ctx(bench_params, L)
+    pats = [0, 1, 3, 7, ELL - 1, ELL - 3, (1 << 252) - 1, 1 << 252] + [int(c * 63, 16) % ELL for c in "37bf5"]
+    N = len(pats)
+    eng = engine_factory(bench_params, L, max_batch=N, transcript=MODES[0])
+    sk = octx.private_key_random(shake("cs-pk", 64))
+    pre = octx.pre_issuance_random(shake("cs-pre", 128))
+    req = eng.request(pre, shake("cs-rq", 128))
+    st, resp = eng.issue(sk, req, scb(1000), shake("cs-ir", 128))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proof, _ = eng.prove_spend(tok, scb(321), shake("cs-pr", octx.prove_rng_bytes))
+    assert st == b"\0"
+    pb = octx.proof_bytes
+    recs = []
+    for n, v in enumerate(pats):
+        t = bytearray(proof)
+        t[32 * (4 + L):32 * (5 + L)] = scb(v)                                           # gamma
+        for j in range(L):
+            w = pats[(n + j) % N]
+            t[32 * (12 + L + j):32 * (13 + L + j)] = scb(w)                             # gamma0_j
+            t[32 * (12 + 2 * L + 2 * j):32 * (13 + 2 * L + 2 * j)] = scb(pats[(n + 2 * j + 1) % N])       # z_j0
+        recs.append(bytes(t))
+    nc = bytearray(recs[3]); nc[32 * (4 + L):32 * (5 + L)] = ((1 << 253) - 1).to_bytes(32, "little"); recs[3] = bytes(nc)   # gamma >= l
+    batch = b"".join(recs)
+    st, kp = eng.verify_spend(sk, batch, True)
+    trs = eng.last_spend_transcripts(N)
+    for i in range(N):
+        so, kpo, tro = octx.verify_spend(sk, recs[i], True)
+        assert so == st[i] and so != 0, i
+        assert trs[i] == tro, i
 
 
 def test_empty_and_single_lane_batches(engine_factory, bench_params):

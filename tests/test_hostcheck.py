@@ -97,6 +97,14 @@ def test_group_and_msm_shapes(hostcheck):
         for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu"):      # radix-4 / radix-4, radix-4 / NAF, buckets / NAF
             ok, o0, o1 = call(hc, fn, e, m.sc_bytes(s), m.sc_bytes(m.ELL - 1 - s), nout=2)
             assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, s)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, m.ELL - 1 - s)), (fn, s)
+    # width-3 NAF recoding of the wave-uniform scalar (msm.h naf3_next): runs of 1s, alternating digits, carries
+    # rippling to the top, and values in [l, 2^253) that only the raw recoder (not the reduced scalar type) can see
+    pats = [int(c * 63, 16) for c in "1357bdf"] + [(1 << 253) - 1, (1 << 253) - 3, (1 << 252) + (1 << 251) + 3,
+                                                   0b011, 0b101, 0b111, 0b1011, (1 << 200) - 1, ((1 << 253) - 1) // 3, ((1 << 253) - 1) // 7 * 3]
+    for su in pats:
+        su %= 1 << 253
+        ok, o0, o1 = call(hc, "hc_chain_bu", e, m.sc_bytes(9), su.to_bytes(32, "little"), nout=2)
+        assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, 9)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, su)), hex(su)
     for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu"):                                     # identity base
         ok, o0, o1 = call(hc, fn, bytes(32), m.sc_bytes(5), m.sc_bytes(m.ELL - 7), nout=2)
         assert o0 == bytes(32) and o1 == bytes(32), fn
