@@ -66,7 +66,9 @@ def engine_factory():
     """HIP engines through the C ABI (GPU tests only)."""
     from act_amd import capi
 
-    def make(h: bytes, L: int = 128, max_batch: int = 0, transcript=None):
+    def make(h: bytes, L: int = 128, max_batch: int = 4096, transcript=None):
+        # engines are cached for the session: keep their workspaces small (the library default, 65536 records per
+        # launch = 29 GB at L = 128, is exercised by bench.py and test_device_memory_path_and_full_size_properties)
         key = (h, L, max_batch)
         if key not in _engines:
             _engines[key] = capi.Engine(h, L, max_batch=max_batch)

@@ -193,7 +193,7 @@ def test_device_memory_path_and_full_size_properties(engine_factory, bench_param
     import torch
     from act_amd import capi
     L, D = 128, 512
-    eng = engine_factory(bench_params, L, max_batch=16384, transcript=capi.TRANSCRIPT_DEVICE)
+    eng = engine_factory(bench_params, L, max_batch=0, transcript=capi.TRANSCRIPT_DEVICE)      # 0 = library default (65536 per launch)
     sk = eng.private_key_random(shake("sk-big", 64))
     pre = eng.pre_issuance_random(shake("pre-big", 128 * D))
     req = eng.request(pre, shake("rq-big", 128 * D))

@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--issue-log2", type=int, default=19)
     ap.add_argument("--refund-log2", type=int, default=18)
     ap.add_argument("--lifecycle-log2", type=int, default=18)
-    ap.add_argument("--max-batch", type=int, default=16384)
+    ap.add_argument("--max-batch", type=int, default=65536)
     a = ap.parse_args()
     out = {}
     h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
