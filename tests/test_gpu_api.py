@@ -61,6 +61,18 @@ def test_large_amounts(env):                              # :641-689, :1007-1059
     assert api.scalar_to_u128(tok2.credits()) == top - 1
 
 
+def test_remaining_balance_bit_patterns(env):              # bits_of_ (src/tests.rs:521-567) seen through the range proof
+    """The prover decomposes the remaining balance m = c - s into bits (src/lib.rs:902-915, :996); the patterns of the
+    reference's own bits_of test must all give proofs the issuer accepts, and the refunded token carries exactly m."""
+    api, params, rng, sk = env
+    for m_ in (2**128 - 1, 0, 0b001, 0b100000000, 7, int("10" * 64, 2), int("01" * 64, 2)):
+        s = 5 if m_ + 5 < 2**128 else 0
+        tok = issue_token(api, params, rng, sk, m_ + s)
+        proof, prerefund = tok.prove_spend(params, s, rng)
+        tok2 = prerefund.to_credit_token(params, proof, sk.refund(params, proof, rng), sk.public())
+        assert api.scalar_to_u128(tok2.credits()) == m_
+
+
 def test_overspend_is_rejected(env):                      # :339-375
     api, params, rng, sk = env
     tok = issue_token(api, params, rng, sk, 10)

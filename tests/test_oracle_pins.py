@@ -54,3 +54,15 @@ def test_curve_constants_satisfy_their_definitions():
     assert m.SQRT_M1 * m.SQRT_M1 % m.P == m.P - 1
     assert (m.D * 121666 + 121665) % m.P == 0
     assert m.pt_on_curve(m.BASEPOINT) and m.pt_eq(m.pt_mul(m.BASEPOINT, m.ELL), m.IDENTITY)
+
+
+def test_bits_of_known_answers():
+    """The reference's own known-answer test for the path's bit decomposition (src/tests.rs:521-567, `bits_of_`)."""
+    L = 128
+    assert m.bits_of(2**128 - 1, L) == [1] * L
+    assert m.bits_of(0, L) == [0] * L
+    assert m.bits_of(0b001, L) == [1 if i == 0 else 0 for i in range(L)]
+    assert m.bits_of(0b100000000, L) == [1 if i == 8 else 0 for i in range(L)]
+    assert m.bits_of(7, L) == [1 if i <= 2 else 0 for i in range(L)]
+    assert m.bits_of(int("10" * 64, 2), L) == [i % 2 for i in range(L)]
+    assert m.bits_of(int("01" * 64, 2), L) == [(i + 1) % 2 for i in range(L)]
