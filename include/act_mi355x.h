@@ -165,8 +165,8 @@ int act_cbor_decode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8
  * inserted.  Nullifier i is the 32 bytes at nullifiers + i*stride (stride = act_spend_proof_bytes reads the `k` field
  * straight out of SpendProof records).  skip_mask (nullable): lanes with a non-zero byte (e.g. the status of a rejected
  * proof) are neither checked nor inserted and report 0.  capacity = the number of nullifiers the set must hold; `salt`
- * (nullable, 16 bytes) keys the slot hash.  Multi-GPU deployments shard the key space (owner = hash mod N) — the one
- * step of this repo that would need an exchange between GPUs. */
+ * (nullable, 16 bytes) keys the slot hash.  Multi-GPU deployments shard the key space (owner = low 64 bits mod N): one
+ * set per GPU behind an all-to-all of the keys, anonymous-credit-tokens_amd/sharded_nullifier.py. */
 typedef struct act_nullifier_set act_nullifier_set;
 int act_nullifier_set_create(int device, size_t capacity, const uint8_t salt[16], act_nullifier_set **out);
 void act_nullifier_set_destroy(act_nullifier_set *set);
