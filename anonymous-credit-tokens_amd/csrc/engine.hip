@@ -75,6 +75,7 @@ namespace {
     hipError_t e_ = (expr);                                                                         \
     if (e_ != hipSuccess) {                                                                         \
       (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
+      (void)hipGetLastError(); /* reported through the C ABI: do not leave it sticky for other HIP users (torch) */ \
       return ACT_ERR_HIP;                                                                           \
     }                                                                                               \
   } while (0)
@@ -270,6 +271,7 @@ int from_uniform_on_device(int device, const uint8_t* in64, int n, uint8_t* out_
   if (!rc) { launch_from_uniform(d, (uint32_t)n, d + (size_t)n * 64, nullptr); if (hipDeviceSynchronize() != hipSuccess) rc = ACT_ERR_HIP; }
   if (!rc && hipMemcpy(out_enc, d + (size_t)n * 64, (size_t)n * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = ACT_ERR_HIP;
   (void)hipFree(d);
+  if (rc) (void)hipGetLastError();
   return rc;
 }
 

@@ -185,6 +185,19 @@ def test_empty_and_single_lane_batches(engine_factory, bench_params):
     assert eng.prove_spend(b"", b"", b"") == (b"", b"", b"")
 
 
+def test_workspace_that_cannot_be_allocated_fails_cleanly(bench_params):
+    """A max_batch whose workspace exceeds the GPU's memory (2^22 records at L = 128 is about 0.9 TB) must come back as an
+    error with a message, release what it had taken, and leave the device usable."""
+    from act_amd import capi
+    with pytest.raises(capi.ActError) as e:
+        capi.Engine(bench_params, 128, max_batch=1 << 22)
+    assert "hip" in str(e.value).lower() or "memory" in str(e.value).lower()
+    eng = capi.Engine(bench_params, 128, max_batch=4)
+    sk = eng.private_key_random(shake("oom-sk", 64))
+    assert len(sk) == 64
+    eng.close()
+
+
 def test_device_memory_path_and_full_size_properties(engine_factory, bench_params):
     """BASELINE sizes through size-independent properties: 2^16 (config 2 count) and 2^20 (metric batch) tiled proofs
     resident in HBM; every valid lane accepted, every tampered lane (1 in 1024) rejected with the right code, and the
