@@ -63,7 +63,7 @@ def test_golden_lifecycle(engine_factory, name, mode):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("L", [128, 64, 8])
+@pytest.mark.parametrize("L", [128, 64, 8, 100, 3])
 def test_random_batches_against_oracle(engine_factory, oracle, bench_params, L, mode):
     """Seeded random batch with tampered / undecodable / identity / overspend lanes, ragged chunks (max_batch = 7)."""
     octx = oracle.ctx(bench_params, L)
@@ -118,7 +118,7 @@ def test_random_batches_against_oracle(engine_factory, oracle, bench_params, L, 
     st_o = octx.verify_spend_batch(sk, t, 8)
     st, kp = eng.verify_spend(sk, t, True)
     assert st == st_o
-    assert {0, 6, 7, 255} <= set(st) or L == 8
+    assert {0, 6, 7, 255} <= set(st) or L <= 8
     trs = eng.last_spend_transcripts(7)            # last chunk: lanes 21, 22
     for k, i in enumerate(range(21, N)):
         so, kpo, tro = octx.verify_spend(sk, t[pb * i:pb * i + pb], True)
