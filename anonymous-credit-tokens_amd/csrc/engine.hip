@@ -24,10 +24,10 @@ const char kProtocolVersion[] = "curve25519-ristretto anonymous-credits v1.0";  
 const uint8_t kGeneratorEnc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
                                    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
 
-enum ProfId { PK_SPEND_PREP, PK_SPEND_BITS, PK_SPEND_TAIL, PK_HASH_SPEND, PK_SPEND_FINISH, PK_SIGN_A, PK_HASH_SMALL, PK_SIGN_B,
+enum ProfId { PK_SPEND_PREP, PK_SPEND_BITS, PK_SPEND_ENC, PK_SPEND_TAIL, PK_HASH_SPEND, PK_SPEND_FINISH, PK_SIGN_A, PK_HASH_SMALL, PK_SIGN_B,
               PK_ISSUE_A, PK_ISSUE_CHECK, PK_REQUEST_A, PK_REQUEST_B, PK_PROVE_HEAD, PK_PROVE_BITS, PK_PROVE_TAIL, PK_PROVE_RESP,
               PK_CLIENT, PK_COUNT };
-const char* const kProfNames[PK_COUNT] = {"k_spend_prep", "k_spend_bits", "k_spend_tail", "k_hash_xof(spend)", "k_spend_finish",
+const char* const kProfNames[PK_COUNT] = {"k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail", "k_hash_xof(spend)", "k_spend_finish",
                                           "k_sign_a", "k_hash_xof(small)", "k_sign_b", "k_issue_a", "k_issue_check", "k_request_a",
                                           "k_request_b", "k_prove_head", "k_prove_bits", "k_prove_tail", "k_prove_resp", "k_client_verify"};
 
@@ -322,6 +322,7 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
   int rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_PREP, ch.m, [&] { launch_spend_prep(a, sl.stream); }))) return rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)ch.m * c->L, [&] { launch_spend_bits(a, sl.stream); }))) return rc;
+  if ((rc = prof_launch(c, sl, PK_SPEND_ENC, (uint64_t)ch.m * c->L * 2, [&] { launch_spend_enc(a, sl.stream); }))) return rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_TAIL, ch.m, [&] { launch_spend_tail(a, sl.stream); }))) return rc;
   if ((rc = hash_begin(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), ch.m))) return rc;
   sl.last_spend_lanes = ch.m;

@@ -139,6 +139,42 @@ ACT_HD void ristretto_encode(uint32_t out[8], const ge& p) {
   fe s = fe_mul(fe_sub4(p.Z, y), den);                       // f = Z - y (<= 1.25*2^28)
   fe_to_words(out, fe_abs(s));
 }
+// ---- double-and-compress: the encoding of 2Q from Q with a field INVERSION instead of an inverse square root, so that a
+// batch shares one exponentiation through Montgomery's trick (the construction of curve25519-dalek's
+// RistrettoPoint::double_and_compress_batch).  The verifier computes the half-points Q = C'/2 (every scalar halved mod
+// l; the representatives may then differ from C' by 4-torsion, which Ristretto encodings do not see) and encodes 2Q.
+//   e = 2XY, f = Z^2 + dT^2, g = Y^2 + X^2, h = Z^2 - dT^2;  inv = 1 / ((e g)(f h)), or 0 when that product is 0
+//   (2Q in the identity class: the encoding is then 32 zero bytes, which is what the formulas give with inv = 0).
+struct dc_efgh { fe e, f, g, h; };       // e tight; f, g, h loose [g]
+ACT_HD dc_efgh dc_prepare(const ge& q) {
+  dc_efgh s;
+  fe xx = fe_sq(q.X), yy = fe_sq(q.Y), zz = fe_sq(q.Z);
+  fe dtt = fe_mul(fe_sq(q.T), fe_d());
+  s.e = fe_mul(q.X, fe_dbl(q.Y));
+  s.f = fe_add(zz, dtt);
+  s.g = fe_add(yy, xx);
+  s.h = fe_sub(zz, dtt);
+  return s;
+}
+// eg, fh and t = eg * fh with zero replaced by one (is_zero reports it)
+ACT_HD fe dc_product(fe& eg, fe& fh, bool& is_zero, const dc_efgh& s) {
+  eg = fe_mul(s.e, s.g); fh = fe_mul(s.f, s.h);
+  fe t = fe_mul(eg, fh);
+  is_zero = fe_is_zero(t);
+  return fe_select(t, fe_one(), is_zero);
+}
+ACT_HD void dc_finish(uint32_t out[8], const dc_efgh& s, const fe& eg, const fe& fh, const fe& inv) {
+  fe zinv = fe_mul(eg, inv), tinv = fe_mul(fh, inv);
+  bool neg1 = fe_is_negative(fe_mul(eg, zinv));
+  fe e = fe_select(s.e, s.g, neg1);                                  // [g]
+  fe g = fe_carry(fe_select(s.g, fe_neg(s.e), neg1));                // tight
+  fe h = fe_carry(fe_select(s.h, fe_mul(s.f, fe_sqrt_m1()), neg1));  // tight
+  fe magic = fe_select(fe_invsqrt_a_minus_d(), fe_sqrt_m1(), neg1);
+  bool neg2 = fe_is_negative(fe_mul(fe_mul(h, e), zinv));
+  g = fe_cneg(g, neg2);                                              // <= 2^27
+  fe r = fe_mul(fe_sub4(h, g), fe_mul(magic, fe_mul(tinv, g)));      // f = h - g (<= 1.25*2^28)
+  fe_to_words(out, fe_abs(r));
+}
 // RFC 9496 4.3.1; returns false for non-canonical / negative / non-square / t negative / y == 0
 ACT_HD bool ristretto_decode(ge& p, const uint32_t in[8]) {
   fe s = fe_from_words(in);

@@ -3,8 +3,10 @@
 // "spend" transcript pre-image (src/lib.rs:831-840) of every proof into HBM, plus the status kernel.
 //
 //   k_spend_prep  lane = proof          A', B_bar checks (:787), A1, A2 (:791-799), w00*h2 / w01*h2 (:806,808)
-//   k_spend_bits  lane = (proof, bit)   C'_j0, C'_j1 (:800-817): decode Com_j, two fixed-base sums, one shared
-//                                       doubling chain over -Com_j with two accumulators, two encodings
+//   k_spend_bits  lane = (proof, bit)   C'_j0 / 2, C'_j1 / 2 (:800-817): decode Com_j, two fixed-base sums, one shared
+//                                       doubling chain over -Com_j (msm.h chain_bu); every scalar halved mod l
+//   k_spend_enc   lane = 8 half-points  encodings of C'_j0, C'_j1 = 2 * (half-point) by batched double-and-compress:
+//                                       one field inversion per 8 encodings instead of one inverse square root each
 //   k_spend_tail  lane = proof          K' by Horner over the decoded Com_j (:819-824), Com, C (:825-829), X_A (:848)
 //   k_spend_finish lane = proof         challenge = XOF mod l ?= gamma (:842-844) -> status
 //
@@ -53,8 +55,8 @@ __global__ void __launch_bounds__(64, 2) k_spend_prep(SpendArgs a) {
   acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_H3], r_bar);
   acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_G], ngamma);
   acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_H2], sc_mul(ngamma, k));
-  ge d0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], w00);
-  ge d1 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], w01);
+  ge d0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w00));     // the bits kernel works on C'/2 (k_spend_enc)
+  ge d1 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w01));
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS, d0);
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS, d1);
 
@@ -92,28 +94,47 @@ __global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
   tr_put_aligned(el + 40 * st.el_com(j), wc);
   niels_store(a.coords + ((size_t)p * L + j) * NIELS_WORDS, niels_from_affine(C));
 
-  sc gamma = load_sc(rec + 32 * pl.gamma());
-  sc g0 = load_sc(rec + 32 * pl.gamma0(j));
+  // Everything below is computed at half scale: Q_j0 = C'_j0 / 2, Q_j1 = C'_j1 / 2 (all scalars halved mod l), because
+  // the encoding of 2Q needs only an inversion, which k_spend_enc batches (ge25519.h dc_*).
+  sc gamma = sc_half(load_sc(rec + 32 * pl.gamma()));
+  sc g0 = sc_half(load_sc(rec + 32 * pl.gamma0(j)));
   sc g1 = sc_sub(gamma, g0);                                                  // src/lib.rs:801, 811
-  sc z0 = load_sc(rec + 32 * pl.z(j, 0)), z1 = load_sc(rec + 32 * pl.z(j, 1));
+  sc z0 = sc_half(load_sc(rec + 32 * pl.z(j, 0))), z1 = sc_half(load_sc(rec + 32 * pl.z(j, 1)));
 
   // C'_j0 = z_j0 h3 + D,  C'_j1 = z_j1 h3 + gamma_j1 h1 + G - D  with D = gamma_j0 N, G = gamma N, N = -Com_j
-  // (gamma_j1 = gamma - gamma_j0).  G's scalar is the proof-wide gamma: uniform NAF digits per wavefront; D's digits go through per-lane buckets (msm.h chain_bu).
+  // (gamma_j1 = gamma - gamma_j0).  G's scalar is the proof-wide gamma: uniform width-3 NAF digits per wavefront; D's digits go through per-lane buckets (msm.h chain_bu).
   ge acc_u = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z1);
   acc_u = fixed_base_acc(acc_u, a.P.tab[BASE_H1], g1);
   if (j == 0) acc_u = ge_add(acc_u, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));      // + w01 h2 (:808)
   ge acc_l = ge_identity();
   __shared__ uint32_t u_lds[(ACT_BITS_BLOCK / 64) * 2 * GE_LDS_WORDS_PER_WAVE];            // 20 KiB per wavefront
-  chain_bu(acc_l, acc_u, ge_neg(C), g0, gamma, a.buckets + (size_t)gid * BUCKET_WORDS, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
+  uint32_t* bk = a.buckets + (size_t)gid * BUCKET_WORDS;
+  chain_bu(acc_l, acc_u, ge_neg(C), g0, gamma, bk, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
   ge f0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
   if (j == 0) f0 = ge_add(f0, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));                        // + w00 h2 (:806)
   ge_cached dl = ge_to_cached(acc_l);
-  ge c0 = ge_add_cached(f0, dl);
-  ge c1 = ge_add_cached(acc_u, ge_cached_cneg(dl, true));
+  // the lane's bucket area is free again: its first two slots carry the half-points to k_spend_enc
+  bucket_store(bk, ge_add_cached(f0, dl));
+  bucket_store(bk + GE_WORDS, ge_add_cached(acc_u, ge_cached_cneg(dl, true)));
+}
 
-  uint32_t enc[8];
-  ristretto_encode(enc, c0); tr_put_aligned(el + 40 * st.el_cprime(j, 0), enc);
-  ristretto_encode(enc, c1); tr_put_aligned(el + 40 * st.el_cprime(j, 1), enc);
+// lane = ENC_BATCH consecutive half-points; point q = 2 * (p * L + j) + b lives in slot b of lane (p, j)'s bucket area
+constexpr int ENC_BATCH = 8;
+__global__ void __launch_bounds__(256, 2) k_spend_enc(SpendArgs a) {
+  const uint32_t L = (uint32_t)a.P.L;
+  const uint64_t total = (uint64_t)a.n * L * 2u;
+  const uint64_t q0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * ENC_BATCH;
+  if (q0 >= total) return;
+  const int count = (int)(total - q0 < (uint64_t)ENC_BATCH ? total - q0 : (uint64_t)ENC_BATCH);
+  const SpendTranscript st{a.P.L};
+  dc_encode_batch<ENC_BATCH>(
+      count,
+      [&](int i) { uint64_t q = q0 + (uint64_t)i; return a.buckets + (size_t)(q >> 1) * BUCKET_WORDS + (q & 1u) * GE_WORDS; },
+      [&](int i, const uint32_t* enc) {
+        uint64_t q = q0 + (uint64_t)i, lane = q >> 1;
+        uint32_t p = (uint32_t)(lane / L), j = (uint32_t)(lane % L);
+        tr_put_aligned(a.tr + (size_t)p * a.tr_stride + 184 + 40 * st.el_cprime(j, (int)(q & 1u)), enc);
+      });
 }
 
 __global__ void __launch_bounds__(64, 2) k_spend_tail(SpendArgs a) {
@@ -170,6 +191,11 @@ void launch_spend_bits(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t lanes = (size_t)a.n * a.P.L;
   hipLaunchKernelGGL(k_spend_bits, dim3((unsigned)((lanes + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK)), dim3(ACT_BITS_BLOCK), 0, s, a);
+}
+void launch_spend_enc(const SpendArgs& a, hipStream_t s) {
+  if (!a.n) return;
+  size_t threads = ((size_t)a.n * a.P.L * 2 + ENC_BATCH - 1) / ENC_BATCH;
+  hipLaunchKernelGGL(k_spend_enc, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
 }
 void launch_spend_tail(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
 void launch_spend_finish(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_finish, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }

@@ -162,6 +162,7 @@ void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hi
 void launch_hash(const HashArgs& a, hipStream_t s);
 void launch_spend_prep(const SpendArgs& a, hipStream_t s);
 void launch_spend_bits(const SpendArgs& a, hipStream_t s);
+void launch_spend_enc(const SpendArgs& a, hipStream_t s);
 void launch_spend_tail(const SpendArgs& a, hipStream_t s);
 void launch_spend_finish(const SpendArgs& a, hipStream_t s);
 void launch_sign_a(const SignArgs& a, hipStream_t s);

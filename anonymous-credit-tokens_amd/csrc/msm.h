@@ -329,4 +329,40 @@ ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc&
   acc_l = R;
 }
 
+// ---- batched double-and-compress (ge25519.h dc_*): one field inversion per E encodings ----------------------
+// Encodes 2*Q_i for `count` <= E points.  `slot(i)` -> the 40 words of point i (X|Y|Z|T); they are overwritten with
+// e|f|g|h between the two passes.  `emit(i, words)` receives the encodings, last point first.
+template <int E, typename Slot, typename Emit>
+ACT_HD void dc_encode_batch(int count, Slot slot, Emit emit) {
+  fe prefix[E];
+  fe acc = fe_one();
+#pragma unroll
+  for (int i = 0; i < E; i++) {
+    if (i < count) {
+      uint32_t* w = slot(i);
+      dc_efgh s = dc_prepare(bucket_load(w));
+      ge t; t.X = s.e; t.Y = s.f; t.Z = s.g; t.T = s.h; bucket_store(w, t);
+      fe eg, fh; bool z;
+      fe prod = dc_product(eg, fh, z, s);
+      prefix[i] = acc;
+      acc = fe_mul(acc, prod);
+    }
+  }
+  fe inv = fe_invert(acc);
+#pragma unroll
+  for (int i = E - 1; i >= 0; i--) {
+    if (i < count) {
+      ge t = bucket_load(slot(i));
+      dc_efgh s; s.e = t.X; s.f = t.Y; s.g = t.Z; s.h = t.T;
+      fe eg, fh; bool z;
+      fe prod = dc_product(eg, fh, z, s);
+      fe mine = fe_select(fe_mul(inv, prefix[i]), fe_zero(), z);
+      inv = fe_mul(inv, prod);
+      uint32_t enc[8];
+      dc_finish(enc, s, eg, fh, mine);
+      emit(i, enc);
+    }
+  }
+}
+
 }  // namespace act

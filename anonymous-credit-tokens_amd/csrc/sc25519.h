@@ -128,6 +128,16 @@ ACT_HD sc sc_sub(const sc& a, const sc& b) {
   bn_add<8>(r.v, a.v, l); bn_sub<8>(r.v, r.v, b.v); sc_cond_sub_l(r.v, 1); return r;
 }
 ACT_HD sc sc_neg(const sc& a) { return sc_sub(sc_zero(), a); }
+// a / 2 mod l for canonical a: a >> 1 if even, (a + l) >> 1 otherwise (l is odd, a + l < 2^254)
+ACT_HD sc sc_half(const sc& a) {
+  const uint32_t odd = 0u - (a.v[0] & 1u);
+  uint32_t t[8]; uint64_t c = 0;
+  for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + (sc_l_word(i) & odd); t[i] = (uint32_t)c; c >>= 32; }
+  sc r;
+  for (int i = 0; i < 7; i++) r.v[i] = (t[i] >> 1) | (t[i + 1] << 31);
+  r.v[7] = t[7] >> 1;
+  return r;
+}
 ACT_HD sc sc_mul(const sc& a, const sc& b) { uint32_t t[16]; bn_mul<8, 8>(t, a.v, b.v); return sc_reduce512(t); }
 ACT_HD sc sc_muladd(const sc& a, const sc& b, const sc& c) { return sc_add(sc_mul(a, b), c); }
 ACT_HD bool sc_equal(const sc& a, const sc& b) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i]; return d == 0; }

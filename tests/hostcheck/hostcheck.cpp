@@ -45,6 +45,7 @@ void hc_sc_from_bytes(const uint8_t* a, uint8_t* o) { sc_out(o, sc_in(a)); }
 void hc_sc_muladd(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* o) { sc_out(o, sc_muladd(sc_in(a), sc_in(b), sc_in(c))); }
 void hc_sc_sub(const uint8_t* a, const uint8_t* b, uint8_t* o) { sc_out(o, sc_sub(sc_in(a), sc_in(b))); }
 void hc_sc_neg(const uint8_t* a, uint8_t* o) { sc_out(o, sc_neg(sc_in(a))); }
+void hc_sc_half(const uint8_t* a, uint8_t* o) { sc_out(o, sc_half(sc_in(a))); }
 void hc_sc_invert(const uint8_t* a, uint8_t* o) { sc_out(o, sc_invert(sc_in(a))); }
 
 int hc_decode_encode(const uint8_t* a, uint8_t* o) {
@@ -104,6 +105,19 @@ extern "C" int hc_chain2u(const uint8_t* pt, const uint8_t* s0, const uint8_t* s
   ge al = ge_identity(), au = ge_identity();
   chain2u(al, au, p, sc_in(s0), sc_in(s1));
   ristretto_encode(r, al); st(o0, r); ristretto_encode(r, au); st(o1, r);
+  return 1;
+}
+// batched double-and-compress: Q_i = a_i + b_i (projective, Z != 1) for i < count <= 8; out_i must be enc(2 Q_i)
+extern "C" int hc_dc_encode_batch(const uint8_t* a_enc, const uint8_t* b_enc, int count, uint8_t* out) {
+  std::vector<uint32_t> slots((size_t)8 * GE_WORDS);
+  for (int i = 0; i < count; i++) {
+    uint32_t w[8]; ge pa, pb;
+    ld(w, a_enc + 32 * i); if (!ristretto_decode(pa, w)) return 0;
+    ld(w, b_enc + 32 * i); if (!ristretto_decode(pb, w)) return 0;
+    ge_store(slots.data() + (size_t)i * GE_WORDS, ge_add(pa, pb));
+  }
+  dc_encode_batch<8>(count, [&](int i) { return slots.data() + (size_t)i * GE_WORDS; },
+                     [&](int i, const uint32_t* enc) { st(out + 32 * i, enc); });
   return 1;
 }
 extern "C" int hc_chain_bu(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {

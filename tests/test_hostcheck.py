@@ -110,10 +110,37 @@ def test_group_and_msm_shapes(hostcheck):
         assert o0 == bytes(32) and o1 == bytes(32), fn
 
 
+def test_batched_double_and_compress(hostcheck):
+    """ge25519.h dc_* / msm.h dc_encode_batch against the model: enc(2Q) for projective Q, batches of every size up to 8,
+    with identity-class members (whose zero must not poison the shared inversion) and torsion-shifted representatives."""
+    hc = hostcheck
+    g = load_golden("primitives.json")
+    mults = [bytes.fromhex(x) for x in g["generator_multiples"]]
+    pts = [m.ristretto_decode(e) for e in mults]
+    ident = bytes(32)
+    for count in range(1, 9):
+        a = [mults[(3 * i + count) % len(mults)] for i in range(count)]
+        b = [mults[(5 * i + 1) % len(mults)] for i in range(count)]
+        if count >= 3:
+            a[1] = ident; b[1] = ident                                   # Q = identity
+        if count >= 5:
+            b[3] = m.ristretto_encode(m.pt_neg(m.ristretto_decode(a[3])))   # Q = P - P
+        out = (C.c_uint8 * (32 * count))()
+        assert hc.hc_dc_encode_batch(b"".join(a), b"".join(b), count, out) == 1
+        for i in range(count):
+            q = m.pt_add(m.ristretto_decode(a[i]), m.ristretto_decode(b[i]))
+            assert bytes(out[32 * i:32 * i + 32]) == m.ristretto_encode(m.pt_double(q)), (count, i)
+    # halving: s/2 mod l
+    for s_ in (0, 1, 2, 3, m.ELL - 1, m.ELL - 2, (1 << 252) + 1, int("5" * 62, 16) % m.ELL):
+        ok, o = call(hc, "hc_sc_half", m.sc_bytes(s_))
+        assert int.from_bytes(o, "little") == s_ * pow(2, m.ELL - 2, m.ELL) % m.ELL, s_
+
+
 def test_limb_bounds_hold(hostcheck):
     """Every operand recorded by the instrumented host build stays inside its class (fe25519.h header comment)."""
     test_field(hostcheck)
     test_group_and_msm_shapes(hostcheck)
+    test_batched_double_and_compress(hostcheck)
     bd = (C.c_uint64 * 6)()
     hostcheck.hc_bounds(bd)
     lim = [1.68 * 2**27, 1.68 * 2**26, 1.5 * 2**28, 1.5 * 2**27, 2**27 - 38, 2**26 - 2]
