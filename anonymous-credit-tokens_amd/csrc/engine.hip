@@ -25,11 +25,11 @@ const uint8_t kGeneratorEnc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x7
                                    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
 
 enum ProfId { PK_SPEND_PREP, PK_SPEND_BITS, PK_SPEND_ENC, PK_SPEND_TAIL, PK_HASH_SPEND, PK_SPEND_FINISH, PK_SIGN_A, PK_HASH_SMALL, PK_SIGN_B,
-              PK_ISSUE_A, PK_ISSUE_CHECK, PK_REQUEST_A, PK_REQUEST_B, PK_PROVE_HEAD, PK_PROVE_BITS, PK_PROVE_TAIL, PK_PROVE_RESP,
+              PK_ISSUE_A, PK_ISSUE_CHECK, PK_REQUEST_A, PK_REQUEST_B, PK_PROVE_HEAD, PK_PROVE_BITS, PK_PROVE_ENC, PK_PROVE_TAIL, PK_PROVE_RESP,
               PK_CLIENT, PK_COUNT };
 const char* const kProfNames[PK_COUNT] = {"k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail", "k_hash_xof(spend)", "k_spend_finish",
                                           "k_sign_a", "k_hash_xof(small)", "k_sign_b", "k_issue_a", "k_issue_check", "k_request_a",
-                                          "k_request_b", "k_prove_head", "k_prove_bits", "k_prove_tail", "k_prove_resp", "k_client_verify"};
+                                          "k_request_b", "k_prove_head", "k_prove_bits", "k_prove_enc", "k_prove_tail", "k_prove_resp", "k_client_verify"};
 
 struct PendingProf { int id; hipEvent_t e0, e1; uint64_t lanes; };
 
@@ -59,6 +59,7 @@ struct act_ctx {
   std::string err;
   Slot slots[2];
   uint32_t* d_tables = nullptr;
+  uint32_t* d_half_h1 = nullptr;
   // key cache
   uint8_t sk_cached[64]{}; bool sk_valid = false; DevKey key{};
   uint8_t w_cached[32]{}; bool w_valid = false; ge w_pub{};
@@ -388,6 +389,9 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
     launch_build_table(d_ext + b * GE_WORDS, c->d_tables + (size_t)b * FB_TABLE_WORDS, s0);
     c->P.tab[b] = c->d_tables + (size_t)b * FB_TABLE_WORDS;
   }
+  HIPCK(c, hipMalloc(&c->d_half_h1, (size_t)2 * NIELS_WORDS * 4));
+  launch_half_point_table(c->P.tab[BASE_H1], c->d_half_h1, s0);
+  c->P.half_h1 = c->d_half_h1;
   HIPCK(c, hipStreamSynchronize(s0));
   HIPCK(c, hipFree(d_enc)); HIPCK(c, hipFree(d_ext)); HIPCK(c, hipFree(d_ok));
   // Transcript::new(params, label) prefixes, src/transcript.rs:54-74
@@ -420,6 +424,7 @@ void act_ctx_destroy(act_ctx* c) {
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->d_tables) (void)hipFree(c->d_tables);
+  if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
   delete c;
 }
@@ -574,7 +579,7 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
     Slot& sl = c->slots[i & 1]; ProveArgs& a = args[i & 1];
     size_t off = i * c->max_batch; uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
     ms[i & 1] = m; offs[i & 1] = off;
-    a = ProveArgs{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.state = sl.d_state;
+    a = ProveArgs{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.half = sl.d_buckets; a.state = sl.d_state;
     a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
     int rc;
     if ((rc = dev_in(c, sl, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
@@ -584,6 +589,7 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
     if ((rc = dev_out_begin(c, sl, 4, mem, out_prerefund + off * 96, (size_t)m * 96, &a.prerefund))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_HEAD, m, [&] { launch_prove_head(a, sl.stream); }))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_BITS, (uint64_t)m * c->L, [&] { launch_prove_bits(a, sl.stream); }))) return rc;
+    if ((rc = prof_launch(c, sl, PK_PROVE_ENC, (uint64_t)m * c->L * 3, [&] { launch_prove_enc(a, sl.stream); }))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_TAIL, m, [&] { launch_prove_tail(a, sl.stream); }))) return rc;
     return hash_begin(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m);
   };

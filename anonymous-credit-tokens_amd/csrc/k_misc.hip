@@ -27,6 +27,17 @@ void launch_build_table(const uint32_t* base_ext, uint32_t* table, hipStream_t s
   hipLaunchKernelGGL(k_build_table, dim3((FB_WINDOWS * FB_ENTRIES + 255) / 256), dim3(256), 0, s, base_ext, table);
 }
 
+// out[0] = identity, out[1] = B / 2 as affine Niels, B the base of `table`: the prover works at half scale (k_prove.hip)
+__global__ void k_half_point_table(const uint32_t* table, uint32_t* out) {
+  if (blockIdx.x || threadIdx.x) return;
+  ge h = fixed_base_acc(ge_identity(), table, sc_half(sc_one()));
+  fe zi = fe_invert(h.Z);
+  ge af; af.X = fe_mul(h.X, zi); af.Y = fe_mul(h.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
+  niels_store(out, niels_from_affine(ge_identity()));
+  niels_store(out + NIELS_WORDS, niels_from_affine(af));
+}
+void launch_half_point_table(const uint32_t* table, uint32_t* out, hipStream_t s) { hipLaunchKernelGGL(k_half_point_table, dim3(1), dim3(64), 0, s, table, out); }
+
 __global__ void __launch_bounds__(64) k_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok) {
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;

@@ -12,7 +12,9 @@
 // reference does with subtle::conditional_select.
 //
 //   k_prove_head  lane = proof         A', B_bar, A1, A2, r3 = 1/r1, the three h2 terms of bit 0
-//   k_prove_bits  lane = (proof, bit)  Com_j, C'_j0, C'_j1 and their encodings
+//   k_prove_bits  lane = (proof, bit)  Com_j / 2, C'_j0 / 2, C'_j1 / 2 (every scalar halved mod l)
+//   k_prove_enc   lane = 8 half-points their encodings by batched double-and-compress (ge25519.h dc_*, msm.h): one field
+//                                      inversion per 8 encodings instead of an inverse square root each
 //   k_prove_tail  lane = proof         r*, C
 //   (transcript hash)
 //   k_prove_resp  lane = (proof, bit)  gamma_j0, z_j0, z_j1; lane bit 0 also writes every proof-level response
@@ -88,9 +90,10 @@ __global__ void __launch_bounds__(64, 2) k_prove_head(ProveArgs a) {
   // bit-0 extras over h2 (src/lib.rs:1001, 1025-1035)
   sc k_star = rv.k_star();
   uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
-  ge_store(d3, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], k_star));
-  ge_store(d3 + GE_WORDS, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], rv.k0_prime()));
-  ge_store(d3 + 2 * GE_WORDS, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star))));
+  // at half scale, like everything k_prove_bits computes
+  ge_store(d3, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(k_star)));
+  ge_store(d3 + GE_WORDS, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(rv.k0_prime())));
+  ge_store(d3 + 2 * GE_WORDS, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star)))));
   sc r3 = sc_invert(r1);                                                      // :992
   uint32_t* stt = a.state + (size_t)p * 24;
   for (int i = 0; i < 8; i++) stt[i] = r3.v[i];
@@ -101,34 +104,53 @@ __global__ void __launch_bounds__(256, 2) k_prove_bits(ProveArgs a) {
   uint32_t gid = blockIdx.x * 256 + threadIdx.x;
   uint32_t p = gid / (uint32_t)L, j = gid % (uint32_t)L;
   if (p >= a.n) return;
-  const ProofLayout pl{L}; const SpendTranscript st{L};
   const uint8_t* tok = a.tok + (size_t)p * 160;
-  uint8_t* rec = a.proof + (size_t)p * pl.bytes();
-  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
   RngView rv{a.rng + (size_t)p * rng_bytes(L), L};
 
   sc m = sc_sub(load_sc(tok + 128), load_sc(a.s + (size_t)p * 32));           // c - s (:996)
   uint32_t bit = (m.v[j >> 5] >> (j & 31)) & 1u;                              // bits_of (:902-915)
   sc s_j = rv.s_i(j), s_jp = rv.s_i_prime(j), g_j = rv.gamma_i(j), z_j = rv.z(j);
 
-  // Com_j = i_j h1 + s_j h3 (+ k* h2)
-  ge com = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], s_j);
-  com = ge_madd(com, niels_load(a.P.tab[BASE_H1] + (size_t)bit * NIELS_WORDS));   // entry 0 = identity, entry 1 = h1
+  // Half scale throughout (k_prove_enc encodes the doubles): Com_j / 2 = i_j (h1 / 2) + (s_j / 2) h3 (+ (k* / 2) h2)
+  ge com = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], sc_half(s_j));
+  com = ge_madd(com, niels_load(a.P.half_h1 + (size_t)bit * NIELS_WORDS));        // entry 0 = identity, entry 1 = h1 / 2
   // real branch: s'_j h3 (+ k0' h2);  simulated: (z_j - gamma_j s_j) h3 -/+ gamma_j h1 (+ (w0 - gamma_0 k*) h2)
-  ge real = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], s_jp);
-  ge sim = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], sc_sub(z_j, sc_mul(g_j, s_j)));
-  sc gh1 = bit ? sc_neg(g_j) : g_j;
+  ge real = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], sc_half(s_jp));
+  ge sim = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], sc_half(sc_sub(z_j, sc_mul(g_j, s_j))));
+  sc gh1 = sc_half(bit ? sc_neg(g_j) : g_j);
   sim = fixed_base_acc(sim, a.P.tab[BASE_H1], gh1);
   if (j == 0) {
     const uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
     com = ge_add(com, ge_load(d3)); real = ge_add(real, ge_load(d3 + GE_WORDS)); sim = ge_add(sim, ge_load(d3 + 2 * GE_WORDS));
   }
-  uint32_t e_com[8], e_real[8], e_sim[8], c0[8], c1[8];
-  ristretto_encode(e_com, com); ristretto_encode(e_real, real); ristretto_encode(e_sim, sim);
-  for (int i = 0; i < 8; i++) { c0[i] = bit ? e_sim[i] : e_real[i]; c1[i] = bit ? e_real[i] : e_sim[i]; }   // :1025-1050
-  tr_put_aligned(el + 40 * st.el_com(j), e_com); store8(rec + 32 * pl.com(j), e_com);
-  tr_put_aligned(el + 40 * st.el_cprime(j, 0), c0);
-  tr_put_aligned(el + 40 * st.el_cprime(j, 1), c1);
+  // C'_j0 = bit ? sim : real, C'_j1 = bit ? real : sim (:1025-1050), chosen with masks
+  const uint32_t mb = fe_mask(bit != 0);
+  ge c0, c1;
+  c0.X = fe_select_m(real.X, sim.X, mb); c0.Y = fe_select_m(real.Y, sim.Y, mb); c0.Z = fe_select_m(real.Z, sim.Z, mb); c0.T = fe_select_m(real.T, sim.T, mb);
+  c1.X = fe_select_m(sim.X, real.X, mb); c1.Y = fe_select_m(sim.Y, real.Y, mb); c1.Z = fe_select_m(sim.Z, real.Z, mb); c1.T = fe_select_m(sim.T, real.T, mb);
+  uint32_t* hp = a.half + (size_t)gid * BUCKET_WORDS;
+  bucket_store(hp, com); bucket_store(hp + GE_WORDS, c0); bucket_store(hp + 2 * GE_WORDS, c1);
+}
+
+// lane = PROVE_ENC_BATCH consecutive half-points; point q = 3 * (p * L + j) + c is slot c of lane (p, j)
+constexpr int PROVE_ENC_BATCH = 8;
+__global__ void __launch_bounds__(256, 2) k_prove_enc(ProveArgs a) {
+  const uint32_t L = (uint32_t)a.P.L;
+  const uint64_t total = (uint64_t)a.n * L * 3u;
+  const uint64_t q0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * PROVE_ENC_BATCH;
+  if (q0 >= total) return;
+  const int count = (int)(total - q0 < (uint64_t)PROVE_ENC_BATCH ? total - q0 : (uint64_t)PROVE_ENC_BATCH);
+  const ProofLayout pl{a.P.L}; const SpendTranscript st{a.P.L};
+  dc_encode_batch<PROVE_ENC_BATCH>(
+      count,
+      [&](int i) { uint64_t q = q0 + (uint64_t)i; return a.half + (size_t)(q / 3u) * BUCKET_WORDS + (q % 3u) * GE_WORDS; },
+      [&](int i, const uint32_t* enc) {
+        uint64_t q = q0 + (uint64_t)i, lane = q / 3u; uint32_t c = (uint32_t)(q % 3u);
+        uint32_t p = (uint32_t)(lane / L), j = (uint32_t)(lane % L);
+        uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
+        if (c == 0) { tr_put_aligned(el + 40 * st.el_com(j), enc); store8(a.proof + (size_t)p * pl.bytes() + 32 * pl.com(j), enc); }
+        else tr_put_aligned(el + 40 * st.el_cprime(j, (int)c - 1), enc);
+      });
 }
 
 __global__ void __launch_bounds__(64, 2) k_prove_tail(ProveArgs a) {
@@ -209,6 +231,11 @@ void launch_prove_bits(const ProveArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t lanes = (size_t)a.n * a.P.L;
   hipLaunchKernelGGL(k_prove_bits, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_prove_enc(const ProveArgs& a, hipStream_t s) {
+  if (!a.n) return;
+  size_t threads = ((size_t)a.n * a.P.L * 3 + PROVE_ENC_BATCH - 1) / PROVE_ENC_BATCH;
+  hipLaunchKernelGGL(k_prove_enc, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
 }
 void launch_prove_tail(const ProveArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_prove_tail, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
 void launch_prove_resp(const ProveArgs& a, hipStream_t s) {

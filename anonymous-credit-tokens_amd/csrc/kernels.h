@@ -19,6 +19,7 @@ constexpr int SMALL_TR_STRIDE = 512;      // request 266 B, respond 466 B, refun
 // Params-dependent constants, by value in every launch (~1 KiB of kernarg, read through the scalar cache)
 struct DevParams {
   const uint32_t* tab[4];                 // position-specific fixed-base tables of g, h1, h2, h3 (msm.h)
+  const uint32_t* half_h1;                // two affine-Niels entries: identity, h1 / 2 (the prover's bit term at half scale)
   uint32_t prefix[4][PREFIX_WORDS];       // Transcript::new(params, label) bytes, zero padded
   uint32_t prefix_len[4];
   int L;                                  // range-proof width (src/lib.rs:116)
@@ -125,7 +126,8 @@ struct ProveArgs {
   const uint8_t* s;          // n * 32
   const uint8_t* rng;        // n * 64*(4L+12), draw order of SURVEY.md Appendix B
   uint8_t* tr; uint32_t tr_stride;
-  uint32_t* d3;              // n * 3 * GE_WORDS : k* h2, k0' h2, (w0 - gamma_0 k*) h2
+  uint32_t* d3;              // n * 3 * GE_WORDS : k* h2, k0' h2, (w0 - gamma_0 k*) h2, each at half scale
+  uint32_t* half;            // n * L * BUCKET_WORDS: slots 0..2 of lane (p, j) = Com_j / 2, C'_j0 / 2, C'_j1 / 2 for k_prove_enc
   uint32_t* state;           // n * 24 words: r3 | r*
   uint32_t* flags;
   const uint32_t* xof;
@@ -155,6 +157,7 @@ struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n;
 
 // launchers (defined in the .hip files)
 void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, hipStream_t s);
+void launch_half_point_table(const uint32_t* table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
 void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s);
 void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s);
 void launch_keygen(const DevParams& P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk, hipStream_t s);
@@ -173,6 +176,7 @@ void launch_request_a(const RequestArgs& a, hipStream_t s);
 void launch_request_b(const RequestArgs& a, hipStream_t s);
 void launch_prove_head(const ProveArgs& a, hipStream_t s);
 void launch_prove_bits(const ProveArgs& a, hipStream_t s);
+void launch_prove_enc(const ProveArgs& a, hipStream_t s);
 void launch_prove_tail(const ProveArgs& a, hipStream_t s);
 void launch_prove_resp(const ProveArgs& a, hipStream_t s);
 void launch_client_decode_com(const ClientArgs& a, hipStream_t s);
