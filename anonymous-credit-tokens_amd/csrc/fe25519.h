@@ -25,18 +25,46 @@
 #endif
 
 #define ACT_MUL64(a, b) ((uint64_t)(a) * (uint64_t)(b))
-// a * b + c.  On the device this is ONE v_mad_u64_u32, written as inline asm so that LLVM's reassociation cannot turn a
-// column  carry + p1 + p2 + ...  back into  (0 + p1 + p2 + ...) + carry  (one more 64-bit addition per limb: 9 of the
-// 152 / 112 instructions of a multiplication / squaring).
+// One column of a product: carry-in + n terms as n v_mad_u64_u32 in ONE asm statement, the carry being the first
+// addend.  Written as asm because LLVM's reassociation otherwise sums the products from zero and adds the carry with a
+// separate 64-bit addition (9 of the 152 / 112 instructions of a multiplication / squaring), and as one statement per
+// column because the compiler puts a wait state after every asm statement whose result the next instruction reads
+// (the hardware needs none between dependent v_mad_u64_u32).  "+v"(c): in the n-term blocks every input is live until its
+// own instruction, so c must not share a register with an input -- it cannot: it is also an input.
 #if defined(__HIP_DEVICE_COMPILE__)
-static __device__ __forceinline__ uint64_t act_madc(uint32_t a, uint32_t b, uint64_t c) {
-  uint64_t r;
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c) : "vcc");
-  return r;
+static __device__ __forceinline__ uint64_t act_col5(uint64_t c, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0" : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4) : "vcc");
+  return c;
 }
-#define ACT_MADC(a, b, c) act_madc((a), (b), (c))
+static __device__ __forceinline__ uint64_t act_col6(uint64_t c, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0" : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5) : "vcc");
+  return c;
+}
+static __device__ __forceinline__ uint64_t act_col10(uint64_t c, uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0" : "+v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9) : "vcc");
+  return c;
+}
+static __device__ __forceinline__ uint64_t act_colz6(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5) {
+  uint64_t c;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0" : "=&v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5) : "vcc");
+  return c;
+}
+static __device__ __forceinline__ uint64_t act_colz10(uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2, uint32_t a3, uint32_t b3, uint32_t a4, uint32_t b4, uint32_t a5, uint32_t b5, uint32_t a6, uint32_t b6, uint32_t a7, uint32_t b7, uint32_t a8, uint32_t b8, uint32_t a9, uint32_t b9) {
+  uint64_t c;
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, 0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0\n\tv_mad_u64_u32 %0, vcc, %13, %14, %0\n\tv_mad_u64_u32 %0, vcc, %15, %16, %0\n\tv_mad_u64_u32 %0, vcc, %17, %18, %0\n\tv_mad_u64_u32 %0, vcc, %19, %20, %0" : "=&v"(c) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9) : "vcc");
+  return c;
+}
+#define ACT_COL5(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4) act_col5(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4)
+#define ACT_COL6(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5) act_col6(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5)
+#define ACT_COL10(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7, a8, b8, a9, b9) act_col10(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7, a8, b8, a9, b9)
+#define ACT_COLZ6(a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5) act_colz6(a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5)
+#define ACT_COLZ10(a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7, a8, b8, a9, b9) act_colz10(a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7, a8, b8, a9, b9)
 #else
-#define ACT_MADC(a, b, c) ((uint64_t)(a) * (uint64_t)(b) + (uint64_t)(c))
+#define ACT_COL5(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4) ((uint64_t)(c) + (uint64_t)(a0) * (uint64_t)(b0) + (uint64_t)(a1) * (uint64_t)(b1) + (uint64_t)(a2) * (uint64_t)(b2) + (uint64_t)(a3) * (uint64_t)(b3) + (uint64_t)(a4) * (uint64_t)(b4))
+#define ACT_COL6(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5) ((uint64_t)(c) + (uint64_t)(a0) * (uint64_t)(b0) + (uint64_t)(a1) * (uint64_t)(b1) + (uint64_t)(a2) * (uint64_t)(b2) + (uint64_t)(a3) * (uint64_t)(b3) + (uint64_t)(a4) * (uint64_t)(b4) + (uint64_t)(a5) * (uint64_t)(b5))
+#define ACT_COL10(c, a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7, a8, b8, a9, b9) ((uint64_t)(c) + (uint64_t)(a0) * (uint64_t)(b0) + (uint64_t)(a1) * (uint64_t)(b1) + (uint64_t)(a2) * (uint64_t)(b2) + (uint64_t)(a3) * (uint64_t)(b3) + (uint64_t)(a4) * (uint64_t)(b4) + (uint64_t)(a5) * (uint64_t)(b5) + (uint64_t)(a6) * (uint64_t)(b6) + (uint64_t)(a7) * (uint64_t)(b7) + (uint64_t)(a8) * (uint64_t)(b8) + (uint64_t)(a9) * (uint64_t)(b9))
+#define ACT_COLZ6(a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5) ((uint64_t)(a0) * (uint64_t)(b0) + (uint64_t)(a1) * (uint64_t)(b1) + (uint64_t)(a2) * (uint64_t)(b2) + (uint64_t)(a3) * (uint64_t)(b3) + (uint64_t)(a4) * (uint64_t)(b4) + (uint64_t)(a5) * (uint64_t)(b5))
+#define ACT_COLZ10(a0, b0, a1, b1, a2, b2, a3, b3, a4, b4, a5, b5, a6, b6, a7, b7, a8, b8, a9, b9) ((uint64_t)(a0) * (uint64_t)(b0) + (uint64_t)(a1) * (uint64_t)(b1) + (uint64_t)(a2) * (uint64_t)(b2) + (uint64_t)(a3) * (uint64_t)(b3) + (uint64_t)(a4) * (uint64_t)(b4) + (uint64_t)(a5) * (uint64_t)(b5) + (uint64_t)(a6) * (uint64_t)(b6) + (uint64_t)(a7) * (uint64_t)(b7) + (uint64_t)(a8) * (uint64_t)(b8) + (uint64_t)(a9) * (uint64_t)(b9))
 #endif
 #include "fe25519_gen.inc"
 
