@@ -9,10 +9,11 @@
 //    (/root/reference/src/lib.rs:814-816), A1/A2 share B_bar (:793-797), A*/Y_A share X_A (:849-853).
 //    Every lane of a wavefront executes the same schedule (a digit-0 lane only sits out an add), so
 //    there is no vartime-wNAF divergence to lose on a 64-wide SIMD.
-// 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as 22 mixed
+// 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as 16 mixed
 //    additions, one per scalar window, from position-specific affine-Niels tables
-//    T[pos][d] = d * 2^(w*pos) * B, w = FB_WBITS = 12 (22 windows x 4096 entries x 128 B = 11 MiB per base,
-//    resident in the 256 MiB Infinity Cache; built once per context by k_build_table).
+//    T[pos][d] = d * 2^(w*pos) * B, w = FB_WBITS = 16 (16 windows x 65536 entries x 128 B = 128 MiB per base,
+//    512 MiB per context of the GPU's 288 GB; built once per context by k_build_table).  Measured on one MI355X
+//    against 12-bit windows (22 additions, 11 MiB per base): verify +2 %, prove_spend +12 %; 14 bits: +1.3 % / +7 %.
 #pragma once
 #include "ge25519.h"
 
@@ -20,13 +21,13 @@ namespace act {
 
 // ---- fixed-base tables -------------------------------------------------------------------------
 #ifndef ACT_FB_WBITS
-#define ACT_FB_WBITS 12
+#define ACT_FB_WBITS 16
 #endif
 constexpr int FB_WBITS = ACT_FB_WBITS;                      // window width in bits
 constexpr int FB_WINDOWS = (253 + FB_WBITS - 1) / FB_WBITS;  // scalars are canonical: < l < 2^253
 constexpr int FB_ENTRIES = 1 << FB_WBITS;
 constexpr int NIELS_WORDS = 32;         // 30 used (ypx, ymx, xy2d), padded to 128 B = one L2 line
-constexpr size_t FB_TABLE_WORDS = (size_t)FB_WINDOWS * FB_ENTRIES * NIELS_WORDS;   // 11 MiB per base at 12 bits
+constexpr size_t FB_TABLE_WORDS = (size_t)FB_WINDOWS * FB_ENTRIES * NIELS_WORDS;   // 128 MiB per base at 16 bits
 
 ACT_HD ge_niels niels_load(const uint32_t* p) {
   ge_niels n;
