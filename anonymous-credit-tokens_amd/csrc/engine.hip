@@ -244,7 +244,7 @@ int workspace_alloc(act_ctx* c) {
     HIPCK(c, hipMalloc(&sl.d_tr, B * st.stride()));
     HIPCK(c, hipMalloc(&sl.d_coords, B * (size_t)c->L * NIELS_WORDS * 4));
     HIPCK(c, hipMalloc(&sl.d_d01, B * 3 * GE_WORDS * 4));
-    HIPCK(c, hipMalloc(&sl.d_buckets, B * (size_t)c->L * BUCKET_WORDS * 4));
+    HIPCK(c, hipMalloc(&sl.d_buckets, B * (size_t)std::max(c->L, 2) * BUCKET_WORDS * 4));   // >= 2 bucket sets per proof for chain_b
     HIPCK(c, hipMalloc(&sl.d_xa, B * GE_WORDS * 4));
     HIPCK(c, hipMalloc(&sl.d_flags, B * 4));
     HIPCK(c, hipMalloc(&sl.d_xof, B * 64));
@@ -302,7 +302,7 @@ int prepare_rng_slots(act_ctx* c, Slot& sl, uint32_t m, size_t off, int mem, con
 
 int sign_phase(act_ctx* c, Slot& sl, uint32_t m, int label, const uint8_t* d_rng, const uint8_t* d_camount, uint8_t* d_out) {
   SignArgs s{}; s.P = c->P; s.K = c->key; s.n = m; s.label = label; s.xa = sl.d_xa; s.status = sl.d_status; s.rng_slot = sl.d_slot;
-  s.rng = d_rng; s.c_amount = d_camount; s.trs = sl.d_trs; s.state = sl.d_state; s.xof = sl.d_xof; s.out = d_out;
+  s.rng = d_rng; s.c_amount = d_camount; s.trs = sl.d_trs; s.state = sl.d_state; s.xof = sl.d_xof; s.out = d_out; s.pbk = sl.d_buckets;
   int rc;
   if ((rc = prof_launch(c, sl, PK_SIGN_A, m, [&] { launch_sign_a(s, sl.stream); }))) return rc;
   uint32_t len = c->P.prefix_len[label] + 40u * (label == LABEL_RESPOND ? 7u : 6u);
@@ -494,7 +494,7 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
   size_t cursor = 0;
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
+    IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.pbk = sl.d_buckets;
     if ((rc = dev_in(c, sl, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, camt + off * 32, (size_t)m * 32, &a.c_amount))) return rc;
     uint8_t* d_out;
@@ -622,7 +622,7 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
   Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = sl.d_coords; a.trs = sl.d_trs; a.flags = sl.d_flags;
+    ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = sl.d_coords; a.trs = sl.d_trs; a.flags = sl.d_flags; a.pbk = sl.d_buckets;
     a.xof = sl.d_xof; a.status = sl.d_status;
     if ((rc = dev_in(c, sl, 0, mem, pre + off * pre_b, (size_t)m * pre_b, &a.pre))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, resp + off * resp_b, (size_t)m * resp_b, &a.resp))) return rc;

@@ -46,9 +46,10 @@ __global__ void __launch_bounds__(64, 2) k_client_a(ClientArgs a) {
   ge acc[2];
   acc[0] = ge_identity();                                                                  // Y_A
   acc[1] = fixed_base_acc(ge_identity(), a.P.tab[BASE_G], sc_sub(z, sc_mul(gamma, e)));   // Y_g
-  sc s1[1] = {z}; chain<1>(acc, A, s1);                                                    // z A
-  sc s2[1] = {ng}; chain<1>(acc, xa, s2);                                                  // - gamma X_A   (:540 / :1233)
-  ge yg[1] = {acc[1]}; chain<1>(yg, a.w, s2);                                              // - gamma w     (:541 / :1234)
+  uint32_t* bk = a.pbk + (size_t)p * 2 * BUCKET_WORDS;
+  sc s1[1] = {z}; chain_b<1>(acc, A, s1, bk);                                                    // z A
+  sc s2[1] = {ng}; chain_b<1>(acc, xa, s2, bk);                                                  // - gamma X_A   (:540 / :1233)
+  ge yg[1] = {acc[1]}; chain_b<1>(yg, a.w, s2, bk);                                              // - gamma w     (:541 / :1234)
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
   tr_put_prefix(tr, a.P, a.label);
   uint8_t* el = tr + a.P.prefix_len[a.label];

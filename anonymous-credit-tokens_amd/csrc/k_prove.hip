@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(64, 2) k_prove_head(ProveArgs a) {
   // A' = (r1 r2) A and the A-part of A1 = e' A' share A's doubling chain
   ge acc[2] = {ge_identity(), ge_identity()};
   sc sa[2] = {r1r2, sc_mul(e_prime, r1r2)};
-  chain<2>(acc, A, sa);
+  chain_b<2>(acc, A, sa, a.half + (size_t)p * 2 * BUCKET_WORDS);       // the half-point area is not in use yet
   sc r1c = sc_mul(r1, c), r1k = sc_mul(r1, k), r1r = sc_mul(r1, r);
   ge bbar = fixed_base_acc(ge_identity(), a.P.tab[BASE_G], r1);
   bbar = fixed_base_acc(bbar, a.P.tab[BASE_H1], r1c);

@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(64, 2) k_sign_a(SignArgs a) {
   ge xa = ge_load(a.xa + (size_t)p * GE_WORDS);
   ge acc[2] = {ge_identity(), ge_identity()};
   sc s[2] = {inv, sc_mul(alpha, inv)};
-  chain<2>(acc, xa, s);                                           // acc[0] = A, acc[1] = Y_A (:650 / :853)
+  chain_b<2>(acc, xa, s, a.pbk + (size_t)p * 2 * BUCKET_WORDS);                                           // acc[0] = A, acc[1] = Y_A (:650 / :853)
   ge xg = ge_add(fixed_base_acc(ge_identity(), a.P.tab[BASE_G], e), a.K.w);     // :646 / :851
   ge yg = fixed_base_acc(ge_identity(), a.P.tab[BASE_G], alpha);                 // :651 / :854
 
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64, 2) k_issue_a(IssueArgs a) {
   acc[0] = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], k_bar);
   acc[0] = fixed_base_acc(acc[0], a.P.tab[BASE_H3], r_bar);
   sc s[1] = {sc_neg(gamma)};
-  chain<1>(acc, K, s);
+  chain_b<1>(acc, K, s, a.pbk + (size_t)p * 2 * BUCKET_WORDS);
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
   tr_put_prefix(tr, a.P, LABEL_REQUEST);
   uint8_t* el = tr + a.P.prefix_len[LABEL_REQUEST];

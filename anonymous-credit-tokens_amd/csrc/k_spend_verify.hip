@@ -63,9 +63,10 @@ __global__ void __launch_bounds__(64, 2) k_spend_prep(SpendArgs a) {
   // A1 = (e_bar - x gamma) A' + r2_bar B_bar ; A2 += r3_bar B_bar
   acc[0] = ge_identity();
   sc sa[1] = {sc_sub(e_bar, sc_mul(a.K.x, gamma))};
-  chain<1>(acc, A, sa);
+  uint32_t* pbk = a.buckets + (size_t)p * 2 * BUCKET_WORDS;      // free until k_spend_bits runs
+  chain_b<1>(acc, A, sa, pbk);
   sc sb[2] = {r2_bar, r3_bar};
-  chain<2>(acc, B, sb);
+  chain_b<2>(acc, B, sb, pbk);
 
   uint32_t enc[8];
   ristretto_encode(enc, acc[0]); tr_put_aligned(el + 40 * st.el_a1(), enc);
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(64, 2) k_spend_tail(SpendArgs a) {
   acc[0] = fixed_base_acc(acc[0], a.P.tab[BASE_H2], k_bar);
   acc[0] = fixed_base_acc(acc[0], a.P.tab[BASE_H3], s_bar);
   sc sk_[1] = {ngamma};
-  chain<1>(acc, kp, sk_);
+  chain_b<1>(acc, kp, sk_, a.buckets + (size_t)p * 2 * BUCKET_WORDS);      // the half-points were consumed by k_spend_enc
   uint32_t enc[8];
   ristretto_encode(enc, acc[0]); tr_put_aligned(el + 40 * st.el_c(), enc);
   ge xa = ge_add(kp, ge_basepoint());                                         // X_A = g + K' (src/lib.rs:848)

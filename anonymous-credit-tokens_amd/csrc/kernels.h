@@ -72,7 +72,8 @@ struct SpendArgs {
   uint32_t tr_stride;
   uint32_t* coords;          // n * L * NIELS_WORDS : affine Niels of every decoded Com_j
   uint32_t* d01;             // n * 2 * GE_WORDS    : w00*h2, w01*h2
-  uint32_t* buckets;         // n * L * BUCKET_WORDS: per-lane Pippenger buckets of k_spend_bits (msm.h chain_bu)
+  uint32_t* buckets;         // n * max(L, 2) * BUCKET_WORDS: per-lane Pippenger buckets of k_spend_bits (msm.h chain_bu); the
+                             // per-proof kernels use the first 2 * BUCKET_WORDS of every 2 * BUCKET_WORDS stride (chain_b)
   uint32_t* xa;              // n * GE_WORDS        : X_A = g + K'
   uint32_t* flags;           // n
   const uint32_t* xof;       // n * 16              : BLAKE3 XOF words of the transcript
@@ -94,6 +95,7 @@ struct SignArgs {
   uint32_t* state;           // n * 24 words: e | alpha | enc(A)
   const uint32_t* xof;
   uint8_t* out;              // n * 128 (refund) or n * 160 (issue)
+  uint32_t* pbk;             // n * 2 * BUCKET_WORDS: per-proof Pippenger buckets (msm.h chain_b)
 };
 
 struct IssueArgs {
@@ -106,6 +108,7 @@ struct IssueArgs {
   uint32_t* flags;
   const uint32_t* xof;
   uint8_t* status;
+  uint32_t* pbk;             // n * 2 * BUCKET_WORDS (msm.h chain_b)
 };
 
 struct RequestArgs {
@@ -151,6 +154,7 @@ struct ClientArgs {
   const uint32_t* xof;
   uint8_t* out_token;        // n * 160
   uint8_t* status;
+  uint32_t* pbk;             // n * 2 * BUCKET_WORDS (msm.h chain_b)
 };
 
 struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n; uint32_t* xof; const uint32_t* len_per_lane; };

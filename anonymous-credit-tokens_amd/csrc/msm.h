@@ -330,6 +330,46 @@ ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc&
   acc_l = R;
 }
 
+// ---- chain_b<NACC>: acc[a] += s[a] * N for per-lane scalars, all through signed radix-16 Pippenger buckets on ONE
+// doubling chain (the bucket half of chain_bu, for the per-proof kernels): 64 bucket additions + a 14-addition
+// combine per scalar and one cached conversion per four doublings, instead of chain<NACC>'s 127 digit additions
+// and two cached conversions per two doublings.  `bk`: NACC * BUCKET_WORDS words owned by this lane.
+template <int NACC>
+ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
+  const ge id = ge_identity();
+  for (int b = 0; b < NACC * BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);
+  uint32_t w[NACC][8], carry[NACC];
+  for (int a = 0; a < NACC; a++) { carry[a] = 0; for (int i = 0; i < 8; i++) w[a][i] = s[a].v[i]; }
+  ge P = N;                                    // position 0, T valid
+  for (int step = 0; step < 64; step++) {
+    ge_cached c = ge_to_cached(P);
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+      uint32_t v = (w[a][0] & 15u) + carry[a];
+      for (int i = 0; i < 7; i++) w[a][i] = (w[a][i] >> 4) | (w[a][i + 1] << 28);
+      w[a][7] >>= 4;
+      carry[a] = v > 8u ? 1u : 0u;
+      bool neg = v > 8u;
+      uint32_t mag = neg ? 16u - v : v;        // 0..8; bucket 0 absorbs the zero digits
+      uint32_t* slot = bk + ((size_t)a * BUCKETS + mag) * GE_WORDS;
+      bucket_store(slot, ge_add_cached(bucket_load(slot), ge_cached_cneg(c, neg)));
+    }
+    if (step == 63) break;
+    P = ge_double_opt(P, false); P = ge_double_opt(P, false); P = ge_double_opt(P, false);
+    P = ge_double_opt(P, true);                // the next bucket point needs T
+  }
+  for (int a = 0; a < NACC; a++) {             // sum_v v * B_v by running sums
+    const uint32_t* ba = bk + (size_t)a * BUCKET_WORDS;
+    ge S = bucket_load(ba + 8 * GE_WORDS);
+    ge R = S;
+    for (int vv = 7; vv >= 1; vv--) {
+      S = ge_add_cached(S, ge_to_cached(bucket_load(ba + vv * GE_WORDS)));
+      R = ge_add_cached(R, ge_to_cached(S));
+    }
+    acc[a] = ge_add_cached(acc[a], ge_to_cached(R));
+  }
+}
+
 // ---- batched double-and-compress (ge25519.h dc_*): one field inversion per E encodings ----------------------
 // Encodes 2*Q_i for `count` <= E points.  `slot(i)` -> the 40 words of point i (X|Y|Z|T); they are overwritten with
 // e|f|g|h between the two passes.  `emit(i, words)` receives the encodings, last point first.

@@ -120,6 +120,15 @@ extern "C" int hc_dc_encode_batch(const uint8_t* a_enc, const uint8_t* b_enc, in
                      [&](int i, const uint32_t* enc) { st(out + 32 * i, enc); });
   return 1;
 }
+extern "C" int hc_chain_b2(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
+  uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
+  ge acc[2] = {ge_identity(), ge_identity()};
+  sc s[2] = {sc_in(s0), sc_in(s1)};
+  std::vector<uint32_t> bk((size_t)2 * BUCKET_WORDS);
+  chain_b<2>(acc, p, s, bk.data());
+  ristretto_encode(r, acc[0]); st(o0, r); ristretto_encode(r, acc[1]); st(o1, r);
+  return 1;
+}
 extern "C" int hc_chain_bu(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
   uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
   ge al = ge_identity(), au = ge_identity();
