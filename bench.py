@@ -178,7 +178,7 @@ def main():
         traffic = None
         valu = None
         try:
-            v = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_valu.json")))
+            v = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_valu.json")))
             # the roofline that actually binds: SIMD issue slots.  A wavefront of k_spend_bits is v instructions at c cycles
             # each with two waves per SIMD; at the measured clock the chip's 1024 SIMDs cannot exceed this many verifies/s.
             per_wave, cyc, clk = v["valu_instructions_per_wave"], v["cycles_per_valu_instruction_per_simd_2waves"], v["effective_clock_ghz"] * 1e9
@@ -186,11 +186,11 @@ def main():
             bound = 1024 * clk / (waves_per_proof * per_wave * cyc)
             valu = {"valu_instructions_per_wave": per_wave, "cycles_per_instruction": cyc, "clock_ghz": v["effective_clock_ghz"],
                     "issue_bound_verifies_per_s_per_gpu": bound, "frac_of_issue_bound": (value / world) / bound,
-                    "source": "profiles/r01_g_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE)"}
+                    "source": "profiles/r01_h_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE)"}
         except (OSError, KeyError, ValueError):
             pass
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_traffic.json")))
+            t = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic.json")))
             if int(t["proofs_per_launch"]) == int(proofs_per_launch):
                 traffic = t["hbm_bytes_per_launch_fetch_x2"]
         except (OSError, KeyError, ValueError):
