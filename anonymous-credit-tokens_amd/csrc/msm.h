@@ -1,14 +1,15 @@
 // msm.h — the two scalar-multiplication shapes every kernel of the engine is built from.
 //
-// 1. chain<NACC>: variable-base, right-to-left, radix 4, NACC accumulators sharing ONE doubling
-//    chain.  For acc_a += s_a * N the lane walks P = 4^i N; per step it has P and 2P in cached form
-//    and adds +-P or 2P (signed digit in {-1,0,1,2}) to each accumulator.  No per-lane table (the
-//    reference's 8-entry table per `point * scalar` — dalek variable_base — would be 1 KiB per lane,
-//    which neither LDS at 2 waves/SIMD nor VGPRs can hold), and the doublings are paid once for all
-//    NACC scalars on the same base: the verifier's C'_j0 / C'_j1 share Com_j
+// 1. Variable-base, right-to-left, every scalar on a base sharing ONE doubling chain P_i = 2^i N, with no per-lane
+//    table of multiples (the reference's 8-entry table per `point * scalar` -- dalek variable_base -- would be
+//    1 KiB per lane, which neither LDS at 2 waves/SIMD nor VGPRs can hold) and the same instruction schedule in all
+//    64 lanes (no vartime-wNAF divergence to lose on a 64-wide SIMD).  The doublings are paid once for all scalars on
+//    the same base: the verifier's C'_j0 / C'_j1 share Com_j
 //    (/root/reference/src/lib.rs:814-816), A1/A2 share B_bar (:793-797), A*/Y_A share X_A (:849-853).
-//    Every lane of a wavefront executes the same schedule (a digit-0 lane only sits out an add), so
-//    there is no vartime-wNAF divergence to lose on a 64-wide SIMD.
+//      chain_bu      (k_spend_bits)      per-lane scalar through signed radix-16 Pippenger buckets in global memory,
+//                                        wave-uniform scalar through two width-3-NAF accumulators in LDS
+//      chain_b<NACC> (per-proof kernels) every scalar through its own bucket set
+//      chain<NACC>, chain2u              the earlier radix-4 / plain-NAF forms, kept as cross-checks for the host build
 // 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as 16 mixed
 //    additions, one per scalar window, from position-specific affine-Niels tables
 //    T[pos][d] = d * 2^(w*pos) * B, w = FB_WBITS = 16 (16 windows x 65536 entries x 128 B = 128 MiB per base,
