@@ -13,8 +13,8 @@
 //
 //   k_prove_head  lane = proof         A', B_bar, A1, A2, r3 = 1/r1, the three h2 terms of bit 0
 //   k_prove_bits  lane = (proof, bit)  Com_j / 2, C'_j0 / 2, C'_j1 / 2 (every scalar halved mod l)
-//   k_prove_enc   lane = 8 half-points their encodings by batched double-and-compress (ge25519.h dc_*, msm.h): one field
-//                                      inversion per 8 encodings instead of an inverse square root each
+//   k_prove_enc   lane = 32 half-points their encodings by batched double-and-compress (ge25519.h dc_*, msm.h): one field
+//                                      inversion per 32 encodings instead of an inverse square root each
 //   k_prove_tail  lane = proof         r*, C
 //   (transcript hash)
 //   k_prove_resp  lane = (proof, bit)  gamma_j0, z_j0, z_j1; lane bit 0 also writes every proof-level response
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) k_prove_bits(ProveArgs a) {
 }
 
 // lane = PROVE_ENC_BATCH consecutive half-points; point q = 3 * (p * L + j) + c is slot c of lane (p, j)
-constexpr int PROVE_ENC_BATCH = 8;
+constexpr int PROVE_ENC_BATCH = 32;
 __global__ void __launch_bounds__(256, 2) k_prove_enc(ProveArgs a) {
   const uint32_t L = (uint32_t)a.P.L;
   const uint64_t total = (uint64_t)a.n * L * 3u;

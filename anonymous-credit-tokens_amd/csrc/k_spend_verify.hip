@@ -5,8 +5,8 @@
 //   k_spend_prep  lane = proof          A', B_bar checks (:787), A1, A2 (:791-799), w00*h2 / w01*h2 (:806,808)
 //   k_spend_bits  lane = (proof, bit)   C'_j0 / 2, C'_j1 / 2 (:800-817): decode Com_j, two fixed-base sums, one shared
 //                                       doubling chain over -Com_j (msm.h chain_bu); every scalar halved mod l
-//   k_spend_enc   lane = 8 half-points  encodings of C'_j0, C'_j1 = 2 * (half-point) by batched double-and-compress:
-//                                       one field inversion per 8 encodings instead of one inverse square root each
+//   k_spend_enc   lane = 32 half-points encodings of C'_j0, C'_j1 = 2 * (half-point) by batched double-and-compress:
+//                                       one field inversion per 32 encodings instead of one inverse square root each
 //   k_spend_tail  lane = proof          K' by Horner over the decoded Com_j (:819-824), Com, C (:825-829), X_A (:848)
 //   k_spend_finish lane = proof         challenge = XOF mod l ?= gamma (:842-844) -> status
 //
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
 }
 
 // lane = ENC_BATCH consecutive half-points; point q = 2 * (p * L + j) + b lives in slot b of lane (p, j)'s bucket area
-constexpr int ENC_BATCH = 8;
+constexpr int ENC_BATCH = 32;
 __global__ void __launch_bounds__(256, 2) k_spend_enc(SpendArgs a) {
   const uint32_t L = (uint32_t)a.P.L;
   const uint64_t total = (uint64_t)a.n * L * 2u;
