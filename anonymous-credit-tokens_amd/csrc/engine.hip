@@ -280,11 +280,13 @@ int from_uniform_on_device(int device, const uint8_t* in64, int n, uint8_t* out_
 // consecutive 128-byte slices to the accepted lanes in lane order, so it must read the chunk's statuses back first.
 int prepare_rng_slots(act_ctx* c, Slot& sl, uint32_t m, size_t off, int mem, const uint8_t* rng, int rng_mode, size_t* seq_cursor,
                       const uint8_t** d_rng) {
+  if (rng_mode == ACT_RNG_PER_LANE) {          // lane i owns slice off + i: filled on the device, nothing for the host to wait for
+    if (mem == ACT_MEM_DEVICE) { *d_rng = rng; launch_iota(sl.d_slot, m, (uint32_t)off, sl.stream); }
+    else { int rc = dev_in(c, sl, 3, mem, rng + off * 128, (size_t)m * 128, d_rng); if (rc) return rc; launch_iota(sl.d_slot, m, 0u, sl.stream); }
+    return ACT_OK;
+  }
   std::vector<uint32_t> slot(m);
-  if (rng_mode == ACT_RNG_PER_LANE) {
-    if (mem == ACT_MEM_DEVICE) { for (uint32_t i = 0; i < m; i++) slot[i] = (uint32_t)(off + i); *d_rng = rng; }
-    else { for (uint32_t i = 0; i < m; i++) slot[i] = i; int rc = dev_in(c, sl, 3, mem, rng + off * 128, (size_t)m * 128, d_rng); if (rc) return rc; }
-  } else {
+  {
     std::vector<uint8_t> st(m);
     HIPCK(c, hipMemcpyAsync(st.data(), sl.d_status, m, hipMemcpyDeviceToHost, sl.stream));
     HIPCK(c, hipStreamSynchronize(sl.stream));
@@ -490,9 +492,12 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
-  Slot& sl = c->slots[0];
-  size_t cursor = 0;
-  for (size_t off = 0; off < n; off += c->max_batch) {
+  size_t cursor = 0, chunk = 0;
+  // chunks alternate between the two slots; with device transcripts and per-lane rng nothing in a chunk waits for the
+  // host, so two chunks are in flight (the per-proof kernels put only one wavefront per SIMD on the GPU per chunk)
+  for (size_t off = 0; off < n; off += c->max_batch, chunk++) {
+    Slot& sl = c->slots[chunk & 1];
+    if (chunk >= 2) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
     IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.pbk = sl.d_buckets;
     if ((rc = dev_in(c, sl, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
@@ -507,9 +512,8 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
     if ((rc = sign_phase(c, sl, m, LABEL_RESPOND, d_rng, a.c_amount, d_out))) return rc;
     if ((rc = dev_out_end(c, sl, mem, out_resp + off * 160, d_out, (size_t)m * 160))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
-    if ((rc = sync_all(c))) return rc;
   }
-  return ACT_OK;
+  return sync_all(c);
 }
 
 // verify (sign == false) or refund (sign == true), two-slot software pipeline: stage 1 of chunk i+1 is enqueued before

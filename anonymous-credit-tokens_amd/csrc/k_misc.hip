@@ -85,6 +85,13 @@ void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hi
   if (n) hipLaunchKernelGGL(k_pre_issuance_random, dim3((n + 255) / 256), dim3(256), 0, s, rng, n, out);
 }
 
+// out[i] = base + i: the rng slice index of lane i in ACT_RNG_PER_LANE mode (no host round trip, so a chunk's launches stay asynchronous)
+__global__ void __launch_bounds__(256) k_iota(uint32_t* out, uint32_t n, uint32_t base) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = base + i;
+}
+void launch_iota(uint32_t* out, uint32_t n, uint32_t base, hipStream_t s) { if (n) hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, out, n, base); }
+
 // Transcript::challenge's hash (src/transcript.rs:149-152): lane = message, 64 XOF bytes out.
 __global__ void __launch_bounds__(64) k_hash_xof(HashArgs a) {
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
