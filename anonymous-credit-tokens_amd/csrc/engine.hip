@@ -3,6 +3,9 @@
 // reference's src/transcript.rs does) and the C ABI of include/act_mi355x.h.
 // There is no CPU compute path here: the host only moves bytes and (optionally) hashes them.
 #include <algorithm>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +40,7 @@ struct PendingProf { int id; hipEvent_t e0, e1; uint64_t lanes; };
 
 // One workspace slot: a stream plus every per-chunk device buffer.  Two slots let chunk i+1's kernels (and the
 // host-side hashing of chunk i in host-transcript mode) overlap chunk i's low-occupancy head/tail kernels.
+constexpr int HASH_PIECES = 8;
 struct Slot {
   hipStream_t stream = nullptr;
   uint8_t *d_tr = nullptr, *d_trs = nullptr, *d_status = nullptr;
@@ -45,6 +49,7 @@ struct Slot {
   size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
   uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
   uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
+  hipEvent_t h_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per returned piece (HASH_PIECES)
   std::vector<PendingProf> pending;
   size_t last_spend_lanes = 0;
 };
@@ -147,8 +152,29 @@ void host_xof64(const std::vector<uint8_t>& msg, uint8_t out[64]) {
   memcpy(out, o, 64);
 }
 
+// CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a 16-CPU container on a
+// 256-thread host reports hardware_concurrency() = 256; hashing with that many threads runs at half the rate of 16)
+int usable_cpus() {
+  int n = (int)std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { int k = CPU_COUNT(&set); if (k > 0 && (n < 1 || k < n)) n = k; }
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "<quota|max> <period>"
+    char q[32]; long period = 0;
+    if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      long k = (atol(q) + period - 1) / period; if (k > 0 && k < n) n = (int)k;
+    }
+    fclose(f);
+  } else {
+    long quota = -1, period = 0;                                              // cgroup v1
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+    if (quota > 0 && period > 0) { long k = (quota + period - 1) / period; if (k > 0 && k < n) n = (int)k; }
+  }
+  return n < 1 ? 1 : n;
+}
 int n_host_threads(const act_ctx* c) {
-  int t = c->host_threads > 0 ? c->host_threads : (int)std::thread::hardware_concurrency();
+  static const int usable = usable_cpus();
+  int t = c->host_threads > 0 ? c->host_threads : usable;
   return t < 1 ? 1 : t;
 }
 // hash n messages of `len` bytes at `stride` (host memory) into xof[n][16] on host threads: groups of sixteen through
@@ -192,13 +218,23 @@ int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_
     sl.h_xof = nullptr; sl.h_xof_cap = 0;
     HIPCK(c, hipHostMalloc(&sl.h_xof, (size_t)n * 64, hipHostMallocDefault)); sl.h_xof_cap = (size_t)n * 64;
   }
-  HIPCK(c, hipMemcpyAsync(sl.h_tr, d_msgs, bytes, hipMemcpyDeviceToHost, sl.stream));
+  // the pre-images come back in HASH_PIECES pieces, each followed by an event, so that hash_end can hash piece k while
+  // piece k+1 is still crossing PCIe
+  for (int k = 0; k < HASH_PIECES; k++) {
+    size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
+    if (!sl.h_ev[k]) HIPCK(c, hipEventCreateWithFlags(&sl.h_ev[k], hipEventDisableTiming));
+    if (i1 > i0) HIPCK(c, hipMemcpyAsync(sl.h_tr + i0 * stride, d_msgs + i0 * stride, (i1 - i0) * stride, hipMemcpyDeviceToHost, sl.stream));
+    HIPCK(c, hipEventRecord(sl.h_ev[k], sl.stream));
+  }
   return ACT_OK;
 }
 int hash_end(act_ctx* c, Slot& sl, uint32_t stride, uint32_t len, uint32_t n) {
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) return ACT_OK;
-  HIPCK(c, hipStreamSynchronize(sl.stream));
-  host_hash_many(c, sl.h_tr, stride, len, n, sl.h_xof);
+  for (int k = 0; k < HASH_PIECES; k++) {
+    size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
+    HIPCK(c, hipEventSynchronize(sl.h_ev[k]));
+    if (i1 > i0) host_hash_many(c, sl.h_tr + i0 * stride, stride, len, i1 - i0, sl.h_xof + i0 * 16);
+  }
   HIPCK(c, hipMemcpyAsync(sl.d_xof, sl.h_xof, (size_t)n * 64, hipMemcpyHostToDevice, sl.stream));
   return ACT_OK;
 }
@@ -423,6 +459,7 @@ void act_ctx_destroy(act_ctx* c) {
     for (int i = 0; i < 6; i++) if (sl.d_stage[i]) { (void)hipMemset(sl.d_stage[i], 0, sl.d_stage_cap[i]); (void)hipFree(sl.d_stage[i]); }   // staging may hold secrets
     if (sl.h_tr) (void)hipHostFree(sl.h_tr);
     if (sl.h_xof) (void)hipHostFree(sl.h_xof);
+    for (hipEvent_t& e : sl.h_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->d_tables) (void)hipFree(c->d_tables);
@@ -523,12 +560,15 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
   const size_t pb = ProofLayout{c->L}.bytes();
-  const size_t nchunks = (n + c->max_batch - 1) / c->max_batch;
+  // host-transcript mode pipelines the device with the D2H copy and the host threads: measured best at 16384 proofs per
+  // chunk (the device kernels themselves like 65536), so its chunks are capped there
+  const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, 16384) : c->max_batch;
+  const size_t nchunks = (n + chunk_len - 1) / chunk_len;
   SpendChunk chunks[2];
   size_t cursor = 0;
   auto stage1 = [&](size_t i) -> int {
     Slot& sl = c->slots[i & 1]; SpendChunk& ch = chunks[i & 1];
-    ch = SpendChunk{}; ch.off = i * c->max_batch; ch.m = (uint32_t)std::min(c->max_batch, n - ch.off);
+    ch = SpendChunk{}; ch.off = i * chunk_len; ch.m = (uint32_t)std::min(chunk_len, n - ch.off);
     int r;
     if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
     if (out_kprime && (r = dev_out_begin(c, sl, 2, mem, out_kprime + ch.off * 32, (size_t)ch.m * 32, &ch.d_kprime))) return r;
