@@ -1,0 +1,54 @@
+"""Randomised soak: thousands of engine-made spend proofs with random field corruption, verified and refunded by the HIP
+engine (both transcript modes) and by the C oracle; every status and every refund record must agree.  Test
+infrastructure (uses oracle/); run on a GPU box:  python tools/soak.py [n] [seed]"""
+import hashlib, os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from act_amd import capi
+from oracle_c import Oracle
+ELL = 2**252 + 27742317777372353535851937790883648493
+sh = lambda l, n: hashlib.shake_256(l.encode()).digest(n)
+scb = lambda v: (v % ELL).to_bytes(32, "little")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+r = random.Random(seed)
+for L in (128, 64):
+    o = Oracle(); h = o.params_new("soak-org", "svc", "env", "v%d" % seed); octx = o.ctx(h, L)
+    eng = capi.Engine(h, L, max_batch=600, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(sh("sk%d" % seed, 64))
+    pre = eng.pre_issuance_random(sh("pre%d" % seed, 128 * n)); req = eng.request(pre, sh("rq%d" % seed, 128 * n))
+    amounts = [r.randrange(1, 1 << min(L, 100)) for _ in range(n)]
+    st, resp = eng.issue(sk, req, b"".join(scb(a) for a in amounts), sh("ir%d" % seed, 128 * n))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    spend = [r.randrange(0, a + 1) if r.random() < 0.9 else a + r.randrange(1, 5) for a in amounts]
+    st, proofs, prer = eng.prove_spend(tok, b"".join(scb(s) for s in spend), sh("pr%d" % seed, eng.prove_rng_bytes * n))
+    pb = eng.proof_bytes
+    t = bytearray(proofs)
+    nf = pb // 32
+    for i in range(n):
+        x = r.random()
+        if x < 0.25:                                   # flip one bit of a random field
+            f = r.randrange(nf); t[pb * i + 32 * f + r.randrange(32)] ^= 1 << r.randrange(8)
+        elif x < 0.30:                                 # a field zeroed (identity point / zero scalar)
+            f = r.randrange(nf); t[pb * i + 32 * f:pb * i + 32 * f + 32] = bytes(32)
+        elif x < 0.33:                                 # a field from another proof
+            f = r.randrange(nf); j = r.randrange(n); t[pb * i + 32 * f:pb * i + 32 * f + 32] = proofs[pb * j + 32 * f:pb * j + 32 * f + 32]
+        elif x < 0.35:                                 # non-canonical bytes
+            f = r.randrange(nf); t[pb * i + 32 * f:pb * i + 32 * f + 32] = bytes([255]) * 32
+    t = bytes(t)
+    rrng = sh("rr%d" % seed, 128 * n)
+    st_o = octx.verify_spend_batch(sk, t, 16)
+    ref_o = [octx.refund(sk, t[pb * i:pb * i + pb], rrng[128 * i:128 * i + 128]) for i in range(0, n, max(1, n // 256))]
+    for mode in (capi.TRANSCRIPT_DEVICE, capi.TRANSCRIPT_HOST):
+        eng.set_transcript_mode(mode)
+        st = eng.verify_spend(sk, t)
+        assert st == st_o, ("status mismatch", L, mode, [i for i in range(n) if st[i] != st_o[i]][:10])
+        st2, rf = eng.refund(sk, t, rrng)
+        assert st2 == st_o
+        for k, i in enumerate(range(0, n, max(1, n // 256))):
+            so, ro = ref_o[k]
+            assert so == st2[i] and ro == rf[128 * i:128 * i + 128], ("refund mismatch", L, mode, i)
+    hist = {}
+    for s_ in st_o: hist[s_] = hist.get(s_, 0) + 1
+    print("L=%d: %d proofs, statuses %s: engine == oracle (both transcript modes, refunds sampled)" % (L, n, dict(sorted(hist.items()))))
+    eng.close()
