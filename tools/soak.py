@@ -12,7 +12,7 @@ scb = lambda v: (v % ELL).to_bytes(32, "little")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 r = random.Random(seed)
-for L in (128, 64):
+for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
     o = Oracle(); h = o.params_new("soak-org", "svc", "env", "v%d" % seed); octx = o.ctx(h, L)
     eng = capi.Engine(h, L, max_batch=600, transcript=capi.TRANSCRIPT_DEVICE)
     sk = eng.private_key_random(sh("sk%d" % seed, 64))
