@@ -27,11 +27,11 @@ dt = timed(lambda: eng._ck(lib.act_cbor_decode_batch(ctx, T, N, 0, wire.ctypes.d
 assert bytes(stt) == bytes(N) and np.array_equal(back, recs)
 print("host memory  decode: %.0f msgs/s" % (N / dt))
 d_recs = torch.from_numpy(recs).cuda(); d_wire = torch.zeros(ml * N, dtype=torch.uint8, device="cuda"); d_back = torch.zeros(rb * N, dtype=torch.uint8, device="cuda")
-d_st = torch.zeros(N, dtype=torch.uint8, device="cuda"); d_offs = torch.from_numpy(offs.astype(np.int64)).cuda(); torch.cuda.synchronize()
+d_st = torch.zeros(N, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
 dt = timed(lambda: eng._ck(lib.act_cbor_encode_batch(ctx, T, N, 1, d_recs.data_ptr(), d_wire.data_ptr())))
 print("device memory encode: %.0f msgs/s" % (N / dt))
 try:
-    dt = timed(lambda: eng._ck(lib.act_cbor_decode_batch(ctx, T, N, 1, d_wire.data_ptr(), d_offs.data_ptr(), d_back.data_ptr(), d_st.data_ptr())))
+    dt = timed(lambda: eng._ck(lib.act_cbor_decode_batch(ctx, T, N, 1, d_wire.data_ptr(), offs.ctypes.data, d_back.data_ptr(), d_st.data_ptr())))
     assert int((d_st == 0).sum()) == N and torch.equal(d_back, d_recs)
     print("device memory decode: %.0f msgs/s" % (N / dt))
 except Exception as e:
