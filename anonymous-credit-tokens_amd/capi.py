@@ -20,7 +20,7 @@ EXPORTS = [
     "act_ctx_set_host_threads", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
-    "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_prof_enable",
+    "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_prof_enable",
     "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
     lib.act_refund_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_refund_to_credit_token_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
     lib.act_debug_last_spend_transcripts.argtypes = [vp, sz, u8p, C.POINTER(sz)]
+    lib.act_debug_scalarmult_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p]
     for f in ("act_cbor_size", "act_cbor_record_bytes"):
         getattr(lib, f).argtypes = [vp, i32]
         getattr(lib, f).restype = sz
@@ -229,6 +230,12 @@ class Engine:
         self._ck(self.lib.act_debug_last_spend_transcripts(self.ctx, max_lanes, out.ctypes.data, C.byref(n)))
         b = out.tobytes()
         return [b[i * self.transcript_bytes:(i + 1) * self.transcript_bytes] for i in range(n.value)]
+
+    def debug_scalarmult(self, points: bytes, scalars: bytes):
+        n = len(points) // 32; out = np.zeros(32 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(points, 32 * n); p1, k1 = _in(scalars, 32 * n)
+        self._ck(self.lib.act_debug_scalarmult_batch(self.ctx, n, MEM_HOST, p0, p1, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
 
     # ---- CBOR wire codec (src/cbor.rs) -----------------------------------------------------------------
     def cbor_size(self, type_name: str) -> int:

@@ -4,6 +4,7 @@
 // There is no CPU compute path here: the host only moves bytes and (optionally) hashes them.
 #include <algorithm>
 #include <sched.h>
+#include <sys/random.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
@@ -259,9 +260,12 @@ int decode_one(act_ctx* c, const uint8_t enc[32], ge* out) {
 }
 int set_key(act_ctx* c, const uint8_t sk[64]) {
   if (c->sk_valid && memcmp(c->sk_cached, sk, 64) == 0) return ACT_OK;
+  // nothing of the cached key changes unless the whole new key is good (a rejected w must not leave its x behind)
   uint32_t w[8]; memcpy(w, sk, 32);
-  c->key.x = sc_from_words(w);
-  int rc = decode_one(c, sk + 32, &c->key.w); if (rc) return rc;
+  ge wpt;
+  int rc = decode_one(c, sk + 32, &wpt); if (rc) return rc;
+  c->sk_valid = false;
+  c->key.x = sc_from_words(w); c->key.w = wpt;
   memcpy(c->sk_cached, sk, 64); c->sk_valid = true;
   return ACT_OK;
 }
@@ -708,6 +712,24 @@ int act_debug_last_spend_transcripts(act_ctx* c, size_t max_lanes, uint8_t* out,
   HIPCK(c, hipMemcpy(tmp.data(), sl.d_tr, tmp.size(), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < m; i++) memcpy(out + i * st.bytes(), tmp.data() + i * st.stride(), st.bytes());
   *n_copied = m;
+  return ACT_OK;
+}
+
+int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* points, const uint8_t* scalars, uint8_t* out, uint8_t* status) {
+  if (!c || (n && (!points || !scalars || !out || !status))) return ACT_ERR_ARG;
+  HIPCK(c, hipSetDevice(c->device));
+  Slot& sl = c->slots[0];
+  for (size_t off = 0; off < n; off += c->max_batch) {
+    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    const uint8_t *d_p, *d_s; uint8_t* d_o; int rc;
+    if ((rc = dev_in(c, sl, 0, mem, points + off * 32, (size_t)m * 32, &d_p))) return rc;
+    if ((rc = dev_in(c, sl, 1, mem, scalars + off * 32, (size_t)m * 32, &d_s))) return rc;
+    if ((rc = dev_out_begin(c, sl, 2, mem, out + off * 32, (size_t)m * 32, &d_o))) return rc;
+    launch_debug_scalarmult(d_p, d_s, m, sl.d_buckets, d_o, sl.d_status, sl.stream);
+    if ((rc = dev_out_end(c, sl, mem, out + off * 32, d_o, (size_t)m * 32))) return rc;
+    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
+    HIPCK(c, hipStreamSynchronize(sl.stream));
+  }
   return ACT_OK;
 }
 

@@ -85,6 +85,25 @@ void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hi
   if (n) hipLaunchKernelGGL(k_pre_issuance_random, dim3((n + 255) / 256), dim3(256), 0, s, rng, n, out);
 }
 
+// Test hook (act_debug_scalarmult_batch): out[i] = enc(s_i * P_i) through the production variable-base chain of the
+// per-proof kernels (msm.h chain_b<1>) and the production decode / encode, so that third-party known answers for
+// `RistrettoPoint * Scalar` (tests/golden/sodium_primitives.json) can be replayed on the device one operation at a time.
+__global__ void __launch_bounds__(64, 2) k_debug_scalarmult(const uint8_t* pts, const uint8_t* scs, uint32_t n, uint32_t* pbk, uint8_t* out, uint8_t* status) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8]; load8(w, pts + (size_t)i * 32);
+  ge p; bool ok = ristretto_decode(p, w);
+  ge acc[1] = {ge_identity()};
+  sc s[1] = {load_sc(scs + (size_t)i * 32)};
+  chain_b<1>(acc, p, s, pbk + (size_t)i * BUCKET_WORDS);
+  uint32_t e[8]; ristretto_encode(e, acc[0]);
+  if (ok) store8(out + (size_t)i * 32, e); else zero8(out + (size_t)i * 32);
+  status[i] = ok ? 0 : 255;
+}
+void launch_debug_scalarmult(const uint8_t* pts, const uint8_t* scs, uint32_t n, uint32_t* pbk, uint8_t* out, uint8_t* status, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_debug_scalarmult, dim3((n + 63) / 64), dim3(64), 0, s, pts, scs, n, pbk, out, status);
+}
+
 // out[i] = base + i: the rng slice index of lane i in ACT_RNG_PER_LANE mode (no host round trip, so a chunk's launches stay asynchronous)
 __global__ void __launch_bounds__(256) k_iota(uint32_t* out, uint32_t n, uint32_t base) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;

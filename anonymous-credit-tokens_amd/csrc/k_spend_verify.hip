@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) k_spend_finish(SpendArgs a) {
   else if (f & FLAG_IDENTITY) stt = 6;                                        // Error::IdentityPointError
   else if (!sc_equal(chal, gamma)) stt = 7;                                   // Error::InvalidClientSpendProof
   a.status[p] = stt;
-  if (a.kprime_enc && stt != 0 && stt != 7) zero8(a.kprime_enc + (size_t)p * 32);
+  if (a.kprime_enc && stt != 0) zero8(a.kprime_enc + (size_t)p * 32);          // the output record of a failed lane is all zero
 }
 
 void launch_spend_prep(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_prep, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }

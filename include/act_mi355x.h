@@ -164,8 +164,9 @@ int act_cbor_decode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8
  * iff nullifier i is already in the set or equals the nullifier of an earlier lane of this batch; fresh nullifiers are
  * inserted.  Nullifier i is the 32 bytes at nullifiers + i*stride (stride = act_spend_proof_bytes reads the `k` field
  * straight out of SpendProof records).  skip_mask (nullable): lanes with a non-zero byte (e.g. the status of a rejected
- * proof) are neither checked nor inserted and report 0.  capacity = the number of nullifiers the set must hold; `salt`
- * (nullable, 16 bytes) keys the slot hash.  Multi-GPU deployments shard the key space (owner = low 64 bits mod N): one
+ * proof) are neither checked nor inserted and report 0.  Keys are compared as scalars: every nullifier is reduced mod l
+ * on input (k and k + l are the same key, as in the reference's HashSet<Scalar>).  capacity = the number of nullifiers
+ * the set must hold; `salt` (16 bytes) keys the SipHash-1-3 slot hash; NULL = 16 bytes from the OS (getrandom).  Multi-GPU deployments shard the key space (owner = low 64 bits mod N): one
  * set per GPU behind an all-to-all of the keys, anonymous-credit-tokens_amd/sharded_nullifier.py. */
 typedef struct act_nullifier_set act_nullifier_set;
 int act_nullifier_set_create(int device, size_t capacity, const uint8_t salt[16], act_nullifier_set **out);
@@ -178,6 +179,13 @@ int act_nullifier_check_and_insert_batch(act_nullifier_set *set, size_t n, int m
 /* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
 int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *out, size_t *n_copied);
+
+/* Debug / test hook: out[i] = enc(scalars[i] * points[i]) (`RistrettoPoint * Scalar`, e.g. src/lib.rs:791) computed by the
+ * engine's production variable-base chain, decode and encode; status[i] = 255 and a zero record when points[i] is not a
+ * canonical encoding.  Exists so that third-party known answers can be replayed on the device one operation at a time
+ * (tests/golden/sodium_primitives.json). */
+int act_debug_scalarmult_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *points, const uint8_t *scalars, uint8_t *out,
+                               uint8_t *status);
 
 /* Kernel timing (HIP events on the context's own stream, which torch.cuda.Event cannot see):
  * enable, run batches, then read per-kernel totals.  names: act_prof_kernel_name(i), i < act_prof_kernel_count(). */

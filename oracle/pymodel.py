@@ -728,7 +728,8 @@ def _pt(b: bytes) -> Point:
 
 
 def _sc(b: bytes) -> int:
-    return int.from_bytes(b, "little")
+    # a Rust `Scalar` is always canonical: decode_scalar reduces with from_bytes_mod_order (src/cbor.rs:85)
+    return int.from_bytes(b, "little") % ELL
 
 
 def parse_spend_proof(rec: bytes, nbits: int = L_DEFAULT) -> SpendProof:

@@ -255,3 +255,23 @@ def test_simd_host_hash_on_this_cpu_matches_scalar_and_device(engine_factory, be
         out[mode] = eng.refund(sk, bytes(bad), shake("rr-simd", 128 * n))
     assert out[capi.TRANSCRIPT_HOST] == out[capi.TRANSCRIPT_DEVICE]
     assert list(out[0][0]) == [7 if i == 40 else 0 for i in range(n)]
+
+
+def test_rejected_private_key_leaves_the_cached_key_untouched(engine_factory, bench_params):
+    """good key -> key whose w is not a canonical encoding (ACT_ERR_PARAMS) -> good key again: the second good call must
+    verify with the good x (a half-updated key cache would report status 7 for a valid proof)."""
+    from act_amd import capi
+    eng = engine_factory(bench_params, 8, max_batch=4)
+    sk = eng.private_key_random(shake("sk-cache", 64))
+    pre = eng.pre_issuance_random(shake("pre-cache", 128)); req = eng.request(pre, shake("rq-cache", 128))
+    st, resp = eng.issue(sk, req, scb(9), shake("ir-cache", 128))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proof, _ = eng.prove_spend(tok, scb(4), shake("pr-cache", eng.prove_rng_bytes))
+    assert eng.verify_spend(sk, proof) == b"\x00"
+    bad = bytearray(eng.private_key_random(shake("sk-cache-other", 64))); bad[32] |= 1        # w: negative s -> undecodable
+    with pytest.raises(capi.ActError) as e:
+        eng.verify_spend(bytes(bad), proof)
+    assert "ACT_ERR_PARAMS" in str(e.value)
+    assert eng.verify_spend(sk, proof) == b"\x00"
+    st, rf = eng.refund(sk, proof, shake("rr-cache", 128))
+    assert st == b"\x00" and eng.refund_to_credit_token(_, proof, rf, sk[32:])[0] == b"\x00"

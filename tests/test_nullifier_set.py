@@ -83,3 +83,23 @@ def test_million_keys_on_device():
     ns.check_and_insert_dev(n, keys.data_ptr(), 32, 0, spent.data_ptr())
     torch.cuda.synchronize()
     assert int(spent.sum()) == n and len(ns) == n // 2
+
+
+def test_keys_are_scalars_not_byte_strings():
+    """A raw record may carry k + l (the verifier reduces it and accepts): it must be the same key as k, as in the
+    reference's HashSet<Scalar> (a Rust Scalar is always canonical, src/cbor.rs:85)."""
+    from act_amd import capi
+    from conftest import ELL
+    ns = capi.NullifierSet(capacity=1000)
+    k = int.from_bytes(shake("ns-canon", 32), "little") % ELL
+    le = lambda v: v.to_bytes(32, "little")
+    assert list(ns.check_and_insert(le(k) + le(k + ELL))) == [0, 1]                      # same batch
+    assert list(ns.check_and_insert(le(k + 2 * ELL) + le(k + 15 * ELL) + le(k))) == [1, 1, 1]   # across batches
+    k2 = (k + 12345) % ELL
+    assert list(ns.check_and_insert(le(k2 + 3 * ELL))) == [0]                            # first seen in non-canonical form
+    assert list(ns.check_and_insert(le(k2) + le(k2 + ELL))) == [1, 1]
+    assert len(ns) == 2
+    # two sets with OS-drawn salts agree on the answers (the salt only moves slots around)
+    a, b = capi.NullifierSet(capacity=100), capi.NullifierSet(capacity=100)
+    keys = b"".join(shake("ns-salt%d" % (i % 7), 32) for i in range(20))
+    assert a.check_and_insert(keys) == b.check_and_insert(keys)
