@@ -266,7 +266,7 @@ def test_rejected_private_key_leaves_the_cached_key_untouched(engine_factory, be
     pre = eng.pre_issuance_random(shake("pre-cache", 128)); req = eng.request(pre, shake("rq-cache", 128))
     st, resp = eng.issue(sk, req, scb(9), shake("ir-cache", 128))
     st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
-    st, proof, _ = eng.prove_spend(tok, scb(4), shake("pr-cache", eng.prove_rng_bytes))
+    st, proof, prer = eng.prove_spend(tok, scb(4), shake("pr-cache", eng.prove_rng_bytes))
     assert eng.verify_spend(sk, proof) == b"\x00"
     bad = bytearray(eng.private_key_random(shake("sk-cache-other", 64))); bad[32] |= 1        # w: negative s -> undecodable
     with pytest.raises(capi.ActError) as e:
@@ -274,4 +274,4 @@ def test_rejected_private_key_leaves_the_cached_key_untouched(engine_factory, be
     assert "ACT_ERR_PARAMS" in str(e.value)
     assert eng.verify_spend(sk, proof) == b"\x00"
     st, rf = eng.refund(sk, proof, shake("rr-cache", 128))
-    assert st == b"\x00" and eng.refund_to_credit_token(_, proof, rf, sk[32:])[0] == b"\x00"
+    assert st == b"\x00" and eng.refund_to_credit_token(prer, proof, rf, sk[32:])[0] == b"\x00"
