@@ -21,7 +21,7 @@ EXPORTS = [
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_prof_enable",
-    "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get",
+    "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
     "act_nullifier_check_and_insert_batch",
@@ -101,6 +101,8 @@ def load() -> C.CDLL:
     lib.act_prof_kernel_name.argtypes = [vp, i32]
     lib.act_prof_kernel_name.restype = C.c_char_p
     lib.act_prof_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.act_prof_get_busy.argtypes = [vp, i32, C.POINTER(C.c_double)]
+    lib.act_ubench_mad_u64_u32.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     _lib = lib
     return lib
 
@@ -130,6 +132,15 @@ def params_random(rng: bytes, device: int = 0) -> bytes:
     if rc:
         raise ActError(f"act_params_random failed: {_ERRS.get(rc, rc)}")
     return out.tobytes()
+
+
+def ubench_mad(device: int = 0):
+    """(lane-MADs per second, probe ms) of the v_mad_u64_u32 roofline probe."""
+    r, ms = C.c_double(0), C.c_double(0)
+    rc = load().act_ubench_mad_u64_u32(device, C.byref(r), C.byref(ms))
+    if rc:
+        raise ActError(f"act_ubench_mad_u64_u32 failed: {_ERRS.get(rc, rc)}")
+    return r.value, ms.value
 
 
 class Engine:
@@ -262,6 +273,11 @@ class Engine:
         ps, ks = _in(sk, 64)
         self._ck(self.lib.act_verify_spend_batch(self.ctx, n, MEM_DEVICE, ps, d_proofs, d_status, d_kprime or None))
 
+    def verify_spend_ptr(self, sk: bytes, n: int, mem: int, p_proofs: int, p_status: int, p_kprime: int = 0):
+        """Raw pointers of either kind (mem = MEM_HOST for e.g. pinned host buffers, MEM_DEVICE for HBM)."""
+        ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_verify_spend_batch(self.ctx, n, mem, ps, p_proofs, p_status, p_kprime or None))
+
     def refund_dev(self, sk: bytes, n: int, d_proofs: int, d_rng: int, rng_mode: int, d_out: int, d_status: int):
         ps, ks = _in(sk, 64)
         self._ck(self.lib.act_refund_batch(self.ctx, n, MEM_DEVICE, ps, d_proofs, d_rng, rng_mode, d_out, d_status))
@@ -289,7 +305,9 @@ class Engine:
             ms, la, ln = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
             self._ck(self.lib.act_prof_get(self.ctx, i, C.byref(ms), C.byref(la), C.byref(ln)))
             if la.value:
-                out[self.lib.act_prof_kernel_name(self.ctx, i).decode()] = {"ms": ms.value, "launches": la.value, "lanes": ln.value}
+                busy = C.c_double(0)
+                self._ck(self.lib.act_prof_get_busy(self.ctx, i, C.byref(busy)))
+                out[self.lib.act_prof_kernel_name(self.ctx, i).decode()] = {"ms": ms.value, "busy_ms": busy.value, "launches": la.value, "lanes": ln.value}
         return out
 
 

@@ -72,6 +72,8 @@ struct act_ctx {
   // profiling
   bool prof_on = false;
   double prof_ms[PK_COUNT]{}; uint64_t prof_launches[PK_COUNT]{}; uint64_t prof_lanes[PK_COUNT]{};
+  hipEvent_t prof_base = nullptr;                                  // time origin of the launch intervals below
+  std::vector<std::pair<float, float>> prof_iv[PK_COUNT];          // [start, end) of every launch, ms since prof_base
   int last_spend_slot = 0;
 };
 
@@ -103,6 +105,10 @@ int prof_collect(act_ctx* c, Slot& sl) {
     HIPCK(c, hipEventSynchronize(p.e1));
     float ms = 0; HIPCK(c, hipEventElapsedTime(&ms, p.e0, p.e1));
     c->prof_ms[p.id] += ms; c->prof_launches[p.id]++; c->prof_lanes[p.id] += p.lanes;
+    if (c->prof_base) {
+      float t0 = 0; HIPCK(c, hipEventElapsedTime(&t0, c->prof_base, p.e0));
+      c->prof_iv[p.id].emplace_back(t0, t0 + ms);
+    }
     hipEventDestroy(p.e0); hipEventDestroy(p.e1);
   }
   sl.pending.clear();
@@ -466,6 +472,7 @@ void act_ctx_destroy(act_ctx* c) {
     for (hipEvent_t& e : sl.h_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
+  if (c->prof_base) (void)hipEventDestroy(c->prof_base);
   if (c->d_tables) (void)hipFree(c->d_tables);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
@@ -715,6 +722,32 @@ int act_debug_last_spend_transcripts(act_ctx* c, size_t max_lanes, uint8_t* out,
   return ACT_OK;
 }
 
+// v_mad_u64_u32 issue-rate micro-benchmark (k_misc.hip k_ubench_mad): the ALU roofline of this arithmetic, measured on the
+// GPU and in the process that runs the workload.  lane_mads_per_s = 64-bit multiply-accumulates per second summed over lanes.
+int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
+  if (!lane_mads_per_s) return ACT_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
+  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = 4096;        // 8 blocks x 4 waves per CU: 8 waves per SIMD
+  uint32_t* d = nullptr; hipEvent_t e0, e1; hipStream_t st;
+  int rc = ACT_OK; float t = 0;
+  if (hipMalloc(&d, (size_t)blocks * 256 * 4) != hipSuccess) return ACT_ERR_HIP;
+  if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(d); return ACT_ERR_HIP; }
+  launch_ubench_mad(d, blocks, iters / 16, st);                               // warm-up (clocks, code load)
+  (void)hipEventRecord(e0, st);
+  launch_ubench_mad(d, blocks, iters, st);
+  (void)hipEventRecord(e1, st);
+  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = ACT_ERR_HIP;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(d);
+  if (rc) { (void)hipGetLastError(); return rc; }
+  *lane_mads_per_s = (double)blocks * 256.0 * iters * UBENCH_MADS_PER_ITER / (t * 1e-3);
+  if (ms) *ms = t;
+  return ACT_OK;
+}
+
 int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* points, const uint8_t* scalars, uint8_t* out, uint8_t* status) {
   if (!c || (n && (!points || !scalars || !out || !status))) return ACT_ERR_ARG;
   HIPCK(c, hipSetDevice(c->device));
@@ -733,10 +766,35 @@ int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* poi
   return ACT_OK;
 }
 
-int act_prof_enable(act_ctx* c, int on) { if (!c) return ACT_ERR_ARG; c->prof_on = on != 0; return ACT_OK; }
+int act_prof_enable(act_ctx* c, int on) {
+  if (!c) return ACT_ERR_ARG;
+  c->prof_on = on != 0;
+  if (c->prof_on && !c->prof_base) {
+    HIPCK(c, hipSetDevice(c->device));
+    HIPCK(c, hipEventCreate(&c->prof_base));
+    HIPCK(c, hipEventRecord(c->prof_base, c->slots[0].stream));
+    HIPCK(c, hipEventSynchronize(c->prof_base));
+  }
+  return ACT_OK;
+}
 int act_prof_reset(act_ctx* c) {
   if (!c) return ACT_ERR_ARG;
-  for (int i = 0; i < PK_COUNT; i++) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_lanes[i] = 0; }
+  for (int i = 0; i < PK_COUNT; i++) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_lanes[i] = 0; c->prof_iv[i].clear(); }
+  return ACT_OK;
+}
+// time during which at least one launch of kernel i was executing (the union of its launch intervals): with two chunks in
+// flight on two streams the launches of a kernel overlap, and the sum of their durations exceeds the wall time
+int act_prof_get_busy(act_ctx* c, int i, double* ms_busy) {
+  if (!c || i < 0 || i >= PK_COUNT || !ms_busy) return ACT_ERR_ARG;
+  std::vector<std::pair<float, float>> iv = c->prof_iv[i];
+  std::sort(iv.begin(), iv.end());
+  double busy = 0; float lo = 0, hi = -1;
+  for (auto& v : iv) {
+    if (hi < lo || v.first > hi) { if (hi >= lo) busy += hi - lo; lo = v.first; hi = v.second; }
+    else if (v.second > hi) hi = v.second;
+  }
+  if (hi >= lo) busy += hi - lo;
+  *ms_busy = busy;
   return ACT_OK;
 }
 int act_prof_kernel_count(const act_ctx*) { return PK_COUNT; }

@@ -3,9 +3,19 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#else
+#include <string.h>      // tests/hostcheck compiles the lane bodies (spend_lanes.h) with g++: never a product path
+#endif
 #include "msm.h"
 #include "blake3_hd.h"
+
+#if defined(__HIPCC__)
+#define ACT_HDC __host__ __device__
+#else
+#define ACT_HDC
+#endif
 
 namespace act {
 
@@ -29,38 +39,38 @@ struct DevKey { sc x; ge w; };            // PrivateKey (src/lib.rs:161-167), w 
 // ---- SpendProof record field indices (32-byte fields; src/cbor.rs:250-268) ----
 struct ProofLayout {
   int L;
-  __host__ __device__ int k() const { return 0; }
-  __host__ __device__ int s() const { return 1; }
-  __host__ __device__ int a_prime() const { return 2; }
-  __host__ __device__ int b_bar() const { return 3; }
-  __host__ __device__ int com(int j) const { return 4 + j; }
-  __host__ __device__ int gamma() const { return 4 + L; }
-  __host__ __device__ int e_bar() const { return 5 + L; }
-  __host__ __device__ int r2_bar() const { return 6 + L; }
-  __host__ __device__ int r3_bar() const { return 7 + L; }
-  __host__ __device__ int c_bar() const { return 8 + L; }
-  __host__ __device__ int r_bar() const { return 9 + L; }
-  __host__ __device__ int w00() const { return 10 + L; }
-  __host__ __device__ int w01() const { return 11 + L; }
-  __host__ __device__ int gamma0(int j) const { return 12 + L + j; }
-  __host__ __device__ int z(int j, int b) const { return 12 + 2 * L + 2 * j + b; }
-  __host__ __device__ int k_bar() const { return 12 + 4 * L; }
-  __host__ __device__ int s_bar() const { return 13 + 4 * L; }
-  __host__ __device__ size_t bytes() const { return 32u * (14u + 4u * (size_t)L); }
+  ACT_HDC int k() const { return 0; }
+  ACT_HDC int s() const { return 1; }
+  ACT_HDC int a_prime() const { return 2; }
+  ACT_HDC int b_bar() const { return 3; }
+  ACT_HDC int com(int j) const { return 4 + j; }
+  ACT_HDC int gamma() const { return 4 + L; }
+  ACT_HDC int e_bar() const { return 5 + L; }
+  ACT_HDC int r2_bar() const { return 6 + L; }
+  ACT_HDC int r3_bar() const { return 7 + L; }
+  ACT_HDC int c_bar() const { return 8 + L; }
+  ACT_HDC int r_bar() const { return 9 + L; }
+  ACT_HDC int w00() const { return 10 + L; }
+  ACT_HDC int w01() const { return 11 + L; }
+  ACT_HDC int gamma0(int j) const { return 12 + L + j; }
+  ACT_HDC int z(int j, int b) const { return 12 + 2 * L + 2 * j + b; }
+  ACT_HDC int k_bar() const { return 12 + 4 * L; }
+  ACT_HDC int s_bar() const { return 13 + 4 * L; }
+  ACT_HDC size_t bytes() const { return 32u * (14u + 4u * (size_t)L); }
 };
 // "spend" transcript element slots (40 bytes each after the prefix; src/lib.rs:831-840)
 struct SpendTranscript {
   int L;
-  __host__ __device__ int el_k() const { return 0; }
-  __host__ __device__ int el_a_prime() const { return 1; }
-  __host__ __device__ int el_b_bar() const { return 2; }
-  __host__ __device__ int el_a1() const { return 3; }
-  __host__ __device__ int el_a2() const { return 4; }
-  __host__ __device__ int el_com(int j) const { return 5 + j; }
-  __host__ __device__ int el_cprime(int j, int b) const { return 5 + L + 2 * j + b; }
-  __host__ __device__ int el_c() const { return 5 + 3 * L; }
-  __host__ __device__ size_t bytes() const { return 184u + 40u * (6u + 3u * (size_t)L); }
-  __host__ __device__ size_t stride() const { return (bytes() + 15u) & ~(size_t)15u; }
+  ACT_HDC int el_k() const { return 0; }
+  ACT_HDC int el_a_prime() const { return 1; }
+  ACT_HDC int el_b_bar() const { return 2; }
+  ACT_HDC int el_a1() const { return 3; }
+  ACT_HDC int el_a2() const { return 4; }
+  ACT_HDC int el_com(int j) const { return 5 + j; }
+  ACT_HDC int el_cprime(int j, int b) const { return 5 + L + 2 * j + b; }
+  ACT_HDC int el_c() const { return 5 + 3 * L; }
+  ACT_HDC size_t bytes() const { return 184u + 40u * (6u + 3u * (size_t)L); }
+  ACT_HDC size_t stride() const { return (bytes() + 15u) & ~(size_t)15u; }
 };
 
 struct SpendArgs {
@@ -159,6 +169,7 @@ struct ClientArgs {
 
 struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n; uint32_t* xof; const uint32_t* len_per_lane; };
 
+#if defined(__HIPCC__)
 // launchers (defined in the .hip files)
 void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, hipStream_t s);
 void launch_half_point_table(const uint32_t* table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
@@ -168,6 +179,8 @@ void launch_keygen(const DevParams& P, const uint8_t* rng64, uint32_t n, uint8_t
 void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hipStream_t s);
 void launch_hash(const HashArgs& a, hipStream_t s);
 void launch_iota(uint32_t* out, uint32_t n, uint32_t base, hipStream_t s);
+constexpr int UBENCH_MADS_PER_ITER = 16;
+void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream_t s);
 void launch_debug_scalarmult(const uint8_t* pts, const uint8_t* scs, uint32_t n, uint32_t* pbk, uint8_t* out, uint8_t* status, hipStream_t s);
 void launch_spend_prep(const SpendArgs& a, hipStream_t s);
 void launch_spend_bits(const SpendArgs& a, hipStream_t s);
@@ -188,40 +201,64 @@ void launch_prove_resp(const ProveArgs& a, hipStream_t s);
 void launch_client_decode_com(const ClientArgs& a, hipStream_t s);
 void launch_client_a(const ClientArgs& a, hipStream_t s);
 void launch_client_b(const ClientArgs& a, hipStream_t s);
+#endif
 
-#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
-// ---- device helpers ----
-__device__ __forceinline__ void load8(uint32_t w[8], const uint8_t* p) {
+// ---- record / transcript access helpers (uint4 / uint2 accesses on the device; memcpy in the g++ test build) ----
+ACT_HD void load8(uint32_t w[8], const uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
   const uint4* q = reinterpret_cast<const uint4*>(p);
   uint4 a = q[0], b = q[1];
   w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+#else
+  memcpy(w, p, 32);
+#endif
 }
-__device__ __forceinline__ void store8(uint8_t* p, const uint32_t w[8]) {
+ACT_HD void store8(uint8_t* p, const uint32_t w[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
   uint4* q = reinterpret_cast<uint4*>(p);
   q[0] = make_uint4(w[0], w[1], w[2], w[3]); q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#else
+  memcpy(p, w, 32);
+#endif
 }
-__device__ __forceinline__ void zero8(uint8_t* p) { uint4* q = reinterpret_cast<uint4*>(p); q[0] = make_uint4(0, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0); }
-__device__ __forceinline__ sc load_sc(const uint8_t* p) { uint32_t w[8]; load8(w, p); return sc_from_words(w); }
-__device__ __forceinline__ sc load_wide(const uint8_t* p) {   // Scalar::random: 64 rng bytes -> mod l
+ACT_HD void zero8(uint8_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint4* q = reinterpret_cast<uint4*>(p); q[0] = make_uint4(0, 0, 0, 0); q[1] = make_uint4(0, 0, 0, 0);
+#else
+  memset(p, 0, 32);
+#endif
+}
+ACT_HD sc load_sc(const uint8_t* p) { uint32_t w[8]; load8(w, p); return sc_from_words(w); }
+ACT_HD sc load_wide(const uint8_t* p) {   // Scalar::random: 64 rng bytes -> mod l
   uint32_t w[16]; load8(w, p); load8(w + 8, p + 32); return sc_from_wide_words(w);
 }
-__device__ __forceinline__ void store_sc(uint8_t* p, const sc& s) { store8(p, s.v); }
+ACT_HD void store_sc(uint8_t* p, const sc& s) { store8(p, s.v); }
 // one transcript element = u64_be(32) | 32 payload bytes (src/transcript.rs:95-98); `slot` 8-byte aligned
-__device__ __forceinline__ void tr_put_aligned(uint8_t* slot, const uint32_t w[8]) {
+ACT_HD void tr_put_aligned(uint8_t* slot, const uint32_t w[8]) {
+#if defined(__HIP_DEVICE_COMPILE__)
   uint2* q = reinterpret_cast<uint2*>(slot);
   q[0] = make_uint2(0u, 0x20000000u);
   q[1] = make_uint2(w[0], w[1]); q[2] = make_uint2(w[2], w[3]); q[3] = make_uint2(w[4], w[5]); q[4] = make_uint2(w[6], w[7]);
+#else
+  const uint32_t head[2] = {0u, 0x20000000u};
+  memcpy(slot, head, 8); memcpy(slot + 8, w, 32);
+#endif
 }
 // same at an arbitrary byte offset (the small transcripts have 185/186-byte prefixes)
-__device__ __forceinline__ void tr_put_bytes(uint8_t* slot, const uint32_t w[8]) {
+ACT_HD void tr_put_bytes(uint8_t* slot, const uint32_t w[8]) {
   for (int i = 0; i < 7; i++) slot[i] = 0;
   slot[7] = 0x20;
   for (int i = 0; i < 8; i++) { uint32_t v = w[i]; slot[8 + 4 * i] = (uint8_t)v; slot[9 + 4 * i] = (uint8_t)(v >> 8); slot[10 + 4 * i] = (uint8_t)(v >> 16); slot[11 + 4 * i] = (uint8_t)(v >> 24); }
 }
-__device__ __forceinline__ void tr_put_prefix(uint8_t* tr, const DevParams& P, int label) {
+ACT_HD void tr_put_prefix(uint8_t* tr, const DevParams& P, int label) {
   uint32_t* q = reinterpret_cast<uint32_t*>(tr);
   for (int i = 0; i < PREFIX_WORDS; i++) if (4u * i < P.prefix_len[label]) q[i] = P.prefix[label][i];
 }
+// per-proof flag words are OR-ed by several lanes of one launch
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ACT_FLAG_OR(ptr, v) atomicOr((ptr), (v))
+#else
+#define ACT_FLAG_OR(ptr, v) ((void)(*(ptr) |= (v)))
 #endif
 
 }  // namespace act

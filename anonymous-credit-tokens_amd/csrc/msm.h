@@ -80,6 +80,7 @@ ACT_HD uint32_t fb_next_digit(uint32_t w[8]) {
   return digit;
 }
 ACT_HD ge fixed_base_acc(ge acc, const uint32_t* table, const sc& s) {
+  fe_count_fixed_base();
   uint32_t w[8];
   for (int i = 0; i < 8; i++) w[i] = s.v[i];
   ge_niels cur = niels_load(table + (size_t)fb_next_digit(w) * NIELS_WORDS);

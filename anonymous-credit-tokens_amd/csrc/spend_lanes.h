@@ -1,0 +1,184 @@
+// spend_lanes.h — the per-lane bodies of the spend-verification kernels (k_spend_verify.hip), as functions that also
+// compile under g++: tests/hostcheck runs them lane by lane on the CPU to (a) compare the transcript bytes this very code
+// writes with the oracle's, (b) count its field multiplications / squarings exactly (the ALU roofline of bench.py), and
+// (c) put it under AddressSanitizer / UBSan, none of which can be done on the GPU pool.  The product only ever runs them
+// inside the __global__ wrappers of k_spend_verify.hip; there is no CPU compute path in libact_mi355x.so.
+//
+// PrivateKey::refund up to the challenge check, /root/reference/src/lib.rs:787-844:
+//   spend_prep_lane   lane = proof          A', B_bar checks (:787), A1, A2 (:791-799), w00*h2 / w01*h2 (:806,808)
+//   spend_bits_lane   lane = (proof, bit)   C'_j0 / 2, C'_j1 / 2 (:800-817): decode Com_j, two fixed-base sums, one shared
+//                                           doubling chain over -Com_j (msm.h chain_bu); every scalar halved mod l
+//   spend_enc_lane    lane = 32 half-points encodings of C'_j0, C'_j1 = 2 * (half-point) by batched double-and-compress:
+//                                           one field inversion per 32 encodings instead of one inverse square root each
+//   spend_tail_lane   lane = proof          K' by Horner over the decoded Com_j (:819-824), Com, C (:825-829), X_A (:848)
+//   spend_finish_lane lane = proof          challenge = XOF mod l ?= gamma (:842-844) -> status
+//
+// Algebraic regrouping that leaves every encoded point (hence every transcript byte) unchanged:
+//   A1 = (e_bar - x*gamma) A' + r2_bar B_bar                       (A_bar = x A' folded in)
+//   A2 = r3_bar B_bar + c_bar h1 + r_bar h3 - gamma g - (gamma k) h2
+//   C'_j1 = z_j1 h3 + gamma_j1 h1 - gamma_j1 Com_j                   (C_j1 = Com_j - h1 expanded)
+//   C  = (-c_bar - gamma s) h1 + k_bar h2 + s_bar h3 - gamma K'
+#pragma once
+#include "kernels.h"
+
+namespace act {
+
+constexpr int ENC_BATCH = 32;   // half-points per lane of k_spend_enc
+
+ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
+  const ProofLayout pl{a.P.L};
+  const SpendTranscript st{a.P.L};
+  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
+  uint8_t* tr = a.tr + (size_t)p * a.tr_stride;
+  uint32_t flags = 0;
+
+  uint32_t wk[8], wa[8], wb[8];
+  load8(wk, rec + 32 * pl.k()); load8(wa, rec + 32 * pl.a_prime()); load8(wb, rec + 32 * pl.b_bar());
+  ge A, B;
+  if (!ristretto_decode(A, wa)) flags |= FLAG_UNDECODABLE;
+  if (!ristretto_decode(B, wb)) flags |= FLAG_UNDECODABLE;
+  if (ristretto_is_identity(A)) flags |= FLAG_IDENTITY;                       // src/lib.rs:787-789
+
+  sc k = sc_from_words(wk);
+  sc gamma = load_sc(rec + 32 * pl.gamma());
+  sc e_bar = load_sc(rec + 32 * pl.e_bar()), r2_bar = load_sc(rec + 32 * pl.r2_bar()), r3_bar = load_sc(rec + 32 * pl.r3_bar());
+  sc c_bar = load_sc(rec + 32 * pl.c_bar()), r_bar = load_sc(rec + 32 * pl.r_bar());
+  sc w00 = load_sc(rec + 32 * pl.w00()), w01 = load_sc(rec + 32 * pl.w01());
+  sc ngamma = sc_neg(gamma);
+
+  // transcript: prefix, k, A', B_bar (compress(decompress(x)) == x for canonical x)
+  tr_put_prefix(tr, a.P, LABEL_SPEND);
+  uint8_t* el = tr + 184;
+  tr_put_aligned(el + 40 * st.el_k(), k.v);                                   // Scalar::as_bytes of the reduced k
+  tr_put_aligned(el + 40 * st.el_a_prime(), wa);
+  tr_put_aligned(el + 40 * st.el_b_bar(), wb);
+
+  // A2's fixed part and the two h2 terms of bit 0
+  ge acc[2];
+  acc[1] = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], c_bar);
+  acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_H3], r_bar);
+  acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_G], ngamma);
+  acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_H2], sc_mul(ngamma, k));
+  ge d0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w00));     // the bits kernel works on C'/2 (k_spend_enc)
+  ge d1 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w01));
+  ge_store(a.d01 + (size_t)p * 2 * GE_WORDS, d0);
+  ge_store(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS, d1);
+
+  // A1 = (e_bar - x gamma) A' + r2_bar B_bar ; A2 += r3_bar B_bar
+  acc[0] = ge_identity();
+  sc sa[1] = {sc_sub(e_bar, sc_mul(a.K.x, gamma))};
+  uint32_t* pbk = a.buckets + (size_t)p * 2 * BUCKET_WORDS;      // free until k_spend_bits runs
+  chain_b<1>(acc, A, sa, pbk);
+  sc sb[2] = {r2_bar, r3_bar};
+  chain_b<2>(acc, B, sb, pbk);
+
+  uint32_t enc[8];
+  ristretto_encode(enc, acc[0]); tr_put_aligned(el + 40 * st.el_a1(), enc);
+  ristretto_encode(enc, acc[1]); tr_put_aligned(el + 40 * st.el_a2(), enc);
+  a.flags[p] = flags;     // bits kernel ORs its decode failures in afterwards (same stream)
+}
+
+// `lds_wave` (device): 2 * GE_LDS_WORDS_PER_WAVE words of LDS owned by the calling wavefront (msm.h chain_bu); unused on the host
+ACT_HD void spend_bits_lane(const SpendArgs& a, uint32_t gid, uint32_t* lds_wave) {
+  const int L = a.P.L;
+  uint32_t p = gid / (uint32_t)L, j = gid % (uint32_t)L;
+  if (p >= a.n) return;
+  const ProofLayout pl{L};
+  const SpendTranscript st{L};
+  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
+  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
+
+  uint32_t wc[8];
+  load8(wc, rec + 32 * pl.com(j));
+  ge C;
+  bool ok = ristretto_decode(C, wc);
+  if (!ok) ACT_FLAG_OR(a.flags + p, FLAG_UNDECODABLE);
+  tr_put_aligned(el + 40 * st.el_com(j), wc);
+  niels_store(a.coords + ((size_t)p * L + j) * NIELS_WORDS, niels_from_affine(C));
+
+  // Everything below is computed at half scale: Q_j0 = C'_j0 / 2, Q_j1 = C'_j1 / 2 (all scalars halved mod l), because
+  // the encoding of 2Q needs only an inversion, which k_spend_enc batches (ge25519.h dc_*).
+  sc gamma = sc_half(load_sc(rec + 32 * pl.gamma()));
+  sc g0 = sc_half(load_sc(rec + 32 * pl.gamma0(j)));
+  sc g1 = sc_sub(gamma, g0);                                                  // src/lib.rs:801, 811
+  sc z0 = sc_half(load_sc(rec + 32 * pl.z(j, 0))), z1 = sc_half(load_sc(rec + 32 * pl.z(j, 1)));
+
+  // C'_j0 = z_j0 h3 + D,  C'_j1 = z_j1 h3 + gamma_j1 h1 + G - D  with D = gamma_j0 N, G = gamma N, N = -Com_j
+  // (gamma_j1 = gamma - gamma_j0).  G's scalar is the proof-wide gamma: uniform width-3 NAF digits per wavefront; D's digits go through per-lane buckets (msm.h chain_bu).
+  ge acc_u = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z1);
+  acc_u = fixed_base_acc(acc_u, a.P.tab[BASE_H1], g1);
+  if (j == 0) acc_u = ge_add(acc_u, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));      // + w01 h2 (:808)
+  ge acc_l = ge_identity();
+  uint32_t* bk = a.buckets + (size_t)gid * BUCKET_WORDS;
+  chain_bu(acc_l, acc_u, ge_neg(C), g0, gamma, bk, lds_wave);
+  ge f0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
+  if (j == 0) f0 = ge_add(f0, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));                        // + w00 h2 (:806)
+  ge_cached dl = ge_to_cached(acc_l);
+  // the lane's bucket area is free again: its first two slots carry the half-points to k_spend_enc
+  bucket_store(bk, ge_add_cached(f0, dl));
+  bucket_store(bk + GE_WORDS, ge_add_cached(acc_u, ge_cached_cneg(dl, true)));
+}
+
+// point q = 2 * (p * L + j) + b lives in slot b of lane (p, j)'s bucket area; this lane encodes q0 .. q0 + ENC_BATCH - 1
+ACT_HD void spend_enc_lane(const SpendArgs& a, uint64_t q0) {
+  const uint32_t L = (uint32_t)a.P.L;
+  const uint64_t total = (uint64_t)a.n * L * 2u;
+  if (q0 >= total) return;
+  const int count = (int)(total - q0 < (uint64_t)ENC_BATCH ? total - q0 : (uint64_t)ENC_BATCH);
+  const SpendTranscript st{a.P.L};
+  dc_encode_batch<ENC_BATCH>(
+      count,
+      [&](int i) { uint64_t q = q0 + (uint64_t)i; return a.buckets + (size_t)(q >> 1) * BUCKET_WORDS + (q & 1u) * GE_WORDS; },
+      [&](int i, const uint32_t* enc) {
+        uint64_t q = q0 + (uint64_t)i, lane = q >> 1;
+        uint32_t p = (uint32_t)(lane / L), j = (uint32_t)(lane % L);
+        tr_put_aligned(a.tr + (size_t)p * a.tr_stride + 184 + 40 * st.el_cprime(j, (int)(q & 1u)), enc);
+      });
+}
+
+ACT_HD void spend_tail_lane(const SpendArgs& a, uint32_t p) {
+  const int L = a.P.L;
+  const ProofLayout pl{L};
+  const SpendTranscript st{L};
+  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
+  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
+
+  // K' = sum_j 2^j Com_j by Horner (the reference does 128 separate mults, src/lib.rs:819-824)
+  ge kp = ge_identity();
+  for (int j = L - 1; j >= 0; j--) {
+    kp = ge_double(kp);
+    kp = ge_madd(kp, niels_load(a.coords + ((size_t)p * L + j) * NIELS_WORDS));
+  }
+  sc gamma = load_sc(rec + 32 * pl.gamma());
+  sc s = load_sc(rec + 32 * pl.s()), c_bar = load_sc(rec + 32 * pl.c_bar());
+  sc k_bar = load_sc(rec + 32 * pl.k_bar()), s_bar = load_sc(rec + 32 * pl.s_bar());
+  sc ngamma = sc_neg(gamma);
+  ge acc[1];
+  acc[0] = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], sc_sub(sc_mul(ngamma, s), c_bar));   // -c_bar - gamma s
+  acc[0] = fixed_base_acc(acc[0], a.P.tab[BASE_H2], k_bar);
+  acc[0] = fixed_base_acc(acc[0], a.P.tab[BASE_H3], s_bar);
+  sc sk_[1] = {ngamma};
+  chain_b<1>(acc, kp, sk_, a.buckets + (size_t)p * 2 * BUCKET_WORDS);      // the half-points were consumed by k_spend_enc
+  uint32_t enc[8];
+  ristretto_encode(enc, acc[0]); tr_put_aligned(el + 40 * st.el_c(), enc);
+  ge xa = ge_add(kp, ge_basepoint());                                         // X_A = g + K' (src/lib.rs:848)
+  ge_store(a.xa + (size_t)p * GE_WORDS, xa);
+  if (a.kprime_enc) { ristretto_encode(enc, kp); store8(a.kprime_enc + (size_t)p * 32, enc); }
+}
+
+ACT_HD void spend_finish_lane(const SpendArgs& a, uint32_t p) {
+  const ProofLayout pl{a.P.L};
+  sc gamma = load_sc(a.proofs + (size_t)p * pl.bytes() + 32 * pl.gamma());
+  uint32_t w[16];
+  for (int i = 0; i < 16; i++) w[i] = a.xof[(size_t)p * 16 + i];
+  sc chal = sc_from_wide_words(w);                                            // src/transcript.rs:149-154
+  uint32_t f = a.flags[p];
+  uint8_t stt = 0;
+  if (f & FLAG_UNDECODABLE) stt = 255;
+  else if (f & FLAG_IDENTITY) stt = 6;                                        // Error::IdentityPointError
+  else if (!sc_equal(chal, gamma)) stt = 7;                                   // Error::InvalidClientSpendProof
+  a.status[p] = stt;
+  if (a.kprime_enc && stt != 0) zero8(a.kprime_enc + (size_t)p * 32);          // the output record of a failed lane is all zero
+}
+
+}  // namespace act

@@ -1,19 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — spend-proof verifies/sec (whole node), batch 2^20 per GPU, L = 128 (BASELINE.json metric).
 
-A step = one pass of the hot path (PrivateKey::refund up to the challenge check, src/lib.rs:787-844) over one
-batch of 2^20 synthetic spend proofs that are already resident in HBM when the timed region starts; transcripts
-are hashed by the device BLAKE3 kernel (byte-identical to the host path; the host-transcript rate is printed as
-an extra key).  One process per GPU; ranks shard independent batches (weak scaling, no data-path collective —
-torch.distributed/RCCL is used only for the barrier and the max-over-ranks reduction of the timing).
+A step = one pass of the hot path (PrivateKey::refund up to the challenge check, src/lib.rs:787-844) over one batch of
+2^20 synthetic spend proofs that are already resident in HBM when the timed region starts, transcripts hashed by the
+device BLAKE3 kernel (byte-identical to the host path).  That is `value`.  One process per GPU; ranks shard independent
+batches (weak scaling, no data-path collective — torch.distributed/RCCL is used only for the barrier and the
+max-over-ranks reduction of the timing).
+
+At N = 1 the same process also measures and prints, inside the one JSON line:
+  extra.host_transcript_hbm      the library's default / north-star contract mode: transcripts hashed on host threads
+  extra.host_transcript_hostmem  ... with the proofs in pinned HOST memory and statuses returned to host memory
+                                 (ACT_MEM_HOST, what a Rust caller passes): the PCIe-inclusive rate, never `value`
+  extra.refund                   verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
+  extra.verify_L64               BASELINE config 2: 2^16 verifies at L = 64
+  roofline                       HBM view the contract asks for (algorithmic bytes / k_spend_bits busy time) ...
+  roofline.alu                   ... and the roofline that actually binds: 64-bit multiply-accumulates per second against
+                                 a v_mad_u64_u32 micro-kernel timed in this run on this GPU; the multiply-accumulates
+                                 per verify are counted, not estimated (the kernels' own lane bodies executed on the
+                                 host with counting field operations, tests/hostcheck)
+  cpu_baseline                   the C oracle (a port of the reference algorithm) on this box's host cores
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
+import ctypes
+import glob
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,9 +37,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ELL = 2**252 + 27742317777372353535851937790883648493
-L = 128
-PROOF_BYTES = 32 * (14 + 4 * L)          # 16 832 (algorithmic bytes in per verify)
-ALGO_BYTES_PER_VERIFY = PROOF_BYTES + 1  # + 1 status byte out
+CSRC = os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc")
+# sources that determine k_spend_bits: PMC summaries under profiles/ are only cited when they were taken from these bytes
+KERNEL_SOURCES = ["fe25519.h", "fe25519_gen.inc", "fe25519_consts.inc", "sc25519.h", "ge25519.h", "msm.h", "kernels.h", "spend_lanes.h",
+                  "k_spend_verify.hip"]
+
+
+def proof_bytes(L):
+    return 32 * (14 + 4 * L)          # algorithmic bytes in per verify (+ 1 status byte out)
 
 
 def shake(label, n):
@@ -32,6 +53,13 @@ def shake(label, n):
 
 def scb(v):
     return (v % ELL).to_bytes(32, "little")
+
+
+def kernel_source_sha16():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def make_inputs(eng, sk, distinct):
@@ -64,11 +92,12 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(proofs_host, h, sk, seconds_target=12.0):
+def cpu_baseline(proofs_host, h, sk, L, seconds_target=12.0):
     """The C oracle (a restatement of the reference algorithm with the reference's operation structure — NOT the
     Rust crate, which cannot be built here) timed on this box's host cores on a bounded sample of the same proofs."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
+    pb = proof_bytes(L)
     native = os.path.join("/tmp", "libact_oracle_native_%d.so" % os.getpid())
     try:
         oracle_c.build(native_out=native)
@@ -77,20 +106,55 @@ def cpu_baseline(proofs_host, h, sk, seconds_target=12.0):
         o = oracle_c.Oracle()
     ctx = o.ctx(h, L)
     cores = usable_cores()
-    t = time.perf_counter(); st = ctx.verify_spend_batch(sk, proofs_host[:PROOF_BYTES * 8], 1); t1 = (time.perf_counter() - t) / 8
+    t = time.perf_counter(); st = ctx.verify_spend_batch(sk, proofs_host[:pb * 8], 1); t1 = (time.perf_counter() - t) / 8
     assert st == bytes(8)
-    n = max(cores, min(len(proofs_host) // PROOF_BYTES, int(seconds_target / t1 * cores * 0.6)))
-    n = min(n, len(proofs_host) // PROOF_BYTES)
-    t = time.perf_counter(); st = ctx.verify_spend_batch(sk, proofs_host[:PROOF_BYTES * n], cores); dt = time.perf_counter() - t
+    n = max(cores, min(len(proofs_host) // pb, int(seconds_target / t1 * cores * 0.6)))
+    n = min(n, len(proofs_host) // pb)
+    t = time.perf_counter(); st = ctx.verify_spend_batch(sk, proofs_host[:pb * n], cores); dt = time.perf_counter() - t
     assert st == bytes(n)
     try:
         os.unlink(native)
     except OSError:
         pass
     return {"value": n / dt, "unit": "verifies/s", "cores": cores, "kind": "port",
-            "sample": "%d of the bench's own L=128 proofs, C oracle (-O3 -march=native), %d threads, %.1f s; 1 thread: %.2f verifies/s"
-                      % (n, cores, dt, 1.0 / t1),
+            "sample": "%d of the bench's own L=%d proofs, C oracle (-O3 -march=native), %d threads, %.1f s; 1 thread: %.2f verifies/s"
+                      % (n, L, cores, dt, 1.0 / t1),
             "single_thread_value": 1.0 / t1}
+
+
+def count_field_ops(h, L, sk, proofs_host, sample=4):
+    """Exact field-operation counts of one verify: the spend kernels' own lane bodies (csrc/spend_lanes.h) executed on the
+    host, with counting fe_mul / fe_sq, by the instrumented test build tests/hostcheck (built here with g++).  A count of
+    operations, not a computation of results: statuses come from the GPU."""
+    src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
+    out = os.path.join("/tmp", "libhostcheck_bench_%d.so" % os.getpid())
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src], check=True)
+    hc = ctypes.CDLL(out)
+    pb = proof_bytes(L); n = sample
+    tb = 184 + 40 * (6 + 3 * L)
+    tr = ctypes.create_string_buffer(n * tb); st = ctypes.create_string_buffer(n); kp = ctypes.create_string_buffer(32 * n)
+    c = (ctypes.c_uint64 * 13)()
+    ok = hc.hc_spend_verify(h, L, sk, n, proofs_host[:pb * n], tr, st, kp, c)
+    os.unlink(out)
+    assert ok == 1 and st.raw == bytes(n)
+    per = {}
+    for k, name in enumerate(("k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail")):
+        mul, sq, fb = c[3 * k], c[3 * k + 1], c[3 * k + 2]
+        per[name] = {"fe_mul": (mul - fb * (c[12] - 16) * 7) / n, "fe_sq": sq / n}      # restated for the product's 16 fixed-base windows
+    return per
+
+
+def newest_matching_pmc(kind, proofs_per_launch, sha):
+    """Newest profiles/*_<kind>.json collected from the kernel sources this run was built from (same hash, same launch size)."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s.json" % kind))):
+        try:
+            j = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if j.get("kernel_source_sha16") == sha and int(j.get("proofs_per_launch", -1)) == int(proofs_per_launch):
+            best = (os.path.relpath(f, ROOT), j)
+    return best
 
 
 def main():
@@ -99,13 +163,18 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--range-bits", type=int, default=128, help="L; 128 is the crate's width and the metric's")
     ap.add_argument("--distinct", type=int, default=4096)
     ap.add_argument("--max-batch", type=int, default=65536)
+    ap.add_argument("--extra-log2", type=int, default=18, help="proofs per extra measurement (contract mode, refund)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     # test hooks: exercise the N>1 control path on a box with one GPU (RCCL refuses two ranks on one device)
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-device", type=int, default=-1)
     args = ap.parse_args()
+    L = args.range_bits
+    PB = proof_bytes(L)
 
     import numpy as np
     import torch
@@ -130,7 +199,7 @@ def main():
     sk = eng.private_key_random(shake("bench-sk", 64))
     distinct = min(args.distinct, n)
     proofs = make_inputs(eng, sk, distinct)
-    host = np.frombuffer(proofs, np.uint8).reshape(distinct, PROOF_BYTES)
+    host = np.frombuffer(proofs, np.uint8).reshape(distinct, PB)
     dev = torch.from_numpy(host.copy()).cuda().repeat(n // distinct, 1).contiguous()      # distinct proofs tiled
     # 1 lane in 1024 tampered: flipped charge bit (-> InvalidClientSpendProof) or A' = identity (-> IdentityPointError)
     idx = torch.arange(513, n, 1024, device="cuda")
@@ -151,7 +220,7 @@ def main():
     torch.cuda.synchronize()      # the engine runs on its own streams: inputs written by torch must be complete first
     for _ in range(args.warmup):
         step()
-    eng.prof_reset(); eng.prof_enable(True)        # HIP events on the engine's own stream (torch events cannot see it)
+    eng.prof_reset(); eng.prof_enable(True)        # HIP events on the engine's own streams (torch events cannot see them)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -168,57 +237,134 @@ def main():
 
     if rank == 0:
         value = world * n * args.steps / elapsed
-        bits = prof.get("k_spend_bits", {"ms": 0.0, "launches": 1, "lanes": 0})
-        launch_s = bits["ms"] / 1e3 / max(1, bits["launches"])
+        ms_per_step = 1e3 * elapsed / args.steps
+        bits = prof.get("k_spend_bits", {"ms": 0.0, "busy_ms": 0.0, "launches": 1, "lanes": 0})
+        launches_per_step = bits["launches"] / args.steps
+        # launches of the two chunks in flight overlap, so a launch's own event-to-event duration double counts; the time
+        # during which the kernel was executing at all (union of the launch intervals), divided by the launches, does not
+        launch_s = bits["busy_ms"] / 1e3 / max(1, bits["launches"])
         proofs_per_launch = bits["lanes"] / max(1, bits["launches"]) / L
-        achieved = ALGO_BYTES_PER_VERIFY * proofs_per_launch / launch_s / 1e9 if launch_s else 0.0
-        kernel_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
-        # PMC counters cannot be collected inside this process, so the figure is read from profiles/ when its launch size matches
-        traffic = None
-        valu = None
-        try:
-            v = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_valu.json")))
-            # the roofline that actually binds: SIMD issue slots.  A wavefront of k_spend_bits is v instructions at c cycles
-            # each with two waves per SIMD; at the measured clock the chip's 1024 SIMDs cannot exceed this many verifies/s.
-            per_wave, cyc, clk = v["valu_instructions_per_wave"], v["cycles_per_valu_instruction_per_simd_2waves"], v["effective_clock_ghz"] * 1e9
-            waves_per_proof = L / 64.0
-            bound = 1024 * clk / (waves_per_proof * per_wave * cyc)
-            valu = {"valu_instructions_per_wave": per_wave, "cycles_per_instruction": cyc, "clock_ghz": v["effective_clock_ghz"],
-                    "issue_bound_verifies_per_s_per_gpu": bound, "frac_of_issue_bound": (value / world) / bound,
-                    "source": "profiles/r01_h_pmc_valu.json (rocprofv3 --pmc SQ_INSTS_VALU, SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE)"}
-        except (OSError, KeyError, ValueError):
-            pass
-        try:
-            t = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_hbm_traffic.json")))
-            if int(t["proofs_per_launch"]) == int(proofs_per_launch):
-                traffic = t["hbm_bytes_per_launch_fetch_x2"]
-        except (OSError, KeyError, ValueError):
-            pass
+        algo_bytes = PB + 1
+        achieved = algo_bytes * proofs_per_launch / launch_s / 1e9 if launch_s else 0.0
+        kernel_ms = {k: {"busy": round(v["busy_ms"] / args.steps, 3), "sum_of_launches": round(v["ms"] / args.steps, 3)} for k, v in prof.items()}
+        assert bits["busy_ms"] / args.steps <= ms_per_step * 1.001, "kernel busy time exceeds the step time"
+
         out = {
             "metric": "spend-proof verifies/sec (whole node), batch=2^20", "value": value, "unit": "verifies/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs / u64 accumulators (integer)",
-            "data": "synthetic: %d distinct valid L=128 proofs made by the engine's own prover, tiled to 2^%d per GPU, 1/1024 lanes tampered; device transcripts"
-                    % (distinct, args.batch_log2),
-            "config": {"workload": "configs[1] scaled to the metric batch: 2^%d spend-proof verifies per GPU, L=128 (the crate's width), inputs resident in HBM"
-                                   % args.batch_log2,
-                       "batch_per_gpu": n, "range_bits": L, "lanes_per_launch": args.max_batch, "transcript": "device BLAKE3", "sharding": "independent batches per rank, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "k_spend_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
-                         "algorithmic_bytes_per_verify": ALGO_BYTES_PER_VERIFY,
-                         "concurrent_launches": 2, "valu_issue": valu,
-                         "note": "integer-VALU-issue bound, not HBM bound (DESIGN.md 6): ~0.78 M VALU instructions per wavefront-lane; two chunks' launches overlap on two streams, so avg_launch_ms is per overlapped launch; traffic (bytes, PMC) is dominated by the per-lane Pippenger buckets cycling through L2/Infinity Cache"},
-            "kernel_ms_per_step": kernel_ms,
+            "data": "synthetic: %d distinct valid L=%d proofs made by the engine's own prover, tiled to 2^%d per GPU, 1/1024 lanes tampered; device transcripts"
+                    % (distinct, L, args.batch_log2),
+            "config": {"workload": "configs[1] scaled to the metric batch: 2^%d spend-proof verifies per GPU, L=%d%s, inputs resident in HBM"
+                                   % (args.batch_log2, L, " (the crate's width)" if L == 128 else ""),
+                       "batch_per_gpu": n, "range_bits": L, "lanes_per_launch": args.max_batch, "transcript": "device BLAKE3",
+                       "sharding": "independent batches per rank, no collective"},
         }
+        roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                "kernel": "k_spend_bits", "avg_launch_ms": 1e3 * launch_s, "launches_per_step": launches_per_step,
+                "avg_launch_ms_x_launches_per_step": 1e3 * launch_s * launches_per_step,
+                "proofs_per_launch": proofs_per_launch, "algorithmic_bytes_per_verify": algo_bytes,
+                "timing": "HIP events on the engine's streams over the timed region; avg_launch_ms = (time during which k_spend_bits was executing) / launches "
+                          "— two chunks' launches overlap on two streams, each launch's own start-to-end duration is kernel_ms_per_step.sum_of_launches",
+                "note": "not HBM bound: 16.8 KB in per verify against ~43 M 64-bit multiply-accumulates (roofline.alu is the binding view); "
+                        "PMC traffic is dominated by the per-lane Pippenger buckets cycling through L2 / Infinity Cache"}
+        sha = kernel_source_sha16()
+        t = newest_matching_pmc("pmc_hbm_traffic", proofs_per_launch, sha)
+        if t:
+            roof["traffic"] = t[1]["hbm_bytes_per_launch_fetch_x2"]; roof["traffic_source"] = t[0]
+        else:
+            roof["traffic_source"] = "none: no profiles/*_pmc_hbm_traffic.json was collected from these kernel sources (sha %s)" % sha
+        v = newest_matching_pmc("pmc_valu", proofs_per_launch, sha)
+        if v:
+            j = v[1]
+            roof["pmc_valu"] = {"source": v[0], "valu_instructions_per_wave": j["valu_instructions_per_wave"],
+                                "cycles_per_valu_instruction_per_simd_2waves": j["cycles_per_valu_instruction_per_simd_2waves"],
+                                "effective_clock_ghz": j["effective_clock_ghz"], "launch_ms_solo_under_pmc": j["launch_ms_under_pmc"].get("SQ_INSTS_VALU")}
+        out["roofline"] = roof
+        out["kernel_ms_per_step"] = kernel_ms
+        out["kernel_source_sha16"] = sha
+
+        if world == 1:
+            # ---- the ALU roofline: measured peak of the multiply-accumulate instruction, counted work per verify -------
+            peak_mad, probe_ms = capi.ubench_mad(local)
+            ops = count_field_ops(h, L, sk, proofs)
+            fe_mul = sum(v["fe_mul"] for v in ops.values()); fe_sq = sum(v["fe_sq"] for v in ops.values())
+            mad_per_verify = 100 * fe_mul + 55 * fe_sq          # fe25519.h: a product is 10 columns x 10 v_mad_u64_u32, a square 55
+            bits_mad = (100 * ops["k_spend_bits"]["fe_mul"] + 55 * ops["k_spend_bits"]["fe_sq"]) * proofs_per_launch
+            roof["alu"] = {"fe_mul_per_verify": fe_mul, "fe_sq_per_verify": fe_sq, "mad_per_verify": mad_per_verify,
+                           "achieved_mad_per_s": value * mad_per_verify, "peak_mad_per_s": peak_mad, "frac": value * mad_per_verify / peak_mad,
+                           "k_spend_bits_frac": bits_mad / launch_s / peak_mad if launch_s else None,
+                           "unit": "lane multiply-accumulates (v_mad_u64_u32) per second", "probe_ms": probe_ms,
+                           "per_kernel_field_ops_per_verify": ops,
+                           "how": "peak: act_ubench_mad_u64_u32 (16 register-resident chains per lane, 8 waves per SIMD) timed in this process; "
+                                  "work: fe_mul / fe_sq executed by the kernels' own lane bodies, counted on the host (tests/hostcheck), x 100 / 55 "
+                                  "multiply-accumulates each; k_spend_bits_frac uses that kernel's busy time alone"}
+
+        if world == 1 and not args.no_extras:
+            out["extra"] = extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(proofs, h, sk)
+            out["cpu_baseline"] = cpu_baseline(proofs, h, sk, L)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def timed(fn, sync):
+    fn(); sync()                       # warm-up (buffers grow, pinned staging is allocated)
+    t = time.perf_counter(); fn(); sync()
+    return time.perf_counter() - t
+
+
+def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB):
+    """Rates the north-star contract and SURVEY.md 8d ask for beside the headline, each over 2^extra_log2 proofs, N = 1 only."""
+    m = min(1 << args.extra_log2, dev.shape[0])
+    sync = torch.cuda.synchronize
+    ex = {"proofs_each": m}
+    st = torch.zeros(m, dtype=torch.uint8, device="cuda")
+    # (1) host transcripts (library default, src/transcript.rs stays on the host), inputs in HBM
+    eng.set_transcript_mode(capi.TRANSCRIPT_HOST)
+    dt = timed(lambda: eng.verify_spend_dev(sk, m, dev.data_ptr(), st.data_ptr()), sync)
+    assert torch.equal(st, expect[:m])
+    ex["host_transcript_hbm"] = {"value": m / dt, "unit": "verifies/s", "what": "ACT_TRANSCRIPT_HOST, proofs and statuses in HBM (ACT_MEM_DEVICE)"}
+    # (2) ... with proofs in pinned host memory and statuses back in host memory: what a Rust caller's slices are
+    hp = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); hp.copy_(dev[:m]); sync()
+    hs = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
+    dt = timed(lambda: eng.verify_spend_ptr(sk, m, capi.MEM_HOST, hp.data_ptr(), hs.data_ptr()), sync)
+    assert torch.equal(hs, expect[:m].cpu())
+    ex["host_transcript_hostmem"] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9, "host_threads": usable_cores(),
+                                     "what": "ACT_TRANSCRIPT_HOST + ACT_MEM_HOST (pinned): the contract mode end to end, PCIe and host BLAKE3 inclusive"}
+    eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
+    dt = timed(lambda: eng.verify_spend_ptr(sk, m, capi.MEM_HOST, hp.data_ptr(), hs.data_ptr()), sync)
+    assert torch.equal(hs, expect[:m].cpu())
+    ex["device_transcript_hostmem"] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9,
+                                       "what": "ACT_TRANSCRIPT_DEVICE + ACT_MEM_HOST (pinned)"}
+    del hp
+    # (3) refund = verify + sign (src/lib.rs:787-868), per-lane rng resident in HBM
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    rng = torch.randint(0, 256, (m, 128), dtype=torch.uint8, device="cuda", generator=g)
+    rf = torch.zeros((m, 128), dtype=torch.uint8, device="cuda")
+    sync()
+    dt = timed(lambda: eng.refund_dev(sk, m, dev.data_ptr(), rng.data_ptr(), capi.RNG_PER_LANE, rf.data_ptr(), st.data_ptr()), sync)
+    assert torch.equal(st, expect[:m])
+    assert bool((rf[expect[:m] != 0] == 0).all()) and bool((rf[expect[:m] == 0].any(dim=1)).all())
+    ex["refund"] = {"value": m / dt, "unit": "refunds/s", "what": "verify + BBS re-sign, device transcripts, HBM-resident, ACT_RNG_PER_LANE"}
+    # (4) BASELINE config 2: 2^16 verifies at L = 64
+    if L == 128:
+        e64 = capi.Engine(h, 64, device=local, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
+        d64 = 1024
+        p64 = make_inputs(e64, sk, d64)
+        n64 = 1 << 16
+        dev64 = torch.from_numpy(np.frombuffer(p64, np.uint8).reshape(d64, proof_bytes(64)).copy()).cuda().repeat(n64 // d64, 1).contiguous()
+        st64 = torch.zeros(n64, dtype=torch.uint8, device="cuda")
+        sync()
+        dt = timed(lambda: e64.verify_spend_dev(sk, n64, dev64.data_ptr(), st64.data_ptr()), sync)
+        assert int(st64.sum()) == 0
+        ex["verify_L64"] = {"value": n64 / dt, "unit": "verifies/s", "what": "BASELINE configs[1]: 2^16 spend-proof verifies, 64-bit range, one launch chunk, device transcripts"}
+        e64.close()
+    return ex
 
 
 if __name__ == "__main__":

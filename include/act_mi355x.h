@@ -194,6 +194,12 @@ int act_prof_reset(act_ctx *ctx);
 int act_prof_kernel_count(const act_ctx *ctx);
 const char *act_prof_kernel_name(const act_ctx *ctx, int i);
 int act_prof_get(act_ctx *ctx, int i, double *ms_total, uint64_t *launches, uint64_t *lanes);
+/* ms during which at least one launch of kernel i was executing (union of the launch intervals; launches of two chunks
+ * in flight overlap, so ms_total of act_prof_get can exceed the wall time) */
+int act_prof_get_busy(act_ctx *ctx, int i, double *ms_busy);
+/* ALU roofline probe: rate of the 64-bit multiply-accumulate (v_mad_u64_u32) the field arithmetic is made of, with every
+ * SIMD of `device` saturated by register-resident dependency chains.  lane_mads_per_s is summed over lanes; ms = probe time. */
+int act_ubench_mad_u64_u32(int device, double *lane_mads_per_s, double *ms);
 
 #ifdef __cplusplus
 }

@@ -6,10 +6,9 @@
 #include <vector>
 #define ACT_FE_BOUNDS 1
 #define ACT_FB_WBITS 6   /* host test of the window logic: small tables (43 windows x 64 entries) */
-#include "../../anonymous-credit-tokens_amd/csrc/msm.h"
-#include "../../anonymous-credit-tokens_amd/csrc/blake3_hd.h"
+#include "../../anonymous-credit-tokens_amd/csrc/spend_lanes.h"
 
-namespace act { fe_bounds_t fe_bounds = {0, 0, 0, 0, 0, 0}; }
+namespace act { fe_bounds_t fe_bounds = {0, 0, 0, 0, 0, 0}; fe_counts_t fe_counts = {0, 0, 0}; }
 using namespace act;
 
 static void ld(uint32_t w[8], const uint8_t* b) { memcpy(w, b, 32); }
@@ -135,5 +134,80 @@ extern "C" int hc_chain_bu(const uint8_t* pt, const uint8_t* s0, const uint8_t* 
   std::vector<uint32_t> bk(BUCKET_WORDS);
   chain_bu(al, au, p, sc_in(s0), sc_in(s1), bk.data());
   ristretto_encode(r, al); st(o0, r); ristretto_encode(r, au); st(o1, r);
+  return 1;
+}
+
+// ---- the spend-verification kernels' own lane bodies (csrc/spend_lanes.h), run lane by lane on the host ---------------
+// Builds Params tables the way k_build_table does, then executes exactly what the five kernels execute for `n` proofs:
+// prep (lane = proof), bits (lane = (proof, bit)), enc (lane = 32 half-points), tail, BLAKE3, finish.  Outputs: the
+// "spend" transcript pre-images, statuses, enc(K'), and the number of field multiplications / squarings each kernel's
+// lanes executed: counts[3*k .. 3*k+2] = fe_mul, fe_sq, fixed_base_acc calls for k = prep, bits, enc, tail.  This build's
+// fixed-base windows are ACT_FB_WBITS = 6 bits wide (43 mixed additions of 7 multiplications per call, tables small enough
+// to build per test); counts[12] = that window count, so the caller can restate the multiplications for the product's
+// 16 windows exactly: mul - calls * (counts[12] - 16) * 7.
+namespace {
+struct HostTables { uint8_t h[96]; std::vector<uint32_t> tab[4]; bool valid = false; };
+HostTables g_tabs;
+const uint8_t kGen[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                          0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+bool build_tables(const uint8_t h[96]) {
+  if (g_tabs.valid && memcmp(g_tabs.h, h, 96) == 0) return true;
+  for (int b = 0; b < 4; b++) {
+    uint32_t w[8]; ld(w, b == 0 ? kGen : h + 32 * (b - 1));
+    ge base; if (!ristretto_decode(base, w)) return false;
+    g_tabs.tab[b].assign((size_t)FB_TABLE_WORDS, 0u);
+    for (int pos = 0; pos < FB_WINDOWS; pos++) {
+      ge acc = ge_identity();
+      for (int e = 0; e < FB_ENTRIES; e++) {
+        fe zi = fe_invert(acc.Z); ge a; a.X = fe_mul(acc.X, zi); a.Y = fe_mul(acc.Y, zi); a.Z = fe_one(); a.T = fe_mul(a.X, a.Y);
+        niels_store(&g_tabs.tab[b][((size_t)pos * FB_ENTRIES + e) * NIELS_WORDS], niels_from_affine(a));
+        acc = ge_add(acc, base);
+      }
+      base = acc;
+    }
+  }
+  memcpy(g_tabs.h, h, 96); g_tabs.valid = true;
+  return true;
+}
+void put_lp(std::vector<uint8_t>& v, const uint8_t* b, size_t n) { for (int i = 7; i >= 0; i--) v.push_back((uint8_t)((uint64_t)n >> (8 * i))); v.insert(v.end(), b, b + n); }
+}  // namespace
+
+extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint32_t n, const uint8_t* proofs, uint8_t* out_transcripts,
+                               uint8_t* out_status, uint8_t* out_kprime, uint64_t* counts) {
+  if (L < 1 || L > 128 || !build_tables(h)) return 0;
+  SpendArgs a{};
+  for (int b = 0; b < 4; b++) a.P.tab[b] = g_tabs.tab[b].data();
+  a.P.half_h1 = nullptr; a.P.L = L;
+  static const char* const labels[4] = {"request", "respond", "spend", "refund"};
+  static const char version[] = "curve25519-ristretto anonymous-credits v1.0";
+  for (int l = 0; l < 4; l++) {
+    std::vector<uint8_t> p; put_lp(p, (const uint8_t*)version, sizeof(version) - 1);
+    put_lp(p, h, 32); put_lp(p, h + 32, 32); put_lp(p, h + 64, 32); put_lp(p, (const uint8_t*)labels[l], strlen(labels[l]));
+    a.P.prefix_len[l] = (uint32_t)p.size(); p.resize(PREFIX_WORDS * 4, 0); memcpy(a.P.prefix[l], p.data(), PREFIX_WORDS * 4);
+  }
+  { uint32_t w[8]; ld(w, sk); a.K.x = sc_from_words(w); ld(w, sk + 32); if (!ristretto_decode(a.K.w, w)) return 0; }
+  const SpendTranscript st{L}; const ProofLayout pl{L};
+  std::vector<uint8_t> tr((size_t)n * st.stride(), 0), status(n, 0), kp((size_t)n * 32, 0);
+  std::vector<uint32_t> coords((size_t)n * L * NIELS_WORDS), d01((size_t)n * 2 * GE_WORDS), buckets((size_t)n * (L < 2 ? 2 : L) * BUCKET_WORDS),
+      xa((size_t)n * GE_WORDS), flags(n, 0), xof((size_t)n * 16);
+  a.proofs = proofs; a.n = n; a.tr = tr.data(); a.tr_stride = (uint32_t)st.stride(); a.coords = coords.data(); a.d01 = d01.data();
+  a.buckets = buckets.data(); a.xa = xa.data(); a.flags = flags.data(); a.xof = xof.data(); a.status = status.data(); a.kprime_enc = kp.data();
+  uint64_t c[13] = {0};
+  c[12] = FB_WINDOWS;
+  auto snap = [&](int k) { c[3 * k] += fe_counts.mul; c[3 * k + 1] += fe_counts.sq; c[3 * k + 2] += fe_counts.fixed_base; fe_counts = fe_counts_t{0, 0, 0}; };
+  fe_counts = fe_counts_t{0, 0, 0};
+  for (uint32_t p = 0; p < n; p++) spend_prep_lane(a, p);
+  snap(0);
+  for (uint32_t g = 0; g < n * (uint32_t)L; g++) spend_bits_lane(a, g, nullptr);
+  snap(1);
+  for (uint64_t q0 = 0; q0 < (uint64_t)n * L * 2; q0 += ENC_BATCH) spend_enc_lane(a, q0);
+  snap(2);
+  for (uint32_t p = 0; p < n; p++) spend_tail_lane(a, p);
+  snap(3);
+  for (uint32_t p = 0; p < n; p++) b3_hash_xof64(&xof[(size_t)p * 16], reinterpret_cast<const uint32_t*>(tr.data() + (size_t)p * st.stride()), (uint32_t)st.bytes());
+  for (uint32_t p = 0; p < n; p++) spend_finish_lane(a, p);
+  for (uint32_t p = 0; p < n; p++) memcpy(out_transcripts + (size_t)p * st.bytes(), tr.data() + (size_t)p * st.stride(), st.bytes());
+  memcpy(out_status, status.data(), n); memcpy(out_kprime, kp.data(), (size_t)n * 32);
+  if (counts) memcpy(counts, c, sizeof(c));
   return 1;
 }

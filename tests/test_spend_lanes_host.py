@@ -1,0 +1,78 @@
+"""The spend-verification kernels' own lane bodies (csrc/spend_lanes.h: what k_spend_prep / bits / enc / tail / finish
+execute per lane), compiled for the host by tests/hostcheck and run lane by lane on the CPU, against the libsodium-made
+fixtures and the C oracle: statuses, enc(K') and the complete "spend" transcript pre-images.  This is a CPU unit test of
+kernel code (the product has no CPU path); the same bodies run on the GPU in tests/test_gpu_*.py."""
+import ctypes as C
+import hashlib
+
+import pytest
+
+from conftest import load_golden, shake, scb
+
+hx = bytes.fromhex
+
+
+def host_verify(hc, h, L, sk, proofs):
+    pb = 32 * (14 + 4 * L)
+    n = len(proofs) // pb
+    tb = 184 + 40 * (6 + 3 * L)
+    tr = C.create_string_buffer(n * tb); st = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
+    counts = (C.c_uint64 * 13)()
+    assert hc.hc_spend_verify(h, L, sk, n, proofs, tr, st, kp, counts) == 1
+    return st.raw, kp.raw, [tr.raw[i * tb:(i + 1) * tb] for i in range(n)], op_counts(list(counts), n)
+
+
+def op_counts(c, n):
+    """Per-proof field operations of each kernel restated for the product's 16 fixed-base windows (this build: c[12])."""
+    out = {}
+    for k, name in enumerate(("k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail")):
+        mul, sq, fb = c[3 * k:3 * k + 3]
+        out[name] = {"fe_mul": (mul - fb * (c[12] - 16) * 7) / n, "fe_sq": sq / n, "fixed_base_mults": fb / n}
+    return out
+
+
+@pytest.mark.parametrize("name", ["sodium_lifecycle_L128.json", "sodium_lifecycle_L64.json"])
+def test_kernel_lane_bodies_reproduce_the_libsodium_fixtures(hostcheck, oracle, name):
+    g = load_golden(name)
+    L, cases = g["L"], g["cases"]
+    sk = hx(g["sk"])
+    proofs = b"".join(hx(c["proof"]) for c in cases)
+    st, kp, trs, counts = host_verify(hostcheck, hx(g["params"]), L, sk, proofs)
+    assert list(st) == [c["status"] for c in cases]
+    octx = oracle.ctx(hx(g["params"]), L)
+    pb = octx.proof_bytes
+    for i, c in enumerate(cases):
+        assert kp[32 * i:32 * i + 32].hex() == (c["kprime"] if c["status"] == 0 else "00" * 32)
+        if "verifier_transcript_sha256" in c:
+            assert hashlib.sha256(trs[i]).hexdigest() == c["verifier_transcript_sha256"], i
+            so, kpo, tro = octx.verify_spend(sk, proofs[pb * i:pb * i + pb], True)
+            assert trs[i] == tro
+    # operation counts per proof are what bench.py's ALU roofline is computed from: sanity-bound them
+    mul = sum(v["fe_mul"] for v in counts.values()); sq = sum(v["fe_sq"] for v in counts.values())
+    assert 2000 * L < mul < 3000 * L and 1000 * L < sq < 1700 * L, (mul, sq)
+    assert counts["k_spend_bits"]["fixed_base_mults"] == 3 * L
+
+
+def test_ragged_and_small_widths(hostcheck, oracle, bench_params):
+    """L = 3 and L = 100 (lanes of several proofs share a 32-point encode batch), a tampered and an identity lane."""
+    for L in (3, 100):
+        octx = oracle.ctx(bench_params, L)
+        sk = octx.private_key_random(shake("hl-sk-%d" % L, 64))
+        recs = []
+        for i in range(3):
+            pre = octx.pre_issuance_random(shake("hl-pre-%d-%d" % (L, i), 128))
+            req = octx.request(pre, shake("hl-rq-%d-%d" % (L, i), 128))
+            st, resp = octx.issue(sk, req, scb(5 + i), shake("hl-ir-%d-%d" % (L, i), 128))
+            st, tok = octx.issuance_to_credit_token(pre, sk[32:], req, resp)
+            st, proof, _ = octx.prove_spend(tok, scb(i), shake("hl-pr-%d-%d" % (L, i), octx.prove_rng_bytes))
+            recs.append(bytearray(proof))
+        recs[1][33] ^= 1
+        recs[2][64:96] = bytes(32)
+        proofs = b"".join(bytes(r) for r in recs)
+        st, kp, trs, _ = host_verify(hostcheck, bench_params, L, sk, proofs)
+        for i in range(3):
+            so, kpo, tro = octx.verify_spend(sk, bytes(recs[i]), True)
+            assert st[i] == so, (L, i)
+            if so in (0, 7):                       # the reference returns before building a transcript when A' is the identity
+                assert trs[i] == tro, (L, i)
+        assert list(st) == [0, 7, 6]
