@@ -1,6 +1,6 @@
 // spend_lanes.h — the per-lane bodies of the spend-verification kernels (k_spend_verify.hip), as functions that also
 // compile under g++: tests/hostcheck runs them lane by lane on the CPU to (a) compare the transcript bytes this very code
-// writes with the oracle's, (b) count its field multiplications / squarings exactly (the ALU roofline of bench.py), and
+// writes with the test suite's CPU checker, (b) count its field multiplications / squarings exactly (the ALU roofline of bench.py), and
 // (c) put it under AddressSanitizer / UBSan, none of which can be done on the GPU pool.  The product only ever runs them
 // inside the __global__ wrappers of k_spend_verify.hip; there is no CPU compute path in libact_mi355x.so.
 //
