@@ -17,7 +17,7 @@ _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_ctx_set_pipeline_depth", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_prof_enable",
@@ -66,6 +66,7 @@ def load() -> C.CDLL:
     lib.act_ctx_destroy.restype = None
     lib.act_ctx_set_transcript_mode.argtypes = [vp, i32]
     lib.act_ctx_set_host_threads.argtypes = [vp, i32]
+    lib.act_ctx_set_pipeline_depth.argtypes = [vp, i32]
     lib.act_last_error.argtypes = [vp]
     lib.act_last_error.restype = C.c_char_p
     for f in ("act_spend_proof_bytes", "act_prove_rng_bytes", "act_spend_transcript_bytes"):
@@ -184,6 +185,9 @@ class Engine:
 
     def set_transcript_mode(self, mode: int):
         self._ck(self.lib.act_ctx_set_transcript_mode(self.ctx, mode))
+
+    def set_pipeline_depth(self, depth: int):
+        self._ck(self.lib.act_ctx_set_pipeline_depth(self.ctx, depth))
 
     # ---- host-memory batch calls ----------------------------------------------------------------
     def private_key_random(self, rng: bytes) -> bytes:

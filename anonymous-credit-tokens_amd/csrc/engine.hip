@@ -61,6 +61,7 @@ struct act_ctx {
   DevParams P{};
   uint8_t henc[96]{};
   int tr_mode = ACT_TRANSCRIPT_HOST;
+  int depth = 2;                       // chunks in flight (act_ctx_set_pipeline_depth): 2 = both slots, 1 = strictly one after the other
   int host_threads = 0;
   std::string err;
   Slot slots[2];
@@ -482,6 +483,7 @@ int act_ctx_set_transcript_mode(act_ctx* c, int mode) {
   if (!c || (mode != ACT_TRANSCRIPT_HOST && mode != ACT_TRANSCRIPT_DEVICE)) return ACT_ERR_ARG;
   c->tr_mode = mode; return ACT_OK;
 }
+int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
 int act_ctx_set_host_threads(act_ctx* c, int n) { if (!c || n < 0) return ACT_ERR_ARG; c->host_threads = n; return ACT_OK; }
 const char* act_last_error(const act_ctx* c) { return c ? c->err.c_str() : "null context"; }
 size_t act_spend_proof_bytes(const act_ctx* c) { return ProofLayout{c->L}.bytes(); }
@@ -544,8 +546,8 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
   // chunks alternate between the two slots; with device transcripts and per-lane rng nothing in a chunk waits for the
   // host, so two chunks are in flight (the per-proof kernels put only one wavefront per SIMD on the GPU per chunk)
   for (size_t off = 0; off < n; off += c->max_batch, chunk++) {
-    Slot& sl = c->slots[chunk & 1];
-    if (chunk >= 2) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }
+    Slot& sl = c->slots[chunk % c->depth];
+    if (chunk >= (size_t)c->depth) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
     IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.pbk = sl.d_buckets;
     if ((rc = dev_in(c, sl, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
@@ -577,8 +579,9 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   const size_t nchunks = (n + chunk_len - 1) / chunk_len;
   SpendChunk chunks[2];
   size_t cursor = 0;
+  const size_t depth = (size_t)c->depth;
   auto stage1 = [&](size_t i) -> int {
-    Slot& sl = c->slots[i & 1]; SpendChunk& ch = chunks[i & 1];
+    Slot& sl = c->slots[i % depth]; SpendChunk& ch = chunks[i % depth];
     ch = SpendChunk{}; ch.off = i * chunk_len; ch.m = (uint32_t)std::min(chunk_len, n - ch.off);
     int r;
     if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
@@ -587,7 +590,7 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
     return spend_stage1(c, sl, ch);
   };
   auto stage2 = [&](size_t i) -> int {
-    Slot& sl = c->slots[i & 1]; SpendChunk& ch = chunks[i & 1];
+    Slot& sl = c->slots[i % depth]; SpendChunk& ch = chunks[i % depth];
     int r;
     if ((r = spend_stage2(c, sl, ch))) return r;
     if (out_kprime && (r = dev_out_end(c, sl, mem, out_kprime + ch.off * 32, ch.d_kprime, (size_t)ch.m * 32))) return r;
@@ -597,16 +600,16 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
       if ((r = sign_phase(c, sl, ch.m, LABEL_REFUND, d_rng, nullptr, ch.d_out))) return r;
       if ((r = dev_out_end(c, sl, mem, out_refund + ch.off * 128, ch.d_out, (size_t)ch.m * 128))) return r;
     }
-    c->last_spend_slot = (int)(i & 1);
+    c->last_spend_slot = (int)(i % depth);
     return copy_status_out(c, sl, mem, status + ch.off, ch.m);
   };
   for (size_t i = 0; i < nchunks; i++) {
-    // slot reuse: chunk i-2's copies out of this slot must have completed before its staging buffers are overwritten
-    if (i >= 2) { HIPCK(c, hipStreamSynchronize(c->slots[i & 1].stream)); }
+    // slot reuse: the copies of the chunk that last used this slot must have completed before its staging buffers are overwritten
+    if (i >= depth) { HIPCK(c, hipStreamSynchronize(c->slots[i % depth].stream)); }
     if ((rc = stage1(i))) return rc;
-    if (i >= 1 && (rc = stage2(i - 1))) return rc;
+    if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
   }
-  if (nchunks && (rc = stage2(nchunks - 1))) return rc;
+  for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
   return sync_all(c);
 }
 
@@ -630,10 +633,11 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
   const size_t nchunks = (n + c->max_batch - 1) / c->max_batch;
   ProveArgs args[2]; uint32_t ms[2] = {0, 0}; size_t offs[2] = {0, 0};
   // two-slot pipeline like spend_batch: head/bits/tail + hash start of chunk i+1 are enqueued before chunk i is finished
+  const size_t depth = (size_t)c->depth;
   auto stage1 = [&](size_t i) -> int {
-    Slot& sl = c->slots[i & 1]; ProveArgs& a = args[i & 1];
+    Slot& sl = c->slots[i % depth]; ProveArgs& a = args[i % depth];
     size_t off = i * c->max_batch; uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    ms[i & 1] = m; offs[i & 1] = off;
+    ms[i % depth] = m; offs[i % depth] = off;
     a = ProveArgs{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.half = sl.d_buckets; a.state = sl.d_state;
     a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
     int rc;
@@ -649,8 +653,8 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
     return hash_begin(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m);
   };
   auto stage2 = [&](size_t i) -> int {
-    Slot& sl = c->slots[i & 1]; ProveArgs& a = args[i & 1];
-    uint32_t m = ms[i & 1]; size_t off = offs[i & 1];
+    Slot& sl = c->slots[i % depth]; ProveArgs& a = args[i % depth];
+    uint32_t m = ms[i % depth]; size_t off = offs[i % depth];
     int rc;
     if ((rc = hash_end(c, sl, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_RESP, (uint64_t)m * c->L, [&] { launch_prove_resp(a, sl.stream); }))) return rc;
@@ -660,11 +664,11 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
   };
   int rc;
   for (size_t i = 0; i < nchunks; i++) {
-    if (i >= 2) { HIPCK(c, hipStreamSynchronize(c->slots[i & 1].stream)); }
+    if (i >= depth) { HIPCK(c, hipStreamSynchronize(c->slots[i % depth].stream)); }
     if ((rc = stage1(i))) return rc;
-    if (i >= 1 && (rc = stage2(i - 1))) return rc;
+    if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
   }
-  if (nchunks && (rc = stage2(nchunks - 1))) return rc;
+  for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
   return sync_all(c);
 }
 

@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4096)
     ap.add_argument("--max-batch", type=int, default=65536)
     ap.add_argument("--extra-log2", type=int, default=18, help="proofs per extra measurement (contract mode, refund)")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="chunks in flight; 1 for profiling runs (rocprofv3 per-kernel durations then do not overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     # test hooks: exercise the N>1 control path on a box with one GPU (RCCL refuses two ranks on one device)
@@ -196,6 +197,7 @@ def main():
     n = 1 << args.batch_log2
     h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01", device=local)    # benches/benchmark.rs:9-16
     eng = capi.Engine(h, L, device=local, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
+    eng.set_pipeline_depth(args.pipeline_depth)
     sk = eng.private_key_random(shake("bench-sk", 64))
     distinct = min(args.distinct, n)
     proofs = make_inputs(eng, sk, distinct)
@@ -257,7 +259,7 @@ def main():
                     % (distinct, L, args.batch_log2),
             "config": {"workload": "configs[1] scaled to the metric batch: 2^%d spend-proof verifies per GPU, L=%d%s, inputs resident in HBM"
                                    % (args.batch_log2, L, " (the crate's width)" if L == 128 else ""),
-                       "batch_per_gpu": n, "range_bits": L, "lanes_per_launch": args.max_batch, "transcript": "device BLAKE3",
+                       "batch_per_gpu": n, "range_bits": L, "lanes_per_launch": args.max_batch, "chunks_in_flight": args.pipeline_depth, "transcript": "device BLAKE3",
                        "sharding": "independent batches per rank, no collective"},
         }
         roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,

@@ -104,6 +104,10 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
 void act_ctx_destroy(act_ctx *ctx);
 int act_ctx_set_transcript_mode(act_ctx *ctx, int mode);    /* default ACT_TRANSCRIPT_HOST */
 int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);   /* host BLAKE3 workers; 0 = hardware concurrency */
+/* chunks in flight per call: 2 (default; chunk i+1's kernels overlap chunk i's low-occupancy head / tail kernels and, in
+ * host-transcript mode, its host hashing) or 1 (strictly one after the other: profiling runs whose per-kernel durations
+ * must not overlap) */
+int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
 const char *act_last_error(const act_ctx *ctx);
 size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
 size_t act_prove_rng_bytes(const act_ctx *ctx);             /* 64*(4L+12) */

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box call that produces the evidence bench.py's roofline cites, for tag $1 (e.g. r02_a):
+#   gpurun_out/<tag>_bench.json                  the default bench line (two chunks in flight, extras, cpu baseline)
+#   gpurun_out/<tag>_bench_depth1.json           the same bench with one chunk in flight, run under rocprofv3 --kernel-trace --stats
+#   gpurun_out/<tag>_kernel_stats_depth1.csv     rocprofv3's per-kernel summary of that run: with one chunk in flight its average
+#                                                k_spend_bits duration is an un-overlapped launch and must agree with roofline.avg_launch_ms
+#   gpurun_out/<tag>_pmc_valu.json, _pmc_hbm_traffic.json   separate --pmc passes (tools/pmc_profile.sh)
+tag=${1:-r02_a}
+root=${GRAFT_REPO_ROOT:-$PWD}
+cd $root
+python3 bench.py --steps 3 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_prof -- python3 $root/bench.py --steps 2 --warmup 1 --pipeline-depth 1 --no-extras --no-cpu-baseline > $root/gpurun_out/${tag}_bench_depth1.json 2> $root/gpurun_out/${tag}_prof.err
+cd $root
+f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats_depth1.csv
+bash tools/pmc_profile.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
+rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_pmc
+head -4 gpurun_out/${tag}_kernel_stats_depth1.csv
+python3 - <<P
+import json
+for n in ("bench", "bench_depth1"):
+    d = json.load(open("gpurun_out/${tag}_%s.json" % n))
+    print(n, round(d["value"]), "avg_launch_ms", round(d["roofline"]["avg_launch_ms"], 2), "alu", d["roofline"].get("alu", {}).get("frac"))
+print(open("gpurun_out/${tag}_pmc.log").read()[-600:])
+P
