@@ -25,6 +25,10 @@ EXPORTS = [
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
     "act_nullifier_check_and_insert_batch",
+    "act_issue_check_batch", "act_issue_sign_batch", "act_refund_sign_batch",
+    "act_node_create", "act_node_destroy", "act_node_device_count", "act_node_ctx", "act_node_last_error", "act_node_set_transcript_mode",
+    "act_node_set_host_threads", "act_node_request_batch", "act_node_issue_batch", "act_node_issuance_to_credit_token_batch",
+    "act_node_prove_spend_batch", "act_node_verify_spend_batch", "act_node_refund_batch", "act_node_refund_to_credit_token_batch",
 ]
 CBOR_TYPES = {"IssuanceRequest": 1, "IssuanceResponse": 2, "SpendProof": 3, "Refund": 4, "PrivateKey": 5, "PublicKey": 6,
               "PreIssuance": 7, "CreditToken": 8, "PreRefund": 9}
@@ -104,6 +108,26 @@ def load() -> C.CDLL:
     lib.act_prof_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.act_prof_get_busy.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.act_ubench_mad_u64_u32.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.act_issue_check_batch.argtypes = [vp, sz, i32, u8p, u8p]
+    lib.act_issue_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_refund_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_node_create.argtypes = [u8p, i32, C.POINTER(C.c_int), i32, sz, C.POINTER(vp)]
+    lib.act_node_destroy.argtypes = [vp]
+    lib.act_node_destroy.restype = None
+    lib.act_node_device_count.argtypes = [vp]
+    lib.act_node_ctx.argtypes = [vp, i32]
+    lib.act_node_ctx.restype = vp
+    lib.act_node_last_error.argtypes = [vp]
+    lib.act_node_last_error.restype = C.c_char_p
+    lib.act_node_set_transcript_mode.argtypes = [vp, i32]
+    lib.act_node_set_host_threads.argtypes = [vp, i32]
+    lib.act_node_request_batch.argtypes = [vp, sz, u8p, u8p, u8p]
+    lib.act_node_issue_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_node_issuance_to_credit_token_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, u8p]
+    lib.act_node_prove_spend_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, u8p]
+    lib.act_node_verify_spend_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p]
+    lib.act_node_refund_batch.argtypes = [vp, sz, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_node_refund_to_credit_token_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, u8p]
     _lib = lib
     return lib
 
@@ -313,6 +337,92 @@ class Engine:
                 self._ck(self.lib.act_prof_get_busy(self.ctx, i, C.byref(busy)))
                 out[self.lib.act_prof_kernel_name(self.ctx, i).decode()] = {"ms": ms.value, "busy_ms": busy.value, "launches": la.value, "lanes": ln.value}
         return out
+
+
+class Node:
+    """The GPUs of one node behind one handle (act_node_*): contiguous shards, one context and host thread per entry of
+    `devices`, outputs in the matching slices; ACT_RNG_SEQUENTIAL exact across shards.  Host memory (bytes) only."""
+
+    def __init__(self, h: bytes, L: int = 128, devices=(0,), max_batch: int = 0, transcript: int = TRANSCRIPT_HOST):
+        self.lib = load()
+        self.L = L
+        nd = C.c_void_p()
+        p, keep = _in(h, 96)
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self.lib.act_node_create(p, L, devs, len(devices), max_batch, C.byref(nd))
+        if rc:
+            msg = self.lib.act_node_last_error(nd).decode() if nd else ""
+            if nd:
+                self.lib.act_node_destroy(nd)
+            raise ActError(f"act_node_create failed: {_ERRS.get(rc, rc)} {msg}")
+        self.nd = nd
+        c0 = self.lib.act_node_ctx(nd, 0)
+        self.proof_bytes = self.lib.act_spend_proof_bytes(c0)
+        self.prove_rng_bytes = self.lib.act_prove_rng_bytes(c0)
+        self._ck(self.lib.act_node_set_transcript_mode(nd, transcript))
+
+    def close(self):
+        if getattr(self, "nd", None):
+            self.lib.act_node_destroy(self.nd)
+            self.nd = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise ActError(f"{_ERRS.get(rc, rc)}: {self.lib.act_node_last_error(self.nd).decode()}")
+
+    def device_count(self) -> int:
+        return self.lib.act_node_device_count(self.nd)
+
+    def set_transcript_mode(self, mode: int):
+        self._ck(self.lib.act_node_set_transcript_mode(self.nd, mode))
+
+    def request(self, pre: bytes, rng: bytes) -> bytes:
+        n = len(pre) // 64; out = np.zeros(128 * n, np.uint8)
+        p0, k0 = _in(pre, 64 * n); p1, k1 = _in(rng, 128 * n)
+        self._ck(self.lib.act_node_request_batch(self.nd, n, p0, p1, out.ctypes.data)); return out.tobytes()
+
+    def issue(self, sk: bytes, req: bytes, c: bytes, rng: bytes, rng_mode: int = RNG_PER_LANE):
+        n = len(req) // 128; out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(req, 128 * n); p1, k1 = _in(c, 32 * n); p2, k2 = _in(rng)
+        self._ck(self.lib.act_node_issue_batch(self.nd, n, ps, p0, p1, p2, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def issuance_to_credit_token(self, pre: bytes, w: bytes, req: bytes, resp: bytes):
+        n = len(pre) // 64; out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(pre, 64 * n); pw, kw = _in(w, 32); p1, k1 = _in(req, 128 * n); p2, k2 = _in(resp, 160 * n)
+        self._ck(self.lib.act_node_issuance_to_credit_token_batch(self.nd, n, p0, pw, p1, p2, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def prove_spend(self, tok: bytes, s: bytes, rng: bytes):
+        n = len(tok) // 160; out = np.zeros(self.proof_bytes * n, np.uint8); pr = np.zeros(96 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(tok, 160 * n); p1, k1 = _in(s, 32 * n); p2, k2 = _in(rng, self.prove_rng_bytes * n)
+        self._ck(self.lib.act_node_prove_spend_batch(self.nd, n, p0, p1, p2, out.ctypes.data, pr.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes(), pr.tobytes()
+
+    def verify_spend(self, sk: bytes, proofs: bytes, want_kprime: bool = False):
+        n = len(proofs) // self.proof_bytes; st = np.zeros(n, np.uint8)
+        kp = np.zeros(32 * n, np.uint8) if want_kprime else None
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n)
+        self._ck(self.lib.act_node_verify_spend_batch(self.nd, n, ps, p0, st.ctypes.data, kp.ctypes.data if want_kprime else None))
+        return (st.tobytes(), kp.tobytes()) if want_kprime else st.tobytes()
+
+    def refund(self, sk: bytes, proofs: bytes, rng: bytes, rng_mode: int = RNG_PER_LANE):
+        n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
+        self._ck(self.lib.act_node_refund_batch(self.nd, n, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def refund_to_credit_token(self, prerefund: bytes, proofs: bytes, refund: bytes, w: bytes):
+        n = len(prerefund) // 96; out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(prerefund, 96 * n); p1, k1 = _in(proofs, self.proof_bytes * n); p2, k2 = _in(refund, 128 * n); pw, kw = _in(w, 32)
+        self._ck(self.lib.act_node_refund_to_credit_token_batch(self.nd, n, p0, p1, p2, pw, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
 
 
 class NullifierSet:

@@ -566,6 +566,65 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
   return sync_all(c);
 }
 
+// The two halves of issue / refund as separate calls, for callers that must see every verdict before any rng is assigned:
+// the node dispatcher (node.cpp) makes ACT_RNG_SEQUENTIAL exact across the GPUs of a node by checking on all shards,
+// counting the accepted lanes of the shards in front, and only then signing.
+int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uint8_t* status) {
+  if (!c || (n && (!req || !status))) return ACT_ERR_ARG;
+  HIPCK(c, hipSetDevice(c->device));
+  int rc; size_t chunk = 0;
+  for (size_t off = 0; off < n; off += c->max_batch, chunk++) {
+    Slot& sl = c->slots[chunk % c->depth];
+    if (chunk >= (size_t)c->depth) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }
+    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.pbk = sl.d_buckets;
+    if ((rc = dev_in(c, sl, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
+    if ((rc = prof_launch(c, sl, PK_ISSUE_A, m, [&] { launch_issue_a(a, sl.stream); }))) return rc;
+    if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, c->P.prefix_len[LABEL_REQUEST] + 80, m))) return rc;
+    if ((rc = prof_launch(c, sl, PK_ISSUE_CHECK, m, [&] { launch_issue_check(a, sl.stream); }))) return rc;
+    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
+  }
+  return sync_all(c);
+}
+// signs the lanes whose status_in is 0; `point` = IssuanceRequest records (label RESPOND, with amounts) or enc(K') (label REFUND)
+static int sign_only_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t sk[64], const uint8_t* point, size_t point_stride,
+                           const uint8_t* camt, const uint8_t* status_in, const uint8_t* rng, int rng_mode, uint8_t* out, uint8_t* status) {
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = set_key(c, sk); if (rc) return rc;
+  const size_t rec = label == LABEL_RESPOND ? 160 : 128;
+  size_t cursor = 0, chunk = 0;
+  for (size_t off = 0; off < n; off += c->max_batch, chunk++) {
+    Slot& sl = c->slots[chunk % c->depth];
+    if (chunk >= (size_t)c->depth) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }
+    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    SignXaArgs x{}; x.P = c->P; x.n = m; x.point_stride = (uint32_t)point_stride; x.xa = sl.d_xa; x.status = sl.d_status;
+    if ((rc = dev_in(c, sl, 0, mem, point + off * point_stride, (size_t)m * point_stride, &x.point))) return rc;
+    if (camt && (rc = dev_in(c, sl, 1, mem, camt + off * 32, (size_t)m * 32, &x.c_amount))) return rc;
+    HIPCK(c, hipMemcpyAsync(sl.d_status, status_in + off, m, mem == ACT_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, sl.stream));
+    uint8_t* d_out;
+    if ((rc = dev_out_begin(c, sl, 2, mem, out + off * rec, (size_t)m * rec, &d_out))) return rc;
+    launch_sign_xa(x, sl.stream);
+    const uint8_t* d_rng;
+    if ((rc = prepare_rng_slots(c, sl, m, off, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
+    if ((rc = sign_phase(c, sl, m, label, d_rng, x.c_amount, d_out))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out + off * rec, d_out, (size_t)m * rec))) return rc;
+    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
+  }
+  return sync_all(c);
+}
+int act_issue_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* status_in,
+                         const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
+  if (!c || !sk || (n && (!req || !camt || !status_in || !rng || !out_resp || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  return sign_only_batch(c, n, mem, LABEL_RESPOND, sk, req, 128, camt, status_in, rng, rng_mode, out_resp, status);
+}
+int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in,
+                          const uint8_t* rng, int rng_mode, uint8_t* out_refund, uint8_t* status) {
+  if (!c || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  return sign_only_batch(c, n, mem, LABEL_REFUND, sk, kprime, 32, nullptr, status_in, rng, rng_mode, out_refund, status);
+}
+
 // verify (sign == false) or refund (sign == true), two-slot software pipeline: stage 1 of chunk i+1 is enqueued before
 // the host touches chunk i again.
 static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,

@@ -75,11 +75,26 @@ __global__ void __launch_bounds__(64, 2) k_issue_a(IssueArgs a) {
   uint32_t enc[8];
   tr_put_bytes(el, wk);                                           // :634 big_k (canonical bytes)
   ristretto_encode(enc, acc[0]); tr_put_bytes(el + 40, enc);      // k1
-  sc c = load_sc(a.c_amount + (size_t)p * 32);
-  ge xa = ge_add(fixed_base_acc(ge_basepoint(), a.P.tab[BASE_H1], c), K);
-  ge_store(a.xa + (size_t)p * GE_WORDS, xa);
+  if (a.c_amount) {                                               // check-only callers (act_issue_check_batch) pass no amounts
+    sc c = load_sc(a.c_amount + (size_t)p * 32);
+    ge xa = ge_add(fixed_base_acc(ge_basepoint(), a.P.tab[BASE_H1], c), K);
+    ge_store(a.xa + (size_t)p * GE_WORDS, xa);
+  }
   a.flags[p] = flags;
 }
+// X_A alone, for the sign-only entry points (act_issue_sign_batch / act_refund_sign_batch: the node dispatcher's second
+// phase): issue X_A = g + c h1 + K (:644) from the request, refund X_A = g + K' (:848) from the enc(K') that
+// act_verify_spend_batch returned.  Lanes whose status is already non-zero are left alone.
+__global__ void __launch_bounds__(64, 2) k_sign_xa(SignXaArgs a) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= a.n || a.status[p] != 0) return;
+  uint32_t w[8]; load8(w, a.point + (size_t)p * a.point_stride);
+  ge K;
+  if (!ristretto_decode(K, w)) { a.status[p] = 255; return; }
+  ge xa = a.c_amount ? ge_add(fixed_base_acc(ge_basepoint(), a.P.tab[BASE_H1], load_sc(a.c_amount + (size_t)p * 32)), K) : ge_add(K, ge_basepoint());
+  ge_store(a.xa + (size_t)p * GE_WORDS, xa);
+}
+void launch_sign_xa(const SignXaArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_sign_xa, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
 __global__ void __launch_bounds__(256) k_issue_check(IssueArgs a) {
   uint32_t p = blockIdx.x * 256 + threadIdx.x;
   if (p >= a.n) return;

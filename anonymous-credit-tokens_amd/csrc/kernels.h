@@ -108,6 +108,17 @@ struct SignArgs {
   uint32_t* pbk;             // n * 2 * BUCKET_WORDS: per-proof Pippenger buckets (msm.h chain_b)
 };
 
+// X_A for the sign-only entry points: from K of the request (+ c h1) or from enc(K') of a verified spend proof
+struct SignXaArgs {
+  DevParams P;
+  uint32_t n;
+  const uint8_t* point;      // n encodings at point_stride: IssuanceRequest records (K first) or enc(K')
+  uint32_t point_stride;
+  const uint8_t* c_amount;   // n * 32 (issue) or null (refund)
+  uint32_t* xa;              // n * GE_WORDS
+  uint8_t* status;           // n: in = verdict of the check phase; a lane whose point does not decode becomes 255
+};
+
 struct IssueArgs {
   DevParams P;
   uint32_t n;
@@ -189,6 +200,7 @@ void launch_spend_tail(const SpendArgs& a, hipStream_t s);
 void launch_spend_finish(const SpendArgs& a, hipStream_t s);
 void launch_sign_a(const SignArgs& a, hipStream_t s);
 void launch_sign_b(const SignArgs& a, hipStream_t s);
+void launch_sign_xa(const SignXaArgs& a, hipStream_t s);
 void launch_issue_a(const IssueArgs& a, hipStream_t s);
 void launch_issue_check(const IssueArgs& a, hipStream_t s);
 void launch_request_a(const RequestArgs& a, hipStream_t s);

@@ -1,0 +1,188 @@
+// node.cpp — the GPUs of one node behind one handle (include/act_mi355x.h act_node_*): a batch is cut into contiguous
+// shards, one per GPU; one host thread per GPU drives that GPU's context through the single-GPU entry points; outputs
+// land in disjoint slices of the caller's arrays.  No collective, no peer traffic: lanes are independent
+// (SURVEY.md section 8e).  The one cross-shard dependency is ACT_RNG_SEQUENTIAL for issue / refund: a lane's rng slice
+// is the number of ACCEPTED lanes in front of it (/root/reference/src/lib.rs:638-643, 842-846 draw only after the proof
+// verifies), so every shard is checked first, the host counts the accepted lanes of the shards in front, and only then
+// every shard signs from its own offset into the stream -- byte for byte what one loop over one generator produces.
+// Plain host C++ over the C ABI: nothing here touches a device.
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/act_mi355x.h"
+
+struct act_node {
+  std::vector<act_ctx*> ctx;
+  std::vector<int> devices;
+  int L = 0;
+  std::string err;
+};
+
+namespace {
+
+struct Shard { size_t off, m; };
+std::vector<Shard> cut(size_t n, size_t parts) {
+  std::vector<Shard> s(parts);
+  for (size_t k = 0; k < parts; k++) { size_t a = n * k / parts, b = n * (k + 1) / parts; s[k] = {a, b - a}; }
+  return s;
+}
+// fn(k, shard) on one thread per GPU; first failure wins and is reported with its device
+template <class F>
+int run(act_node* nd, size_t n, F fn) {
+  const size_t parts = nd->ctx.size();
+  const std::vector<Shard> sh = cut(n, parts);
+  std::vector<int> rc(parts, ACT_OK);
+  std::vector<std::thread> th;
+  for (size_t k = 1; k < parts; k++) th.emplace_back([&, k] { rc[k] = fn(k, sh[k]); });
+  rc[0] = fn(0, sh[0]);
+  for (auto& t : th) t.join();
+  for (size_t k = 0; k < parts; k++)
+    if (rc[k]) { nd->err = "device " + std::to_string(nd->devices[k]) + ": " + act_last_error(nd->ctx[k]); return rc[k]; }
+  return ACT_OK;
+}
+inline const uint8_t* at(const uint8_t* p, size_t off, size_t rec) { return p ? p + off * rec : nullptr; }
+inline uint8_t* at(uint8_t* p, size_t off, size_t rec) { return p ? p + off * rec : nullptr; }
+
+// accepted lanes in front of each shard (exclusive prefix over the shards)
+std::vector<size_t> accepted_before(const std::vector<Shard>& sh, const uint8_t* status) {
+  std::vector<size_t> base(sh.size(), 0);
+  size_t acc = 0;
+  for (size_t k = 0; k < sh.size(); k++) {
+    base[k] = acc;
+    for (size_t i = 0; i < sh[k].m; i++) acc += status[sh[k].off + i] == 0;
+  }
+  return base;
+}
+
+}  // namespace
+
+extern "C" {
+
+int act_node_create(const uint8_t h[96], int L, const int* devices, int n_devices, size_t max_batch, act_node** out) {
+  if (!h || !devices || n_devices < 1 || !out) return ACT_ERR_ARG;
+  act_node* nd = new act_node();
+  *out = nd;      // returned even on failure so that act_node_last_error() can be read; the caller destroys it
+  nd->L = L;
+  // contexts are created one after the other: table construction saturates a GPU anyway, and a failure leaves a clean prefix
+  for (int k = 0; k < n_devices; k++) {
+    act_ctx* c = nullptr;
+    int rc = act_ctx_create(h, L, devices[k], max_batch, &c);
+    if (rc) {
+      nd->err = "device " + std::to_string(devices[k]) + ": " + (c ? act_last_error(c) : "context creation failed");
+      if (c) act_ctx_destroy(c);
+      return rc;
+    }
+    nd->ctx.push_back(c); nd->devices.push_back(devices[k]);
+  }
+  return ACT_OK;
+}
+void act_node_destroy(act_node* nd) {
+  if (!nd) return;
+  for (act_ctx* c : nd->ctx) act_ctx_destroy(c);
+  delete nd;
+}
+int act_node_device_count(const act_node* nd) { return nd ? (int)nd->ctx.size() : 0; }
+act_ctx* act_node_ctx(act_node* nd, int k) { return (nd && k >= 0 && k < (int)nd->ctx.size()) ? nd->ctx[k] : nullptr; }
+const char* act_node_last_error(const act_node* nd) { return nd ? nd->err.c_str() : "null node"; }
+int act_node_set_transcript_mode(act_node* nd, int mode) {
+  if (!nd) return ACT_ERR_ARG;
+  for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_transcript_mode(c, mode); if (rc) return rc; }
+  return ACT_OK;
+}
+int act_node_set_host_threads(act_node* nd, int per_gpu) {
+  if (!nd) return ACT_ERR_ARG;
+  for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_host_threads(c, per_gpu); if (rc) return rc; }
+  return ACT_OK;
+}
+
+int act_node_request_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
+  if (!nd || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_request_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(pre, s.off, 64), at(rng, s.off, 128), at(out_req, s.off, 128));
+  });
+}
+
+int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* req, const uint8_t* c, const uint8_t* rng,
+                         int rng_mode, uint8_t* out_resp, uint8_t* status) {
+  if (!nd || !sk || (n && (!req || !c || !rng || !out_resp || !status))) return ACT_ERR_ARG;
+  if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
+    return run(nd, n, [&](size_t k, Shard s) {
+      return act_issue_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(req, s.off, 128), at(c, s.off, 32),
+                             rng_mode == ACT_RNG_PER_LANE ? at(rng, s.off, 128) : rng, rng_mode, at(out_resp, s.off, 160), status + s.off);
+    });
+  if (rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  int rc = run(nd, n, [&](size_t k, Shard s) { return act_issue_check_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(req, s.off, 128), status + s.off); });
+  if (rc) return rc;
+  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status);
+  const std::vector<uint8_t> checked(status, status + n);
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_issue_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(req, s.off, 128), at(c, s.off, 32), checked.data() + s.off, rng + base[k] * 128,
+                                ACT_RNG_SEQUENTIAL, at(out_resp, s.off, 160), status + s.off);
+  });
+}
+
+int act_node_issuance_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
+                                            const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
+  if (!nd || !w || (n && (!pre || !req || !resp || !out_token || !status))) return ACT_ERR_ARG;
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_issuance_to_credit_token_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(pre, s.off, 64), w, at(req, s.off, 128), at(resp, s.off, 160),
+                                              at(out_token, s.off, 160), status + s.off);
+  });
+}
+
+int act_node_prove_spend_batch(act_node* nd, size_t n, const uint8_t* token, const uint8_t* s_, const uint8_t* rng, uint8_t* out_proof,
+                               uint8_t* out_prerefund, uint8_t* status) {
+  if (!nd || (n && (!token || !s_ || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+  const size_t pb = act_spend_proof_bytes(nd->ctx[0]), rb = act_prove_rng_bytes(nd->ctx[0]);
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_prove_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(token, s.off, 160), at(s_, s.off, 32), at(rng, s.off, rb), at(out_proof, s.off, pb),
+                                 at(out_prerefund, s.off, 96), status + s.off);
+  });
+}
+
+int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
+  if (!nd || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
+  const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_verify_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(proof, s.off, pb), status + s.off, at(out_kprime, s.off, 32));
+  });
+}
+
+int act_node_refund_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
+                          uint8_t* out_refund, uint8_t* status) {
+  if (!nd || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
+  if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
+    return run(nd, n, [&](size_t k, Shard s) {
+      return act_refund_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(proof, s.off, pb), rng_mode == ACT_RNG_PER_LANE ? at(rng, s.off, 128) : rng,
+                              rng_mode, at(out_refund, s.off, 128), status + s.off);
+    });
+  if (rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  // phase 1: verification on every shard, keeping enc(K') (32 bytes per lane) -- the only thing the signature needs
+  std::vector<uint8_t> kprime(n * 32);
+  int rc = run(nd, n, [&](size_t k, Shard s) {
+    return act_verify_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(proof, s.off, pb), status + s.off, kprime.data() + s.off * 32);
+  });
+  if (rc) return rc;
+  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status);
+  const std::vector<uint8_t> checked(status, status + n);
+  // phase 2: X_A = g + K', then the BBS signature (src/lib.rs:846-868), each shard from its own offset into the stream
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_refund_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, kprime.data() + s.off * 32, checked.data() + s.off, rng + base[k] * 128, ACT_RNG_SEQUENTIAL,
+                                 at(out_refund, s.off, 128), status + s.off);
+  });
+}
+
+int act_node_refund_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* prerefund, const uint8_t* proof, const uint8_t* refund,
+                                          const uint8_t w[32], uint8_t* out_token, uint8_t* status) {
+  if (!nd || !w || (n && (!prerefund || !proof || !refund || !out_token || !status))) return ACT_ERR_ARG;
+  const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_refund_to_credit_token_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(prerefund, s.off, 96), at(proof, s.off, pb), at(refund, s.off, 128), w,
+                                            at(out_token, s.off, 160), status + s.off);
+  });
+}
+
+}  // extern "C"

@@ -138,6 +138,51 @@ int act_refund_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], cons
 int act_refund_to_credit_token_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *prerefund, const uint8_t *proof,
                                      const uint8_t *refund, const uint8_t w[32], uint8_t *out_token, uint8_t *status);
 
+/* The two halves of issue / refund as separate calls, for callers that must see every verdict before any rng is assigned
+ * (the node dispatcher below; a caller with its own admission step between check and signature):
+ *   act_issue_check_batch   the PoK check alone (src/lib.rs:629-640): req n*128 -> status n
+ *   act_issue_sign_batch    the BBS signature (:643-660) for lanes with status_in == 0: X_A = g + c h1 + K from the request
+ *   act_refund_sign_batch   the BBS signature (:846-868) for lanes with status_in == 0: X_A = g + K', kprime n*32 as returned
+ *                           by act_verify_spend_batch
+ * rng / rng_mode as in act_issue_batch; check + sign with the same rng gives the bytes of the one-call form. */
+int act_issue_check_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *req, uint8_t *status);
+int act_issue_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *req, const uint8_t *c,
+                         const uint8_t *status_in, const uint8_t *rng, int rng_mode, uint8_t *out_resp, uint8_t *status);
+int act_refund_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *kprime, const uint8_t *status_in,
+                          const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
+
+/* Node-level dispatch: the GPUs of one node behind one handle.  act_node_create builds one context per
+ * entry of devices[] (the same device may be listed more than once: each entry is its own context, stream set and
+ * workspace).  Every act_node_*_batch call cuts its batch into n_devices contiguous shards (shard k = lanes
+ * [n*k/N, n*(k+1)/N)), runs shard k on context k from its own host thread through the single-GPU entry point of the same
+ * name, and writes outputs into the matching slices of the caller's arrays: no collective, no peer traffic.  All bulk
+ * pointers are host memory.  ACT_RNG_SEQUENTIAL stays exact across shards -- the bytes of one sequential loop over one
+ * generator (src/lib.rs:638-643, 842-846 draw only for accepted lanes): all shards are checked first, the host counts
+ * the accepted lanes in front of every shard, then all shards sign from their offsets into the stream; refund carries
+ * only enc(K') between the two phases.  ACT_RNG_PER_LANE needs no such barrier and is one pass.  A node handle may be
+ * used by one host thread at a time. */
+typedef struct act_node act_node;
+int act_node_create(const uint8_t h[96], int L, const int *devices, int n_devices, size_t max_batch, act_node **out);
+void act_node_destroy(act_node *node);
+int act_node_device_count(const act_node *node);
+act_ctx *act_node_ctx(act_node *node, int k);                  /* context k, e.g. for act_ctx_set_* / act_prof_* */
+const char *act_node_last_error(const act_node *node);
+int act_node_set_transcript_mode(act_node *node, int mode);
+int act_node_set_host_threads(act_node *node, int per_gpu);    /* host BLAKE3 workers of every context */
+int act_node_request_batch(act_node *node, size_t n, const uint8_t *pre, const uint8_t *rng, uint8_t *out_req);
+int act_node_issue_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *req, const uint8_t *c, const uint8_t *rng,
+                         int rng_mode, uint8_t *out_resp, uint8_t *status);
+int act_node_issuance_to_credit_token_batch(act_node *node, size_t n, const uint8_t *pre, const uint8_t w[32], const uint8_t *req,
+                                            const uint8_t *resp, uint8_t *out_token, uint8_t *status);
+int act_node_prove_spend_batch(act_node *node, size_t n, const uint8_t *token, const uint8_t *s, const uint8_t *rng,
+                               uint8_t *out_proof, uint8_t *out_prerefund, uint8_t *status);
+int act_node_verify_spend_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *proof, uint8_t *status,
+                                uint8_t *out_kprime);
+int act_node_refund_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *proof, const uint8_t *rng, int rng_mode,
+                          uint8_t *out_refund, uint8_t *status);
+int act_node_refund_to_credit_token_batch(act_node *node, size_t n, const uint8_t *prerefund, const uint8_t *proof,
+                                          const uint8_t *refund, const uint8_t w[32], uint8_t *out_token, uint8_t *status);
+
 /* Batch CBOR codec (src/cbor.rs: to_cbor / from_cbor of the nine wire and state types; deterministic RFC 8949
  * encoding, int-keyed maps, 32-byte byte strings).  `type` selects the struct; records are the raw layouts above.
  * Encoding writes n canonical messages of act_cbor_size(ctx, type) bytes each, back to back.  Decoding takes n

@@ -1,0 +1,119 @@
+// abi_conformance.cpp — a C++ caller compiled against include/act_mi355x.h and linked to libact_mi355x.so (no ctypes, no
+// Python, no torch in the process): replays a golden lifecycle fixture through the hot-path entry points exactly as the
+// crate's `mod mi355x` would call them and exits non-zero on the first byte that differs.  The fixture
+// arrives as a flat binary written by tests/test_gpu_abi_conformance.py from tests/golden/sodium_lifecycle_L128.json
+// (known answers computed by libsodium + LLVM BLAKE3), so this is at once a prototype check of the header (a drifted
+// argument order or width does not compile or does not reproduce the bytes) and a parity test of the C ABI itself.
+//
+//   g++ -std=c++17 -Iinclude tests/abi_conformance.cpp -o conf -Lanonymous-credit-tokens_amd -lact_mi355x ...
+//   ./conf fixture.bin
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "act_mi355x.h"
+
+typedef std::vector<uint8_t> bytes;
+
+static FILE* g_f;
+static uint64_t rd_u64() { uint64_t v; if (fread(&v, 8, 1, g_f) != 1) { fprintf(stderr, "short fixture\n"); exit(2); } return v; }
+static bytes rd_blob() { uint64_t n = rd_u64(); bytes b(n); if (n && fread(b.data(), 1, n, g_f) != n) { fprintf(stderr, "short fixture\n"); exit(2); } return b; }
+
+static int g_fail = 0;
+static void expect(const char* what, const bytes& got, const bytes& want) {
+  if (got.size() != want.size() || memcmp(got.data(), want.data(), got.size()) != 0) {
+    size_t i = 0; while (i < got.size() && i < want.size() && got[i] == want[i]) i++;
+    fprintf(stderr, "MISMATCH %s: first difference at byte %zu of %zu\n", what, i, want.size());
+    g_fail++;
+  } else {
+    printf("ok  %-44s %zu bytes\n", what, got.size());
+  }
+}
+#define CK(call) do { int rc_ = (call); if (rc_ != ACT_OK) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, ctx ? act_last_error(ctx) : ""); return 3; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 2 || !(g_f = fopen(argv[1], "rb"))) { fprintf(stderr, "usage: %s fixture.bin\n", argv[0]); return 2; }
+  const int L = (int)rd_u64();
+  const size_t n = (size_t)rd_u64();
+  std::vector<std::string> pa;
+  for (int i = 0; i < 4; i++) { bytes b = rd_blob(); pa.emplace_back(b.begin(), b.end()); }
+  const bytes h = rd_blob(), sk_rng = rd_blob(), sk = rd_blob(), sk_other = rd_blob();
+  const bytes pre_rng = rd_blob(), pre = rd_blob(), req_rng = rd_blob(), req = rd_blob(), camt = rd_blob(), issue_rng = rd_blob(), resp = rd_blob();
+  const bytes tok = rd_blob(), s = rd_blob(), prove_rng = rd_blob(), proof_made = rd_blob(), prerefund = rd_blob(), proof_in = rd_blob();
+  const bytes status = rd_blob(), kprime = rd_blob(), refund_rng = rd_blob(), refund = rd_blob(), tok2 = rd_blob(), status_tok2 = rd_blob(), status_other = rd_blob();
+  const bytes seq_refund = rd_blob();       // refunds under ACT_RNG_SEQUENTIAL with refund_rng as the one stream
+  fclose(g_f);
+
+  act_ctx* ctx = nullptr;
+  bytes out_h(96);
+  CK(act_params_new(0, pa[0].c_str(), pa[1].c_str(), pa[2].c_str(), pa[3].c_str(), out_h.data()));
+  expect("act_params_new", out_h, h);
+  CK(act_ctx_create(h.data(), L, 0, 7, &ctx));                                   // ragged chunks: 7 records per launch
+  if (act_spend_proof_bytes(ctx) != 32u * (14 + 4 * (size_t)L) || act_prove_rng_bytes(ctx) != 64u * (4 * (size_t)L + 12)) { fprintf(stderr, "size queries wrong\n"); return 4; }
+  const size_t pb = act_spend_proof_bytes(ctx);
+
+  for (int mode = ACT_TRANSCRIPT_HOST; mode <= ACT_TRANSCRIPT_DEVICE; mode++) {
+    printf("-- transcript mode %d\n", mode);
+    CK(act_ctx_set_transcript_mode(ctx, mode));
+    bytes o_sk(64); CK(act_private_key_random(ctx, sk_rng.data(), o_sk.data())); expect("act_private_key_random", o_sk, sk);
+    bytes o_pre(n * 64); CK(act_pre_issuance_random_batch(ctx, n, ACT_MEM_HOST, pre_rng.data(), o_pre.data())); expect("act_pre_issuance_random_batch", o_pre, pre);
+    bytes o_req(n * 128); CK(act_request_batch(ctx, n, ACT_MEM_HOST, pre.data(), req_rng.data(), o_req.data())); expect("act_request_batch", o_req, req);
+    bytes o_resp(n * 160), st(n);
+    CK(act_issue_batch(ctx, n, ACT_MEM_HOST, sk.data(), req.data(), camt.data(), issue_rng.data(), ACT_RNG_PER_LANE, o_resp.data(), st.data()));
+    expect("act_issue_batch", o_resp, resp); expect("act_issue_batch status", st, bytes(n, 0));
+    bytes o_tok(n * 160);
+    CK(act_issuance_to_credit_token_batch(ctx, n, ACT_MEM_HOST, pre.data(), sk.data() + 32, req.data(), resp.data(), o_tok.data(), st.data()));
+    expect("act_issuance_to_credit_token_batch", o_tok, tok); expect("  status", st, bytes(n, 0));
+    bytes o_proof(n * pb), o_prer(n * 96);
+    CK(act_prove_spend_batch(ctx, n, ACT_MEM_HOST, tok.data(), s.data(), prove_rng.data(), o_proof.data(), o_prer.data(), st.data()));
+    expect("act_prove_spend_batch proofs", o_proof, proof_made); expect("act_prove_spend_batch prerefunds", o_prer, prerefund);
+    bytes o_kp(n * 32);
+    CK(act_verify_spend_batch(ctx, n, ACT_MEM_HOST, sk.data(), proof_in.data(), st.data(), o_kp.data()));
+    expect("act_verify_spend_batch status", st, status); expect("act_verify_spend_batch K'", o_kp, kprime);
+    CK(act_verify_spend_batch(ctx, n, ACT_MEM_HOST, sk_other.data(), proof_in.data(), st.data(), nullptr));
+    expect("act_verify_spend_batch (other issuer)", st, status_other);
+    bytes o_rf(n * 128);
+    CK(act_refund_batch(ctx, n, ACT_MEM_HOST, sk.data(), proof_in.data(), refund_rng.data(), ACT_RNG_PER_LANE, o_rf.data(), st.data()));
+    expect("act_refund_batch", o_rf, refund); expect("act_refund_batch status", st, status);
+    CK(act_refund_batch(ctx, n, ACT_MEM_HOST, sk.data(), proof_in.data(), refund_rng.data(), ACT_RNG_SEQUENTIAL, o_rf.data(), st.data()));
+    expect("act_refund_batch (sequential rng)", o_rf, seq_refund);
+    bytes o_tok2(n * 160);
+    CK(act_refund_to_credit_token_batch(ctx, n, ACT_MEM_HOST, prerefund.data(), proof_in.data(), refund.data(), sk.data() + 32, o_tok2.data(), st.data()));
+    expect("act_refund_to_credit_token_batch", o_tok2, tok2); expect("  status", st, status_tok2);
+    // the two halves of refund through the split entry points
+    CK(act_verify_spend_batch(ctx, n, ACT_MEM_HOST, sk.data(), proof_in.data(), st.data(), o_kp.data()));
+    bytes st2(n);
+    CK(act_refund_sign_batch(ctx, n, ACT_MEM_HOST, sk.data(), o_kp.data(), st.data(), refund_rng.data(), ACT_RNG_SEQUENTIAL, o_rf.data(), st2.data()));
+    expect("act_verify_spend_batch + act_refund_sign_batch", o_rf, seq_refund);
+  }
+
+  // the node handle over three contexts on device 0: same bytes, both rng modes
+  act_node* node = nullptr;
+  const int devs[3] = {0, 0, 0};
+  int rc = act_node_create(h.data(), L, devs, 3, 7, &node);
+  if (rc) { fprintf(stderr, "act_node_create -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
+  bytes st(n), o_rf(n * 128), o_kp(n * 32);
+  rc = act_node_verify_spend_batch(node, n, sk.data(), proof_in.data(), st.data(), o_kp.data());
+  if (rc) { fprintf(stderr, "act_node_verify_spend_batch -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
+  expect("act_node_verify_spend_batch status", st, status); expect("act_node_verify_spend_batch K'", o_kp, kprime);
+  rc = act_node_refund_batch(node, n, sk.data(), proof_in.data(), refund_rng.data(), ACT_RNG_PER_LANE, o_rf.data(), st.data());
+  if (rc) { fprintf(stderr, "act_node_refund_batch -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
+  expect("act_node_refund_batch", o_rf, refund);
+  rc = act_node_refund_batch(node, n, sk.data(), proof_in.data(), refund_rng.data(), ACT_RNG_SEQUENTIAL, o_rf.data(), st.data());
+  if (rc) { fprintf(stderr, "act_node_refund_batch -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
+  expect("act_node_refund_batch (sequential rng)", o_rf, seq_refund);
+  act_node_destroy(node);
+
+  // failure path from C: a context is returned for its error text and must be destroyed by the caller
+  bytes bad_h = h; bad_h[0] |= 1;
+  act_ctx* bad = nullptr;
+  rc = act_ctx_create(bad_h.data(), L, 0, 4, &bad);
+  if (rc != ACT_ERR_PARAMS || !bad || !*act_last_error(bad)) { fprintf(stderr, "bad params: rc %d\n", rc); g_fail++; } else printf("ok  act_ctx_create rejects a non-canonical h1: \"%s\"\n", act_last_error(bad));
+  act_ctx_destroy(bad);
+  act_ctx_destroy(ctx);
+  if (g_fail) { fprintf(stderr, "%d mismatches\n", g_fail); return 1; }
+  printf("conformance: all entry points reproduce the fixture\n");
+  return 0;
+}
