@@ -29,6 +29,7 @@ EXPORTS = [
     "act_node_create", "act_node_destroy", "act_node_device_count", "act_node_ctx", "act_node_last_error", "act_node_set_transcript_mode",
     "act_node_set_host_threads", "act_node_request_batch", "act_node_issue_batch", "act_node_issuance_to_credit_token_batch",
     "act_node_prove_spend_batch", "act_node_verify_spend_batch", "act_node_refund_batch", "act_node_refund_to_credit_token_batch",
+    "act_node_issue_check_batch", "act_node_issue_sign_batch", "act_node_refund_sign_batch",
 ]
 CBOR_TYPES = {"IssuanceRequest": 1, "IssuanceResponse": 2, "SpendProof": 3, "Refund": 4, "PrivateKey": 5, "PublicKey": 6,
               "PreIssuance": 7, "CreditToken": 8, "PreRefund": 9}
@@ -128,6 +129,9 @@ def load() -> C.CDLL:
     lib.act_node_verify_spend_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p]
     lib.act_node_refund_batch.argtypes = [vp, sz, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_node_refund_to_credit_token_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, u8p]
+    lib.act_node_issue_check_batch.argtypes = [vp, sz, u8p, u8p]
+    lib.act_node_issue_sign_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_node_refund_sign_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     _lib = lib
     return lib
 
@@ -416,6 +420,22 @@ class Node:
         n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
         ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
         self._ck(self.lib.act_node_refund_batch(self.nd, n, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def refund_sign(self, sk: bytes, kprime: bytes, status_in: bytes, rng: bytes, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(status_in); out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(kprime, 32 * n); p1, k1 = _in(status_in, n); p2, k2 = _in(rng)
+        self._ck(self.lib.act_node_refund_sign_batch(self.nd, n, ps, p0, p1, p2, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def issue_check(self, req: bytes) -> bytes:
+        n = len(req) // 128; st = np.zeros(n, np.uint8); p0, k0 = _in(req, 128 * n)
+        self._ck(self.lib.act_node_issue_check_batch(self.nd, n, p0, st.ctypes.data)); return st.tobytes()
+
+    def issue_sign(self, sk: bytes, req: bytes, c: bytes, status_in: bytes, rng: bytes, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(status_in); out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(req, 128 * n); p1, k1 = _in(c, 32 * n); p2, k2 = _in(status_in, n); p3, k3 = _in(rng)
+        self._ck(self.lib.act_node_issue_sign_batch(self.nd, n, ps, p0, p1, p2, p3, rng_mode, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
 
     def refund_to_credit_token(self, prerefund: bytes, proofs: bytes, refund: bytes, w: bytes):

@@ -123,6 +123,35 @@ int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uin
   });
 }
 
+// The halves on their own, for a caller that draws its rng between them (the Rust binding advances the caller's generator
+// by exactly 128 bytes per accepted lane, as the sequential loop would: INTEGRATION.md).
+int act_node_issue_check_batch(act_node* nd, size_t n, const uint8_t* req, uint8_t* status) {
+  if (!nd || (n && (!req || !status))) return ACT_ERR_ARG;
+  return run(nd, n, [&](size_t k, Shard s) { return act_issue_check_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(req, s.off, 128), status + s.off); });
+}
+int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* req, const uint8_t* c, const uint8_t* status_in,
+                              const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
+  if (!nd || !sk || (n && (!req || !c || !status_in || !rng || !out_resp || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
+  const std::vector<uint8_t> checked(status_in, status_in + n);
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_issue_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(req, s.off, 128), at(c, s.off, 32), checked.data() + s.off,
+                                rng + (rng_mode == ACT_RNG_PER_LANE ? s.off : base[k]) * 128, rng_mode, at(out_resp, s.off, 160), status + s.off);
+  });
+}
+int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
+                               int rng_mode, uint8_t* out_refund, uint8_t* status) {
+  if (!nd || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
+  const std::vector<uint8_t> checked(status_in, status_in + n);
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_refund_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(kprime, s.off, 32), checked.data() + s.off,
+                                 rng + (rng_mode == ACT_RNG_PER_LANE ? s.off : base[k]) * 128, rng_mode, at(out_refund, s.off, 128), status + s.off);
+  });
+}
+
 int act_node_issuance_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                                             const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
   if (!nd || !w || (n && (!pre || !req || !resp || !out_token || !status))) return ACT_ERR_ARG;

@@ -174,6 +174,13 @@ int act_node_issue_batch(act_node *node, size_t n, const uint8_t sk[64], const u
                          int rng_mode, uint8_t *out_resp, uint8_t *status);
 int act_node_issuance_to_credit_token_batch(act_node *node, size_t n, const uint8_t *pre, const uint8_t w[32], const uint8_t *req,
                                             const uint8_t *resp, uint8_t *out_token, uint8_t *status);
+/* the halves on their own (cf. act_issue_check_batch ...): a caller that draws its rng between check and signature -- the
+ * Rust binding advances the caller's generator by exactly 128 bytes per accepted lane, as the sequential loop would */
+int act_node_issue_check_batch(act_node *node, size_t n, const uint8_t *req, uint8_t *status);
+int act_node_issue_sign_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *req, const uint8_t *c,
+                              const uint8_t *status_in, const uint8_t *rng, int rng_mode, uint8_t *out_resp, uint8_t *status);
+int act_node_refund_sign_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *kprime, const uint8_t *status_in,
+                               const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
 int act_node_prove_spend_batch(act_node *node, size_t n, const uint8_t *token, const uint8_t *s, const uint8_t *rng,
                                uint8_t *out_proof, uint8_t *out_prerefund, uint8_t *status);
 int act_node_verify_spend_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *proof, uint8_t *status,

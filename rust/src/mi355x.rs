@@ -1,0 +1,394 @@
+//! src/mi355x.rs — MI355X batch engine behind the crate's own API (feature `mi355x`).
+//!
+//! UNCOMPILED in the authoring environment (no Rust toolchain there; rust/README.md).  Binds `libact_mi355x.so`
+//! (C ABI: include/act_mi355x.h).  Every `*_batch` method equals the loop
+//! `items.iter().map(|x| x.method(params, .., &mut rng))` byte for byte, including the state `rng` is left in:
+//! lane i of a batch is one call of the method, raw records are the structs' fields in CBOR key order
+//! (src/cbor.rs:105-110, 163-169, 250-268, 422-427, 546-549, 596-602, 656-660), every `Scalar::random` is one 64-byte
+//! `fill_bytes`, and issue / refund draw only for accepted lanes (src/lib.rs:638-643, 842-846).
+//!
+//! The existing single-call signatures are kept (bottom of this file): with the feature on they are batches of one.
+use crate::{
+    CreditToken, Error, IssuanceRequest, IssuanceResponse, Params, PreIssuance, PreRefund, PrivateKey, PublicKey, Refund,
+    SpendProof, L,
+};
+use curve25519_dalek::{ristretto::CompressedRistretto, RistrettoPoint, Scalar};
+use rand_core::CryptoRngCore;
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int};
+use std::sync::OnceLock;
+
+#[repr(C)]
+pub struct ActNode {
+    _private: [u8; 0],
+}
+const ACT_RNG_SEQUENTIAL: c_int = 1;
+const PROOF_FIELDS: usize = 14 + 4 * L;
+const PROOF_BYTES: usize = 32 * PROOF_FIELDS; // 16 832
+const PROVE_RNG_BYTES: usize = 64 * (4 * L + 12); // 33 536: draw order of src/lib.rs:978-1058
+
+// one declaration per entry point used, prototypes as in include/act_mi355x.h
+extern "C" {
+    fn act_node_create(h: *const u8, l: c_int, devices: *const c_int, n_devices: c_int, max_batch: usize, out: *mut *mut ActNode) -> c_int;
+    fn act_node_destroy(node: *mut ActNode);
+    fn act_node_last_error(node: *const ActNode) -> *const c_char;
+    fn act_node_request_batch(node: *mut ActNode, n: usize, pre: *const u8, rng: *const u8, out_req: *mut u8) -> c_int;
+    fn act_node_issue_check_batch(node: *mut ActNode, n: usize, req: *const u8, status: *mut u8) -> c_int;
+    fn act_node_issue_sign_batch(node: *mut ActNode, n: usize, sk: *const u8, req: *const u8, c: *const u8, status_in: *const u8,
+                                 rng: *const u8, rng_mode: c_int, out_resp: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_issuance_to_credit_token_batch(node: *mut ActNode, n: usize, pre: *const u8, w: *const u8, req: *const u8,
+                                               resp: *const u8, out_token: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_prove_spend_batch(node: *mut ActNode, n: usize, token: *const u8, s: *const u8, rng: *const u8,
+                                  out_proof: *mut u8, out_prerefund: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_verify_spend_batch(node: *mut ActNode, n: usize, sk: *const u8, proof: *const u8, status: *mut u8, out_kprime: *mut u8) -> c_int;
+    fn act_node_refund_sign_batch(node: *mut ActNode, n: usize, sk: *const u8, kprime: *const u8, status_in: *const u8,
+                                  rng: *const u8, rng_mode: c_int, out_refund: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_refund_to_credit_token_batch(node: *mut ActNode, n: usize, prerefund: *const u8, proof: *const u8, refund: *const u8,
+                                             w: *const u8, out_token: *mut u8, status: *mut u8) -> c_int;
+}
+
+/// All GPUs of the node behind one handle (contiguous shards, no collective).  `Params` owns one lazily:
+/// add `#[cfg(feature = "mi355x")] gpu: OnceLock<Gpu>` to `Params` (src/lib.rs:222-229) and `Params::gpu()` below.
+pub struct Gpu(*mut ActNode);
+unsafe impl Send for Gpu {}
+unsafe impl Sync for Gpu {} // the engine serialises nothing: callers must not share one Gpu between threads concurrently
+impl Drop for Gpu {
+    fn drop(&mut self) {
+        unsafe { act_node_destroy(self.0) }
+    }
+}
+
+impl Gpu {
+    fn new(params: &Params) -> Gpu {
+        let mut h = [0u8; 96]; // enc(h1) | enc(h2) | enc(h3), as Transcript::new hashes them (src/transcript.rs:64-66)
+        h[..32].copy_from_slice(params.h1.basepoint().compress().as_bytes());
+        h[32..64].copy_from_slice(params.h2.basepoint().compress().as_bytes());
+        h[64..].copy_from_slice(params.h3.basepoint().compress().as_bytes());
+        // ACT_MI355X_DEVICES = "0,1,2,3,4,5,6,7" (default: device 0)
+        let devices: Vec<c_int> = std::env::var("ACT_MI355X_DEVICES")
+            .map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect())
+            .unwrap_or_else(|_| vec![0]);
+        let mut node = std::ptr::null_mut();
+        let rc = unsafe { act_node_create(h.as_ptr(), L as c_int, devices.as_ptr(), devices.len() as c_int, 0, &mut node) };
+        if rc != 0 {
+            let msg = if node.is_null() { String::new() } else { unsafe { CStr::from_ptr(act_node_last_error(node)) }.to_string_lossy().into_owned() };
+            panic!("act_node_create failed ({rc}): {msg}"); // infrastructure failure, not a protocol error
+        }
+        Gpu(node)
+    }
+    fn check(&self, rc: c_int) {
+        if rc != 0 {
+            let msg = unsafe { CStr::from_ptr(act_node_last_error(self.0)) }.to_string_lossy().into_owned();
+            panic!("MI355X engine failure ({rc}): {msg}");
+        }
+    }
+}
+
+impl Params {
+    pub(crate) fn gpu(&self) -> &Gpu {
+        self.gpu.get_or_init(|| Gpu::new(self))
+    }
+}
+
+fn status_to_error(s: u8) -> Error {
+    match s {
+        // 1 + discriminant, src/lib.rs:102-112
+        1 => Error::InvalidIssuanceRequestProof,
+        2 => Error::InvalidIssuanceResponseProof,
+        3 => Error::DoubleSpendError,
+        4 => Error::InvalidRefundProof,
+        5 => Error::InvalidRefundResponseProof,
+        6 => Error::IdentityPointError,
+        7 => Error::InvalidClientSpendProof,
+        8 => Error::AmountTooBigError,
+        _ => Error::ScalarOutOfRangeError, // 255 cannot occur: every point of a Rust struct is a valid RistrettoPoint
+    }
+}
+
+// ---- record marshalling ------------------------------------------------------------------------------------------
+fn put_s(out: &mut Vec<u8>, s: &Scalar) {
+    out.extend_from_slice(s.as_bytes());
+}
+fn put_p(out: &mut Vec<u8>, p: &RistrettoPoint) {
+    out.extend_from_slice(p.compress().as_bytes());
+}
+fn get_s(rec: &[u8], field: usize) -> Scalar {
+    // the engine writes canonical scalars
+    Scalar::from_canonical_bytes(rec[32 * field..32 * field + 32].try_into().unwrap()).unwrap()
+}
+fn get_p(rec: &[u8], field: usize) -> RistrettoPoint {
+    CompressedRistretto::from_slice(&rec[32 * field..32 * field + 32]).unwrap().decompress().expect("engine wrote a valid point")
+}
+/// `count` x `Scalar::random` worth of bytes, drawn exactly as dalek draws them: one 64-byte `fill_bytes` each.
+fn draw(rng: &mut impl CryptoRngCore, count: usize) -> Vec<u8> {
+    let mut buf = vec![0u8; 64 * count];
+    for chunk in buf.chunks_exact_mut(64) {
+        rng.fill_bytes(chunk);
+    }
+    buf
+}
+
+impl PrivateKey {
+    fn record(&self) -> [u8; 64] {
+        // x | w (src/cbor.rs:477-480)
+        let mut r = [0u8; 64];
+        r[..32].copy_from_slice(self.x.as_bytes());
+        r[32..].copy_from_slice(self.public.w.compress().as_bytes());
+        r
+    }
+}
+impl IssuanceRequest {
+    fn write_record(&self, out: &mut Vec<u8>) {
+        // K | gamma | k_bar | r_bar (src/cbor.rs:105-110)
+        put_p(out, &self.big_k);
+        put_s(out, &self.gamma);
+        put_s(out, &self.k_bar);
+        put_s(out, &self.r_bar);
+    }
+    fn from_record(r: &[u8]) -> Self {
+        IssuanceRequest { big_k: get_p(r, 0), gamma: get_s(r, 1), k_bar: get_s(r, 2), r_bar: get_s(r, 3) }
+    }
+}
+impl IssuanceResponse {
+    fn write_record(&self, out: &mut Vec<u8>) {
+        // A | e | gamma | z | c (src/cbor.rs:163-169)
+        put_p(out, &self.a);
+        for s in [&self.e, &self.gamma, &self.z, &self.c] {
+            put_s(out, s);
+        }
+    }
+    fn from_record(r: &[u8]) -> Self {
+        IssuanceResponse { a: get_p(r, 0), e: get_s(r, 1), gamma: get_s(r, 2), z: get_s(r, 3), c: get_s(r, 4) }
+    }
+}
+impl CreditToken {
+    fn write_record(&self, out: &mut Vec<u8>) {
+        // a | e | k | r | c (src/cbor.rs:596-602)
+        put_p(out, &self.a);
+        for s in [&self.e, &self.k, &self.r, &self.c] {
+            put_s(out, s);
+        }
+    }
+    fn from_record(r: &[u8]) -> Self {
+        CreditToken { a: get_p(r, 0), e: get_s(r, 1), k: get_s(r, 2), r: get_s(r, 3), c: get_s(r, 4) }
+    }
+}
+impl SpendProof {
+    /// k | s | A' | B_bar | Com[L] | gamma | e_bar | r2_bar | r3_bar | c_bar | r_bar | w00 | w01 | gamma0[L] | z[L][2] | k_bar | s_bar
+    /// (src/cbor.rs:250-268)
+    fn write_record(&self, out: &mut Vec<u8>) {
+        put_s(out, &self.k);
+        put_s(out, &self.s);
+        put_p(out, &self.a_prime);
+        put_p(out, &self.b_bar);
+        self.com.iter().for_each(|c| put_p(out, c));
+        for s in [&self.gamma, &self.e_bar, &self.r2_bar, &self.r3_bar, &self.c_bar, &self.r_bar, &self.w00, &self.w01] {
+            put_s(out, s);
+        }
+        self.gamma0.iter().for_each(|g| put_s(out, g));
+        self.z.iter().for_each(|z| {
+            put_s(out, &z[0]);
+            put_s(out, &z[1]);
+        });
+        put_s(out, &self.k_bar);
+        put_s(out, &self.s_bar);
+    }
+    fn from_record(r: &[u8]) -> Self {
+        let mut com = [RistrettoPoint::default(); L];
+        let mut gamma0 = [Scalar::ZERO; L];
+        let mut z = [[Scalar::ZERO; 2]; L];
+        for j in 0..L {
+            com[j] = get_p(r, 4 + j);
+            gamma0[j] = get_s(r, 12 + L + j);
+            z[j] = [get_s(r, 12 + 2 * L + 2 * j), get_s(r, 13 + 2 * L + 2 * j)];
+        }
+        SpendProof {
+            k: get_s(r, 0), s: get_s(r, 1), a_prime: get_p(r, 2), b_bar: get_p(r, 3), com,
+            gamma: get_s(r, 4 + L), e_bar: get_s(r, 5 + L), r2_bar: get_s(r, 6 + L), r3_bar: get_s(r, 7 + L),
+            c_bar: get_s(r, 8 + L), r_bar: get_s(r, 9 + L), w00: get_s(r, 10 + L), w01: get_s(r, 11 + L),
+            gamma0, z, k_bar: get_s(r, 12 + 4 * L), s_bar: get_s(r, 13 + 4 * L),
+        }
+    }
+}
+impl Refund {
+    fn write_record(&self, out: &mut Vec<u8>) {
+        // A* | e | gamma | z (src/cbor.rs:422-427)
+        put_p(out, &self.a);
+        for s in [&self.e, &self.gamma, &self.z] {
+            put_s(out, s);
+        }
+    }
+    fn from_record(r: &[u8]) -> Self {
+        Refund { a: get_p(r, 0), e: get_s(r, 1), gamma: get_s(r, 2), z: get_s(r, 3) }
+    }
+}
+
+// ---- the batch siblings ----------------------------------------------------------------------------------------------
+impl PreIssuance {
+    /// Batch sibling of `request` (src/lib.rs:463-487): lane i draws k', r' (2 x 64 bytes), in lane order.
+    pub fn request_batch(pres: &[PreIssuance], params: &Params, mut rng: impl CryptoRngCore) -> Vec<IssuanceRequest> {
+        let n = pres.len();
+        let mut rec = Vec::with_capacity(64 * n);
+        for p in pres {
+            put_s(&mut rec, &p.r); // r | k (src/cbor.rs:546-549)
+            put_s(&mut rec, &p.k);
+        }
+        let rng_bytes = draw(&mut rng, 2 * n);
+        let mut out = vec![0u8; 128 * n];
+        let gpu = params.gpu();
+        gpu.check(unsafe { act_node_request_batch(gpu.0, n, rec.as_ptr(), rng_bytes.as_ptr(), out.as_mut_ptr()) });
+        out.chunks_exact(128).map(IssuanceRequest::from_record).collect()
+    }
+
+    /// Batch sibling of `to_credit_token` (src/lib.rs:528-562).
+    pub fn to_credit_token_batch(pres: &[PreIssuance], params: &Params, public: &PublicKey, requests: &[IssuanceRequest],
+                                 responses: &[IssuanceResponse]) -> Vec<Result<CreditToken, Error>> {
+        let n = pres.len();
+        assert!(requests.len() == n && responses.len() == n);
+        let (mut pre, mut req, mut resp) = (Vec::with_capacity(64 * n), Vec::with_capacity(128 * n), Vec::with_capacity(160 * n));
+        for i in 0..n {
+            put_s(&mut pre, &pres[i].r);
+            put_s(&mut pre, &pres[i].k);
+            requests[i].write_record(&mut req);
+            responses[i].write_record(&mut resp);
+        }
+        let w = public.w.compress();
+        let (mut out, mut status) = (vec![0u8; 160 * n], vec![0u8; n]);
+        let gpu = params.gpu();
+        gpu.check(unsafe {
+            act_node_issuance_to_credit_token_batch(gpu.0, n, pre.as_ptr(), w.as_bytes().as_ptr(), req.as_ptr(), resp.as_ptr(), out.as_mut_ptr(), status.as_mut_ptr())
+        });
+        (0..n).map(|i| if status[i] == 0 { Ok(CreditToken::from_record(&out[160 * i..160 * i + 160])) } else { Err(status_to_error(status[i])) }).collect()
+    }
+}
+
+impl PrivateKey {
+    /// Batch sibling of `issue` (src/lib.rs:621-663).  e, alpha are drawn only for lanes whose PoK verified, in lane order.
+    pub fn issue_batch(&self, params: &Params, requests: &[IssuanceRequest], amounts: &[Scalar], mut rng: impl CryptoRngCore)
+        -> Vec<Result<IssuanceResponse, Error>> {
+        let n = requests.len();
+        assert_eq!(amounts.len(), n);
+        let (mut req, mut c) = (Vec::with_capacity(128 * n), Vec::with_capacity(32 * n));
+        requests.iter().for_each(|r| r.write_record(&mut req));
+        amounts.iter().for_each(|a| put_s(&mut c, a));
+        let sk = self.record();
+        let gpu = params.gpu();
+        let mut checked = vec![0u8; n];
+        gpu.check(unsafe { act_node_issue_check_batch(gpu.0, n, req.as_ptr(), checked.as_mut_ptr()) }); // :629-640
+        let accepted = checked.iter().filter(|&&s| s == 0).count();
+        let rng_bytes = draw(&mut rng, 2 * accepted); // :643, :649 -- exactly what the sequential loop would have drawn
+        let (mut out, mut status) = (vec![0u8; 160 * n], vec![0u8; n]);
+        gpu.check(unsafe {
+            act_node_issue_sign_batch(gpu.0, n, sk.as_ptr(), req.as_ptr(), c.as_ptr(), checked.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL,
+                                      out.as_mut_ptr(), status.as_mut_ptr())
+        });
+        (0..n).map(|i| if status[i] == 0 { Ok(IssuanceResponse::from_record(&out[160 * i..160 * i + 160])) } else { Err(status_to_error(status[i])) }).collect()
+    }
+
+    /// Batch sibling of `refund` (src/lib.rs:781-869): verification (:787-844) on the GPUs, then e, alpha for the accepted
+    /// lanes only (:846, :852), then the BBS signature on K' (:848-868).
+    pub fn refund_batch(&self, params: &Params, proofs: &[SpendProof], mut rng: impl CryptoRngCore) -> Vec<Result<Refund, Error>> {
+        let n = proofs.len();
+        let mut rec = Vec::with_capacity(n * PROOF_BYTES);
+        proofs.iter().for_each(|p| p.write_record(&mut rec));
+        let sk = self.record();
+        let gpu = params.gpu();
+        let (mut checked, mut kprime) = (vec![0u8; n], vec![0u8; 32 * n]);
+        gpu.check(unsafe { act_node_verify_spend_batch(gpu.0, n, sk.as_ptr(), rec.as_ptr(), checked.as_mut_ptr(), kprime.as_mut_ptr()) });
+        let accepted = checked.iter().filter(|&&s| s == 0).count();
+        let rng_bytes = draw(&mut rng, 2 * accepted);
+        let (mut out, mut status) = (vec![0u8; 128 * n], vec![0u8; n]);
+        gpu.check(unsafe {
+            act_node_refund_sign_batch(gpu.0, n, sk.as_ptr(), kprime.as_ptr(), checked.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL,
+                                       out.as_mut_ptr(), status.as_mut_ptr())
+        });
+        (0..n).map(|i| if status[i] == 0 { Ok(Refund::from_record(&out[128 * i..128 * i + 128])) } else { Err(status_to_error(status[i])) }).collect()
+    }
+}
+
+impl CreditToken {
+    /// Batch sibling of `prove_spend` (src/lib.rs:972-1152): lane i draws its 4L + 12 scalars in the order of :978-1058.
+    pub fn prove_spend_batch(tokens: &[CreditToken], params: &Params, charges: &[Scalar], mut rng: impl CryptoRngCore)
+        -> Vec<(SpendProof, PreRefund)> {
+        let n = tokens.len();
+        assert_eq!(charges.len(), n);
+        let (mut tok, mut s) = (Vec::with_capacity(160 * n), Vec::with_capacity(32 * n));
+        tokens.iter().for_each(|t| t.write_record(&mut tok));
+        charges.iter().for_each(|c| put_s(&mut s, c));
+        let rng_bytes = draw(&mut rng, (4 * L + 12) * n);
+        debug_assert_eq!(rng_bytes.len(), PROVE_RNG_BYTES * n);
+        let (mut proofs, mut prer, mut status) = (vec![0u8; PROOF_BYTES * n], vec![0u8; 96 * n], vec![0u8; n]);
+        let gpu = params.gpu();
+        gpu.check(unsafe {
+            act_node_prove_spend_batch(gpu.0, n, tok.as_ptr(), s.as_ptr(), rng_bytes.as_ptr(), proofs.as_mut_ptr(), prer.as_mut_ptr(), status.as_mut_ptr())
+        });
+        (0..n).map(|i| {
+            let p = &prer[96 * i..96 * i + 96]; // r | k | m (src/cbor.rs:656-660)
+            (SpendProof::from_record(&proofs[PROOF_BYTES * i..PROOF_BYTES * (i + 1)]), PreRefund { r: get_s(p, 0), k: get_s(p, 1), m: get_s(p, 2) })
+        }).collect()
+    }
+}
+
+impl PreRefund {
+    /// Batch sibling of `to_credit_token` (src/lib.rs:1217-1253).
+    pub fn to_credit_token_batch(pres: &[PreRefund], params: &Params, proofs: &[SpendProof], refunds: &[Refund], public_key: &PublicKey)
+        -> Vec<Result<CreditToken, Error>> {
+        let n = pres.len();
+        assert!(proofs.len() == n && refunds.len() == n);
+        let (mut pre, mut rec, mut rf) = (Vec::with_capacity(96 * n), Vec::with_capacity(PROOF_BYTES * n), Vec::with_capacity(128 * n));
+        for i in 0..n {
+            put_s(&mut pre, &pres[i].r);
+            put_s(&mut pre, &pres[i].k);
+            put_s(&mut pre, &pres[i].m);
+            proofs[i].write_record(&mut rec);
+            refunds[i].write_record(&mut rf);
+        }
+        let w = public_key.w.compress();
+        let (mut out, mut status) = (vec![0u8; 160 * n], vec![0u8; n]);
+        let gpu = params.gpu();
+        gpu.check(unsafe {
+            act_node_refund_to_credit_token_batch(gpu.0, n, pre.as_ptr(), rec.as_ptr(), rf.as_ptr(), w.as_bytes().as_ptr(), out.as_mut_ptr(), status.as_mut_ptr())
+        });
+        (0..n).map(|i| if status[i] == 0 { Ok(CreditToken::from_record(&out[160 * i..160 * i + 160])) } else { Err(status_to_error(status[i])) }).collect()
+    }
+}
+
+// ---- the kept single-call signatures: batches of one ------------------------------------------------------------------
+// In src/lib.rs the six existing method bodies become `#[cfg(not(feature = "mi355x"))]`; these take their place otherwise.
+#[cfg(feature = "mi355x")]
+impl PreIssuance {
+    pub fn request(&self, params: &Params, rng: impl CryptoRngCore) -> IssuanceRequest {
+        // src/lib.rs:463
+        Self::request_batch(std::slice::from_ref(self), params, rng).pop().unwrap()
+    }
+    pub fn to_credit_token(&self, params: &Params, public: &PublicKey, request: &IssuanceRequest, response: &IssuanceResponse)
+        -> Result<CreditToken, Error> {
+        // src/lib.rs:528-534
+        Self::to_credit_token_batch(std::slice::from_ref(self), params, public, std::slice::from_ref(request), std::slice::from_ref(response)).pop().unwrap()
+    }
+}
+#[cfg(feature = "mi355x")]
+impl PrivateKey {
+    pub fn issue(&self, params: &Params, request: &IssuanceRequest, c: Scalar, rng: impl CryptoRngCore) -> Result<IssuanceResponse, Error> {
+        // src/lib.rs:621-627
+        self.issue_batch(params, std::slice::from_ref(request), &[c], rng).pop().unwrap()
+    }
+    pub fn refund(&self, params: &Params, spend_proof: &SpendProof, rng: impl CryptoRngCore) -> Result<Refund, Error> {
+        // src/lib.rs:781-786
+        self.refund_batch(params, std::slice::from_ref(spend_proof), rng).pop().unwrap()
+    }
+}
+#[cfg(feature = "mi355x")]
+impl CreditToken {
+    pub fn prove_spend(&self, params: &Params, s: Scalar, rng: impl CryptoRngCore) -> (SpendProof, PreRefund) {
+        // src/lib.rs:972-977
+        Self::prove_spend_batch(std::slice::from_ref(self), params, &[s], rng).pop().unwrap()
+    }
+}
+#[cfg(feature = "mi355x")]
+impl PreRefund {
+    pub fn to_credit_token(&self, params: &Params, spend_proof: &SpendProof, refund: &Refund, public_key: &PublicKey) -> Result<CreditToken, Error> {
+        // src/lib.rs:1217-1223
+        Self::to_credit_token_batch(std::slice::from_ref(self), params, std::slice::from_ref(spend_proof), std::slice::from_ref(refund), public_key).pop().unwrap()
+    }
+}

@@ -57,6 +57,13 @@ def test_node_equals_single_context(engine_factory, bench_params, devices, mode)
         got = node.refund(sk, proofs, rrng, rng_mode)
         assert got == want, rng_mode
         assert {0, 6, 7} <= set(want[0])
+    # the halves through the node handle: check, draw exactly 128 bytes per accepted lane, sign -- what the Rust binding does
+    st, kp = node.verify_spend(sk, proofs, True)
+    accepted = sum(1 for v in st if v == 0)
+    assert node.refund_sign(sk, kp, st, rrng[:128 * accepted]) == eng.refund(sk, proofs, rrng, capi.RNG_SEQUENTIAL)
+    st = node.issue_check(bad)
+    accepted = sum(1 for v in st if v == 0)
+    assert node.issue_sign(sk, bad, cam, st, irng[:128 * accepted]) == eng.issue(sk, bad, cam, irng, capi.RNG_SEQUENTIAL)
     st, rf = eng.refund(sk, proofs, rrng)
     assert node.refund_to_credit_token(prer, proofs, rf, sk[32:]) == eng.refund_to_credit_token(prer, proofs, rf, sk[32:])
     # fewer lanes than shards, and an empty batch
