@@ -45,7 +45,7 @@ constexpr int HASH_PIECES = 8;
 struct Slot {
   hipStream_t stream = nullptr;
   uint8_t *d_tr = nullptr, *d_trs = nullptr, *d_status = nullptr;
-  uint32_t *d_buckets = nullptr, *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr;
+  uint32_t *d_buckets = nullptr, *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr, *d_naf = nullptr, *d_dig = nullptr;
   uint8_t* d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // staging for host-memory callers (grow-only)
   size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
   uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
@@ -299,6 +299,8 @@ int workspace_alloc(act_ctx* c) {
     HIPCK(c, hipMalloc(&sl.d_trs, B * SMALL_TR_STRIDE));
     HIPCK(c, hipMalloc(&sl.d_state, B * 24 * 4));
     HIPCK(c, hipMalloc(&sl.d_slot, B * 4));
+    HIPCK(c, hipMalloc(&sl.d_naf, B * NAF_WORDS * 4));
+    HIPCK(c, hipMalloc(&sl.d_dig, B * (size_t)c->L * 8 * 4));
     HIPCK(c, hipMemsetAsync(sl.d_trs, 0, B * SMALL_TR_STRIDE, sl.stream));
   }
   return ACT_OK;
@@ -368,7 +370,7 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
   SpendArgs& a = ch.a;
   a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = ch.d_proofs; a.n = ch.m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride();
   a.coords = sl.d_coords; a.d01 = sl.d_d01; a.buckets = sl.d_buckets; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
-  a.kprime_enc = ch.d_kprime;
+  a.kprime_enc = ch.d_kprime; a.naf = sl.d_naf; a.dig = sl.d_dig;
   int rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_PREP, ch.m, [&] { launch_spend_prep(a, sl.stream); }))) return rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)ch.m * c->L, [&] { launch_spend_bits(a, sl.stream); }))) return rc;
@@ -465,7 +467,7 @@ void act_ctx_destroy(act_ctx* c) {
     // d_state held the signing nonces (e, alpha) / the prover's r3, r*; d_d01 the prover's k* h2 terms: wipe before freeing
     if (sl.d_state) (void)hipMemset(sl.d_state, 0, c->max_batch * 24 * 4);
     if (sl.d_d01) (void)hipMemset(sl.d_d01, 0, c->max_batch * 3 * GE_WORDS * 4);
-    void* ptrs[] = {sl.d_buckets, sl.d_tr, sl.d_trs, sl.d_status, sl.d_coords, sl.d_d01, sl.d_xa, sl.d_flags, sl.d_xof, sl.d_state, sl.d_slot};
+    void* ptrs[] = {sl.d_buckets, sl.d_tr, sl.d_trs, sl.d_status, sl.d_coords, sl.d_d01, sl.d_xa, sl.d_flags, sl.d_xof, sl.d_state, sl.d_slot, sl.d_naf, sl.d_dig};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int i = 0; i < 6; i++) if (sl.d_stage[i]) { (void)hipMemset(sl.d_stage[i], 0, sl.d_stage_cap[i]); (void)hipFree(sl.d_stage[i]); }   // staging may hold secrets
     if (sl.h_tr) (void)hipHostFree(sl.h_tr);

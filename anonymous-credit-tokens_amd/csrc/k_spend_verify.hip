@@ -15,9 +15,11 @@ __global__ void __launch_bounds__(64, 2) k_spend_prep(SpendArgs a) {
 #ifndef ACT_BITS_BLOCK
 #define ACT_BITS_BLOCK 256
 #endif
+// UNIFORM: L is a multiple of 64, so a wavefront holds bits of ONE proof and reads that proof's challenge digits into SGPRs
+template <bool UNIFORM>
 __global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
   __shared__ uint32_t u_lds[(ACT_BITS_BLOCK / 64) * 2 * GE_LDS_WORDS_PER_WAVE];            // 20 KiB per wavefront
-  spend_bits_lane(a, blockIdx.x * ACT_BITS_BLOCK + threadIdx.x, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
+  spend_bits_lane<UNIFORM>(a, blockIdx.x * ACT_BITS_BLOCK + threadIdx.x, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
 }
 
 __global__ void __launch_bounds__(256, 2) k_spend_enc(SpendArgs a) {
@@ -38,7 +40,9 @@ void launch_spend_prep(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKe
 void launch_spend_bits(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t lanes = (size_t)a.n * a.P.L;
-  hipLaunchKernelGGL(k_spend_bits, dim3((unsigned)((lanes + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK)), dim3(ACT_BITS_BLOCK), 0, s, a);
+  const dim3 grid((unsigned)((lanes + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK));
+  if (a.P.L % 64 == 0) hipLaunchKernelGGL(k_spend_bits<true>, grid, dim3(ACT_BITS_BLOCK), 0, s, a);
+  else hipLaunchKernelGGL(k_spend_bits<false>, grid, dim3(ACT_BITS_BLOCK), 0, s, a);
 }
 void launch_spend_enc(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;

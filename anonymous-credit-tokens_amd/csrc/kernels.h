@@ -89,6 +89,8 @@ struct SpendArgs {
   const uint32_t* xof;       // n * 16              : BLAKE3 XOF words of the transcript
   uint8_t* status;           // n
   uint8_t* kprime_enc;       // n * 32 or null
+  uint32_t* naf;             // n * NAF_WORDS       : width-3-NAF digit string of gamma / 2 (k_spend_prep -> k_spend_bits, msm.h)
+  uint32_t* dig;             // n * L * 8           : biased radix-16 digit words of gamma_j0 / 2, per (proof, bit) lane
 };
 
 struct SignArgs {

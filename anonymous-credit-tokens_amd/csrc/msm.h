@@ -262,6 +262,97 @@ __device__ __forceinline__ ge ge_from_lds(const uint32_t* lds_wave) {
 // (acc_u += U1 + U3 + 2*U3 at the end: ~63 + 3 additions instead of ~84 with plain NAF).  On the device both live in
 // LDS between their additions -- one addition site per position, its operand picked by address -- which also takes
 // the 40 accumulator registers out of the loop's live set.
+// Digit strings of chain_bu, recoded once instead of inside the chain loop (where the 9-word NAF state with its 64-bit
+// carries and the 8-word radix-16 state would sit in the loop's VGPR set):
+//   naf3_recode   the wave-uniform scalar -> 64 words, word `step` = the width-3-NAF digits of chain positions 4*step .. 4*step+3
+//                 as four signed bytes (0, +-1, +-3); written once per proof by k_spend_prep, read with scalar loads
+//   radix16_bias  the per-lane scalar s -> t = s + 0x88...8 (8 words): nibble i of t, minus 8, is signed radix-16 digit i in
+//                 [-8, 7] (sum (nib_i - 8) 16^i = t - 0x88...8 = s; s < 2^253 so t < 2^256), no carry to propagate
+constexpr int NAF_WORDS = 64;
+ACT_HD void naf3_recode(uint32_t out[NAF_WORDS], const sc& s) {
+  naf_state n = naf_init(s);
+  for (int step = 0; step < NAF_WORDS; step++) {
+    uint32_t wd = 0;
+    for (int k = 0; k < 4; k++) wd |= ((uint32_t)naf3_next(n) & 0xffu) << (8 * k);
+    out[step] = wd;
+  }
+}
+ACT_HD void radix16_bias(uint32_t t[8], const sc& s) {
+  uint64_t c = 0;
+  for (int i = 0; i < 8; i++) { c += (uint64_t)s.v[i] + 0x88888888u; t[i] = (uint32_t)c; c >>= 32; }
+}
+ACT_HD int naf_byte(uint32_t wd, int k) { return (int)(int8_t)(wd >> (8 * k)); }
+
+// chain_bu with both digit strings taken from memory: `nafw` = NAF_WORDS words of the uniform scalar (naf3_recode), `dg` = the
+// lane's 8 radix16_bias words (in global memory: one load per 8 steps instead of 8 live registers).  UNIFORM: every lane of
+// the wavefront reads the same nafw (L a multiple of 64), so the word is moved to an SGPR and its branches are scalar.
+template <bool UNIFORM>
+ACT_HD void chain_bu_pre(ge& acc_l, ge& acc_u, const ge& N, const uint32_t* dg, const uint32_t* nafw, uint32_t* bk, uint32_t* lds_wave = nullptr) {
+  const ge id = ge_identity();
+  for (int b = 0; b < BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);
+#if defined(__HIP_DEVICE_COMPILE__)
+  ge_to_lds(lds_wave, id);
+  ge_to_lds(lds_wave + GE_LDS_WORDS_PER_WAVE, id);
+  auto add_u = [&](const ge_cached& q, int d) {
+    uint32_t* home = lds_wave + ((d == 3 || d == -3) ? GE_LDS_WORDS_PER_WAVE : 0);
+    ge_to_lds(home, ge_add_cached(ge_from_lds(home), ge_cached_cneg(q, d < 0)));
+  };
+#else
+  ge U[2] = {id, id};
+  auto add_u = [&](const ge_cached& q, int d) {
+    ge& t = U[(d == 3 || d == -3) ? 1 : 0];
+    t = ge_add_cached(t, ge_cached_cneg(q, d < 0));
+  };
+#endif
+  ge P = N;                                    // position 0, T valid
+  uint32_t dw = 0;
+  for (int step = 0; step < 64; step++) {
+    if ((step & 7) == 0) dw = dg[step >> 3];
+    const uint32_t nib = dw & 15u; dw >>= 4;
+    const bool neg = nib < 8u;
+    const uint32_t mag = neg ? 8u - nib : nib - 8u;     // 0..8
+    uint32_t nw = nafw[step];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (UNIFORM) nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw);
+#endif
+    const int u = naf_byte(nw, 0), u1 = naf_byte(nw, 1), u2 = naf_byte(nw, 2), u3 = naf_byte(nw, 3);
+    ge_cached c = ge_to_cached(P);
+    uint32_t* slot = bk + mag * GE_WORDS;
+    ge B = bucket_load(slot);
+    B = ge_add_cached(B, ge_cached_cneg(c, neg));
+    bucket_store(slot, B);
+    if (u != 0) add_u(c, u);
+    if (step == 63) {                          // position 253 (u1) is the last possible digit of a scalar < 2^253; 254, 255 are zero
+      if (u1 != 0) { P = ge_double_opt(P, true); add_u(ge_to_cached(P), u1); }
+      break;
+    }
+    P = ge_double_opt(P, u1 != 0);
+    if (u1 != 0) add_u(ge_to_cached(P), u1);
+    P = ge_double_opt(P, u2 != 0);
+    if (u2 != 0) add_u(ge_to_cached(P), u2);
+    P = ge_double_opt(P, u3 != 0);
+    if (u3 != 0) add_u(ge_to_cached(P), u3);
+    P = ge_double_opt(P, true);                // next step's bucket point needs T
+  }
+  {                                            // acc_u += U1 + 3 * U3
+#if defined(__HIP_DEVICE_COMPILE__)
+    const ge U1 = ge_from_lds(lds_wave), U3 = ge_from_lds(lds_wave + GE_LDS_WORDS_PER_WAVE);
+#else
+    const ge U1 = U[0], U3 = U[1];
+#endif
+    acc_u = ge_add_cached(acc_u, ge_to_cached(U1));
+    acc_u = ge_add_cached(acc_u, ge_to_cached(U3));
+    acc_u = ge_add_cached(acc_u, ge_to_cached(ge_double_opt(U3, true)));
+  }
+  ge S = bucket_load(bk + 8 * GE_WORDS);
+  ge R = S;
+  for (int vv = 7; vv >= 1; vv--) {
+    S = ge_add_cached(S, ge_to_cached(bucket_load(bk + vv * GE_WORDS)));
+    R = ge_add_cached(R, ge_to_cached(S));
+  }
+  acc_l = R;
+}
+
 ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& s_u, uint32_t* bk, uint32_t* lds_wave = nullptr) {
   const ge id = ge_identity();
   for (int b = 0; b < BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);

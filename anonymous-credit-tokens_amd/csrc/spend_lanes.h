@@ -63,6 +63,12 @@ ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
   ge d1 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w01));
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS, d0);
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS, d1);
+  {                                                                            // the proof-wide challenge's digit string for k_spend_bits (msm.h naf3_recode)
+    uint32_t nf[NAF_WORDS];
+    naf3_recode(nf, sc_half(gamma));
+    uint32_t* dst = a.naf + (size_t)p * NAF_WORDS;
+    for (int i = 0; i < NAF_WORDS; i++) dst[i] = nf[i];
+  }
 
   // A1 = (e_bar - x gamma) A' + r2_bar B_bar ; A2 += r3_bar B_bar
   acc[0] = ge_identity();
@@ -79,6 +85,7 @@ ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
 }
 
 // `lds_wave` (device): 2 * GE_LDS_WORDS_PER_WAVE words of LDS owned by the calling wavefront (msm.h chain_bu); unused on the host
+template <bool UNIFORM>
 ACT_HD void spend_bits_lane(const SpendArgs& a, uint32_t gid, uint32_t* lds_wave) {
   const int L = a.P.L;
   uint32_t p = gid / (uint32_t)L, j = gid % (uint32_t)L;
@@ -110,7 +117,9 @@ ACT_HD void spend_bits_lane(const SpendArgs& a, uint32_t gid, uint32_t* lds_wave
   if (j == 0) acc_u = ge_add(acc_u, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));      // + w01 h2 (:808)
   ge acc_l = ge_identity();
   uint32_t* bk = a.buckets + (size_t)gid * BUCKET_WORDS;
-  chain_bu(acc_l, acc_u, ge_neg(C), g0, gamma, bk, lds_wave);
+  uint32_t* dg = a.dig + (size_t)gid * 8;
+  { uint32_t t[8]; radix16_bias(t, g0); for (int i = 0; i < 8; i++) dg[i] = t[i]; }
+  chain_bu_pre<UNIFORM>(acc_l, acc_u, ge_neg(C), dg, a.naf + (size_t)p * NAF_WORDS, bk, lds_wave);
   ge f0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
   if (j == 0) f0 = ge_add(f0, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));                        // + w00 h2 (:806)
   ge_cached dl = ge_to_cached(acc_l);

@@ -189,16 +189,16 @@ extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint3
   const SpendTranscript st{L}; const ProofLayout pl{L};
   std::vector<uint8_t> tr((size_t)n * st.stride(), 0), status(n, 0), kp((size_t)n * 32, 0);
   std::vector<uint32_t> coords((size_t)n * L * NIELS_WORDS), d01((size_t)n * 2 * GE_WORDS), buckets((size_t)n * (L < 2 ? 2 : L) * BUCKET_WORDS),
-      xa((size_t)n * GE_WORDS), flags(n, 0), xof((size_t)n * 16);
+      xa((size_t)n * GE_WORDS), flags(n, 0), xof((size_t)n * 16), naf((size_t)n * NAF_WORDS), dig((size_t)n * L * 8);
   a.proofs = proofs; a.n = n; a.tr = tr.data(); a.tr_stride = (uint32_t)st.stride(); a.coords = coords.data(); a.d01 = d01.data();
-  a.buckets = buckets.data(); a.xa = xa.data(); a.flags = flags.data(); a.xof = xof.data(); a.status = status.data(); a.kprime_enc = kp.data();
+  a.buckets = buckets.data(); a.xa = xa.data(); a.flags = flags.data(); a.xof = xof.data(); a.status = status.data(); a.kprime_enc = kp.data(); a.naf = naf.data(); a.dig = dig.data();
   uint64_t c[13] = {0};
   c[12] = FB_WINDOWS;
   auto snap = [&](int k) { c[3 * k] += fe_counts.mul; c[3 * k + 1] += fe_counts.sq; c[3 * k + 2] += fe_counts.fixed_base; fe_counts = fe_counts_t{0, 0, 0}; };
   fe_counts = fe_counts_t{0, 0, 0};
   for (uint32_t p = 0; p < n; p++) spend_prep_lane(a, p);
   snap(0);
-  for (uint32_t g = 0; g < n * (uint32_t)L; g++) spend_bits_lane(a, g, nullptr);
+  for (uint32_t g = 0; g < n * (uint32_t)L; g++) { if (L % 64 == 0) spend_bits_lane<true>(a, g, nullptr); else spend_bits_lane<false>(a, g, nullptr); }
   snap(1);
   for (uint64_t q0 = 0; q0 < (uint64_t)n * L * 2; q0 += ENC_BATCH) spend_enc_lane(a, q0);
   snap(2);
