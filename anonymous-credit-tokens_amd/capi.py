@@ -20,7 +20,7 @@ EXPORTS = [
     "act_ctx_set_host_threads", "act_ctx_set_pipeline_depth", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
-    "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_prof_enable",
+    "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
     "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
@@ -88,6 +88,7 @@ def load() -> C.CDLL:
     lib.act_refund_to_credit_token_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
     lib.act_debug_last_spend_transcripts.argtypes = [vp, sz, u8p, C.POINTER(sz)]
     lib.act_debug_scalarmult_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p]
+    lib.act_debug_secret_residue.argtypes = [vp, C.POINTER(sz)]
     for f in ("act_cbor_size", "act_cbor_record_bytes"):
         getattr(lib, f).argtypes = [vp, i32]
         getattr(lib, f).restype = sz
@@ -273,6 +274,10 @@ class Engine:
         self._ck(self.lib.act_debug_last_spend_transcripts(self.ctx, max_lanes, out.ctypes.data, C.byref(n)))
         b = out.tobytes()
         return [b[i * self.transcript_bytes:(i + 1) * self.transcript_bytes] for i in range(n.value)]
+
+    def secret_residue(self) -> int:
+        n = C.c_size_t(0)
+        self._ck(self.lib.act_debug_secret_residue(self.ctx, C.byref(n))); return n.value
 
     def debug_scalarmult(self, points: bytes, scalars: bytes):
         n = len(points) // 32; out = np.zeros(32 * n, np.uint8); st = np.zeros(n, np.uint8)

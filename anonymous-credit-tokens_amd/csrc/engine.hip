@@ -48,6 +48,7 @@ struct Slot {
   uint32_t *d_buckets = nullptr, *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr, *d_naf = nullptr, *d_dig = nullptr;
   uint8_t* d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // staging for host-memory callers (grow-only)
   size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
+  size_t d_stage_dirty[6] = {0, 0, 0, 0, 0, 0};     // bytes written since the last wipe (finish_call)
   uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
   uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
   hipEvent_t h_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per returned piece (HASH_PIECES)
@@ -119,8 +120,11 @@ int prof_collect(act_ctx* c, Slot& sl) {
 int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
   if (bytes <= sl.d_stage_cap[slot]) return ACT_OK;
   HIPCK(c, hipStreamSynchronize(sl.stream));
-  if (sl.d_stage[slot]) HIPCK(c, hipFree(sl.d_stage[slot]));
-  sl.d_stage[slot] = nullptr; sl.d_stage_cap[slot] = 0;
+  if (sl.d_stage[slot]) {
+    if (sl.d_stage_dirty[slot]) HIPCK(c, hipMemset(sl.d_stage[slot], 0, sl.d_stage_dirty[slot]));     // never hand secrets back to the allocator
+    HIPCK(c, hipFree(sl.d_stage[slot]));
+  }
+  sl.d_stage[slot] = nullptr; sl.d_stage_cap[slot] = 0; sl.d_stage_dirty[slot] = 0;
   HIPCK(c, hipMalloc(&sl.d_stage[slot], bytes));
   sl.d_stage_cap[slot] = bytes;
   return ACT_OK;
@@ -130,12 +134,14 @@ int dev_in(act_ctx* c, Slot& sl, int slot, int mem, const uint8_t* p, size_t byt
   if (mem == ACT_MEM_DEVICE || bytes == 0) { *out = p; return ACT_OK; }
   int rc = stage_reserve(c, sl, slot, bytes); if (rc) return rc;
   HIPCK(c, hipMemcpyAsync(sl.d_stage[slot], p, bytes, hipMemcpyHostToDevice, sl.stream));
+  sl.d_stage_dirty[slot] = std::max(sl.d_stage_dirty[slot], bytes);
   *out = sl.d_stage[slot];
   return ACT_OK;
 }
 int dev_out_begin(act_ctx* c, Slot& sl, int slot, int mem, uint8_t* p, size_t bytes, uint8_t** out) {
   if (mem == ACT_MEM_DEVICE || bytes == 0) { *out = p; return ACT_OK; }
   int rc = stage_reserve(c, sl, slot, bytes); if (rc) return rc;
+  sl.d_stage_dirty[slot] = std::max(sl.d_stage_dirty[slot], bytes);
   *out = sl.d_stage[slot];
   return ACT_OK;
 }
@@ -308,6 +314,26 @@ int workspace_alloc(act_ctx* c) {
 int sync_all(act_ctx* c) {
   for (Slot& sl : c->slots) { HIPCK(c, hipStreamSynchronize(sl.stream)); int rc = prof_collect(c, sl); if (rc) return rc; }
   return ACT_OK;
+}
+
+// End of every entry point that ran kernels: wipe what the call left behind in the context's own memory, then wait.
+// The reference zeroizes its secret-bearing values when they go out of scope (#[derive(ZeroizeOnDrop)],
+// /root/reference/src/lib.rs:160, 362, 393, 878); here that means the staging copies of host buffers (tokens,
+// PreIssuance, rng, keys), the signer's nonces / the prover's r3, r* (d_state), the prover's k* h2 terms (d_d01) and the
+// per-proof Pippenger buckets, whose contents depend on secret scalar digits (x in A1, (e+x)^-1, r1 r2 ...).
+// Only the extent this call touched is cleared: n lanes (at most max_batch) of the per-proof buffers.
+int finish_call(act_ctx* c, size_t n) {
+  const size_t lanes = std::min(n, c->max_batch);
+  for (Slot& sl : c->slots) {
+    for (int i = 0; i < 6; i++)
+      if (sl.d_stage_dirty[i]) { HIPCK(c, hipMemsetAsync(sl.d_stage[i], 0, sl.d_stage_dirty[i], sl.stream)); sl.d_stage_dirty[i] = 0; }
+    if (lanes) {
+      HIPCK(c, hipMemsetAsync(sl.d_state, 0, lanes * 24 * 4, sl.stream));
+      HIPCK(c, hipMemsetAsync(sl.d_d01, 0, lanes * 3 * GE_WORDS * 4, sl.stream));
+      HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, lanes * 2 * BUCKET_WORDS * 4, sl.stream));
+    }
+  }
+  return sync_all(c);
 }
 
 int from_uniform_on_device(int device, const uint8_t* in64, int n, uint8_t* out_enc) {
@@ -500,8 +526,8 @@ int act_private_key_random(act_ctx* c, const uint8_t rng[64], uint8_t out_sk[64]
   HIPCK(c, hipMemcpyAsync(sl.d_stage[0], rng, 64, hipMemcpyHostToDevice, sl.stream));
   launch_keygen(c->P, sl.d_stage[0], 1, sl.d_stage[0] + 64, sl.stream);
   HIPCK(c, hipMemcpyAsync(out_sk, sl.d_stage[0] + 64, 64, hipMemcpyDeviceToHost, sl.stream));
-  HIPCK(c, hipStreamSynchronize(sl.stream));
-  return ACT_OK;
+  sl.d_stage_dirty[0] = std::max<size_t>(sl.d_stage_dirty[0], 128);
+  return finish_call(c, 0);
 }
 int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* rng, uint8_t* out_pre) {
   if (!c || (n && (!rng || !out_pre))) return ACT_ERR_ARG;
@@ -516,7 +542,7 @@ int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* 
     if ((rc = dev_out_end(c, sl, mem, out_pre + off * 64, d_out, (size_t)m * 64))) return rc;
     HIPCK(c, hipStreamSynchronize(sl.stream));
   }
-  return ACT_OK;
+  return finish_call(c, 0);
 }
 
 int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
@@ -535,7 +561,7 @@ int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const u
     if ((rc = dev_out_end(c, sl, mem, out_req + off * 128, a.out, (size_t)m * 128))) return rc;
     if ((rc = sync_all(c))) return rc;
   }
-  return ACT_OK;
+  return finish_call(c, 0);
 }
 
 int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
@@ -565,7 +591,7 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
     if ((rc = dev_out_end(c, sl, mem, out_resp + off * 160, d_out, (size_t)m * 160))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
   }
-  return sync_all(c);
+  return finish_call(c, n);
 }
 
 // The two halves of issue / refund as separate calls, for callers that must see every verdict before any rng is assigned:
@@ -586,7 +612,7 @@ int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uin
     if ((rc = prof_launch(c, sl, PK_ISSUE_CHECK, m, [&] { launch_issue_check(a, sl.stream); }))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
   }
-  return sync_all(c);
+  return finish_call(c, n);
 }
 // signs the lanes whose status_in is 0; `point` = IssuanceRequest records (label RESPOND, with amounts) or enc(K') (label REFUND)
 static int sign_only_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t sk[64], const uint8_t* point, size_t point_stride,
@@ -612,7 +638,7 @@ static int sign_only_batch(act_ctx* c, size_t n, int mem, int label, const uint8
     if ((rc = dev_out_end(c, sl, mem, out + off * rec, d_out, (size_t)m * rec))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
   }
-  return sync_all(c);
+  return finish_call(c, n);
 }
 int act_issue_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* status_in,
                          const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
@@ -671,7 +697,7 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
     if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
   }
   for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
-  return sync_all(c);
+  return finish_call(c, n);
 }
 
 int act_verify_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
@@ -730,7 +756,7 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
     if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
   }
   for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
-  return sync_all(c);
+  return finish_call(c, n);
 }
 
 static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
@@ -761,7 +787,7 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
     if ((rc = sync_all(c))) return rc;
   }
-  return ACT_OK;
+  return finish_call(c, n);
 }
 int act_issuance_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                                        const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
@@ -828,6 +854,30 @@ int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* poi
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
     HIPCK(c, hipStreamSynchronize(sl.stream));
   }
+  return finish_call(c, n);
+}
+
+// Test hook: bytes that are not zero in the context's secret-bearing buffers (what finish_call wipes), read back to the host.
+int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
+  if (!c || !nonzero_bytes) return ACT_ERR_ARG;
+  HIPCK(c, hipSetDevice(c->device));
+  size_t total = 0, nz = 0;
+  std::vector<std::pair<const void*, size_t>> regions;
+  for (Slot& sl : c->slots) {
+    for (int i = 0; i < 6; i++) if (sl.d_stage[i]) regions.emplace_back(sl.d_stage[i], sl.d_stage_cap[i]);
+    regions.emplace_back(sl.d_state, c->max_batch * 24 * 4);
+    regions.emplace_back(sl.d_d01, c->max_batch * 3 * GE_WORDS * 4);
+    regions.emplace_back(sl.d_buckets, c->max_batch * 2 * BUCKET_WORDS * 4);
+  }
+  for (auto& r : regions) total += r.second;
+  if (total > ((size_t)1 << 28)) { c->err = "act_debug_secret_residue: context too large to read back (use a small max_batch)"; return ACT_ERR_ARG; }
+  std::vector<uint8_t> buf;
+  for (auto& r : regions) {
+    buf.resize(r.second);
+    HIPCK(c, hipMemcpy(buf.data(), r.first, r.second, hipMemcpyDeviceToHost));
+    for (uint8_t b : buf) nz += b != 0;
+  }
+  *nonzero_bytes = nz;
   return ACT_OK;
 }
 

@@ -236,6 +236,10 @@ int act_nullifier_check_and_insert_batch(act_nullifier_set *set, size_t n, int m
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
 int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *out, size_t *n_copied);
 
+/* Debug / test hook: number of non-zero bytes left in the context's secret-bearing device buffers -- the staging copies of
+ * host inputs (tokens, PreIssuance, rng), the signer's nonces, the prover's r3 / r* / k* terms and the per-proof Pippenger
+ * buckets -- all of which every entry point clears before it returns (the crate's ZeroizeOnDrop, src/lib.rs:160,362,393). */
+int act_debug_secret_residue(act_ctx *ctx, size_t *nonzero_bytes);
 /* Debug / test hook: out[i] = enc(scalars[i] * points[i]) (`RistrettoPoint * Scalar`, e.g. src/lib.rs:791) computed by the
  * engine's production variable-base chain, decode and encode; status[i] = 255 and a zero record when points[i] is not a
  * canonical encoding.  Exists so that third-party known answers can be replayed on the device one operation at a time

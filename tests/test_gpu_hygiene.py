@@ -1,0 +1,37 @@
+"""Secret hygiene to the reference's standard (#[derive(ZeroizeOnDrop)] on every secret-bearing struct,
+/root/reference/src/lib.rs:160, 362, 393, 878): after EVERY entry point returns, the context's own device memory holds no
+copy of the caller's secrets -- staged tokens / PreIssuance / rng bytes, the signer's nonces (e, alpha), the prover's r3,
+r*, k* terms, and the per-proof Pippenger buckets whose contents depend on secret scalar digits."""
+import pytest
+
+from conftest import shake, scb
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_no_secret_residue_after_any_call(bench_params, mode):
+    from act_amd import capi
+    L, N = 8, 13
+    eng = capi.Engine(bench_params, L, max_batch=5, transcript=mode)          # a fresh context: nothing cached from other tests
+    assert eng.secret_residue() == 0
+    sk = eng.private_key_random(shake("hy-sk", 64)); assert eng.secret_residue() == 0
+    pre = eng.pre_issuance_random(shake("hy-pre", 128 * N)); assert eng.secret_residue() == 0
+    req = eng.request(pre, shake("hy-rq", 128 * N)); assert eng.secret_residue() == 0
+    st, resp = eng.issue(sk, req, scb(40) * N, shake("hy-ir", 128 * N), capi.RNG_SEQUENTIAL); assert eng.secret_residue() == 0
+    assert st == bytes(N)
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp); assert eng.secret_residue() == 0
+    st, proofs, prer = eng.prove_spend(tok, scb(7) * N, shake("hy-pr", eng.prove_rng_bytes * N)); assert eng.secret_residue() == 0
+    assert st == bytes(N)
+    st, kp = eng.verify_spend(sk, proofs, True); assert eng.secret_residue() == 0
+    assert st == bytes(N)
+    st, rf = eng.refund(sk, proofs, shake("hy-rr", 128 * N)); assert eng.secret_residue() == 0
+    st, tok2 = eng.refund_to_credit_token(prer, proofs, rf, sk[32:]); assert eng.secret_residue() == 0
+    assert st == bytes(N)
+    st, out = eng.debug_scalarmult(proofs[64:96] * 3, sk[:32] * 3); assert eng.secret_residue() == 0
+    # staging that has to grow (a larger batch than any before) frees the old buffers only after clearing them, and the
+    # results are still right
+    pre2 = eng.pre_issuance_random(shake("hy-pre2", 128 * 40)); req2 = eng.request(pre2, shake("hy-rq2", 128 * 40))
+    assert eng.secret_residue() == 0
+    st, resp2 = eng.issue(sk, req2, scb(3) * 40, shake("hy-ir2", 128 * 40)); assert st == bytes(40) and eng.secret_residue() == 0
+    eng.close()
