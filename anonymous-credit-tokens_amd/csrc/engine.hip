@@ -308,6 +308,11 @@ int workspace_alloc(act_ctx* c) {
     HIPCK(c, hipMalloc(&sl.d_naf, B * NAF_WORDS * 4));
     HIPCK(c, hipMalloc(&sl.d_dig, B * (size_t)c->L * 8 * 4));
     HIPCK(c, hipMemsetAsync(sl.d_trs, 0, B * SMALL_TR_STRIDE, sl.stream));
+    // the secret-bearing buffers start clean (the allocator may hand back another context's freed memory) and are
+    // returned to that state by every call (finish_call)
+    HIPCK(c, hipMemsetAsync(sl.d_state, 0, B * 24 * 4, sl.stream));
+    HIPCK(c, hipMemsetAsync(sl.d_d01, 0, B * 3 * GE_WORDS * 4, sl.stream));
+    HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, B * 2 * BUCKET_WORDS * 4, sl.stream));
   }
   return ACT_OK;
 }
