@@ -261,6 +261,7 @@ int hash_step(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_t
 int decode_one(act_ctx* c, const uint8_t enc[32], ge* out) {
   Slot& sl = c->slots[0];
   int rc = stage_reserve(c, sl, 5, 32 + GE_WORDS * 4 + 16); if (rc) return rc;
+  sl.d_stage_dirty[5] = std::max<size_t>(sl.d_stage_dirty[5], 32 + GE_WORDS * 4 + 16);
   uint8_t* d = sl.d_stage[5];
   HIPCK(c, hipMemcpyAsync(d, enc, 32, hipMemcpyHostToDevice, sl.stream));
   launch_decode_points(d, 1, reinterpret_cast<uint32_t*>(d + 32), reinterpret_cast<uint32_t*>(d + 32 + GE_WORDS * 4), sl.stream);
