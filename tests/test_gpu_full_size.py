@@ -1,0 +1,170 @@
+"""BASELINE.json's configurations at their full single-GPU sizes, checked for correctness (not only timed):
+  config 2  2^16 spend-proof verifies at L = 64, HBM-resident, 1/1024 lanes tampered: statuses exact, the first 256 lanes
+            and every tampered lane re-verified by the oracle
+  config 3  2^20 prove_spend at L = 128 in 2^16-lane chunks with device-resident rng: every proof fed back through the
+            verifier (all accepted), 512 sampled proofs byte-compared with the oracle's proof for the same token / rng
+  config 5  2^20 full lifecycles (request -> issue -> token -> prove_spend -> refund -> token) streamed through PINNED
+            HOST memory in 2^16-lane chunks over two contexts working concurrently (the node handle: one context moves
+            and hashes while the other computes); every final balance checked
+Rates are written to gpurun_out/ when ACT_WRITE_RATES is set (tools/profile_round.sh copies them into profiles/)."""
+import json
+import os
+import time
+
+import pytest
+
+from conftest import ELL, ROOT, shake, scb
+
+pytestmark = pytest.mark.gpu
+
+
+def note_rate(key, value):
+    if not os.environ.get("ACT_WRITE_RATES"):
+        return
+    path = os.path.join(ROOT, "gpurun_out", os.environ["ACT_WRITE_RATES"])
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    d = json.load(open(path)) if os.path.exists(path) else {}
+    d[key] = value
+    json.dump(d, open(path, "w"), indent=1)
+
+
+def make_tokens(eng, sk, D, L, tag):
+    pre = eng.pre_issuance_random(shake(tag + "-pre", 128 * D))
+    req = eng.request(pre, shake(tag + "-rq", 128 * D))
+    cs = [(i * 2654435761 + 17) % (2 ** min(L, 64)) for i in range(D)]
+    st, resp = eng.issue(sk, req, b"".join(scb(c) for c in cs), shake(tag + "-ir", 128 * D))
+    assert st == bytes(D)
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    assert st == bytes(D)
+    return tok, cs
+
+
+def test_config2_2_16_verifies_at_L64(engine_factory, oracle, bench_params):
+    import numpy as np
+    import torch
+    from act_amd import capi
+    L, D, n = 64, 1024, 1 << 16
+    eng = engine_factory(bench_params, L, max_batch=0, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("c2-sk", 64))
+    tok, cs = make_tokens(eng, sk, D, L, "c2")
+    ss = [c // 3 for c in cs]
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(s) for s in ss), shake("c2-pr", eng.prove_rng_bytes * D))
+    assert st == bytes(D)
+    pb = eng.proof_bytes
+    assert pb == 8640
+    dev = torch.from_numpy(np.frombuffer(proofs, np.uint8).reshape(D, pb).copy()).cuda().repeat(n // D, 1).contiguous()
+    idx = torch.arange(513, n, 1024, device="cuda")
+    dev[idx[0::2], 32] ^= 1                   # charge s
+    dev[idx[1::2], 64:96] = 0                 # A' = identity
+    status = torch.full((n,), 99, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    t = time.perf_counter(); eng.verify_spend_dev(sk, n, dev.data_ptr(), status.data_ptr()); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    exp = torch.zeros(n, dtype=torch.uint8, device="cuda"); exp[idx[0::2]] = 7; exp[idx[1::2]] = 6
+    assert torch.equal(status, exp)
+    # the oracle on the first 256 lanes and on every tampered lane
+    lanes = list(range(256)) + idx.cpu().tolist()
+    host = dev[torch.tensor(lanes, device="cuda")].cpu().numpy().tobytes()
+    octx = oracle.ctx(bench_params, L)
+    st_o = octx.verify_spend_batch(sk, host, 8)
+    assert list(st_o) == status[torch.tensor(lanes, device="cuda")].cpu().tolist()
+    note_rate("config2_verify_L64_2^16", {"verifies_per_s": n / dt, "ms": 1e3 * dt, "note": "first (cold) call"})
+
+
+def test_config3_2_20_prove_spend_at_L128(engine_factory, oracle, bench_params):
+    import numpy as np
+    import torch
+    from act_amd import capi
+    L, chunk, nchunks, sample = 128, 1 << 16, 16, 32
+    eng = engine_factory(bench_params, L, max_batch=0, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("c3-sk", 64))
+    D = 4096
+    tok, cs = make_tokens(eng, sk, D, L, "c3")
+    ss = [c // 2 for c in cs]
+    ss[5] = cs[5]; ss[6] = 0                                  # spend everything / nothing
+    s_b = b"".join(scb(s) for s in ss)
+    pb, rb = eng.proof_bytes, eng.prove_rng_bytes
+    d_tok = torch.from_numpy(np.frombuffer(tok, np.uint8).reshape(D, 160).copy()).cuda().repeat(chunk // D, 1).contiguous()
+    d_s = torch.from_numpy(np.frombuffer(s_b, np.uint8).reshape(D, 32).copy()).cuda().repeat(chunk // D, 1).contiguous()
+    d_proof = torch.empty((chunk, pb), dtype=torch.uint8, device="cuda"); d_prer = torch.empty((chunk, 96), dtype=torch.uint8, device="cuda")
+    d_st = torch.empty(chunk, dtype=torch.uint8, device="cuda"); d_vst = torch.empty(chunk, dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(2024)
+    octx = oracle.ctx(bench_params, L)
+    t_prove = 0.0
+    picked = []
+    for c in range(nchunks):
+        d_rng = torch.randint(0, 256, (chunk, rb), dtype=torch.uint8, device="cuda", generator=g)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        eng.prove_spend_dev(chunk, d_tok.data_ptr(), d_s.data_ptr(), d_rng.data_ptr(), d_proof.data_ptr(), d_prer.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize(); t_prove += time.perf_counter() - t
+        assert int(d_st.sum()) == 0
+        eng.verify_spend_dev(sk, chunk, d_proof.data_ptr(), d_vst.data_ptr()); torch.cuda.synchronize()
+        assert int(d_vst.sum()) == 0, "every GPU-made proof must verify (chunk %d)" % c
+        lanes = torch.tensor([(c * 977 + k * 2039) % chunk for k in range(sample)], device="cuda")
+        picked.append((lanes.cpu().tolist(), d_rng[lanes].cpu().numpy().tobytes(), d_proof[lanes].cpu().numpy().tobytes(), d_prer[lanes].cpu().numpy().tobytes()))
+        del d_rng
+    # 512 sampled proofs against the oracle's proof for the same token, charge and rng bytes
+    for lanes, rng, got_p, got_r in picked:
+        toks = b"".join(tok[160 * (i % D):160 * (i % D) + 160] for i in lanes)
+        sb = b"".join(s_b[32 * (i % D):32 * (i % D) + 32] for i in lanes)
+        want_p, want_r = octx.prove_spend_batch(toks, sb, rng, 8)
+        assert got_p == want_p and got_r == want_r
+    note_rate("config3_prove_spend_L128_2^20", {"proofs_per_s": nchunks * chunk / t_prove, "ms": 1e3 * t_prove, "chunks": nchunks})
+
+
+def test_config5_2_20_lifecycles_streamed_from_pinned_host_memory(bench_params):
+    import numpy as np
+    import torch
+    from act_amd import capi
+    L, chunk, nchunks = 128, 1 << 16, 16
+    node = capi.Node(bench_params, L, devices=(0, 0), max_batch=1 << 14, transcript=capi.TRANSCRIPT_DEVICE)
+    pb, rb = node.proof_bytes, node.prove_rng_bytes
+    eng0 = capi.Engine(bench_params, 8, max_batch=4)
+    sk = eng0.private_key_random(shake("c5-sk", 64)); eng0.close()
+    pin = lambda *shape: torch.empty(shape, dtype=torch.uint8, pin_memory=True)
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    rnd = lambda *shape: torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
+    # rng streams: the 2.2 GB of prover bytes are drawn once and reused by every chunk (tokens differ per chunk)
+    r_pr = pin(chunk, rb); r_pr.copy_(rnd(chunk, rb))
+    amounts = np.array([(i * 40503 + 11) % 100000 + 1 for i in range(chunk)], dtype=np.uint64)
+    charges = amounts // np.uint64(3)
+    le32 = lambda v: np.concatenate([v.astype("<u8").view(np.uint8).reshape(-1, 8), np.zeros((len(v), 24), np.uint8)], axis=1)
+    c_b, s_b, m_b = le32(amounts).tobytes(), le32(charges).tobytes(), le32(amounts - charges)
+    lib, nd = node.lib, node.nd
+    ptr = lambda t: t.data_ptr()
+    bufs = {k: pin(chunk, v) for k, v in dict(pre=64, req=128, resp=160, tok=160, proof=pb, prer=96, rf=128, tok2=160).items()}
+    r128 = {k: pin(chunk, 128) for k in ("pre", "rq", "ir", "rr")}
+    st = pin(chunk)
+    import ctypes as C
+    skb = (C.c_uint8 * 64).from_buffer_copy(sk); wb = (C.c_uint8 * 32).from_buffer_copy(sk[32:])
+    cb = np.frombuffer(c_b, np.uint8); sb = np.frombuffer(s_b, np.uint8)
+    # PreIssuance::random has no node-level twin (it is two scalar reductions): context 0 of the node does it
+    ctx0 = lib.act_node_ctx(nd, 0)
+    ck = node._ck
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for c in range(nchunks):
+        for k in r128:
+            r128[k].copy_(rnd(chunk, 128))
+        torch.cuda.synchronize()
+        assert lib.act_pre_issuance_random_batch(ctx0, chunk, capi.MEM_HOST, ptr(r128["pre"]), ptr(bufs["pre"])) == 0
+        ck(lib.act_node_request_batch(nd, chunk, ptr(bufs["pre"]), ptr(r128["rq"]), ptr(bufs["req"])))
+        ck(lib.act_node_issue_batch(nd, chunk, skb, ptr(bufs["req"]), cb.ctypes.data, ptr(r128["ir"]), capi.RNG_PER_LANE, ptr(bufs["resp"]), ptr(st)))
+        assert int(st.sum()) == 0
+        ck(lib.act_node_issuance_to_credit_token_batch(nd, chunk, ptr(bufs["pre"]), wb, ptr(bufs["req"]), ptr(bufs["resp"]), ptr(bufs["tok"]), ptr(st)))
+        assert int(st.sum()) == 0
+        ck(lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st)))
+        assert int(st.sum()) == 0
+        ck(lib.act_node_refund_batch(nd, chunk, skb, ptr(bufs["proof"]), ptr(r128["rr"]), capi.RNG_PER_LANE, ptr(bufs["rf"]), ptr(st)))
+        assert int(st.sum()) == 0, "every honest spend must be refunded (chunk %d)" % c
+        ck(lib.act_node_refund_to_credit_token_batch(nd, chunk, ptr(bufs["prer"]), ptr(bufs["proof"]), ptr(bufs["rf"]), wb, ptr(bufs["tok2"]), ptr(st)))
+        assert int(st.sum()) == 0
+        # final balances: the new token carries c - s; its nullifier k is the fresh k* of the spend, not the old one
+        t2 = bufs["tok2"].numpy()
+        assert np.array_equal(t2[:, 128:160], m_b), "balance c - s wrong in chunk %d" % c
+        assert np.array_equal(t2[:, 64:96], bufs["prer"].numpy()[:, 32:64])
+        assert not np.array_equal(t2[:, 64:96], bufs["tok"].numpy()[:, 64:96])
+    dt = time.perf_counter() - t0
+    node.close()
+    note_rate("config5_lifecycles_L128_2^20_streamed_pinned_host", {"lifecycles_per_s": nchunks * chunk / dt, "ms": 1e3 * dt,
+              "note": "2^16-lane chunks through pinned host memory, two contexts on one GPU (node handle), device transcripts; includes drawing the rng bytes"})
