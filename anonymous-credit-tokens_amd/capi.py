@@ -30,6 +30,8 @@ EXPORTS = [
     "act_node_set_host_threads", "act_node_request_batch", "act_node_issue_batch", "act_node_issuance_to_credit_token_batch",
     "act_node_prove_spend_batch", "act_node_verify_spend_batch", "act_node_refund_batch", "act_node_refund_to_credit_token_batch",
     "act_node_issue_check_batch", "act_node_issue_sign_batch", "act_node_refund_sign_batch",
+    "act_node_nullifier_set_create", "act_node_nullifier_set_destroy", "act_node_nullifier_set_len", "act_node_nullifier_set_last_error",
+    "act_node_nullifier_check_and_insert_batch",
 ]
 CBOR_TYPES = {"IssuanceRequest": 1, "IssuanceResponse": 2, "SpendProof": 3, "Refund": 4, "PrivateKey": 5, "PublicKey": 6,
               "PreIssuance": 7, "CreditToken": 8, "PreRefund": 9}
@@ -133,6 +135,14 @@ def load() -> C.CDLL:
     lib.act_node_issue_check_batch.argtypes = [vp, sz, u8p, u8p]
     lib.act_node_issue_sign_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_node_refund_sign_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_node_nullifier_set_create.argtypes = [C.POINTER(C.c_int), i32, sz, u8p, C.POINTER(vp)]
+    lib.act_node_nullifier_set_destroy.argtypes = [vp]
+    lib.act_node_nullifier_set_destroy.restype = None
+    lib.act_node_nullifier_set_len.argtypes = [vp]
+    lib.act_node_nullifier_set_len.restype = sz
+    lib.act_node_nullifier_set_last_error.argtypes = [vp]
+    lib.act_node_nullifier_set_last_error.restype = C.c_char_p
+    lib.act_node_nullifier_check_and_insert_batch.argtypes = [vp, sz, u8p, sz, u8p, u8p]
     _lib = lib
     return lib
 
@@ -489,3 +499,43 @@ class NullifierSet:
 
     def check_and_insert_dev(self, n: int, d_nullifiers: int, stride: int, d_skip_mask: int, d_out_spent: int):
         self._ck(self.lib.act_nullifier_check_and_insert_batch(self.h, n, MEM_DEVICE, d_nullifiers, stride, d_skip_mask or None, d_out_spent))
+
+
+class NodeNullifierSet:
+    """The double-spend set over the GPUs of a node (act_node_nullifier_*): host-side routing by owner, one set per device."""
+
+    def __init__(self, capacity_per_device: int, devices=(0,), salt: bytes = None):
+        self.lib = load()
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        p, keep = _in(salt, 16) if salt else (None, None)
+        rc = self.lib.act_node_nullifier_set_create(devs, len(devices), capacity_per_device, p, C.byref(h))
+        if rc:
+            msg = self.lib.act_node_nullifier_set_last_error(h).decode() if h else ""
+            if h:
+                self.lib.act_node_nullifier_set_destroy(h)
+            raise ActError(f"act_node_nullifier_set_create failed: {_ERRS.get(rc, rc)} {msg}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.act_node_nullifier_set_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.lib.act_node_nullifier_set_len(self.h)
+
+    def check_and_insert(self, nullifiers: bytes, stride: int = 32, skip_mask: bytes = None) -> bytes:
+        n = (len(nullifiers) + stride - 32) // stride if nullifiers else 0
+        out = np.zeros(n, np.uint8)
+        p0, k0 = _in(nullifiers); pm, km = _in(skip_mask, n) if skip_mask is not None else (None, None)
+        rc = self.lib.act_node_nullifier_check_and_insert_batch(self.h, n, p0, stride, pm, out.ctypes.data)
+        if rc:
+            raise ActError(f"{_ERRS.get(rc, rc)}: {self.lib.act_node_nullifier_set_last_error(self.h).decode()}")
+        return out.tobytes()

@@ -215,3 +215,94 @@ int act_node_refund_to_credit_token_batch(act_node* nd, size_t n, const uint8_t*
 }
 
 }  // extern "C"
+
+// ---- the double-spend set over the GPUs of a node ----------------------------------------------------------------------
+// One act_nullifier_set per device; a nullifier lives on exactly one of them (owner = a keyed hash of the REDUCED scalar, so
+// k and k + l go to the same owner), so the answer for a key only ever depends on one set and the batch keeps the meaning
+// of the reference's sequential loop (`if is_spent(k) reject else insert(k)`, /root/reference/src/tests.rs:29-50) in lane
+// order: the host buckets the keys by owner preserving lane order, every GPU checks-and-inserts its bucket on its own
+// thread, the answers are scattered back.  33 bytes per spend cross PCIe; no peer traffic, no collective.
+struct act_node_nullifier_set {
+  std::vector<act_nullifier_set*> sets;
+  std::vector<int> devices;
+  uint64_t route_key[2] = {0, 0};
+  std::string err;
+};
+
+namespace {
+// 256-bit little-endian value mod l, l = 2^252 + 27742317777372353535851937790883648493 (the set itself reduces again on
+// the device; here only the owner must not depend on the representative)
+void reduce_mod_l(const uint8_t in[32], uint64_t out[4]) {
+  static const uint64_t Lw[4] = {0x5812631a5cf5d3edull, 0x14def9dea2f79cd6ull, 0, 0x1000000000000000ull};
+  uint64_t v[4]; memcpy(v, in, 32);
+  for (int rep = 0; rep < 16; rep++) {                     // v < 2^256 < 16 l: at most 15 subtractions
+    uint64_t t[4]; unsigned __int128 borrow = 0;
+    for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)v[i] - Lw[i] - (uint64_t)borrow; t[i] = (uint64_t)d; borrow = (d >> 64) & 1; }
+    if (borrow) break;
+    memcpy(v, t, 32);
+  }
+  memcpy(out, v, 32);
+}
+uint64_t route_hash(const uint64_t k[4], const uint64_t key[2]) {     // keyed mix (the per-GPU tables use their own SipHash keys)
+  uint64_t h = key[0];
+  for (int i = 0; i < 4; i++) { h ^= k[i] + key[1]; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
+  return h;
+}
+}  // namespace
+
+extern "C" {
+int act_node_nullifier_set_create(const int* devices, int n_devices, size_t capacity_per_device, const uint8_t salt[16], act_node_nullifier_set** out) {
+  if (!devices || n_devices < 1 || !out || !capacity_per_device) return ACT_ERR_ARG;
+  act_node_nullifier_set* ns = new act_node_nullifier_set();
+  *out = ns;
+  if (salt) memcpy(ns->route_key, salt, 16);
+  for (int k = 0; k < n_devices; k++) {
+    act_nullifier_set* s = nullptr;
+    int rc = act_nullifier_set_create(devices[k], capacity_per_device, nullptr, &s);     // every table draws its own slot-hash key
+    if (rc) { ns->err = "device " + std::to_string(devices[k]) + ": " + (s ? act_nullifier_set_last_error(s) : "create failed"); if (s) act_nullifier_set_destroy(s); return rc; }
+    ns->sets.push_back(s); ns->devices.push_back(devices[k]);
+  }
+  return ACT_OK;
+}
+void act_node_nullifier_set_destroy(act_node_nullifier_set* ns) {
+  if (!ns) return;
+  for (act_nullifier_set* s : ns->sets) act_nullifier_set_destroy(s);
+  delete ns;
+}
+size_t act_node_nullifier_set_len(const act_node_nullifier_set* ns) {
+  size_t n = 0;
+  if (ns) for (act_nullifier_set* s : ns->sets) n += act_nullifier_set_len(s);
+  return n;
+}
+const char* act_node_nullifier_set_last_error(const act_node_nullifier_set* ns) { return ns ? ns->err.c_str() : "null set"; }
+
+int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t n, const uint8_t* nullifiers, size_t stride, const uint8_t* skip_mask,
+                                              uint8_t* out_spent) {
+  if (!ns || (n && (!nullifiers || !out_spent)) || stride < 32) return ACT_ERR_ARG;
+  const size_t parts = ns->sets.size();
+  std::vector<std::vector<uint32_t>> lanes(parts);
+  std::vector<std::vector<uint8_t>> keys(parts), spent(parts);
+  for (size_t i = 0; i < n; i++) {
+    out_spent[i] = 0;
+    if (skip_mask && skip_mask[i]) continue;                   // e.g. the status of a rejected proof: neither checked nor inserted
+    uint64_t k[4]; reduce_mod_l(nullifiers + i * stride, k);
+    const size_t owner = (size_t)(route_hash(k, ns->route_key) % parts);
+    lanes[owner].push_back((uint32_t)i);
+    keys[owner].insert(keys[owner].end(), nullifiers + i * stride, nullifiers + i * stride + 32);
+  }
+  std::vector<int> rc(parts, ACT_OK);
+  std::vector<std::thread> th;
+  auto work = [&](size_t p) {
+    spent[p].assign(lanes[p].size(), 0);
+    if (!lanes[p].empty()) rc[p] = act_nullifier_check_and_insert_batch(ns->sets[p], lanes[p].size(), ACT_MEM_HOST, keys[p].data(), 32, nullptr, spent[p].data());
+  };
+  for (size_t p = 1; p < parts; p++) th.emplace_back(work, p);
+  work(0);
+  for (auto& t : th) t.join();
+  for (size_t p = 0; p < parts; p++) {
+    if (rc[p]) { ns->err = "device " + std::to_string(ns->devices[p]) + ": " + act_nullifier_set_last_error(ns->sets[p]); return rc[p]; }
+    for (size_t j = 0; j < lanes[p].size(); j++) out_spent[lanes[p][j]] = spent[p][j];
+  }
+  return ACT_OK;
+}
+}  // extern "C"

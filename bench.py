@@ -112,14 +112,42 @@ def cpu_baseline(proofs_host, h, sk, L, seconds_target=12.0):
     n = min(n, len(proofs_host) // pb)
     t = time.perf_counter(); st = ctx.verify_spend_batch(sk, proofs_host[:pb * n], cores); dt = time.perf_counter() - t
     assert st == bytes(n)
+    per_fn = config1_round_trip(ctx, L)
     try:
         os.unlink(native)
     except OSError:
         pass
-    return {"value": n / dt, "unit": "verifies/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "verifies/s", "cores": cores, "kind": "port", "config1_single_round_trip_ms": per_fn,
             "sample": "%d of the bench's own L=%d proofs, C oracle (-O3 -march=native), %d threads, %.1f s; 1 thread: %.2f verifies/s"
                       % (n, L, cores, dt, 1.0 / t1),
             "single_thread_value": 1.0 / t1}
+
+
+def config1_round_trip(ctx, L, reps=6):
+    """BASELINE configs[0]: the single issue -> prove_spend -> refund round trip of benches/benchmark.rs:34-212 on ONE host
+    thread, each function timed on its own (ms per call, C oracle = port of the reference algorithm): bench Params, credit
+    in [20, 1000), charge in [1, c-1] (benches/benchmark.rs:131, 147-154)."""
+    import random
+    r = random.Random(1)
+    acc = {k: 0.0 for k in ("request", "issue", "issuance_to_credit_token", "prove_spend", "refund", "refund_to_credit_token")}
+
+    def t(key, fn):
+        t0 = time.perf_counter(); out = fn(); acc[key] += time.perf_counter() - t0
+        return out
+    sk = ctx.private_key_random(shake("c1-sk", 64))
+    for i in range(reps):
+        c = r.randrange(20, 1000); s = r.randrange(1, c)
+        pre = ctx.pre_issuance_random(shake("c1-pre%d" % i, 128))
+        req = t("request", lambda: ctx.request(pre, shake("c1-rq%d" % i, 128)))
+        st, resp = t("issue", lambda: ctx.issue(sk, req, scb(c), shake("c1-ir%d" % i, 128)))
+        st, tok = t("issuance_to_credit_token", lambda: ctx.issuance_to_credit_token(pre, sk[32:], req, resp))
+        rng = shake("c1-pr%d" % i, 64 * (4 * L + 12))
+        st, proof, prer = t("prove_spend", lambda: ctx.prove_spend(tok, scb(s), rng))
+        st, rf = t("refund", lambda: ctx.refund(sk, proof, shake("c1-rr%d" % i, 128)))
+        assert st == 0
+        st, tok2 = t("refund_to_credit_token", lambda: ctx.refund_to_credit_token(prer, proof, rf, sk[32:]))
+        assert st == 0
+    return {k: round(1e3 * v / reps, 3) for k, v in acc.items()}
 
 
 def count_field_ops(h, L, sk, proofs_host, sample=4):

@@ -198,6 +198,9 @@ int act_node_refund_to_credit_token_batch(act_node *node, size_t n, const uint8_
  * wins; bytes after the first item ignored).  Scalars come out reduced mod l (decode_scalar, src/cbor.rs:80-91).
  * status[i]: 0 ok, 1 malformed CBOR (CborError::Ciborium), 2 CborError::InvalidStructure, 3 CborError::InvalidValue
  * (a point that is not a canonical Ristretto encoding, src/cbor.rs:59-78); the record of a failed message is zero.
+ * Accept / reject always agrees with from_cbor.  Where a message is wrong in two ways the code can differ: from_cbor
+ * reports the first problem in map order, this codec validates points after the structural pass, so a message with an
+ * invalid point AND a later missing or mis-shaped field reports 2 where the crate reports InvalidValue.
  * Canonical messages are framed / unframed on the GPU (one lane per 32-byte field); others take a host reader. */
 #define ACT_CBOR_ISSUANCE_REQUEST 1
 #define ACT_CBOR_ISSUANCE_RESPONSE 2
@@ -231,6 +234,19 @@ size_t act_nullifier_set_len(const act_nullifier_set *set);
 const char *act_nullifier_set_last_error(const act_nullifier_set *set);
 int act_nullifier_check_and_insert_batch(act_nullifier_set *set, size_t n, int mem, const uint8_t *nullifiers, size_t stride,
                                          const uint8_t *skip_mask, uint8_t *out_spent);
+
+/* The same set spread over the GPUs of a node: one set per entry of devices[], a nullifier owned by exactly one of them
+ * (keyed hash of the reduced scalar), so a batch keeps the sequential meaning above in lane order.  The host buckets the
+ * keys by owner (stable), every GPU checks-and-inserts its bucket from its own thread, answers are scattered back:
+ * 33 bytes per spend over PCIe, no peer traffic.  Host memory only.  `salt` (16 bytes, nullable) keys the routing. */
+typedef struct act_node_nullifier_set act_node_nullifier_set;
+int act_node_nullifier_set_create(const int *devices, int n_devices, size_t capacity_per_device, const uint8_t salt[16],
+                                  act_node_nullifier_set **out);
+void act_node_nullifier_set_destroy(act_node_nullifier_set *set);
+size_t act_node_nullifier_set_len(const act_node_nullifier_set *set);
+const char *act_node_nullifier_set_last_error(const act_node_nullifier_set *set);
+int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set *set, size_t n, const uint8_t *nullifiers, size_t stride,
+                                              const uint8_t *skip_mask, uint8_t *out_spent);
 
 /* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */

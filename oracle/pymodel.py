@@ -829,6 +829,11 @@ def _cbor_parse(b: bytes, pos: int, depth: int = 0):
         if not ind:
             if pos + val > len(b):
                 raise _CborParseError
+            if major == 3:
+                try:                                    # ciborium hands text strings to str::from_utf8: not UTF-8 = parse error
+                    b[pos:pos + val].decode("utf-8")
+                except UnicodeDecodeError:
+                    raise _CborParseError
             return (("bytes" if major == 2 else "text"), b[pos:pos + val]), pos + val
         acc = b""
         while True:

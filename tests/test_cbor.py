@@ -50,6 +50,10 @@ def _variants(t, rec, L):
     out.append((hd(n + 2) + kb(99) + b"\x63abc" + body(ents) + b"\x20" + b"\x82\x01\xf6", None))   # unknown int key, negative-int key
     out.append((hd(n + 1) + b"\x61k" + b"\xa1\x01\x02" + body(ents), None))               # text key with a nested map value
     out.append((b"\xbf" + body(ents) + b"\xff", None))                                    # indefinite-length map
+    out.append((hd(n + 1) + b"\x62\xc3\xa9" + b"\x01" + body(ents), None))                 # text key "e-acute": valid UTF-8, ignored
+    out.append((hd(n + 1) + b"\x61\xff" + b"\x01" + body(ents), None))                     # text key that is not UTF-8: ciborium refuses to parse
+    out.append((hd(n + 1) + kb(98) + b"\x63\xed\xa0\x80" + body(ents), None))              # text VALUE holding a UTF-16 surrogate: parse error
+    out.append((hd(n + 1) + kb(98) + b"\x7f\x62\xc3\xa9\x61\xc3\xff" + body(ents), None))  # chunked text whose second chunk is a truncated sequence
     out.append((hd(n) + b"\x18\x01" + ents[0][1] + body(ents[1:]), None))                 # non-minimal key encoding
     out.append((hd(n + 1) + kb(ents[0][0]) + bstr(bytes(32)) + body(ents), None))         # duplicate key: the last one wins
     out.append((hd(n - 1) + body(ents[1:]), None))                                        # missing field 1

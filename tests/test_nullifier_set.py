@@ -103,3 +103,23 @@ def test_keys_are_scalars_not_byte_strings():
     a, b = capi.NullifierSet(capacity=100), capi.NullifierSet(capacity=100)
     keys = b"".join(shake("ns-salt%d" % (i % 7), 32) for i in range(20))
     assert a.check_and_insert(keys) == b.check_and_insert(keys)
+
+
+def test_node_level_set_keeps_the_sequential_meaning():
+    """act_node_nullifier_*: three per-device sets behind host-side routing answer like one sequential HashSet<Scalar>."""
+    from act_amd import capi
+    from conftest import ELL
+    r = random.Random(11)
+    ns = capi.NodeNullifierSet(capacity_per_device=100_000, devices=(0, 0, 0))
+    db = set()
+    pool = [(int.from_bytes(shake("nnul%d" % i, 32), "little") % ELL).to_bytes(32, "little") for i in range(2000)]
+    for rnd in range(5):
+        n = [1, 19, 3000, 4096, 2][rnd]
+        keys = [r.choice(pool) for _ in range(n)]
+        mask = bytes(1 if r.random() < 0.15 else 0 for _ in range(n)) if rnd % 2 else None
+        assert ns.check_and_insert(b"".join(keys), 32, mask) == sequential(db, keys, mask), rnd
+        assert len(ns) == len(db)
+    k = int.from_bytes(shake("nnul-canon", 32), "little") % ELL
+    le = lambda v: v.to_bytes(32, "little")
+    assert list(ns.check_and_insert(le(k + 3 * ELL) + le(k) + le(k + ELL))) == [0, 1, 1]      # one scalar, three byte strings, one owner
+    assert ns.check_and_insert(b"") == b""
