@@ -17,7 +17,7 @@ _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_ctx_set_pipeline_depth", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_ctx_set_pipeline_depth", "act_build_has_ct_secret_tables", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
@@ -43,7 +43,9 @@ class ActError(RuntimeError):
 
 def build(jobs: int = 8) -> str:
     """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}", "-s"], check=True)
+    # `all` = libact_mi355x.so; `ct` = libact_mi355x_ct.so, the same library with address-independent table / bucket
+    # selection for secret scalars (-DACT_CT_SECRET_TABLES)
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}", "-s", "all", "ct"], check=True)
     return LIB_PATH
 
 
@@ -74,6 +76,7 @@ def load() -> C.CDLL:
     lib.act_ctx_set_transcript_mode.argtypes = [vp, i32]
     lib.act_ctx_set_host_threads.argtypes = [vp, i32]
     lib.act_ctx_set_pipeline_depth.argtypes = [vp, i32]
+    lib.act_build_has_ct_secret_tables.argtypes = []
     lib.act_last_error.argtypes = [vp]
     lib.act_last_error.restype = C.c_char_p
     for f in ("act_spend_proof_bytes", "act_prove_rng_bytes", "act_spend_transcript_bytes"):

@@ -68,6 +68,7 @@ struct act_ctx {
   Slot slots[2];
   uint32_t* d_tables = nullptr;
   uint32_t* d_half_h1 = nullptr;
+  uint32_t* d_tables_ct = nullptr;     // ACT_CT_SECRET_TABLES builds only
   // key cache
   uint8_t sk_cached[64]{}; bool sk_valid = false; DevKey key{};
   uint8_t w_cached[32]{}; bool w_valid = false; ge w_pub{};
@@ -472,6 +473,13 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
     launch_build_table(d_ext + b * GE_WORDS, c->d_tables + (size_t)b * FB_TABLE_WORDS, s0);
     c->P.tab[b] = c->d_tables + (size_t)b * FB_TABLE_WORDS;
   }
+#if defined(ACT_CT_SECRET_TABLES)
+  HIPCK(c, hipMalloc(&c->d_tables_ct, (size_t)4 * CT_TABLE_WORDS * 4));
+  for (int b = 0; b < 4; b++) {
+    launch_build_table_ct(d_ext + b * GE_WORDS, c->d_tables_ct + (size_t)b * CT_TABLE_WORDS, s0);
+    c->P.tab_ct[b] = c->d_tables_ct + (size_t)b * CT_TABLE_WORDS;
+  }
+#endif
   HIPCK(c, hipMalloc(&c->d_half_h1, (size_t)2 * NIELS_WORDS * 4));
   launch_half_point_table(c->P.tab[BASE_H1], c->d_half_h1, s0);
   c->P.half_h1 = c->d_half_h1;
@@ -510,12 +518,20 @@ void act_ctx_destroy(act_ctx* c) {
   if (c->prof_base) (void)hipEventDestroy(c->prof_base);
   if (c->d_tables) (void)hipFree(c->d_tables);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
+  if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
   delete c;
 }
 int act_ctx_set_transcript_mode(act_ctx* c, int mode) {
   if (!c || (mode != ACT_TRANSCRIPT_HOST && mode != ACT_TRANSCRIPT_DEVICE)) return ACT_ERR_ARG;
   c->tr_mode = mode; return ACT_OK;
+}
+int act_build_has_ct_secret_tables(void) {
+#if defined(ACT_CT_SECRET_TABLES)
+  return 1;
+#else
+  return 0;
+#endif
 }
 int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
 int act_ctx_set_host_threads(act_ctx* c, int n) { if (!c || n < 0) return ACT_ERR_ARG; c->host_threads = n; return ACT_OK; }

@@ -38,6 +38,9 @@ ACT_HD ge_cached ge_cached_cneg(const ge_cached& c, bool neg) {
   r.T2d = fe_select_m(c.T2d, fe_neg(c.T2d), m);   // <= 2^27 [g]
   return r;
 }
+ACT_HD ge ge_select_m(const ge& a, const ge& b, uint32_t m) {      // m all-ones: b, all-zeros: a
+  ge r; r.X = fe_select_m(a.X, b.X, m); r.Y = fe_select_m(a.Y, b.Y, m); r.Z = fe_select_m(a.Z, b.Z, m); r.T = fe_select_m(a.T, b.T, m); return r;
+}
 ACT_HD ge_niels ge_niels_cneg(const ge_niels& c, bool neg) {
   ge_niels r = c;
   uint32_t m = fe_mask(neg);

@@ -27,6 +27,29 @@ void launch_build_table(const uint32_t* base_ext, uint32_t* table, hipStream_t s
   hipLaunchKernelGGL(k_build_table, dim3((FB_WINDOWS * FB_ENTRIES + 255) / 256), dim3(256), 0, s, base_ext, table);
 }
 
+#if defined(ACT_CT_SECRET_TABLES)
+// T[pos][e-1] = e * 16^pos * B, e = 1..8, as affine Niels: the small tables the secret-scalar products scan in full (msm.h)
+__global__ void __launch_bounds__(64) k_build_table_ct(const uint32_t* base_ext, uint32_t* table) {
+  uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+  if (gid >= (uint32_t)(CT_WINDOWS * CT_ENTRIES)) return;
+  uint32_t pos = gid / CT_ENTRIES, e = gid % CT_ENTRIES + 1;
+  ge b = ge_load(base_ext);
+  for (uint32_t i = 0; i < 4u * pos; i++) b = ge_double(b);
+  ge acc = ge_identity();
+  ge_cached bc = ge_to_cached(b);
+  for (int bit = 3; bit >= 0; bit--) {
+    acc = ge_double(acc);
+    if ((e >> bit) & 1u) acc = ge_add_cached(acc, bc);
+  }
+  fe zi = fe_invert(acc.Z);
+  ge af; af.X = fe_mul(acc.X, zi); af.Y = fe_mul(acc.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
+  niels_store(table + (size_t)gid * NIELS_WORDS, niels_from_affine(af));
+}
+void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_table_ct, dim3((CT_WINDOWS * CT_ENTRIES + 63) / 64), dim3(64), 0, s, base_ext, table);
+}
+#endif
+
 // out[0] = identity, out[1] = B / 2 as affine Niels, B the base of `table`: the prover works at half scale (k_prove.hip)
 __global__ void k_half_point_table(const uint32_t* table, uint32_t* out) {
   if (blockIdx.x || threadIdx.x) return;
@@ -67,7 +90,7 @@ __global__ void __launch_bounds__(64) k_keygen(DevParams P, const uint8_t* rng64
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   sc x = load_wide(rng64 + (size_t)i * 64);
-  ge w = fixed_base_acc(ge_identity(), P.tab[BASE_G], x);
+  ge w = fixed_base_acc_s(ge_identity(), ACT_FB_S(P, BASE_G), x);
   uint32_t e[8]; ristretto_encode(e, w);
   store_sc(out_sk + (size_t)i * 64, x); store8(out_sk + (size_t)i * 64 + 32, e);
 }

@@ -63,20 +63,20 @@ __global__ void __launch_bounds__(64, 2) k_prove_head(ProveArgs a) {
   // A' = (r1 r2) A and the A-part of A1 = e' A' share A's doubling chain
   ge acc[2] = {ge_identity(), ge_identity()};
   sc sa[2] = {r1r2, sc_mul(e_prime, r1r2)};
-  chain_b<2>(acc, A, sa, a.half + (size_t)p * 2 * BUCKET_WORDS);       // the half-point area is not in use yet
+  chain_s<2>(acc, A, sa, a.half + (size_t)p * 2 * BUCKET_WORDS);       // the half-point area is not in use yet
   sc r1c = sc_mul(r1, c), r1k = sc_mul(r1, k), r1r = sc_mul(r1, r);
-  ge bbar = fixed_base_acc(ge_identity(), a.P.tab[BASE_G], r1);
-  bbar = fixed_base_acc(bbar, a.P.tab[BASE_H1], r1c);
-  bbar = fixed_base_acc(bbar, a.P.tab[BASE_H2], r1k);
-  bbar = fixed_base_acc(bbar, a.P.tab[BASE_H3], r1r);
-  ge a1 = fixed_base_acc(acc[1], a.P.tab[BASE_G], sc_mul(r2_prime, r1));
-  a1 = fixed_base_acc(a1, a.P.tab[BASE_H1], sc_mul(r2_prime, r1c));
-  a1 = fixed_base_acc(a1, a.P.tab[BASE_H2], sc_mul(r2_prime, r1k));
-  a1 = fixed_base_acc(a1, a.P.tab[BASE_H3], sc_mul(r2_prime, r1r));
-  ge a2 = fixed_base_acc(ge_identity(), a.P.tab[BASE_G], sc_mul(r3_prime, r1));
-  a2 = fixed_base_acc(a2, a.P.tab[BASE_H1], sc_muladd(r3_prime, r1c, c_prime));
-  a2 = fixed_base_acc(a2, a.P.tab[BASE_H2], sc_mul(r3_prime, r1k));
-  a2 = fixed_base_acc(a2, a.P.tab[BASE_H3], sc_muladd(r3_prime, r1r, r_prime));
+  ge bbar = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), r1);
+  bbar = fixed_base_acc_s(bbar, ACT_FB_S(a.P, BASE_H1), r1c);
+  bbar = fixed_base_acc_s(bbar, ACT_FB_S(a.P, BASE_H2), r1k);
+  bbar = fixed_base_acc_s(bbar, ACT_FB_S(a.P, BASE_H3), r1r);
+  ge a1 = fixed_base_acc_s(acc[1], ACT_FB_S(a.P, BASE_G), sc_mul(r2_prime, r1));
+  a1 = fixed_base_acc_s(a1, ACT_FB_S(a.P, BASE_H1), sc_mul(r2_prime, r1c));
+  a1 = fixed_base_acc_s(a1, ACT_FB_S(a.P, BASE_H2), sc_mul(r2_prime, r1k));
+  a1 = fixed_base_acc_s(a1, ACT_FB_S(a.P, BASE_H3), sc_mul(r2_prime, r1r));
+  ge a2 = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), sc_mul(r3_prime, r1));
+  a2 = fixed_base_acc_s(a2, ACT_FB_S(a.P, BASE_H1), sc_muladd(r3_prime, r1c, c_prime));
+  a2 = fixed_base_acc_s(a2, ACT_FB_S(a.P, BASE_H2), sc_mul(r3_prime, r1k));
+  a2 = fixed_base_acc_s(a2, ACT_FB_S(a.P, BASE_H3), sc_muladd(r3_prime, r1r, r_prime));
 
   tr_put_prefix(a.tr + (size_t)p * a.tr_stride, a.P, LABEL_SPEND);
   uint32_t enc[8];
@@ -91,9 +91,9 @@ __global__ void __launch_bounds__(64, 2) k_prove_head(ProveArgs a) {
   sc k_star = rv.k_star();
   uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
   // at half scale, like everything k_prove_bits computes
-  ge_store(d3, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(k_star)));
-  ge_store(d3 + GE_WORDS, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(rv.k0_prime())));
-  ge_store(d3 + 2 * GE_WORDS, fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star)))));
+  ge_store(d3, fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), sc_half(k_star)));
+  ge_store(d3 + GE_WORDS, fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), sc_half(rv.k0_prime())));
+  ge_store(d3 + 2 * GE_WORDS, fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), sc_half(sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star)))));
   sc r3 = sc_invert(r1);                                                      // :992
   uint32_t* stt = a.state + (size_t)p * 24;
   for (int i = 0; i < 8; i++) stt[i] = r3.v[i];
@@ -112,13 +112,22 @@ __global__ void __launch_bounds__(256, 2) k_prove_bits(ProveArgs a) {
   sc s_j = rv.s_i(j), s_jp = rv.s_i_prime(j), g_j = rv.gamma_i(j), z_j = rv.z(j);
 
   // Half scale throughout (k_prove_enc encodes the doubles): Com_j / 2 = i_j (h1 / 2) + (s_j / 2) h3 (+ (k* / 2) h2)
-  ge com = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], sc_half(s_j));
+  ge com = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H3), sc_half(s_j));
+#if defined(ACT_CT_SECRET_TABLES)
+  {                                                                                // both entries read, the bit picks with masks
+    const ge_niels e0 = niels_load(a.P.half_h1), e1 = niels_load(a.P.half_h1 + NIELS_WORDS);
+    const uint32_t m = fe_mask(bit != 0);
+    ge_niels q; q.ypx = fe_select_m(e0.ypx, e1.ypx, m); q.ymx = fe_select_m(e0.ymx, e1.ymx, m); q.xy2d = fe_select_m(e0.xy2d, e1.xy2d, m);
+    com = ge_madd(com, q);
+  }
+#else
   com = ge_madd(com, niels_load(a.P.half_h1 + (size_t)bit * NIELS_WORDS));        // entry 0 = identity, entry 1 = h1 / 2
+#endif
   // real branch: s'_j h3 (+ k0' h2);  simulated: (z_j - gamma_j s_j) h3 -/+ gamma_j h1 (+ (w0 - gamma_0 k*) h2)
-  ge real = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], sc_half(s_jp));
-  ge sim = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], sc_half(sc_sub(z_j, sc_mul(g_j, s_j))));
+  ge real = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H3), sc_half(s_jp));
+  ge sim = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H3), sc_half(sc_sub(z_j, sc_mul(g_j, s_j))));
   sc gh1 = sc_half(bit ? sc_neg(g_j) : g_j);
-  sim = fixed_base_acc(sim, a.P.tab[BASE_H1], gh1);
+  sim = fixed_base_acc_s(sim, ACT_FB_S(a.P, BASE_H1), gh1);
   if (j == 0) {
     const uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
     com = ge_add(com, ge_load(d3)); real = ge_add(real, ge_load(d3 + GE_WORDS)); sim = ge_add(sim, ge_load(d3 + 2 * GE_WORDS));
@@ -162,9 +171,9 @@ __global__ void __launch_bounds__(64, 2) k_prove_tail(ProveArgs a) {
   RngView rv{a.rng + (size_t)p * rng_bytes(L), L};
   sc rstar = sc_zero();                                                       // r* = sum s_j 2^j (:1052-1056), Horner
   for (int j = L - 1; j >= 0; j--) rstar = sc_add(sc_add(rstar, rstar), rv.s_i(j));
-  ge cc = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], sc_neg(rv.c_prime()));   // :1059
-  cc = fixed_base_acc(cc, a.P.tab[BASE_H2], rv.k_prime());
-  cc = fixed_base_acc(cc, a.P.tab[BASE_H3], rv.s_prime());
+  ge cc = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H1), sc_neg(rv.c_prime()));   // :1059
+  cc = fixed_base_acc_s(cc, ACT_FB_S(a.P, BASE_H2), rv.k_prime());
+  cc = fixed_base_acc_s(cc, ACT_FB_S(a.P, BASE_H3), rv.s_prime());
   uint32_t enc[8]; ristretto_encode(enc, cc); tr_put_aligned(el + 40 * st.el_c(), enc);
   uint32_t* stt = a.state + (size_t)p * 24;
   for (int i = 0; i < 8; i++) stt[8 + i] = rstar.v[i];

@@ -18,9 +18,9 @@ __global__ void __launch_bounds__(64, 2) k_sign_a(SignArgs a) {
   ge xa = ge_load(a.xa + (size_t)p * GE_WORDS);
   ge acc[2] = {ge_identity(), ge_identity()};
   sc s[2] = {inv, sc_mul(alpha, inv)};
-  chain_b<2>(acc, xa, s, a.pbk + (size_t)p * 2 * BUCKET_WORDS);                                           // acc[0] = A, acc[1] = Y_A (:650 / :853)
-  ge xg = ge_add(fixed_base_acc(ge_identity(), a.P.tab[BASE_G], e), a.K.w);     // :646 / :851
-  ge yg = fixed_base_acc(ge_identity(), a.P.tab[BASE_G], alpha);                 // :651 / :854
+  chain_s<2>(acc, xa, s, a.pbk + (size_t)p * 2 * BUCKET_WORDS);                                           // acc[0] = A, acc[1] = Y_A (:650 / :853)
+  ge xg = ge_add(fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), e), a.K.w);     // :646 / :851
+  ge yg = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), alpha);                 // :651 / :854
 
   // transcript: prefix | [c] | e | A | X_A | X_g | Y_A | Y_g   (:654-657 / :856-859)
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
@@ -115,8 +115,8 @@ __global__ void __launch_bounds__(64, 2) k_request_a(RequestArgs a) {
   if (p >= a.n) return;
   sc r = load_sc(a.pre + (size_t)p * 64), k = load_sc(a.pre + (size_t)p * 64 + 32);
   sc kp = load_wide(a.rng + (size_t)p * 128), rp = load_wide(a.rng + (size_t)p * 128 + 64);      // :468-469
-  ge big_k = fixed_base_acc(fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], k), a.P.tab[BASE_H3], r);     // :465
-  ge k1 = fixed_base_acc(fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], kp), a.P.tab[BASE_H3], rp);      // :470
+  ge big_k = fixed_base_acc_s(fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), k), ACT_FB_S(a.P, BASE_H3), r);     // :465
+  ge k1 = fixed_base_acc_s(fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), kp), ACT_FB_S(a.P, BASE_H3), rp);      // :470
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
   tr_put_prefix(tr, a.P, LABEL_REQUEST);
   uint8_t* el = tr + a.P.prefix_len[LABEL_REQUEST];

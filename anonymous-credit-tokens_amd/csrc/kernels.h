@@ -30,6 +30,9 @@ constexpr int SMALL_TR_STRIDE = 512;      // request 266 B, respond 466 B, refun
 struct DevParams {
   const uint32_t* tab[4];                 // position-specific fixed-base tables of g, h1, h2, h3 (msm.h)
   const uint32_t* half_h1;                // two affine-Niels entries: identity, h1 / 2 (the prover's bit term at half scale)
+#if defined(ACT_CT_SECRET_TABLES)
+  const uint32_t* tab_ct[4];              // small tables the secret-scalar products scan in full (msm.h fixed_base_acc_ct)
+#endif
   uint32_t prefix[4][PREFIX_WORDS];       // Transcript::new(params, label) bytes, zero padded
   uint32_t prefix_len[4];
   int L;                                  // range-proof width (src/lib.rs:116)
@@ -185,6 +188,9 @@ struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n;
 #if defined(__HIPCC__)
 // launchers (defined in the .hip files)
 void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, hipStream_t s);
+#if defined(ACT_CT_SECRET_TABLES)
+void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_t s);
+#endif
 void launch_half_point_table(const uint32_t* table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
 void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s);
 void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s);

@@ -427,7 +427,10 @@ ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc&
 // doubling chain (the bucket half of chain_bu, for the per-proof kernels): 64 bucket additions + a 14-addition
 // combine per scalar and one cached conversion per four doublings, instead of chain<NACC>'s 127 digit additions
 // and two cached conversions per two doublings.  `bk`: NACC * BUCKET_WORDS words owned by this lane.
-template <int NACC>
+// CT = true (chain_s under ACT_CT_SECRET_TABLES): the bucket a digit selects is not an address -- all nine buckets of the
+// scalar are read, the addressed one is picked with masks, and all nine are written back, so the memory trace is the same
+// for every scalar (the reference scans its lookup tables with `subtle`, /root/reference/src/lib.rs:98).
+template <int NACC, bool CT = false>
 ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
   const ge id = ge_identity();
   for (int b = 0; b < NACC * BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);
@@ -444,8 +447,16 @@ ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
       carry[a] = v > 8u ? 1u : 0u;
       bool neg = v > 8u;
       uint32_t mag = neg ? 16u - v : v;        // 0..8; bucket 0 absorbs the zero digits
-      uint32_t* slot = bk + ((size_t)a * BUCKETS + mag) * GE_WORDS;
-      bucket_store(slot, ge_add_cached(bucket_load(slot), ge_cached_cneg(c, neg)));
+      if (!CT) {
+        uint32_t* slot = bk + ((size_t)a * BUCKETS + mag) * GE_WORDS;
+        bucket_store(slot, ge_add_cached(bucket_load(slot), ge_cached_cneg(c, neg)));
+      } else {
+        uint32_t* row = bk + (size_t)a * BUCKET_WORDS;
+        ge B = ge_identity();
+        for (uint32_t v = 0; v < (uint32_t)BUCKETS; v++) B = ge_select_m(B, bucket_load(row + v * GE_WORDS), fe_mask(v == mag));
+        B = ge_add_cached(B, ge_cached_cneg(c, neg));
+        for (uint32_t v = 0; v < (uint32_t)BUCKETS; v++) bucket_store(row + v * GE_WORDS, ge_select_m(bucket_load(row + v * GE_WORDS), B, fe_mask(v == mag)));
+      }
     }
     if (step == 63) break;
     P = ge_double_opt(P, false); P = ge_double_opt(P, false); P = ge_double_opt(P, false);
@@ -462,6 +473,50 @@ ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
     acc[a] = ge_add_cached(acc[a], ge_to_cached(R));
   }
 }
+
+// ---- secret scalars --------------------------------------------------------------------------------------------
+// fixed_base_acc_s / chain_s are what the prover, the signer, key generation and the x-dependent product of the verifier
+// call.  By default they are fixed_base_acc / chain_b: table entries and buckets are addressed by scalar digits, so the
+// memory-access pattern depends on secrets (the instruction stream does not).  Built with -DACT_CT_SECRET_TABLES (make ct ->
+// libact_mi355x_ct.so) neither does the access pattern, to the standard the reference sets with `subtle`
+// (/root/reference/src/lib.rs:98, 1025-1118) and dalek's table scans: fixed-base products use signed radix-16 windows over
+// small tables (64 windows x 8 entries x 128 B = 64 KiB per base) whose eight entries are ALL read and masked, and the
+// Pippenger buckets are all read and all written back every step (chain_b<NACC, true>).  Cost: DESIGN.md section 4.
+#if defined(ACT_CT_SECRET_TABLES)
+constexpr int CT_WINDOWS = 64, CT_ENTRIES = 8;
+constexpr size_t CT_TABLE_WORDS = (size_t)CT_WINDOWS * CT_ENTRIES * NIELS_WORDS;       // T[pos][e-1] = e * 16^pos * B, e = 1..8
+ACT_HD ge fixed_base_acc_ct(ge acc, const uint32_t* table, const sc& s) {
+  uint32_t t[8];
+  radix16_bias(t, s);                                  // nibble - 8 = signed digit in [-8, 7]
+#pragma unroll 1
+  for (int wd = 0; wd < 8; wd++) {
+    uint32_t word = t[0];
+    for (int i = 0; i < 7; i++) t[i] = t[i + 1];       // static indices only: the digit words never live in scratch
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+      const uint32_t nib = word & 15u; word >>= 4;
+      const bool neg = nib < 8u;
+      const uint32_t mag = neg ? 8u - nib : nib - 8u;  // 0..8
+      const uint32_t* row = table + (size_t)(wd * 8 + k) * CT_ENTRIES * NIELS_WORDS;
+      ge_niels q = ge_niels_identity();
+      for (uint32_t e = 1; e <= (uint32_t)CT_ENTRIES; e++) {
+        const ge_niels c = niels_load(row + (size_t)(e - 1) * NIELS_WORDS);
+        const uint32_t m = fe_mask(e == mag);
+        q.ypx = fe_select_m(q.ypx, c.ypx, m); q.ymx = fe_select_m(q.ymx, c.ymx, m); q.xy2d = fe_select_m(q.xy2d, c.xy2d, m);
+      }
+      acc = ge_madd(acc, ge_niels_cneg(q, neg));
+    }
+  }
+  return acc;
+}
+#define ACT_FB_S(P, base) ((P).tab_ct[base])
+ACT_HD ge fixed_base_acc_s(ge acc, const uint32_t* table_ct, const sc& s) { return fixed_base_acc_ct(acc, table_ct, s); }
+template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t* bk) { chain_b<NACC, true>(acc, N, s, bk); }
+#else
+#define ACT_FB_S(P, base) ((P).tab[base])
+ACT_HD ge fixed_base_acc_s(ge acc, const uint32_t* table, const sc& s) { return fixed_base_acc(acc, table, s); }
+template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t* bk) { chain_b<NACC, false>(acc, N, s, bk); }
+#endif
 
 // ---- batched double-and-compress (ge25519.h dc_*): one field inversion per E encodings ----------------------
 // Encodes 2*Q_i for `count` <= E points.  `slot(i)` -> the 40 words of point i (X|Y|Z|T); they are overwritten with

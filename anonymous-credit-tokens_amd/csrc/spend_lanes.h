@@ -74,7 +74,7 @@ ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
   acc[0] = ge_identity();
   sc sa[1] = {sc_sub(e_bar, sc_mul(a.K.x, gamma))};
   uint32_t* pbk = a.buckets + (size_t)p * 2 * BUCKET_WORDS;      // free until k_spend_bits runs
-  chain_b<1>(acc, A, sa, pbk);
+  chain_s<1>(acc, A, sa, pbk);                                   // the scalar depends on the issuer's x
   sc sb[2] = {r2_bar, r3_bar};
   chain_b<2>(acc, B, sb, pbk);
 

@@ -108,6 +108,11 @@ int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);   /* host BLAKE3 worke
  * host-transcript mode, its host hashing) or 1 (strictly one after the other: profiling runs whose per-kernel durations
  * must not overlap) */
 int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
+/* 1 if this library was built with -DACT_CT_SECRET_TABLES (libact_mi355x_ct.so): table entries and Pippenger buckets selected
+ * by digits of SECRET scalars (prover, signer, key generation, the verifier's x-dependent product) are read / written in
+ * full and picked with masks, so the memory-access pattern is independent of secrets, as the reference's use of `subtle`
+ * and dalek's table scans are (src/lib.rs:98, 1025-1118).  0 = default build: addressed look-ups. */
+int act_build_has_ct_secret_tables(void);
 const char *act_last_error(const act_ctx *ctx);
 size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
 size_t act_prove_rng_bytes(const act_ctx *ctx);             /* 64*(4L+12) */
