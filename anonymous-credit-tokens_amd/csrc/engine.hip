@@ -684,7 +684,8 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   const size_t pb = ProofLayout{c->L}.bytes();
   // host-transcript mode pipelines the device with the D2H copy and the host threads: measured best at 16384 proofs per
   // chunk (the device kernels themselves like 65536), so its chunks are capped there
-  const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, 16384) : c->max_batch;
+  static const size_t host_chunk = [] { const char* e = getenv("ACT_HOST_CHUNK"); size_t v = e ? (size_t)atol(e) : 0; return v ? v : (size_t)16384; }();   // tuning knob
+  const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
   const size_t nchunks = (n + chunk_len - 1) / chunk_len;
   SpendChunk chunks[2];
   size_t cursor = 0;
