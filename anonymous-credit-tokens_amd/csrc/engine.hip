@@ -452,7 +452,7 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   act_ctx* c = new act_ctx();
   *out = c;   // returned even on failure so that act_last_error() can be read; the caller destroys it
   // lanes per launch = max_batch * L must stay below 2^31 (kernels index lanes with 32-bit integers)
-  if (max_batch > ((size_t)1 << 22)) max_batch = (size_t)1 << 22;
+  if (max_batch > ((size_t)1 << 22)) { c->err = "max_batch above 2^22: lanes per launch (max_batch * L) must stay below 2^31"; return ACT_ERR_ARG; }
   c->device = device; c->L = L; c->max_batch = max_batch ? max_batch : 65536;     // throughput saturates from here on
   memcpy(c->henc, h, 96);
   HIPCK(c, hipSetDevice(device));

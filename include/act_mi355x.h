@@ -99,7 +99,9 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
  * thereby the workspace: about 220 KB per record at L = 128 (1.7 KB per range-proof bit), times two
  * pipeline slots.  0 = default = 65536 (29 GB of the 288 GB at L = 128), from which size on the
  * throughput of every entry point is flat; 16384 costs about 5 % of the verify rate and two thirds
- * of the issue/request rate.  Batches of any length are accepted and processed in such chunks. */
+ * of the issue/request rate.  Batches of any length are accepted and processed in such chunks.  max_batch > 2^22 is
+ * refused (ACT_ERR_ARG).  On failure *out still receives a context whose only use is act_last_error() and
+ * act_ctx_destroy(). */
 int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act_ctx **out);
 void act_ctx_destroy(act_ctx *ctx);
 int act_ctx_set_transcript_mode(act_ctx *ctx, int mode);    /* default ACT_TRANSCRIPT_HOST */

@@ -192,6 +192,9 @@ def test_workspace_that_cannot_be_allocated_fails_cleanly(bench_params):
     with pytest.raises(capi.ActError) as e:
         capi.Engine(bench_params, 128, max_batch=1 << 22)
     assert "hip" in str(e.value).lower() or "memory" in str(e.value).lower()
+    with pytest.raises(capi.ActError) as e:                 # above the 32-bit lane-index limit: refused, not clamped
+        capi.Engine(bench_params, 128, max_batch=(1 << 22) + 1)
+    assert "ACT_ERR_ARG" in str(e.value) and "2^22" in str(e.value)
     eng = capi.Engine(bench_params, 128, max_batch=4)
     sk = eng.private_key_random(shake("oom-sk", 64))
     assert len(sk) == 64
