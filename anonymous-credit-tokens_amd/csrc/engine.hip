@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -245,10 +246,20 @@ int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_
 }
 int hash_end(act_ctx* c, Slot& sl, uint32_t stride, uint32_t len, uint32_t n) {
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) return ACT_OK;
+  static const bool trace = getenv("ACT_TRACE") != nullptr;      // where the host side of the host-transcript mode spends its time
+  static double t_wait = 0, t_hash = 0; static size_t n_msgs = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int k = 0; k < HASH_PIECES; k++) {
     size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
+    double t0 = trace ? now() : 0;
     HIPCK(c, hipEventSynchronize(sl.h_ev[k]));
+    double t1 = trace ? now() : 0;
     if (i1 > i0) host_hash_many(c, sl.h_tr + i0 * stride, stride, len, i1 - i0, sl.h_xof + i0 * 16);
+    if (trace) { t_wait += t1 - t0; t_hash += now() - t1; }
+  }
+  if (trace && len > 1024) {
+    n_msgs += n;
+    if (n_msgs >= ((size_t)1 << 18)) { fprintf(stderr, "[act trace] %zu transcripts: waited for the device %.1f ms, hashed %.1f ms (%.2f GB/s)\n", n_msgs, 1e3 * t_wait, 1e3 * t_hash, n_msgs * (double)len / t_hash / 1e9); n_msgs = 0; t_wait = t_hash = 0; }
   }
   HIPCK(c, hipMemcpyAsync(sl.d_xof, sl.h_xof, (size_t)n * 64, hipMemcpyHostToDevice, sl.stream));
   return ACT_OK;
