@@ -53,6 +53,7 @@ struct Slot {
   uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
   uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
   hipEvent_t h_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per returned piece (HASH_PIECES)
+  hipEvent_t bits_ev = nullptr;        // recorded after this slot's k_spend_bits (staggering, spend_stage1)
   std::vector<PendingProf> pending;
   size_t last_spend_lanes = 0;
 };
@@ -79,6 +80,7 @@ struct act_ctx {
   hipEvent_t prof_base = nullptr;                                  // time origin of the launch intervals below
   std::vector<std::pair<float, float>> prof_iv[PK_COUNT];          // [start, end) of every launch, ms since prof_base
   int last_spend_slot = 0;
+  hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
 };
 
 namespace {
@@ -406,7 +408,7 @@ int sign_phase(act_ctx* c, Slot& sl, uint32_t m, int label, const uint8_t* d_rng
 }
 
 // ---- spend verification, pipelined over two slots ----------------------------------------------------------
-struct SpendChunk { uint32_t m = 0; size_t off = 0; const uint8_t* d_proofs = nullptr; uint8_t* d_kprime = nullptr; uint8_t* d_out = nullptr; SpendArgs a{}; };
+struct SpendChunk { uint32_t m = 0; size_t off = 0; const uint8_t* d_proofs = nullptr; uint8_t* d_kprime = nullptr; uint8_t* d_out = nullptr; SpendArgs a{}; bool stagger = false; };
 
 // stage 1: everything up to (and including the start of) the transcript hash
 int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
@@ -417,7 +419,18 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
   a.kprime_enc = ch.d_kprime; a.naf = sl.d_naf; a.dig = sl.d_dig;
   int rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_PREP, ch.m, [&] { launch_spend_prep(a, sl.stream); }))) return rc;
+  // Staggering.  Left alone, the range kernels of the two chunks in flight run side by side, finish together, and then
+  // both chunks do their copies (H2D of the next proofs, D2H of the transcripts) at the same moment with no kernel
+  // running: rocprofv3 --memory-copy-trace showed 38 ms of PCIe per 290 ms of compute fully exposed for host-memory
+  // callers.  When a call moves data over PCIe, every range kernel therefore waits for the previous chunk's (one of them
+  // fills the GPU anyway): chunk i's encodes, tail, copies and host hashing then run under chunk i+1's range kernel.
+  if (ch.stagger && c->last_bits_ev) HIPCK(c, hipStreamWaitEvent(sl.stream, c->last_bits_ev, 0));
   if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)ch.m * c->L, [&] { launch_spend_bits(a, sl.stream); }))) return rc;
+  if (ch.stagger) {
+    if (!sl.bits_ev) HIPCK(c, hipEventCreateWithFlags(&sl.bits_ev, hipEventDisableTiming));
+    HIPCK(c, hipEventRecord(sl.bits_ev, sl.stream));
+    c->last_bits_ev = sl.bits_ev;
+  }
   if ((rc = prof_launch(c, sl, PK_SPEND_ENC, (uint64_t)ch.m * c->L * 2, [&] { launch_spend_enc(a, sl.stream); }))) return rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_TAIL, ch.m, [&] { launch_spend_tail(a, sl.stream); }))) return rc;
   if ((rc = hash_begin(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), ch.m))) return rc;
@@ -524,6 +537,7 @@ void act_ctx_destroy(act_ctx* c) {
     if (sl.h_tr) (void)hipHostFree(sl.h_tr);
     if (sl.h_xof) (void)hipHostFree(sl.h_xof);
     for (hipEvent_t& e : sl.h_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (sl.bits_ev) (void)hipEventDestroy(sl.bits_ev);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->prof_base) (void)hipEventDestroy(c->prof_base);
@@ -693,17 +707,23 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
   const size_t pb = ProofLayout{c->L}.bytes();
-  // host-transcript mode pipelines the device with the D2H copy and the host threads: measured best at 16384 proofs per
-  // chunk (the device kernels themselves like 65536), so its chunks are capped there
-  static const size_t host_chunk = [] { const char* e = getenv("ACT_HOST_CHUNK"); size_t v = e ? (size_t)atol(e) : 0; return v ? v : (size_t)16384; }();   // tuning knob
+  static const size_t host_chunk_env = [] { const char* e = getenv("ACT_HOST_CHUNK"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning knob
+  // host-transcript mode: a chunk's transcripts go to the host, are hashed there and come back before its status kernel, all
+  // of which only overlaps with compute if there are other chunks to compute: long batches use full-size chunks (the
+  // kernels' best size), short ones are cut finer so that there is something to pipeline
+  const size_t host_chunk = host_chunk_env ? host_chunk_env : (n >= 4 * c->max_batch ? c->max_batch : (size_t)16384);
   const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
   const size_t nchunks = (n + chunk_len - 1) / chunk_len;
   SpendChunk chunks[2];
   size_t cursor = 0;
   const size_t depth = (size_t)c->depth;
+  static const int stagger_env = [] { const char* e = getenv("ACT_STAGGER"); return e ? atoi(e) : -1; }();      // tuning knob: force on / off
+  const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (mem == ACT_MEM_HOST || c->tr_mode == ACT_TRANSCRIPT_HOST);
+  c->last_bits_ev = nullptr;
   auto stage1 = [&](size_t i) -> int {
     Slot& sl = c->slots[i % depth]; SpendChunk& ch = chunks[i % depth];
     ch = SpendChunk{}; ch.off = i * chunk_len; ch.m = (uint32_t)std::min(chunk_len, n - ch.off);
+    ch.stagger = stagger;
     int r;
     if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
     if (out_kprime && (r = dev_out_begin(c, sl, 2, mem, out_kprime + ch.off * 32, (size_t)ch.m * 32, &ch.d_kprime))) return r;

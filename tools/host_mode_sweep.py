@@ -19,3 +19,6 @@ for thr in (0,):
     eng.lib.act_ctx_set_host_threads(eng.ctx, thr)
     a=t(lambda: eng.verify_spend_dev(sk,n,dev.data_ptr(),st.data_ptr())); b=t(lambda: eng.verify_spend_ptr(sk,n,capi.MEM_HOST,hp.data_ptr(),hs.data_ptr()))
     print("chunk",os.environ.get("ACT_HOST_CHUNK"),"threads",thr,"hbm",round(n/a),"hostmem",round(n/b), flush=True)
+eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
+a=t(lambda: eng.verify_spend_dev(sk,n,dev.data_ptr(),st.data_ptr())); b=t(lambda: eng.verify_spend_ptr(sk,n,capi.MEM_HOST,hp.data_ptr(),hs.data_ptr()))
+print("device transcripts: hbm",round(n/a),"hostmem",round(n/b), flush=True)
