@@ -711,7 +711,7 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   // host-transcript mode: a chunk's transcripts go to the host, are hashed there and come back before its status kernel, all
   // of which only overlaps with compute if there are other chunks to compute: long batches use full-size chunks (the
   // kernels' best size), short ones are cut finer so that there is something to pipeline
-  const size_t host_chunk = host_chunk_env ? host_chunk_env : (n >= 4 * c->max_batch ? c->max_batch : (size_t)16384);
+  const size_t host_chunk = host_chunk_env ? host_chunk_env : (n >= 8 * c->max_batch ? c->max_batch : (size_t)16384);
   const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
   const size_t nchunks = (n + chunk_len - 1) / chunk_len;
   SpendChunk chunks[2];
