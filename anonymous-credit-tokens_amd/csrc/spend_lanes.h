@@ -64,10 +64,7 @@ ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS, d0);
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS, d1);
   {                                                                            // the proof-wide challenge's digit string for k_spend_bits (msm.h naf3_recode)
-    uint32_t nf[NAF_WORDS];
-    naf3_recode(nf, sc_half(gamma));
-    uint32_t* dst = a.naf + (size_t)p * NAF_WORDS;
-    for (int i = 0; i < NAF_WORDS; i++) dst[i] = nf[i];
+    naf3_recode(a.naf + (size_t)p * NAF_WORDS, sc_half(gamma));
   }
 
   // A1 = (e_bar - x gamma) A' + r2_bar B_bar ; A2 += r3_bar B_bar

@@ -359,6 +359,13 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB):
     dt = timed(lambda: eng.verify_spend_dev(sk, m, dev.data_ptr(), st.data_ptr()), sync)
     assert torch.equal(st, expect[:m])
     ex["host_transcript_hbm"] = {"value": m / dt, "unit": "verifies/s", "what": "ACT_TRANSCRIPT_HOST, proofs and statuses in HBM (ACT_MEM_DEVICE)"}
+    nfull = dev.shape[0]
+    if nfull > m:                         # the same at the metric batch: pipeline fill and drain amortised over 16 chunks
+        stf = torch.zeros(nfull, dtype=torch.uint8, device="cuda")
+        dt = timed(lambda: eng.verify_spend_dev(sk, nfull, dev.data_ptr(), stf.data_ptr()), sync)
+        assert torch.equal(stf, expect)
+        ex["host_transcript_hbm_metric_batch"] = {"value": nfull / dt, "unit": "verifies/s", "proofs": nfull,
+                                                  "what": "ACT_TRANSCRIPT_HOST over the whole 2^%d batch, proofs in HBM" % args.batch_log2}
     # (2) ... with proofs in pinned host memory and statuses back in host memory: what a Rust caller's slices are
     hp = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); hp.copy_(dev[:m]); sync()
     hs = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
