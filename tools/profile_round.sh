@@ -16,7 +16,7 @@ f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats_depth1.csv
 bash tools/pmc_profile.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
 # the suite (incl. the full-size BASELINE configurations, whose rates land in <tag>_configs_from_tests.json) and the other configs
-ACT_WRITE_RATES=${tag}_configs_from_tests.json python3 -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${tag}_gpu_tests.log
+ACT_WRITE_RATES=${tag}_configs_from_tests.json python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > gpurun_out/${tag}_gpu_tests.log
 python3 tools/bench_configs.py > gpurun_out/${tag}_other_configs_1gpu.json 2> /dev/null
 rm -rf gpurun_out/${tag}_prof gpurun_out/${tag}_pmc
 head -4 gpurun_out/${tag}_kernel_stats_depth1.csv
