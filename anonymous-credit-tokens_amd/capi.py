@@ -17,7 +17,7 @@ _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_ctx_set_pipeline_depth", "act_build_has_ct_secret_tables", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_ctx_set_pipeline_depth", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     lib.act_ctx_set_host_threads.argtypes = [vp, i32]
     lib.act_ctx_set_pipeline_depth.argtypes = [vp, i32]
     lib.act_build_has_ct_secret_tables.argtypes = []
+    lib.act_ctx_fixed_base_bits.argtypes = [vp, i32]
     lib.act_last_error.argtypes = [vp]
     lib.act_last_error.restype = C.c_char_p
     for f in ("act_spend_proof_bytes", "act_prove_rng_bytes", "act_spend_transcript_bytes"):
@@ -227,6 +228,10 @@ class Engine:
 
     def set_transcript_mode(self, mode: int):
         self._ck(self.lib.act_ctx_set_transcript_mode(self.ctx, mode))
+
+    def fixed_base_bits(self):
+        """Window widths of the g, h1, h2, h3 tables of this context."""
+        return [self.lib.act_ctx_fixed_base_bits(self.ctx, b) for b in range(4)]
 
     def set_pipeline_depth(self, depth: int):
         self._ck(self.lib.act_ctx_set_pipeline_depth(self.ctx, depth))

@@ -68,7 +68,8 @@ struct act_ctx {
   int host_threads = 0;
   std::string err;
   Slot slots[2];
-  uint32_t* d_tables = nullptr;
+  uint32_t* d_tables[4] = {nullptr, nullptr, nullptr, nullptr};
+  int fb_bits[4] = {0, 0, 0, 0};        // window width of each base's table
   uint32_t* d_half_h1 = nullptr;
   uint32_t* d_tables_ct = nullptr;     // ACT_CT_SECRET_TABLES builds only
   // key cache
@@ -492,10 +493,19 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   HIPCK(c, hipMemcpyAsync(ok, d_ok, 16, hipMemcpyDeviceToHost, s0));
   HIPCK(c, hipStreamSynchronize(s0));
   if (!(ok[0] && ok[1] && ok[2] && ok[3])) { c->err = "h1/h2/h3 is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
-  HIPCK(c, hipMalloc(&c->d_tables, (size_t)4 * FB_TABLE_WORDS * 4));
+  // window widths: 16 bits everywhere by default (128 MiB per base); in contexts sized for throughput the two bases the
+  // range kernel multiplies (h1, h3: 48 of its table additions per proof-bit) get 24-bit windows, 23.6 GB each of the 288 GB
+  {
+    static const int wide_env = [] { const char* e = getenv("ACT_FB_WIDE_BITS"); return e ? atoi(e) : 0; }();          // tuning knobs
+    static const bool all_wide = getenv("ACT_FB_ALL_WIDE") != nullptr;                                                 // also g, h2 (prover-heavy deployments)
+    int wide = wide_env ? wide_env : (c->max_batch >= 32768 ? 24 : FB_WBITS);
+    if (wide < 4 || wide > 24) wide = FB_WBITS;
+    for (int b = 0; b < 4; b++) c->fb_bits[b] = (b == BASE_H1 || b == BASE_H3 || all_wide) ? wide : FB_WBITS;
+  }
   for (int b = 0; b < 4; b++) {
-    launch_build_table(d_ext + b * GE_WORDS, c->d_tables + (size_t)b * FB_TABLE_WORDS, s0);
-    c->P.tab[b] = c->d_tables + (size_t)b * FB_TABLE_WORDS;
+    HIPCK(c, hipMalloc(&c->d_tables[b], fb_table_words((uint32_t)c->fb_bits[b]) * 4));
+    launch_build_table(d_ext + b * GE_WORDS, c->d_tables[b], (uint32_t)c->fb_bits[b], s0);
+    c->P.tab[b] = FbTab{c->d_tables[b], (uint32_t)c->fb_bits[b], (uint32_t)b};
   }
 #if defined(ACT_CT_SECRET_TABLES)
   HIPCK(c, hipMalloc(&c->d_tables_ct, (size_t)4 * CT_TABLE_WORDS * 4));
@@ -541,7 +551,7 @@ void act_ctx_destroy(act_ctx* c) {
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->prof_base) (void)hipEventDestroy(c->prof_base);
-  if (c->d_tables) (void)hipFree(c->d_tables);
+  for (uint32_t* t : c->d_tables) if (t) (void)hipFree(t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
@@ -551,6 +561,7 @@ int act_ctx_set_transcript_mode(act_ctx* c, int mode) {
   if (!c || (mode != ACT_TRANSCRIPT_HOST && mode != ACT_TRANSCRIPT_DEVICE)) return ACT_ERR_ARG;
   c->tr_mode = mode; return ACT_OK;
 }
+int act_ctx_fixed_base_bits(const act_ctx* c, int base) { return (c && base >= 0 && base < 4) ? c->fb_bits[base] : 0; }
 int act_build_has_ct_secret_tables(void) {
 #if defined(ACT_CT_SECRET_TABLES)
   return 1;

@@ -82,18 +82,18 @@ inline void fe_note_g(const fe& g) { for (int i = 0; i < 10; i++) { uint64_t& m 
 inline void fe_note_f(const fe& f) { for (int i = 0; i < 10; i++) { uint64_t& m = (i & 1) ? fe_bounds.max_f_odd : fe_bounds.max_f_even; if (f.v[i] > m) m = f.v[i]; } }
 inline void fe_note_sub(const fe& g) { for (int i = 0; i < 10; i++) { uint64_t& m = (i & 1) ? fe_bounds.max_sub_odd : fe_bounds.max_sub_even; if (g.v[i] > m) m = g.v[i]; } }
 // ... and count the multiplications / squarings executed (the exact operation counts behind bench.py's ALU roofline)
-struct fe_counts_t { uint64_t mul, sq, fixed_base; };
+struct fe_counts_t { uint64_t mul, sq, fixed_base[4]; };
 extern fe_counts_t fe_counts;
 #define fe_count_mul() ((void)++fe_counts.mul)
 #define fe_count_sq() ((void)++fe_counts.sq)
-#define fe_count_fixed_base() ((void)++fe_counts.fixed_base)   // calls of msm.h fixed_base_acc: the host test build uses narrower windows
+#define fe_count_fixed_base(id) ((void)++fe_counts.fixed_base[(id) & 3u])   // calls of msm.h fixed_base_acc per base: the host test build uses narrower windows
 #else
 #define fe_note_g(x) ((void)0)
 #define fe_note_f(x) ((void)0)
 #define fe_note_sub(x) ((void)0)
 #define fe_count_mul() ((void)0)
 #define fe_count_sq() ((void)0)
-#define fe_count_fixed_base() ((void)0)
+#define fe_count_fixed_base(id) ((void)0)
 #endif
 
 ACT_HD fe fe_zero() { fe r; for (int i = 0; i < 10; i++) r.v[i] = 0; return r; }

@@ -7,15 +7,15 @@ namespace act {
 // T[pos][e] = e * 2^(w*pos) * B as affine Niels (msm.h).  lane = (pos, e): w*pos doublings of B, a
 // w-bit double-and-add, one inversion.  Runs once per context (cf. RistrettoBasepointTable::create,
 // /root/reference/src/lib.rs:311-313).
-__global__ void __launch_bounds__(256) k_build_table(const uint32_t* base_ext, uint32_t* table) {
+__global__ void __launch_bounds__(256) k_build_table(const uint32_t* base_ext, uint32_t* table, uint32_t wbits) {
   uint32_t gid = blockIdx.x * 256 + threadIdx.x;
-  if (gid >= (uint32_t)(FB_WINDOWS * FB_ENTRIES)) return;
-  uint32_t pos = gid / FB_ENTRIES, e = gid % FB_ENTRIES;
+  if (gid >= fb_windows(wbits) << wbits) return;
+  uint32_t pos = gid >> wbits, e = gid & ((1u << wbits) - 1u);
   ge b = ge_load(base_ext);
-  for (uint32_t i = 0; i < (uint32_t)FB_WBITS * pos; i++) b = ge_double(b);
+  for (uint32_t i = 0; i < wbits * pos; i++) b = ge_double(b);
   ge acc = ge_identity();
   ge_cached bc = ge_to_cached(b);
-  for (int bit = FB_WBITS - 1; bit >= 0; bit--) {
+  for (int bit = (int)wbits - 1; bit >= 0; bit--) {
     acc = ge_double(acc);
     if ((e >> bit) & 1u) acc = ge_add_cached(acc, bc);
   }
@@ -23,8 +23,9 @@ __global__ void __launch_bounds__(256) k_build_table(const uint32_t* base_ext, u
   ge af; af.X = fe_mul(acc.X, zi); af.Y = fe_mul(acc.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
   niels_store(table + (size_t)gid * NIELS_WORDS, niels_from_affine(af));
 }
-void launch_build_table(const uint32_t* base_ext, uint32_t* table, hipStream_t s) {
-  hipLaunchKernelGGL(k_build_table, dim3((FB_WINDOWS * FB_ENTRIES + 255) / 256), dim3(256), 0, s, base_ext, table);
+void launch_build_table(const uint32_t* base_ext, uint32_t* table, uint32_t wbits, hipStream_t s) {
+  const uint32_t lanes = fb_windows(wbits) << wbits;
+  hipLaunchKernelGGL(k_build_table, dim3((lanes + 255) / 256), dim3(256), 0, s, base_ext, table, wbits);
 }
 
 #if defined(ACT_CT_SECRET_TABLES)
@@ -51,7 +52,7 @@ void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_
 #endif
 
 // out[0] = identity, out[1] = B / 2 as affine Niels, B the base of `table`: the prover works at half scale (k_prove.hip)
-__global__ void k_half_point_table(const uint32_t* table, uint32_t* out) {
+__global__ void k_half_point_table(FbTab table, uint32_t* out) {
   if (blockIdx.x || threadIdx.x) return;
   ge h = fixed_base_acc(ge_identity(), table, sc_half(sc_one()));
   fe zi = fe_invert(h.Z);
@@ -59,7 +60,7 @@ __global__ void k_half_point_table(const uint32_t* table, uint32_t* out) {
   niels_store(out, niels_from_affine(ge_identity()));
   niels_store(out + NIELS_WORDS, niels_from_affine(af));
 }
-void launch_half_point_table(const uint32_t* table, uint32_t* out, hipStream_t s) { hipLaunchKernelGGL(k_half_point_table, dim3(1), dim3(64), 0, s, table, out); }
+void launch_half_point_table(FbTab table, uint32_t* out, hipStream_t s) { hipLaunchKernelGGL(k_half_point_table, dim3(1), dim3(64), 0, s, table, out); }
 
 __global__ void __launch_bounds__(64) k_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok) {
   uint32_t i = blockIdx.x * 64 + threadIdx.x;

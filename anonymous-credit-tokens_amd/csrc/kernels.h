@@ -28,7 +28,7 @@ constexpr int SMALL_TR_STRIDE = 512;      // request 266 B, respond 466 B, refun
 
 // Params-dependent constants, by value in every launch (~1 KiB of kernarg, read through the scalar cache)
 struct DevParams {
-  const uint32_t* tab[4];                 // position-specific fixed-base tables of g, h1, h2, h3 (msm.h)
+  FbTab tab[4];                           // position-specific fixed-base tables of g, h1, h2, h3 with their window widths (msm.h)
   const uint32_t* half_h1;                // two affine-Niels entries: identity, h1 / 2 (the prover's bit term at half scale)
 #if defined(ACT_CT_SECRET_TABLES)
   const uint32_t* tab_ct[4];              // small tables the secret-scalar products scan in full (msm.h fixed_base_acc_ct)
@@ -187,11 +187,11 @@ struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n;
 
 #if defined(__HIPCC__)
 // launchers (defined in the .hip files)
-void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, hipStream_t s);
+void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, uint32_t wbits, hipStream_t s);
 #if defined(ACT_CT_SECRET_TABLES)
 void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_t s);
 #endif
-void launch_half_point_table(const uint32_t* table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
+void launch_half_point_table(FbTab table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
 void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s);
 void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s);
 void launch_keygen(const DevParams& P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk, hipStream_t s);

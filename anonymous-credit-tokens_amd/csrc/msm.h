@@ -70,22 +70,32 @@ ACT_HD ge ge_load(const uint32_t* p) {
 }
 constexpr int GE_WORDS = 40;
 
-// acc += s * B using B's table; s canonical (< l).  FB_WINDOWS mixed additions, no doublings.  The entry of window
-// pos+1 is loaded before the addition of window pos (the tables live in L2 / Infinity Cache: ~550-cycle loads).
-ACT_HD uint32_t fb_next_digit(uint32_t w[8]) {
-  uint32_t digit = w[0] & (uint32_t)(FB_ENTRIES - 1);
+// A fixed-base table and its window width.  The width is a property of the table, chosen per base when a context is created
+// (engine.hip): 16 bits by default; the two bases of the range kernel (h1, h3) get 24-bit windows -- 11 instead of 16 table
+// additions per product, 23.6 GB per base -- in contexts sized for throughput (measured on one MI355X against 16 bits:
+// 20 bits +1.6 %, 22 bits +2.0 %, 24 bits +2.7 % verifies/s).  `id` = which base (host-side operation counting only).
+struct FbTab { const uint32_t* p; uint32_t wbits; uint32_t id; };
+ACT_HD uint32_t fb_windows(uint32_t wbits) { return (253u + wbits - 1u) / wbits; }      // scalars are canonical: < l < 2^253
+ACT_HD size_t fb_table_words(uint32_t wbits) { return (size_t)fb_windows(wbits) * ((size_t)1 << wbits) * NIELS_WORDS; }
+
+// acc += s * B using B's table; s canonical (< l).  fb_windows(wbits) mixed additions, no doublings.  The entry of window
+// pos+1 is loaded before the addition of window pos (the tables live in L2 / Infinity Cache / HBM: ~550-cycle loads).
+ACT_HD uint32_t fb_next_digit(uint32_t w[8], uint32_t wbits) {
+  uint32_t digit = w[0] & ((1u << wbits) - 1u);
   // shift the scalar down one window (static indices only: a runtime-indexed limb array would live in scratch)
-  for (int i = 0; i < 7; i++) w[i] = (w[i] >> FB_WBITS) | (w[i + 1] << (32 - FB_WBITS));
-  w[7] >>= FB_WBITS;
+  for (int i = 0; i < 7; i++) w[i] = (w[i] >> wbits) | (w[i + 1] << (32u - wbits));
+  w[7] >>= wbits;
   return digit;
 }
-ACT_HD ge fixed_base_acc(ge acc, const uint32_t* table, const sc& s) {
-  fe_count_fixed_base();
+ACT_HD ge fixed_base_acc(ge acc, const FbTab& t, const sc& s) {
+  fe_count_fixed_base(t.id);
   uint32_t w[8];
   for (int i = 0; i < 8; i++) w[i] = s.v[i];
-  ge_niels cur = niels_load(table + (size_t)fb_next_digit(w) * NIELS_WORDS);
-  for (int pos = 1; pos < FB_WINDOWS; pos++) {
-    ge_niels nxt = niels_load(table + ((size_t)pos * FB_ENTRIES + fb_next_digit(w)) * NIELS_WORDS);
+  const uint32_t nw = fb_windows(t.wbits);
+  const size_t entries = (size_t)1 << t.wbits;
+  ge_niels cur = niels_load(t.p + (size_t)fb_next_digit(w, t.wbits) * NIELS_WORDS);
+  for (uint32_t pos = 1; pos < nw; pos++) {
+    ge_niels nxt = niels_load(t.p + ((size_t)pos * entries + fb_next_digit(w, t.wbits)) * NIELS_WORDS);
     acc = ge_madd(acc, cur);
     cur = nxt;
   }
@@ -514,7 +524,7 @@ ACT_HD ge fixed_base_acc_s(ge acc, const uint32_t* table_ct, const sc& s) { retu
 template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t* bk) { chain_b<NACC, true>(acc, N, s, bk); }
 #else
 #define ACT_FB_S(P, base) ((P).tab[base])
-ACT_HD ge fixed_base_acc_s(ge acc, const uint32_t* table, const sc& s) { return fixed_base_acc(acc, table, s); }
+ACT_HD ge fixed_base_acc_s(ge acc, const FbTab& table, const sc& s) { return fixed_base_acc(acc, table, s); }
 template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t* bk) { chain_b<NACC, false>(acc, N, s, bk); }
 #endif
 

@@ -150,10 +150,11 @@ def config1_round_trip(ctx, L, reps=6):
     return {k: round(1e3 * v / reps, 3) for k, v in acc.items()}
 
 
-def count_field_ops(h, L, sk, proofs_host, sample=4):
+def count_field_ops(h, L, sk, proofs_host, fb_bits, sample=4):
     """Exact field-operation counts of one verify: the spend kernels' own lane bodies (csrc/spend_lanes.h) executed on the
     host, with counting fe_mul / fe_sq, by the instrumented test build tests/hostcheck (built here with g++).  A count of
-    operations, not a computation of results: statuses come from the GPU."""
+    operations, not a computation of results: statuses come from the GPU.  fb_bits = the context's table window widths
+    (g, h1, h2, h3): a fixed-base product is ceil(253 / bits) mixed additions of 7 multiplications."""
     src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
     out = os.path.join("/tmp", "libhostcheck_bench_%d.so" % os.getpid())
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src], check=True)
@@ -161,14 +162,16 @@ def count_field_ops(h, L, sk, proofs_host, sample=4):
     pb = proof_bytes(L); n = sample
     tb = 184 + 40 * (6 + 3 * L)
     tr = ctypes.create_string_buffer(n * tb); st = ctypes.create_string_buffer(n); kp = ctypes.create_string_buffer(32 * n)
-    c = (ctypes.c_uint64 * 13)()
+    c = (ctypes.c_uint64 * 25)()
     ok = hc.hc_spend_verify(h, L, sk, n, proofs_host[:pb * n], tr, st, kp, c)
     os.unlink(out)
     assert ok == 1 and st.raw == bytes(n)
+    windows = [-(-253 // b) for b in fb_bits]
     per = {}
     for k, name in enumerate(("k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail")):
-        mul, sq, fb = c[3 * k], c[3 * k + 1], c[3 * k + 2]
-        per[name] = {"fe_mul": (mul - fb * (c[12] - 16) * 7) / n, "fe_sq": sq / n}      # restated for the product's 16 fixed-base windows
+        mul, sq = c[6 * k], c[6 * k + 1]
+        fb = [c[6 * k + 2 + b] for b in range(4)]
+        per[name] = {"fe_mul": (mul - sum(fb[b] * (c[24] - windows[b]) * 7 for b in range(4))) / n, "fe_sq": sq / n}
     return per
 
 
@@ -288,6 +291,7 @@ def main():
             "config": {"workload": "configs[1] scaled to the metric batch: 2^%d spend-proof verifies per GPU, L=%d%s, inputs resident in HBM"
                                    % (args.batch_log2, L, " (the crate's width)" if L == 128 else ""),
                        "batch_per_gpu": n, "range_bits": L, "lanes_per_launch": args.max_batch, "chunks_in_flight": args.pipeline_depth, "transcript": "device BLAKE3",
+                       "fixed_base_window_bits_g_h1_h2_h3": eng.fixed_base_bits(),
                        "sharding": "independent batches per rank, no collective"},
         }
         roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
@@ -317,7 +321,7 @@ def main():
         if world == 1:
             # ---- the ALU roofline: measured peak of the multiply-accumulate instruction, counted work per verify -------
             peak_mad, probe_ms = capi.ubench_mad(local)
-            ops = count_field_ops(h, L, sk, proofs)
+            ops = count_field_ops(h, L, sk, proofs, eng.fixed_base_bits())
             fe_mul = sum(v["fe_mul"] for v in ops.values()); fe_sq = sum(v["fe_sq"] for v in ops.values())
             mad_per_verify = 100 * fe_mul + 55 * fe_sq          # fe25519.h: a product is 10 columns x 10 v_mad_u64_u32, a square 55
             bits_mad = (100 * ops["k_spend_bits"]["fe_mul"] + 55 * ops["k_spend_bits"]["fe_sq"]) * proofs_per_launch

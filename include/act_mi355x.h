@@ -97,7 +97,8 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
  * RistrettoBasepointTables of src/lib.rs:222-229) + the range-proof width L (src/lib.rs:116; 128 is the
  * crate's value, 1..128 accepted) + one GPU.  max_batch bounds the records per internal launch and
  * thereby the workspace: about 220 KB per record at L = 128 (1.7 KB per range-proof bit), times two
- * pipeline slots.  0 = default = 65536 (29 GB of the 288 GB at L = 128), from which size on the
+ * pipeline slots, plus the fixed-base tables (0.5 GB; 48 GB from max_batch 32768 up, where h1 and h3 get 24-bit windows).
+ * 0 = default = 65536 (29 GB of workspace at L = 128), from which size on the
  * throughput of every entry point is flat; 16384 costs about 5 % of the verify rate and two thirds
  * of the issue/request rate.  Batches of any length are accepted and processed in such chunks.  max_batch > 2^22 is
  * refused (ACT_ERR_ARG).  On failure *out still receives a context whose only use is act_last_error() and
@@ -115,6 +116,9 @@ int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
  * full and picked with masks, so the memory-access pattern is independent of secrets, as the reference's use of `subtle`
  * and dalek's table scans are (src/lib.rs:98, 1025-1118).  0 = default build: addressed look-ups. */
 int act_build_has_ct_secret_tables(void);
+/* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
+ * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 when max_batch >= 32768 (23.6 GB per base) */
+int act_ctx_fixed_base_bits(const act_ctx *ctx, int base);
 const char *act_last_error(const act_ctx *ctx);
 size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
 size_t act_prove_rng_bytes(const act_ctx *ctx);             /* 64*(4L+12) */

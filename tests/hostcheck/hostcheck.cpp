@@ -8,7 +8,7 @@
 #define ACT_FB_WBITS 6   /* host test of the window logic: small tables (43 windows x 64 entries) */
 #include "../../anonymous-credit-tokens_amd/csrc/spend_lanes.h"
 
-namespace act { fe_bounds_t fe_bounds = {0, 0, 0, 0, 0, 0}; fe_counts_t fe_counts = {0, 0, 0}; }
+namespace act { fe_bounds_t fe_bounds = {0, 0, 0, 0, 0, 0}; fe_counts_t fe_counts = {0, 0, {0, 0, 0, 0}}; }
 using namespace act;
 
 static void ld(uint32_t w[8], const uint8_t* b) { memcpy(w, b, 32); }
@@ -83,7 +83,7 @@ int hc_fixed_base(const uint8_t* pt, const uint8_t* s, uint8_t* o) {
     }
     base = acc;   // 2^w * base
   }
-  ge acc = fixed_base_acc(ge_identity(), tab.data(), sc_in(s));
+  ge acc = fixed_base_acc(ge_identity(), FbTab{tab.data(), (uint32_t)FB_WBITS, 0u}, sc_in(s));
   ristretto_encode(r, acc); st(o, r);
   return 1;
 }
@@ -141,10 +141,10 @@ extern "C" int hc_chain_bu(const uint8_t* pt, const uint8_t* s0, const uint8_t* 
 // Builds Params tables the way k_build_table does, then executes exactly what the five kernels execute for `n` proofs:
 // prep (lane = proof), bits (lane = (proof, bit)), enc (lane = 32 half-points), tail, BLAKE3, finish.  Outputs: the
 // "spend" transcript pre-images, statuses, enc(K'), and the number of field multiplications / squarings each kernel's
-// lanes executed: counts[3*k .. 3*k+2] = fe_mul, fe_sq, fixed_base_acc calls for k = prep, bits, enc, tail.  This build's
-// fixed-base windows are ACT_FB_WBITS = 6 bits wide (43 mixed additions of 7 multiplications per call, tables small enough
-// to build per test); counts[12] = that window count, so the caller can restate the multiplications for the product's
-// 16 windows exactly: mul - calls * (counts[12] - 16) * 7.
+// lanes executed: counts[6*k .. 6*k+5] = fe_mul, fe_sq, fixed_base_acc calls on g, h1, h2, h3 for k = prep, bits, enc, tail.
+// This build's fixed-base windows are ACT_FB_WBITS = 6 bits wide (43 mixed additions of 7 multiplications per call, tables
+// small enough to build per test); counts[24] = that window count, so the caller can restate the multiplications for the
+// product's windows exactly: mul - sum_b calls_b * (counts[24] - product_windows_b) * 7.
 namespace {
 struct HostTables { uint8_t h[96]; std::vector<uint32_t> tab[4]; bool valid = false; };
 HostTables g_tabs;
@@ -176,7 +176,7 @@ extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint3
                                uint8_t* out_status, uint8_t* out_kprime, uint64_t* counts) {
   if (L < 1 || L > 128 || !build_tables(h)) return 0;
   SpendArgs a{};
-  for (int b = 0; b < 4; b++) a.P.tab[b] = g_tabs.tab[b].data();
+  for (int b = 0; b < 4; b++) a.P.tab[b] = FbTab{g_tabs.tab[b].data(), (uint32_t)FB_WBITS, (uint32_t)b};
   a.P.half_h1 = nullptr; a.P.L = L;
   static const char* const labels[4] = {"request", "respond", "spend", "refund"};
   static const char version[] = "curve25519-ristretto anonymous-credits v1.0";
@@ -192,10 +192,14 @@ extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint3
       xa((size_t)n * GE_WORDS), flags(n, 0), xof((size_t)n * 16), naf((size_t)n * NAF_WORDS), dig((size_t)n * L * 8);
   a.proofs = proofs; a.n = n; a.tr = tr.data(); a.tr_stride = (uint32_t)st.stride(); a.coords = coords.data(); a.d01 = d01.data();
   a.buckets = buckets.data(); a.xa = xa.data(); a.flags = flags.data(); a.xof = xof.data(); a.status = status.data(); a.kprime_enc = kp.data(); a.naf = naf.data(); a.dig = dig.data();
-  uint64_t c[13] = {0};
-  c[12] = FB_WINDOWS;
-  auto snap = [&](int k) { c[3 * k] += fe_counts.mul; c[3 * k + 1] += fe_counts.sq; c[3 * k + 2] += fe_counts.fixed_base; fe_counts = fe_counts_t{0, 0, 0}; };
-  fe_counts = fe_counts_t{0, 0, 0};
+  uint64_t c[25] = {0};
+  c[24] = FB_WINDOWS;
+  auto snap = [&](int k) {
+    c[6 * k] += fe_counts.mul; c[6 * k + 1] += fe_counts.sq;
+    for (int b = 0; b < 4; b++) c[6 * k + 2 + b] += fe_counts.fixed_base[b];
+    fe_counts = fe_counts_t{0, 0, {0, 0, 0, 0}};
+  };
+  fe_counts = fe_counts_t{0, 0, {0, 0, 0, 0}};
   for (uint32_t p = 0; p < n; p++) spend_prep_lane(a, p);
   snap(0);
   for (uint32_t g = 0; g < n * (uint32_t)L; g++) { if (L % 64 == 0) spend_bits_lane<true>(a, g, nullptr); else spend_bits_lane<false>(a, g, nullptr); }

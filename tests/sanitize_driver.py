@@ -92,7 +92,7 @@ def device_headers(path):
     proofs = b"".join(hx(c["proof"]) for c in cases)
     tb = 184 + 40 * (6 + 3 * L)
     tr = C.create_string_buffer(n * tb); st = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
-    counts = (C.c_uint64 * 13)()
+    counts = (C.c_uint64 * 25)()
     assert hc.hc_spend_verify(hx(g["params"]), L, hx(g["sk"]), n, proofs, tr, st, kp, counts) == 1
     assert list(st.raw) == [c["status"] for c in cases]
     for i, c in enumerate(cases):

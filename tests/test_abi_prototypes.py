@@ -42,7 +42,7 @@ def test_every_prototype_matches_the_binding():
     from act_amd import capi
     lib = capi.load()
     protos = parse_header()
-    assert len(protos) >= 65, sorted(protos)
+    assert len(protos) >= 66, sorted(protos)
     assert set(protos) == set(capi.EXPORTS), set(protos) ^ set(capi.EXPORTS)
     for name, (ret, params) in protos.items():
         fn = getattr(lib, name)

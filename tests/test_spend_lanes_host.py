@@ -17,17 +17,20 @@ def host_verify(hc, h, L, sk, proofs):
     n = len(proofs) // pb
     tb = 184 + 40 * (6 + 3 * L)
     tr = C.create_string_buffer(n * tb); st = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
-    counts = (C.c_uint64 * 13)()
+    counts = (C.c_uint64 * 25)()
     assert hc.hc_spend_verify(h, L, sk, n, proofs, tr, st, kp, counts) == 1
     return st.raw, kp.raw, [tr.raw[i * tb:(i + 1) * tb] for i in range(n)], op_counts(list(counts), n)
 
 
-def op_counts(c, n):
-    """Per-proof field operations of each kernel restated for the product's 16 fixed-base windows (this build: c[12])."""
+def op_counts(c, n, product_windows=(16, 16, 16, 16)):
+    """Per-proof field operations of each kernel restated for the product's fixed-base windows per base g, h1, h2, h3
+    (this build: c[24] windows of 6 bits)."""
     out = {}
     for k, name in enumerate(("k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail")):
-        mul, sq, fb = c[3 * k:3 * k + 3]
-        out[name] = {"fe_mul": (mul - fb * (c[12] - 16) * 7) / n, "fe_sq": sq / n, "fixed_base_mults": fb / n}
+        mul, sq = c[6 * k], c[6 * k + 1]
+        fb = c[6 * k + 2:6 * k + 6]
+        out[name] = {"fe_mul": (mul - sum(fb[b] * (c[24] - product_windows[b]) * 7 for b in range(4))) / n, "fe_sq": sq / n,
+                     "fixed_base_mults": sum(fb) / n}
     return out
 
 
