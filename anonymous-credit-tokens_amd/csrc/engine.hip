@@ -82,6 +82,7 @@ struct act_ctx {
   std::vector<std::pair<float, float>> prof_iv[PK_COUNT];          // [start, end) of every launch, ms since prof_base
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
+  double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
 };
 
 namespace {
@@ -250,7 +251,7 @@ int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_
 int hash_end(act_ctx* c, Slot& sl, uint32_t stride, uint32_t len, uint32_t n) {
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) return ACT_OK;
   static const bool trace = getenv("ACT_TRACE") != nullptr;      // where the host side of the host-transcript mode spends its time
-  static double t_wait = 0, t_hash = 0; static size_t n_msgs = 0;
+  double& t_wait = c->trace_wait_s; double& t_hash = c->trace_hash_s; size_t& n_msgs = c->trace_msgs;      // per context: contexts run on their own threads
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int k = 0; k < HASH_PIECES; k++) {
     size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
