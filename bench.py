@@ -175,15 +175,16 @@ def count_field_ops(h, L, sk, proofs_host, fb_bits, sample=4):
     return per
 
 
-def newest_matching_pmc(kind, proofs_per_launch, sha):
-    """Newest profiles/*_<kind>.json collected from the kernel sources this run was built from (same hash, same launch size)."""
+def newest_matching_pmc(kind, proofs_per_launch, sha, L=128):
+    """Newest profiles/*_<kind>.json collected from the kernel sources this run was built from (same hash, same launch size,
+    same range width)."""
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s.json" % kind))):
         try:
             j = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if j.get("kernel_source_sha16") == sha and int(j.get("proofs_per_launch", -1)) == int(proofs_per_launch):
+        if j.get("kernel_source_sha16") == sha and int(j.get("proofs_per_launch", -1)) == int(proofs_per_launch) and int(j.get("range_bits", 128)) == L:
             best = (os.path.relpath(f, ROOT), j)
     return best
 
@@ -303,12 +304,12 @@ def main():
                 "note": "not HBM bound: 16.8 KB in per verify against ~43 M 64-bit multiply-accumulates (roofline.alu is the binding view); "
                         "PMC traffic is dominated by the per-lane Pippenger buckets cycling through L2 / Infinity Cache"}
         sha = kernel_source_sha16()
-        t = newest_matching_pmc("pmc_hbm_traffic", proofs_per_launch, sha)
+        t = newest_matching_pmc("pmc_hbm_traffic", proofs_per_launch, sha, L)
         if t:
             roof["traffic"] = t[1]["hbm_bytes_per_launch_fetch_x2"]; roof["traffic_source"] = t[0]
         else:
-            roof["traffic_source"] = "none: no profiles/*_pmc_hbm_traffic.json was collected from these kernel sources (sha %s)" % sha
-        v = newest_matching_pmc("pmc_valu", proofs_per_launch, sha)
+            roof["traffic_source"] = "none: no profiles/*_pmc_hbm_traffic.json was collected from these kernel sources (sha %s) at L = %d" % (sha, L)
+        v = newest_matching_pmc("pmc_valu", proofs_per_launch, sha, L)
         if v:
             j = v[1]
             roof["pmc_valu"] = {"source": v[0], "valu_instructions_per_wave": j["valu_instructions_per_wave"],

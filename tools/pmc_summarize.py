@@ -17,7 +17,7 @@ for d in sorted(glob.glob("gpurun_out/%s_pmc/p*" % tag)):
             if "k_spend_bits" in r["Kernel_Name"]:
                 for n in names: dur[n] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 waves = tot["SQ_WAVES"]
-valu = {"kernel": "k_spend_bits", "kernel_source_sha16": SHA, "proofs_per_launch": NB, "waves": waves,
+valu = {"kernel": "k_spend_bits", "kernel_source_sha16": SHA, "range_bits": 128, "proofs_per_launch": NB, "waves": waves,
         "valu_instructions_per_wave": tot["SQ_INSTS_VALU"] / waves,
         "wave_lifetime_cycles": 4 * tot["SQ_WAVE_CYCLES"] / waves,
         "cycles_per_valu_instruction_per_simd_2waves": 4 * tot["SQ_WAVE_CYCLES"] / (2 * tot["SQ_INSTS_VALU"]),
@@ -31,7 +31,7 @@ valu = {"kernel": "k_spend_bits", "kernel_source_sha16": SHA, "proofs_per_launch
         "note": "rocprofv3 --pmc (tools/pmc_profile.sh, one chunk in flight); SQ_WAVE_CYCLES counts quad-cycles; two waves share a SIMD"}
 json.dump(valu, open("gpurun_out/%s_pmc_valu.json" % tag, "w"), indent=1)
 f, w = tot["FETCH_SIZE"] * 1024, tot["WRITE_SIZE"] * 1024
-json.dump({"kernel": "k_spend_bits", "kernel_source_sha16": SHA, "proofs_per_launch": NB, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
+json.dump({"kernel": "k_spend_bits", "kernel_source_sha16": SHA, "range_bits": 128, "proofs_per_launch": NB, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
            "hbm_bytes_per_launch_uncorrected": f + w, "hbm_bytes_per_launch_fetch_x2": 2 * f + w,
            "note": "separate --pmc passes (tools/pmc_profile.sh, NB=%d); gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), both figures given; includes the per-lane Pippenger bucket and scratch traffic, counted at the L2's memory side (Infinity-Cache hits are not excluded)" % NB},
           open("gpurun_out/%s_pmc_hbm_traffic.json" % tag, "w"), indent=1)
