@@ -4,7 +4,8 @@ The reference leaves the double-spend database to the caller (/root/reference/sr
 `HashSet<Scalar>` driven by `if is_spent(k) { reject } else { insert(k) }` in src/tests.rs:29-50).  On one GPU that
 loop is `act_nullifier_check_and_insert_batch` (include/act_mi355x.h).  With one process per GPU, every rank verifies
 its own shard of spend proofs, but a nullifier must be looked up where *all* earlier spends of it were recorded,
-so the key space is partitioned: owner(k) = low 64 bits of k mod world (nullifiers are uniform scalars).  A batch
+so the key space is partitioned: owner(k) = low 64 bits of (k mod l) mod world (nullifiers are uniform scalars; the
+reduction makes k and k + l one key, as in the reference's HashSet<Scalar>).  A batch
 call is then
 
     1. bucket this rank's nullifiers by owner (stable, on the GPU),
@@ -24,6 +25,40 @@ from typing import Optional
 
 import torch
 import torch.distributed as dist
+
+
+_ELL = 2**252 + 27742317777372353535851937790883648493
+
+
+def reduce_mod_l(keys: torch.Tensor) -> torch.Tensor:
+    """[n, 32] uint8 little-endian 256-bit values -> their canonical representatives mod l, same shape.  A nullifier is a
+    SCALAR (the reference keeps a HashSet<Scalar>, and decode_scalar reduces, src/cbor.rs:85): k and k + l are one key, so
+    the owner must be computed from -- and the owning shard must store -- the reduced value.  x < 2^256 < 16 l:
+    with q = x >> 252 and l = 2^252 + c, x - q l = (x mod 2^252) - q c, plus l once if that went negative."""
+    n = keys.shape[0]
+    if n == 0:
+        return keys.reshape(0, 32)
+    w = keys.contiguous().view(torch.int32).reshape(n, 8).to(torch.int64) & 0xFFFFFFFF
+    q = w[:, 7] >> 28
+    limbs = [w[:, i].clone() for i in range(8)]
+    limbs[7] = limbs[7] & 0x0FFFFFFF
+    c = _ELL - 2**252
+    qc, carry = [], torch.zeros_like(q)
+    for i in range(4):
+        t = q * ((c >> (32 * i)) & 0xFFFFFFFF) + carry
+        qc.append(t & 0xFFFFFFFF); carry = t >> 32
+    qc.append(carry)
+    borrow = torch.zeros_like(q)
+    for i in range(8):
+        t = limbs[i] - (qc[i] if i < 5 else 0) - borrow
+        borrow = (t < 0).to(torch.int64)
+        limbs[i] = t + (borrow << 32)
+    carry = torch.zeros_like(q)
+    for i in range(8):                                  # + l where the difference was negative
+        t = limbs[i] + borrow * ((_ELL >> (32 * i)) & 0xFFFFFFFF) + carry
+        limbs[i] = t & 0xFFFFFFFF; carry = t >> 32
+    cols = [((limbs[i] >> (8 * b)) & 0xFF) for i in range(8) for b in range(4)]
+    return torch.stack(cols, dim=1).to(torch.uint8)
 
 
 class _HipLocalSet:
@@ -72,7 +107,7 @@ class ShardedNullifierSet:
         dev = keys.device
         spent = torch.zeros(n, dtype=torch.uint8, device=dev)
         active = torch.arange(n, device=dev) if skip_mask is None else torch.nonzero(skip_mask == 0).reshape(-1)
-        k = keys[active] if n else keys.reshape(0, 32)
+        k = reduce_mod_l(keys[active]) if n else keys.reshape(0, 32)      # route and store scalars, not byte strings
         own = self.owner(k) if k.shape[0] else torch.zeros(0, dtype=torch.int64, device=dev)
         order = torch.argsort(own, stable=True)                       # lane order survives inside each owner's bucket
         send = k[order].contiguous()

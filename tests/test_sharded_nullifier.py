@@ -153,3 +153,18 @@ def test_hip_set_behind_a_one_rank_rccl_group():
         s.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_keys_are_reduced_before_routing():
+    """k and k + l (the verifier accepts both spellings) must go to one owner as one key: reduce_mod_l against Python integers,
+    incl. the values whose (x mod 2^252) - q c goes negative."""
+    import act_amd  # noqa: F401
+    from act_amd.sharded_nullifier import reduce_mod_l, _ELL
+    r = random.Random(3)
+    vals = [0, 1, _ELL - 1, _ELL, _ELL + 1, 2 * _ELL - 1, 15 * _ELL, 15 * _ELL + 5, 2**256 - 1, 2**252, 2**252 + 5, 2**253, 3 * 2**252 + 7,
+            15 * 2**252, 15 * 2**252 + (_ELL - 2**252) * 15 - 1] + [r.randrange(2**256) for _ in range(500)]
+    t = torch.tensor([list(v.to_bytes(32, "little")) for v in vals], dtype=torch.uint8)
+    out = reduce_mod_l(t)
+    for v, row in zip(vals, out.tolist()):
+        assert int.from_bytes(bytes(row), "little") == v % _ELL, hex(v)
+    assert reduce_mod_l(t[:0]).shape == (0, 32)
