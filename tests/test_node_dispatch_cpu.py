@@ -1,0 +1,135 @@
+"""The node dispatcher (csrc/node.cpp: shard cutting, per-shard pointer arithmetic, the check -> count -> sign protocol that
+keeps ACT_RNG_SEQUENTIAL exact across shards, host-side routing of the node-level nullifier set) linked against TEST-ONLY
+stand-ins for the single-GPU entry points (tests/node_mock/node_mock.cpp), so that it runs without a device.  The mock
+makes every slicing decision visible: a lane's output is its record's tag followed by the rng bytes it was handed.  The same
+dispatcher over real contexts is tests/test_gpu_node.py."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+PB = 64
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("node_mock") / "libnode_mock.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Werror", "-pthread", "-o", out,
+                    os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc", "node.cpp"), os.path.join(ROOT, "tests", "node_mock", "node_mock.cpp")], check=True)
+    l = C.CDLL(out)
+    l.act_node_ctx.restype = C.c_void_p
+    l.act_node_ctx.argtypes = [C.c_void_p, C.c_int]
+    l.act_mock_lanes.restype = C.c_size_t
+    l.act_mock_lanes.argtypes = [C.c_void_p]
+    l.act_node_nullifier_set_len.restype = C.c_size_t
+    return l
+
+
+def make_node(lib, ndev):
+    nd = C.c_void_p()
+    devs = (C.c_int * ndev)(*range(ndev))
+    assert lib.act_node_create(bytes(96), 128, devs, ndev, C.c_size_t(0), C.byref(nd)) == 0
+    return nd
+
+
+def records(n, rec, seed):
+    r = random.Random(seed)
+    out = bytearray()
+    for i in range(n):
+        out += bytes([r.randrange(256)]) + i.to_bytes(7, "little") + bytes(r.randrange(256) for _ in range(rec - 8))
+    return bytes(out)
+
+
+@pytest.mark.parametrize("ndev", [1, 2, 3, 8])
+@pytest.mark.parametrize("n", [0, 1, 5, 23, 1000])
+def test_sequential_rng_is_exact_across_shards(lib, ndev, n):
+    nd = make_node(lib, ndev)
+    proofs = records(n, PB, 1000 * ndev + n)
+    rng = records(n, 128, 7)                         # slice j starts with a byte and then j itself
+    sk = bytes(64)
+    for fn, rec_in, rec_out, bad in (("act_node_refund_batch", PB, 128, 7), ("act_node_issue_batch", 128, 160, 1)):
+        inp = proofs if rec_in == PB else records(n, 128, 99 + n)
+        for mode in (0, 1):
+            out = C.create_string_buffer(max(1, rec_out * n)); st = C.create_string_buffer(max(1, n))
+            args = [nd, C.c_size_t(n), sk, inp] + ([bytes(32 * n)] if fn.endswith("issue_batch") else []) + [rng, mode, out, st]
+            assert getattr(lib, fn)(*args) == 0
+            cur = 0
+            for i in range(n):
+                acc = inp[rec_in * i] % 2 == 0
+                assert st.raw[i] == (0 if acc else bad), (fn, mode, i)
+                got = out.raw[rec_out * i:rec_out * (i + 1)]
+                if not acc:
+                    assert got == bytes(rec_out)
+                    continue
+                slot = i if mode == 0 else cur
+                cur += 1
+                assert got[:8] == inp[rec_in * i:rec_in * i + 8], "lane %d carries another lane's record" % i
+                assert got[8:16] == rng[128 * slot:128 * slot + 8], "lane %d (mode %d) was handed rng slice %d" % (i, mode, int.from_bytes(got[9:16], "little"))
+    # the halves on their own: verify -> count -> sign with exactly accepted * 128 bytes
+    st = C.create_string_buffer(max(1, n)); kp = C.create_string_buffer(max(1, 32 * n))
+    assert lib.act_node_verify_spend_batch(nd, C.c_size_t(n), sk, proofs, st, kp) == 0
+    accepted = sum(1 for i in range(n) if st.raw[i] == 0)
+    out = C.create_string_buffer(max(1, 128 * n)); st2 = C.create_string_buffer(max(1, n))
+    assert lib.act_node_refund_sign_batch(nd, C.c_size_t(n), sk, kp.raw[:32 * n], st.raw[:n], rng[:128 * accepted] + b"\0", 1, out, st2) == 0
+    one = C.create_string_buffer(max(1, 128 * n)); st3 = C.create_string_buffer(max(1, n))
+    assert lib.act_node_refund_batch(nd, C.c_size_t(n), sk, proofs, rng, 1, one, st3) == 0
+    assert out.raw[:128 * n] == one.raw[:128 * n] and st2.raw[:n] == st3.raw[:n]
+    # every context got its contiguous share
+    if n >= ndev:
+        lanes = [lib.act_mock_lanes(lib.act_node_ctx(nd, k)) for k in range(ndev)]
+        assert min(lanes) > 0 and max(lanes) - min(lanes) <= 12 * (n // ndev + 1)
+    lib.act_node_destroy(nd)
+
+
+def test_other_entry_points_slice_consistently(lib):
+    nd = make_node(lib, 3)
+    n = 29
+    pre = records(n, 64, 1); rng = records(n, 128, 2)
+    out = C.create_string_buffer(128 * n)
+    assert lib.act_node_request_batch(nd, C.c_size_t(n), pre, rng, out) == 0
+    for i in range(n):
+        assert out.raw[128 * i:128 * i + 8] == pre[64 * i:64 * i + 8] and out.raw[128 * i + 8:128 * i + 16] == rng[128 * i:128 * i + 8]
+    tok = records(n, 160, 3); s = records(n, 32, 4); prng = records(n, 256, 5)
+    proof = C.create_string_buffer(PB * n); prer = C.create_string_buffer(96 * n); st = C.create_string_buffer(n)
+    assert lib.act_node_prove_spend_batch(nd, C.c_size_t(n), tok, s, prng, proof, prer, st) == 0
+    for i in range(n):
+        assert proof.raw[PB * i:PB * i + 8] == tok[160 * i:160 * i + 8] and proof.raw[PB * i + 8:PB * i + 16] == prng[256 * i:256 * i + 8]
+        assert prer.raw[96 * i:96 * i + 8] == s[32 * i:32 * i + 8] and prer.raw[96 * i + 8:96 * i + 16] == prng[256 * i + 128:256 * i + 136]
+    refund = records(n, 128, 6); w = bytes(32)
+    t2 = C.create_string_buffer(160 * n)
+    assert lib.act_node_refund_to_credit_token_batch(nd, C.c_size_t(n), prer.raw, proof.raw, refund, w, t2, st) == 0
+    for i in range(n):
+        assert t2.raw[160 * i:160 * i + 8] == prer.raw[96 * i:96 * i + 8] and t2.raw[160 * i + 8:160 * i + 16] == refund[128 * i:128 * i + 8]
+        assert t2.raw[160 * i + 159] == proof.raw[PB * i]
+    lib.act_node_destroy(nd)
+
+
+def test_node_nullifier_routing_is_by_scalar(lib):
+    """k and k + l must reach the same per-device set; masks and repeats keep the sequential meaning across the four sets."""
+    ELL = 2**252 + 27742317777372353535851937790883648493
+    ns = C.c_void_p()
+    devs = (C.c_int * 4)(0, 1, 2, 3)
+    assert lib.act_node_nullifier_set_create(devs, 4, C.c_size_t(1000), None, C.byref(ns)) == 0
+    r = random.Random(5)
+    ks = [r.randrange(ELL) for _ in range(300)]
+    le = lambda v: v.to_bytes(32, "little")
+    keys = b"".join(le(k) for k in ks)
+    spent = C.create_string_buffer(300)
+    assert lib.act_node_nullifier_check_and_insert_batch(ns, C.c_size_t(300), keys, C.c_size_t(32), None, spent) == 0
+    assert spent.raw == bytes(300) and lib.act_node_nullifier_set_len(ns) == 300
+    assert lib.act_node_nullifier_check_and_insert_batch(ns, C.c_size_t(300), keys, C.c_size_t(32), None, spent) == 0
+    assert spent.raw == bytes([1]) * 300
+    # k + l, k + 7 l: other spellings of scalars already stored.  Each per-device mock set reduces like the real one, so they
+    # are reported spent if and only if the dispatcher routed them to the set that holds k -- i.e. routed by scalar
+    alias = b"".join(le(k + (1 + 6 * (j % 2)) * ELL) for j, k in enumerate(ks[:50]))
+    sp = C.create_string_buffer(50)
+    assert lib.act_node_nullifier_check_and_insert_batch(ns, C.c_size_t(50), alias, C.c_size_t(32), None, sp) == 0
+    assert sp.raw == bytes([1]) * 50 and lib.act_node_nullifier_set_len(ns) == 300
+    mask = bytes([1 if i % 3 == 0 else 0 for i in range(300)])
+    assert lib.act_node_nullifier_check_and_insert_batch(ns, C.c_size_t(300), keys, C.c_size_t(32), mask, spent) == 0
+    assert spent.raw == bytes(0 if i % 3 == 0 else 1 for i in range(300))
+    lib.act_node_nullifier_set_destroy(ns)
