@@ -504,7 +504,11 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
     for (int b = 0; b < 4; b++) c->fb_bits[b] = (b == BASE_H1 || b == BASE_H3 || all_wide) ? wide : FB_WBITS;
   }
   for (int b = 0; b < 4; b++) {
-    HIPCK(c, hipMalloc(&c->d_tables[b], fb_table_words((uint32_t)c->fb_bits[b]) * 4));
+    if (c->fb_bits[b] > FB_WBITS && hipMalloc(&c->d_tables[b], fb_table_words((uint32_t)c->fb_bits[b]) * 4) != hipSuccess) {
+      (void)hipGetLastError(); c->d_tables[b] = nullptr;
+      c->fb_bits[b] = FB_WBITS;                 // no room for the wide table (a GPU shared with other contexts): the default width
+    }
+    if (!c->d_tables[b]) HIPCK(c, hipMalloc(&c->d_tables[b], fb_table_words((uint32_t)c->fb_bits[b]) * 4));
     launch_build_table(d_ext + b * GE_WORDS, c->d_tables[b], (uint32_t)c->fb_bits[b], s0);
     c->P.tab[b] = FbTab{c->d_tables[b], (uint32_t)c->fb_bits[b], (uint32_t)b};
   }
