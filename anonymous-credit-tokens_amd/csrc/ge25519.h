@@ -53,10 +53,12 @@ ACT_HD ge_niels ge_niels_cneg(const ge_niels& c, bool neg) {
 template <bool WITH_T = true>
 ACT_HD ge ge_from_completed(const fe& cx, const fe& cy, const fe& cz, const fe& ct) {
   ge r;
+  // operand order: fe_mul doubles the odd limbs of its first and 19-folds its second operand; each of ct, cy is a first
+  // operand twice and each of cx, cz a second operand twice, so those preparations are shared
   r.X = fe_mul(ct, cx);
-  r.Y = fe_mul(cz, cy);
+  r.Y = fe_mul(cy, cz);
   r.Z = fe_mul(ct, cz);
-  if (WITH_T) r.T = fe_mul(cx, cy); else r.T = fe_zero();
+  if (WITH_T) r.T = fe_mul(cy, cx); else r.T = fe_zero();
   return r;
 }
 
@@ -90,6 +92,44 @@ ACT_HD ge ge_madd(const ge& p, const ge_niels& q) {
   fe ct = fe_sub(zz2, tt2d);
   return ge_from_completed<WITH_T>(cx, cy, cz, ct);
 }
+// ---- d-free ("dedicated") addition, Hisil-Wong-Carter-Dawson 2008 section 3.2 for a = -1 -----------------------------
+// A = (Y1-X1)(Y2+X2), B = (Y1+X1)(Y2-X2), C = 2 Z1 T2, D = 2 T1 Z2; (X3 : Y3 : Z3 : T3) = ((D+C)(B-A) : (B+A)(D-C) :
+// (B-A)(B+A) : (D+C)(D-C)).  8M with NO multiplication by 2d, so the second operand is the point itself plus one lazy
+// sum and difference (ge_ded) instead of a ge_cached that costs a multiplication to make.  The price: it is not complete.
+// With q - p in E[4] (q = p, or q = p + a point of order 2 or 4) both B-A and D-C (or B+A) vanish and the result is
+// (0,0,0,0); everywhere else it is the sum (p = identity included when q is not in E[4]).  msm.h chain_bu_pre uses it only
+// where q - p in E[4] is impossible for ANY digit string (proof there) and keeps the complete formulas everywhere else.
+struct ge_ded { fe YpX, YmX, Z, T; };          // YpX, YmX loose [g]; Z, T tight
+ACT_HD ge_ded ge_to_ded(const ge& p) {
+  ge_ded c;
+  c.YpX = fe_add(p.Y, p.X);          // <= 2^27            [g]
+  c.YmX = fe_sub(p.Y, p.X);          // <= 1.5 * 2^27      [g]
+  c.Z = p.Z; c.T = p.T;
+  return c;
+}
+ACT_HD ge_ded ge_ded_cneg(const ge_ded& c, bool neg) {
+  ge_ded r = c;
+  uint32_t m = fe_mask(neg);
+  fe_cswap_m(r.YpX, r.YmX, m);
+  r.T = fe_select_m(c.T, fe_neg(c.T), m);         // <= 2^27 [g]
+  return r;
+}
+ACT_HD ge ge_add_ded(const ge& p, const ge_ded& q) {
+  fe A = fe_mul(fe_sub(p.Y, p.X), q.YpX);
+  fe B = fe_mul(fe_add(p.Y, p.X), q.YmX);
+  fe C = fe_mul(fe_dbl(p.Z), q.T);               // [f] 2^27 x [g] 2^27
+  fe D = fe_mul(fe_dbl(p.T), q.Z);
+  fe E = fe_add(D, C);                           // 2^27
+  fe F = fe_sub(B, A);                           // 1.5 * 2^27
+  fe G = fe_add(B, A);                           // 2^27
+  fe H = fe_sub(D, C);                           // 1.5 * 2^27
+  ge r;                                          // E, G are first operands twice and F, H second operands twice (shared preparation)
+  r.X = fe_mul(E, F);
+  r.Y = fe_mul(G, H);
+  r.Z = fe_mul(G, F);
+  r.T = fe_mul(E, H);
+  return r;
+}
 ACT_HD ge ge_add(const ge& p, const ge& q) { return ge_add_cached(p, ge_to_cached(q)); }
 ACT_HD ge ge_sub(const ge& p, const ge& q) { return ge_add_cached(p, ge_cached_cneg(ge_to_cached(q), true)); }
 
@@ -104,10 +144,10 @@ ACT_HD ge ge_double_opt(const ge& p, bool with_t) {
   fe ct = fe_sub4(zz2, yymxx);
   ge r;
   r.X = fe_mul(ct, cx);
-  r.Y = fe_mul(yymxx, yypxx);
+  r.Y = fe_mul(yypxx, yymxx);
   r.Z = fe_mul(ct, yymxx);
   r.T = fe_zero();
-  if (with_t) r.T = fe_mul(cx, yypxx);
+  if (with_t) r.T = fe_mul(yypxx, cx);
   return r;
 }
 // 2p.  4S + 4M (3M without T).  Input T unused.

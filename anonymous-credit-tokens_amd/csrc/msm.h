@@ -296,22 +296,36 @@ ACT_HD int naf_byte(uint32_t wd, int k) { return (int)(int8_t)(wd >> (8 * k)); }
 // chain_bu with both digit strings taken from memory: `nafw` = NAF_WORDS words of the uniform scalar (naf3_recode), `dg` = the
 // lane's 8 radix16_bias words (in global memory: one load per 8 steps instead of 8 live registers).  UNIFORM: every lane of
 // the wavefront reads the same nafw (L a multiple of 64), so the word is moved to an SGPR and its branches are scalar.
+//
+// The additions of a chain point into a bucket or into U1 / U3 use the d-free formulas (ge25519.h ge_add_ded: no cached form,
+// one multiplication less per addition, ~127 per lane).  They fail only when (chain point) - (accumulator) lies in E[4].
+// Accumulator and chain point are multiples of N: accumulator = a N with a = sum of +-B^i over earlier positions i < k
+// that carried this bucket's (this accumulator's) digit magnitude, chain point = +-B^k N (B = 16 resp. 2), so the
+// difference is m N with m = a -+ B^k, a nonzero integer (|a| < B^k) below 2^257.  N is a decoded ristretto point: a point of
+// order l plus an element of E[4], hence m N in E[4] iff l | m, unless N itself is in E[4], which only the all-zero encoding
+// decodes to (`n_small`: the caller says so and gets the identity for both results, which is what 0 * scalar is).
+// m = t l is impossible: the digits of m are in {-1, 0, 1} at distinct positions, and such a string IS the canonical signed
+// radix-16 expansion (resp. the non-adjacent form: width-3 NAF positions are >= 3 apart) of its value, which is unique --
+// but the expansion of t l has at least 24 digits outside {-1, 0, 1} and its NAF at least 15 adjacent-but-one pairs for
+// every 1 <= |t| < 40 (tests/test_hostcheck.py::test_dedicated_addition_never_exceptional recomputes this).  An empty
+// accumulator (identity) is fine: identity + q is exact for q outside E[4].  The bucket combine, U1 + 3 U3 and everything
+// outside this function can meet equal operands (two empty buckets) and keep the complete formulas.
 template <bool UNIFORM>
-ACT_HD void chain_bu_pre(ge& acc_l, ge& acc_u, const ge& N, const uint32_t* dg, const uint32_t* nafw, uint32_t* bk, uint32_t* lds_wave = nullptr) {
+ACT_HD void chain_bu_pre(ge& acc_l, ge& acc_u, const ge& N, const uint32_t* dg, const uint32_t* nafw, uint32_t* bk, uint32_t* lds_wave = nullptr, bool n_small = false) {
   const ge id = ge_identity();
   for (int b = 0; b < BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);
 #if defined(__HIP_DEVICE_COMPILE__)
   ge_to_lds(lds_wave, id);
   ge_to_lds(lds_wave + GE_LDS_WORDS_PER_WAVE, id);
-  auto add_u = [&](const ge_cached& q, int d) {
+  auto add_u = [&](const ge_ded& q, int d) {
     uint32_t* home = lds_wave + ((d == 3 || d == -3) ? GE_LDS_WORDS_PER_WAVE : 0);
-    ge_to_lds(home, ge_add_cached(ge_from_lds(home), ge_cached_cneg(q, d < 0)));
+    ge_to_lds(home, ge_add_ded(ge_from_lds(home), ge_ded_cneg(q, d < 0)));
   };
 #else
   ge U[2] = {id, id};
-  auto add_u = [&](const ge_cached& q, int d) {
+  auto add_u = [&](const ge_ded& q, int d) {
     ge& t = U[(d == 3 || d == -3) ? 1 : 0];
-    t = ge_add_cached(t, ge_cached_cneg(q, d < 0));
+    t = ge_add_ded(t, ge_ded_cneg(q, d < 0));
   };
 #endif
   ge P = N;                                    // position 0, T valid
@@ -326,30 +340,32 @@ ACT_HD void chain_bu_pre(ge& acc_l, ge& acc_u, const ge& N, const uint32_t* dg, 
     if (UNIFORM) nw = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw);
 #endif
     const int u = naf_byte(nw, 0), u1 = naf_byte(nw, 1), u2 = naf_byte(nw, 2), u3 = naf_byte(nw, 3);
-    ge_cached c = ge_to_cached(P);
+    ge_ded c = ge_to_ded(P);
     uint32_t* slot = bk + mag * GE_WORDS;
     ge B = bucket_load(slot);
-    B = ge_add_cached(B, ge_cached_cneg(c, neg));
+    B = ge_add_ded(B, ge_ded_cneg(c, neg));
     bucket_store(slot, B);
     if (u != 0) add_u(c, u);
     if (step == 63) {                          // position 253 (u1) is the last possible digit of a scalar < 2^253; 254, 255 are zero
-      if (u1 != 0) { P = ge_double_opt(P, true); add_u(ge_to_cached(P), u1); }
+      if (u1 != 0) { P = ge_double_opt(P, true); add_u(ge_to_ded(P), u1); }
       break;
     }
     P = ge_double_opt(P, u1 != 0);
-    if (u1 != 0) add_u(ge_to_cached(P), u1);
+    if (u1 != 0) add_u(ge_to_ded(P), u1);
     P = ge_double_opt(P, u2 != 0);
-    if (u2 != 0) add_u(ge_to_cached(P), u2);
+    if (u2 != 0) add_u(ge_to_ded(P), u2);
     P = ge_double_opt(P, u3 != 0);
-    if (u3 != 0) add_u(ge_to_cached(P), u3);
+    if (u3 != 0) add_u(ge_to_ded(P), u3);
     P = ge_double_opt(P, true);                // next step's bucket point needs T
   }
   {                                            // acc_u += U1 + 3 * U3
 #if defined(__HIP_DEVICE_COMPILE__)
-    const ge U1 = ge_from_lds(lds_wave), U3 = ge_from_lds(lds_wave + GE_LDS_WORDS_PER_WAVE);
+    ge U1 = ge_from_lds(lds_wave), U3 = ge_from_lds(lds_wave + GE_LDS_WORDS_PER_WAVE);
 #else
-    const ge U1 = U[0], U3 = U[1];
+    ge U1 = U[0], U3 = U[1];
 #endif
+    const uint32_t ms = fe_mask(n_small);
+    U1 = ge_select_m(U1, id, ms); U3 = ge_select_m(U3, id, ms);
     acc_u = ge_add_cached(acc_u, ge_to_cached(U1));
     acc_u = ge_add_cached(acc_u, ge_to_cached(U3));
     acc_u = ge_add_cached(acc_u, ge_to_cached(ge_double_opt(U3, true)));
@@ -360,7 +376,7 @@ ACT_HD void chain_bu_pre(ge& acc_l, ge& acc_u, const ge& N, const uint32_t* dg, 
     S = ge_add_cached(S, ge_to_cached(bucket_load(bk + vv * GE_WORDS)));
     R = ge_add_cached(R, ge_to_cached(S));
   }
-  acc_l = R;
+  acc_l = ge_select_m(R, id, fe_mask(n_small));
 }
 
 ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& s_u, uint32_t* bk, uint32_t* lds_wave = nullptr) {

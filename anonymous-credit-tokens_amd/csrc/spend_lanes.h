@@ -116,7 +116,9 @@ ACT_HD void spend_bits_lane(const SpendArgs& a, uint32_t gid, uint32_t* lds_wave
   uint32_t* bk = a.buckets + (size_t)gid * BUCKET_WORDS;
   uint32_t* dg = a.dig + (size_t)gid * 8;
   { uint32_t t[8]; radix16_bias(t, g0); for (int i = 0; i < 8; i++) dg[i] = t[i]; }
-  chain_bu_pre<UNIFORM>(acc_l, acc_u, ge_neg(C), dg, a.naf + (size_t)p * NAF_WORDS, bk, lds_wave);
+  // Com_j in E[4] <=> its encoding is all zero (or it did not decode: the proof is rejected anyway): D = G = identity
+  const bool n_small = !ok || (wc[0] | wc[1] | wc[2] | wc[3] | wc[4] | wc[5] | wc[6] | wc[7]) == 0u;
+  chain_bu_pre<UNIFORM>(acc_l, acc_u, ge_neg(C), dg, a.naf + (size_t)p * NAF_WORDS, bk, lds_wave, n_small);
   ge f0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H3], z0);
   if (j == 0) f0 = ge_add(f0, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS));                        // + w00 h2 (:806)
   ge_cached dl = ge_to_cached(acc_l);

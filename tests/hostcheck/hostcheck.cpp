@@ -137,6 +137,30 @@ extern "C" int hc_chain_bu(const uint8_t* pt, const uint8_t* s0, const uint8_t* 
   return 1;
 }
 
+// the digit-strings-from-memory form the range kernel runs (msm.h chain_bu_pre: d-free additions inside), called the way
+// spend_lanes.h spend_bits_lane calls it
+extern "C" int hc_chain_bu_pre(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
+  uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
+  ge al = ge_identity(), au = ge_identity();
+  std::vector<uint32_t> bk(BUCKET_WORDS), naf(NAF_WORDS);
+  uint32_t dg[8]; radix16_bias(dg, sc_in(s0));
+  sc su; memcpy(su.v, s1, 32);                                   // raw: values in [l, 2^253) reach the recoder unreduced
+  naf3_recode(naf.data(), su);
+  const bool n_small = (w[0] | w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) == 0u;
+  chain_bu_pre<false>(al, au, p, dg, naf.data(), bk.data(), nullptr, n_small);
+  ristretto_encode(r, al); st(o0, r); ristretto_encode(r, au); st(o1, r);
+  return 1;
+}
+// p + q by the d-free formulas; returns 2 when the result is (0,0,0,0) (q - p in E[4]), 1 otherwise with the encoding
+extern "C" int hc_add_ded(const uint8_t* a, const uint8_t* b, int b_plus_order2, uint8_t* o) {
+  uint32_t w[8], r[8]; ge p, q; ld(w, a); if (!ristretto_decode(p, w)) return 0; ld(w, b); if (!ristretto_decode(q, w)) return 0;
+  if (b_plus_order2) { q.X = fe_carry(fe_neg(q.X)); q.Y = fe_carry(fe_neg(q.Y)); }       // q + (0, -1) = (-x, -y)
+  ge s = ge_add_ded(p, ge_to_ded(q));
+  if (fe_is_zero(s.X) && fe_is_zero(s.Y) && fe_is_zero(s.Z) && fe_is_zero(s.T)) return 2;
+  ristretto_encode(r, s); st(o, r);
+  return 1;
+}
+
 // ---- the spend-verification kernels' own lane bodies (csrc/spend_lanes.h), run lane by lane on the host ---------------
 // Builds Params tables the way k_build_table does, then executes exactly what the five kernels execute for `n` proofs:
 // prep (lane = proof), bits (lane = (proof, bit)), enc (lane = 32 half-points), tail, BLAKE3, finish.  Outputs: the

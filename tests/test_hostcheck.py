@@ -85,7 +85,7 @@ def test_group_and_msm_shapes(hostcheck):
         assert ok and o0.hex() == v["mul"]
         s1 = m.sc_from_wide(shake("hc-s1-%d" % i, 64))
         pm = m.ristretto_decode(e)
-        for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_b2"):
+        for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_bu_pre", "hc_chain_b2"):
             ok, o0, o1 = call(hc, fn, e, s, m.sc_bytes(s1), nout=2)
             assert o0.hex() == v["mul"] and o1 == m.ristretto_encode(m.pt_mul(pm, s1)), fn
         if i < 4:
@@ -94,7 +94,7 @@ def test_group_and_msm_shapes(hostcheck):
     # digit-recoding corner cases of the radix-4 chain
     e = bytes.fromhex(g["generator_multiples"][1])
     for s in (0, 1, 2, 3, 4, m.ELL - 1, (1 << 252) + 5, (1 << 252) - 1, int("3" * 60, 16) % m.ELL, int("2" * 63, 16) % m.ELL):
-        for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_b2"):      # radix-4 / radix-4, radix-4 / NAF, buckets / NAF, buckets / buckets
+        for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_bu_pre", "hc_chain_b2"):      # radix-4 / radix-4, radix-4 / NAF, buckets / NAF (twice), buckets / buckets
             ok, o0, o1 = call(hc, fn, e, m.sc_bytes(s), m.sc_bytes(m.ELL - 1 - s), nout=2)
             assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, s)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, m.ELL - 1 - s)), (fn, s)
     # width-3 NAF recoding of the wave-uniform scalar (msm.h naf3_next): runs of 1s, alternating digits, carries
@@ -103,9 +103,10 @@ def test_group_and_msm_shapes(hostcheck):
                                                    0b011, 0b101, 0b111, 0b1011, (1 << 200) - 1, ((1 << 253) - 1) // 3, ((1 << 253) - 1) // 7 * 3]
     for su in pats:
         su %= 1 << 253
-        ok, o0, o1 = call(hc, "hc_chain_bu", e, m.sc_bytes(9), su.to_bytes(32, "little"), nout=2)
-        assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, 9)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, su)), hex(su)
-    for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_b2"):                      # identity base
+        for fn in ("hc_chain_bu", "hc_chain_bu_pre"):
+            ok, o0, o1 = call(hc, fn, e, m.sc_bytes(9), su.to_bytes(32, "little"), nout=2)
+            assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, 9)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, su)), (fn, hex(su))
+    for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_bu_pre", "hc_chain_b2"):   # identity base
         ok, o0, o1 = call(hc, fn, bytes(32), m.sc_bytes(5), m.sc_bytes(m.ELL - 7), nout=2)
         assert o0 == bytes(32) and o1 == bytes(32), fn
 
@@ -136,11 +137,64 @@ def test_batched_double_and_compress(hostcheck):
         assert int.from_bytes(o, "little") == s_ * pow(2, m.ELL - 2, m.ELL) % m.ELL, s_
 
 
+def test_dedicated_addition_never_exceptional(hostcheck):
+    """msm.h chain_bu_pre adds chain points into buckets / NAF accumulators with the d-free formulas (ge25519.h ge_add_ded),
+    which return (0,0,0,0) when the operands differ by an element of E[4].  (i) The formulas: sums, the identity as first
+    operand, p + (-p), and the failures p + p, p + (p + order-2 point).  (ii) The arithmetic fact the proof in msm.h rests on:
+    no multiple t*l, |t| < 40, is a signed radix-16 string over {-1, 0, 1} or a NAF whose non-zero digits are >= 3 apart.
+    (iii) Digit strings that put many chain points into one accumulator, and every single-bucket string."""
+    hc = hostcheck
+    g = load_golden("primitives.json")
+    enc = [e for e in (bytes.fromhex(v["encoding"]) for v in g["from_uniform_bytes"]) if e != bytes(32)][:6]
+    pts = [m.ristretto_decode(e) for e in enc]
+    for i, (ea, pa) in enumerate(zip(enc, pts)):
+        for eb, pb in zip(enc[i + 1:], pts[i + 1:]):
+            rc, o = call(hc, "hc_add_ded", ea, eb, C.c_int(0))
+            assert rc == 1 and o == m.ristretto_encode(m.pt_add(pa, pb))
+            rc, o = call(hc, "hc_add_ded", ea, eb, C.c_int(1))
+            assert rc == 1 and o == m.ristretto_encode(m.pt_add(pa, pb))          # + (0,-1): same ristretto element
+        rc, o = call(hc, "hc_add_ded", bytes(32), ea, C.c_int(0))
+        assert rc == 1 and o == ea                                                 # identity + q
+        rc, o = call(hc, "hc_add_ded", ea, m.ristretto_encode(m.pt_neg(pa)), C.c_int(0))
+        assert rc == 1 and o == bytes(32)                                          # p + (-p) is not exceptional
+        assert call(hc, "hc_add_ded", ea, ea, C.c_int(0))[0] == 2                  # p + p
+        assert call(hc, "hc_add_ded", ea, ea, C.c_int(1))[0] == 2                  # p + (p + (0,-1))
+    assert call(hc, "hc_add_ded", bytes(32), bytes(32), C.c_int(0))[0] == 2        # identity + identity: why n_small exists
+
+    def signed16(n):
+        d = []
+        while n:
+            r = n % 16
+            r -= 16 if r >= 8 else 0
+            d.append(r); n = (n - r) // 16
+        return d
+
+    def naf(n):
+        d = []
+        while n:
+            r = (2 - n % 4) if n & 1 else 0
+            n -= r; d.append(r); n //= 2
+        return d
+    for t in range(1, 40):
+        assert sum(abs(x) > 1 for x in signed16(t * m.ELL)) >= 24
+        pos = [i for i, x in enumerate(naf(t * m.ELL)) if x]
+        assert sum(b - a == 2 for a, b in zip(pos, pos[1:])) >= 15
+
+    e = enc[0]; pm = pts[0]
+    one_bucket = [int(("%x" % v) * 64, 16) % m.ELL for v in range(1, 9)] + [int("0" + "f" * 62 + "1", 16), int("08" * 32, 16), int("80" * 31 + "08", 16) % m.ELL]
+    sparse_naf = [sum(1 << i for i in range(0, 253, 3)), sum(3 << i for i in range(0, 250, 3)) % (1 << 253), sum(((-1) ** (i // 3)) * (1 << i) for i in range(0, 252, 3)) % m.ELL, 1 << 252, (1 << 253) - 1]
+    for sl in one_bucket + [0, 1, m.ELL - 1]:
+        for su in sparse_naf + [0, 1, 3]:
+            ok, o0, o1 = call(hc, "hc_chain_bu_pre", e, m.sc_bytes(sl), su.to_bytes(32, "little"), nout=2)
+            assert ok and o0 == m.ristretto_encode(m.pt_mul(pm, sl)) and o1 == m.ristretto_encode(m.pt_mul(pm, su)), (hex(sl), hex(su))
+
+
 def test_limb_bounds_hold(hostcheck):
     """Every operand recorded by the instrumented host build stays inside its class (fe25519.h header comment)."""
     test_field(hostcheck)
     test_group_and_msm_shapes(hostcheck)
     test_batched_double_and_compress(hostcheck)
+    test_dedicated_addition_never_exceptional(hostcheck)
     bd = (C.c_uint64 * 6)()
     hostcheck.hc_bounds(bd)
     lim = [1.68 * 2**27, 1.68 * 2**26, 1.5 * 2**28, 1.5 * 2**27, 2**27 - 38, 2**26 - 2]

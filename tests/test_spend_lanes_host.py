@@ -57,12 +57,13 @@ def test_kernel_lane_bodies_reproduce_the_libsodium_fixtures(hostcheck, oracle, 
 
 
 def test_ragged_and_small_widths(hostcheck, oracle, bench_params):
-    """L = 3 and L = 100 (lanes of several proofs share a 32-point encode batch), a tampered and an identity lane."""
+    """L = 3 and L = 100 (lanes of several proofs share a 32-point encode batch), a tampered lane, an identity A' and a proof
+    with identity commitments."""
     for L in (3, 100):
         octx = oracle.ctx(bench_params, L)
         sk = octx.private_key_random(shake("hl-sk-%d" % L, 64))
         recs = []
-        for i in range(3):
+        for i in range(4):
             pre = octx.pre_issuance_random(shake("hl-pre-%d-%d" % (L, i), 128))
             req = octx.request(pre, shake("hl-rq-%d-%d" % (L, i), 128))
             st, resp = octx.issue(sk, req, scb(5 + i), shake("hl-ir-%d-%d" % (L, i), 128))
@@ -71,11 +72,13 @@ def test_ragged_and_small_widths(hostcheck, oracle, bench_params):
             recs.append(bytearray(proof))
         recs[1][33] ^= 1
         recs[2][64:96] = bytes(32)
+        for j in (0, L - 1):                       # Com_j = identity: the one base the d-free additions of msm.h chain_bu_pre cannot take
+            recs[3][32 * (4 + j):32 * (5 + j)] = bytes(32)
         proofs = b"".join(bytes(r) for r in recs)
         st, kp, trs, _ = host_verify(hostcheck, bench_params, L, sk, proofs)
-        for i in range(3):
+        for i in range(4):
             so, kpo, tro = octx.verify_spend(sk, bytes(recs[i]), True)
             assert st[i] == so, (L, i)
             if so in (0, 7):                       # the reference returns before building a transcript when A' is the identity
                 assert trs[i] == tro, (L, i)
-        assert list(st) == [0, 7, 6]
+        assert list(st) == [0, 7, 6, 7]
