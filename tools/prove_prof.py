@@ -7,6 +7,7 @@ from act_amd import capi
 L = 128; n = 1 << 18; D = 4096
 h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
 eng = capi.Engine(h, L, max_batch=65536, transcript=capi.TRANSCRIPT_DEVICE)
+if os.environ.get("DEPTH"): eng.set_pipeline_depth(int(os.environ["DEPTH"]))      # DEPTH=1: one chunk in flight, the kernels' own durations
 sk = eng.private_key_random(bench.shake("sk", 64))
 pre = eng.pre_issuance_random(bench.shake("pre", 128 * D)); req = eng.request(pre, bench.shake("rq", 128 * D))
 cs = [(i * 2654435761) % 2**64 for i in range(D)]
