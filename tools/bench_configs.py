@@ -140,6 +140,14 @@ def main():
         t = time.perf_counter(); ns.check_and_insert_dev(nn, keys2.data_ptr(), 32, 0, spent.data_ptr()); torch.cuda.synchronize(); dt = time.perf_counter() - t
         assert int(spent.sum()) == nn // 2
         out["nullifier_set_check_insert_2^22"] = {"nullifiers_per_s": nn / dt, "ms": 1e3 * dt}
+        # the node-level set (act_node_nullifier_*: host memory in, host-side routing by owner, one HBM set per device) on this one GPU
+        nh = 1 << 20
+        hk = keys2[:nh].cpu().numpy().tobytes(); hk0 = keys[:nh].cpu().numpy().tobytes()
+        nns = capi.NodeNullifierSet(4 * nh, devices=(0,))
+        nns.check_and_insert(hk0)
+        t = time.perf_counter(); sp = nns.check_and_insert(hk); dt = time.perf_counter() - t
+        assert sum(sp) == nh // 2
+        out["node_nullifier_set_1gpu_host_memory_2^20"] = {"nullifiers_per_s": nh / dt, "ms": 1e3 * dt}
     print(json.dumps(out))
 
 
