@@ -189,6 +189,53 @@ def test_dedicated_addition_never_exceptional(hostcheck):
             assert ok and o0 == m.ristretto_encode(m.pt_mul(pm, sl)) and o1 == m.ristretto_encode(m.pt_mul(pm, su)), (hex(sl), hex(su))
 
 
+def test_dedicated_addition_chain_agrees_with_the_complete_one_on_structured_digit_strings(hostcheck):
+    """3 000 digit strings built to be as structured as the recoders allow (few distinct digit values, long runs, sparse
+    supports, values next to multiples of l): msm.h chain_bu_pre (d-free additions) against chain_bu (complete additions
+    only), both on the host build; a sample against the Python model."""
+    import random
+    hc = hostcheck
+    g = load_golden("primitives.json")
+    encs = [e for e in (bytes.fromhex(v["encoding"]) for v in g["from_uniform_bytes"]) if e != bytes(32)][:8]
+    r = random.Random(20260101)
+
+    def radix16_string():
+        kind = r.randrange(5)
+        if kind == 0:                                   # two digit values only
+            a, b = r.randrange(16), r.randrange(16)
+            return int("".join("%x" % r.choice((a, b)) for _ in range(63)), 16)
+        if kind == 1:                                   # sparse support
+            return sum(r.randrange(1, 16) << (4 * i) for i in r.sample(range(63), r.randrange(1, 6)))
+        if kind == 2:                                   # runs
+            d = []
+            while len(d) < 63:
+                d += ["%x" % r.randrange(16)] * r.randrange(1, 20)
+            return int("".join(d[:63]), 16)
+        if kind == 3:                                   # next to a multiple of l / a power of 16
+            return (r.randrange(1, 8) * m.ELL + r.randrange(-40, 40)) % m.ELL if r.random() < 0.5 else ((1 << (4 * r.randrange(1, 63))) + r.randrange(-3, 4)) % m.ELL
+        return r.randrange(m.ELL)
+
+    def naf_string():
+        kind = r.randrange(4)
+        if kind == 0:                                   # non-zero digits exactly three apart, random signs and magnitudes
+            return sum(r.choice((1, 3, -1, -3)) << i for i in range(r.randrange(3), 250, 3)) % (1 << 253)
+        if kind == 1:
+            return sum(1 << i for i in r.sample(range(253), r.randrange(1, 8)))
+        if kind == 2:
+            return (r.randrange(1, 3) * m.ELL + r.randrange(-40, 40)) % (1 << 253)
+        return r.randrange(1 << 253)
+
+    for it in range(3000):
+        e = encs[it % len(encs)]
+        sl, su = radix16_string() % m.ELL, naf_string()
+        ok, a0, a1 = call(hc, "hc_chain_bu_pre", e, m.sc_bytes(sl), su.to_bytes(32, "little"), nout=2)
+        ok2, b0, b1 = call(hc, "hc_chain_bu", e, m.sc_bytes(sl), su.to_bytes(32, "little"), nout=2)
+        assert ok and ok2 and a0 == b0 and a1 == b1, (it, hex(sl), hex(su))
+        if it % 300 == 0:
+            pm = m.ristretto_decode(e)
+            assert a0 == m.ristretto_encode(m.pt_mul(pm, sl)) and a1 == m.ristretto_encode(m.pt_mul(pm, su))
+
+
 def test_limb_bounds_hold(hostcheck):
     """Every operand recorded by the instrumented host build stays inside its class (fe25519.h header comment)."""
     test_field(hostcheck)
