@@ -892,7 +892,10 @@ int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
   if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
-  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = 4096;        // 8 blocks x 4 waves per CU: 8 waves per SIMD
+  static const int iters_env = [] { const char* e = getenv("ACT_UBENCH_ITERS"); return e ? atoi(e) : 0; }();        // tuning knob: probe length
+  // 8 blocks x 4 waves per CU: 8 waves per SIMD.  Long enough (~0.3 s) for the clock to settle where a sustained ALU load
+  // leaves it (the measured rate rises from 2.8e13 over 6 ms to 3.49e13 over 0.3 s and stays there)
+  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = iters_env > 0 ? (uint32_t)iters_env : 262144u;
   uint32_t* d = nullptr; hipEvent_t e0, e1; hipStream_t st;
   int rc = ACT_OK; float t = 0;
   if (hipMalloc(&d, (size_t)blocks * 256 * 4) != hipSuccess) return ACT_ERR_HIP;

@@ -128,21 +128,27 @@ void launch_debug_scalarmult(const uint8_t* pts, const uint8_t* scs, uint32_t n,
   if (n) hipLaunchKernelGGL(k_debug_scalarmult, dim3((n + 63) / 64), dim3(64), 0, s, pts, scs, n, pbk, out, status);
 }
 
-// ALU roofline probe: UBENCH_MADS_PER_ITER independent v_mad_u64_u32 dependency chains per lane, register resident (no memory
-// traffic inside the loop), every SIMD of the chip holding 8 wavefronts.  The multiply-accumulate the whole field
-// arithmetic is built from (fe25519.h) cannot issue faster than this.
+// ALU roofline probe: 8 register-resident accumulators per lane, each advanced by one block of 10 dependent v_mad_u64_u32
+// per iteration -- the form a column of fe25519.h's multiplication has (one asm statement per column; single-instruction asm
+// statements would measure the wait states the compiler puts between them, 4.7 instead of 4.06 cycles) -- no memory traffic
+// inside the loop, every SIMD of the chip holding 8 wavefronts.  The multiply-accumulate the whole field arithmetic is built
+// from cannot issue faster than this.
 __global__ void __launch_bounds__(256) k_ubench_mad(uint32_t* out, uint32_t iters) {
   uint32_t a = threadIdx.x * 2654435761u + blockIdx.x, b = a ^ 0x9e3779b9u;
-  uint64_t r[UBENCH_MADS_PER_ITER];
+  constexpr int CHAINS = UBENCH_MADS_PER_ITER / 10;
+  uint64_t r[CHAINS];
 #pragma unroll
-  for (int i = 0; i < UBENCH_MADS_PER_ITER; i++) r[i] = ((uint64_t)a << 32 | b) + i;
+  for (int i = 0; i < CHAINS; i++) r[i] = ((uint64_t)a << 32 | b) + i;
   for (uint32_t it = 0; it < iters; it++) {
 #pragma unroll
-    for (int i = 0; i < UBENCH_MADS_PER_ITER; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc");
+    for (int i = 0; i < CHAINS; i++)
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %1, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\t"
+                   "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %1, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\t"
+                   "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc");
   }
   uint64_t x = 0;
 #pragma unroll
-  for (int i = 0; i < UBENCH_MADS_PER_ITER; i++) x ^= r[i];
+  for (int i = 0; i < CHAINS; i++) x ^= r[i];
   out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)x ^ (uint32_t)(x >> 32);
 }
 void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream_t s) { hipLaunchKernelGGL(k_ubench_mad, dim3(blocks), dim3(256), 0, s, out, iters); }

@@ -331,7 +331,7 @@ def main():
                            "k_spend_bits_frac": bits_mad / launch_s / peak_mad if launch_s else None,
                            "unit": "lane multiply-accumulates (v_mad_u64_u32) per second", "probe_ms": probe_ms,
                            "per_kernel_field_ops_per_verify": ops,
-                           "how": "peak: act_ubench_mad_u64_u32 (16 register-resident chains per lane, 8 waves per SIMD) timed in this process; "
+                           "how": "peak: act_ubench_mad_u64_u32 (8 register-resident accumulators per lane advanced by blocks of 10 dependent multiply-accumulates, 8 waves per SIMD, ~0.3 s so that the clock settles) timed in this process; "
                                   "work: fe_mul / fe_sq executed by the kernels' own lane bodies, counted on the host (tests/hostcheck), x 100 / 55 "
                                   "multiply-accumulates each; k_spend_bits_frac uses that kernel's busy time alone"}
 

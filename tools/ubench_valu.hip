@@ -22,13 +22,14 @@ constexpr int ITER = 16384;
 
 enum Op { MAD_U64_U32, MUL_LO_U32, MUL_HI_U32, MAD_U32_U24, MUL_HI_U32_U24, ADD_U32, ADDC_CHAIN,
           FMA_F64, MUL_F64, ADD_F64, FMA_F32, PK_FMA_F32, LSHL_ADD, ALIGNBIT, CNDMASK, MAD_I64_I32,
-          MAD_MIX_ADDC, DOT4_U8, DOT2_U16, ADD3_U32, LSHLREV_B64, CNDMASK_SGPR, BFI, AND_B32, SUB_U32, XOR_B32, LSHL_ADD_U64, LSHRREV_B64, LSHRREV_B32, CNDMASK_VCC_SET, NOPS };
+          MAD_MIX_ADDC, DOT4_U8, DOT2_U16, ADD3_U32, LSHLREV_B64, CNDMASK_SGPR, BFI, AND_B32, SUB_U32, XOR_B32, LSHL_ADD_U64, LSHRREV_B64, LSHRREV_B32, CNDMASK_VCC_SET, MAD_U64_SGPR, MAD_U64_ALT, MAD_AND_MIX, MAD_SHIFT_MIX, MAD_DEP10, MAD_DEP10_SHIFT_AND, MAD_2X10, MAD_DEP40, MAD10_AND10, AND20, MAD10_SHL10, NOPS };
 
 static const char* op_name[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24",
   "v_add_u32", "v_add_co+v_addc_co (pair)", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_fma_f32", "v_pk_fma_f32",
   "v_lshl_add_u32", "v_alignbit_b32", "v_cndmask_b32", "v_mad_i64_i32", "v_mad_u64_u32+v_addc (pair)",
   "v_dot4_u32_u8", "v_dot2_u32_u16", "v_add3_u32", "v_lshlrev_b64", "v_cndmask_b32 (sgpr mask)", "v_bfi_b32", "v_and_b32", "v_sub_u32", "v_xor_b32",
-  "v_lshl_add_u64", "v_lshrrev_b64", "v_lshrrev_b32", "v_cndmask_b32 (vcc set by v_cmp)"};
+  "v_lshl_add_u64", "v_lshrrev_b64", "v_lshrrev_b32", "v_cndmask_b32 (vcc set by v_cmp)",
+  "v_mad_u64_u32 sdst=s[10:11]", "v_mad_u64_u32 sdst alternating", "5 mad + 1 v_and (per instr)", "5 mad + 1 v_lshrrev_b64 (per instr)", "10 dependent mad per asm block", "10 dep mad + shift64 + and (per instr)", "2 chains x 10 mad interleaved per block", "40 dependent mad per asm block", "10 mad + 10 v_and interleaved (per instr)", "20 v_and on 2 regs per block", "10 mad + 10 v_lshlrev_b32 (per instr)"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) k_rate(uint32_t* out, unsigned long long* cyc, uint32_t seed) {
@@ -54,6 +55,21 @@ __global__ void __launch_bounds__(256) k_rate(uint32_t* out, unsigned long long*
     for (int i = 0; i < 8; i++) {
       uint32_t lo = (uint32_t)r[i], hi = (uint32_t)(r[i] >> 32);
       if constexpr (OP == MAD_U64_U32) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc");
+      else if constexpr (OP == MAD_U64_SGPR) asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "s10", "s11");
+      else if constexpr (OP == MAD_U64_ALT) {
+        if (i & 1) asm volatile("v_mad_u64_u32 %0, s[12:13], %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "s12", "s13");
+        else if (i & 2) asm volatile("v_mad_u64_u32 %0, s[14:15], %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "s14", "s15");
+        else asm volatile("v_mad_u64_u32 %0, s[10:11], %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "s10", "s11");
+      }
+      else if constexpr (OP == MAD_AND_MIX) { asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %0, vcc, %3, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1" : "+v"(r[i]), "+v"(hi) : "v"(a), "v"(b) : "vcc"); r[i] += hi; }
+      else if constexpr (OP == MAD_SHIFT_MIX) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %1, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_lshrrev_b64 %0, 3, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc"); }
+      else if constexpr (OP == MAD_DEP10) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %1, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %1, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc"); }
+      else if constexpr (OP == MAD_DEP10_SHIFT_AND) { asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %0, vcc, %3, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %0, vcc, %3, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %3, %0\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshrrev_b64 %0, 26, %0\n\tv_and_b32 %1, 0x3ffffff, %1" : "+v"(r[i]), "+v"(lo) : "v"(a), "v"(b) : "vcc"); f[i] += (float)lo; }
+      else if constexpr (OP == MAD_DEP40) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc"); }
+      else if constexpr (OP == MAD_2X10) { if (i < 4) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_mad_u64_u32 %1, vcc, %3, %2, %1" : "+v"(r[i]), "+v"(r[i + 4]) : "v"(a), "v"(b) : "vcc"); }
+      else if constexpr (OP == MAD10_AND10) { asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_and_b32 %1, 0x3ffffff, %1" : "+v"(r[i]), "+v"(lo) : "v"(a), "v"(b) : "vcc"); f[i] += (float)lo; }
+      else if constexpr (OP == AND20) { asm volatile("v_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1\n\tv_and_b32 %0, 0x3ffffff, %0\n\tv_and_b32 %1, 0x3ffffff, %1" : "+v"(hi), "+v"(lo) : : ); r[i] = (uint64_t)hi << 32 | lo; }
+      else if constexpr (OP == MAD10_SHL10) { asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1\n\tv_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_lshlrev_b32 %1, 1, %1" : "+v"(r[i]), "+v"(lo) : "v"(a), "v"(b) : "vcc"); f[i] += (float)lo; }
       else if constexpr (OP == MAD_I64_I32) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(r[i]) : "v"(a), "v"(b) : "vcc");
       else if constexpr (OP == MUL_LO_U32) { asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(a)); r[i] = lo; }
       else if constexpr (OP == MUL_HI_U32) { asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(lo) : "v"(a)); r[i] = lo; }
@@ -96,7 +112,7 @@ __global__ void __launch_bounds__(256) k_rate(uint32_t* out, unsigned long long*
 template <int OP>
 static void run(uint32_t* out, unsigned long long* cyc, int ncu) {
   printf("%-30s", op_name[OP]);
-  for (int wps : {1, 2, 4}) {  // waves per SIMD = blocks of 256 threads per CU
+  for (int wps : {1, 2, 4, 8}) {  // waves per SIMD = blocks of 256 threads per CU
     int blocks = ncu * wps;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     k_rate<OP><<<blocks, 256>>>(out, cyc, 1); CK(hipDeviceSynchronize());
@@ -107,7 +123,7 @@ static void run(uint32_t* out, unsigned long long* cyc, int ncu) {
     std::vector<unsigned long long> h(blocks);
     CK(hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long mx = 0; for (auto v : h) mx = v > mx ? v : mx;
-    double ninstr = (double)ITER * 8 * ((OP == ADDC_CHAIN || OP == MAD_MIX_ADDC) ? 2 : 1);
+    double ninstr = (double)ITER * 8 * ((OP == ADDC_CHAIN || OP == MAD_MIX_ADDC) ? 2 : (OP == MAD_AND_MIX || OP == MAD_SHIFT_MIX) ? 6 : OP == MAD_DEP10 ? 10 : OP == MAD_DEP10_SHIFT_AND ? 12 : OP == MAD_DEP40 ? 40 : OP == MAD_2X10 ? 10 : (OP == MAD10_AND10 || OP == AND20 || OP == MAD10_SHL10) ? 20 : 1);
     // s_memtime ticks at a constant 100 MHz on gfx9 — so also derive cycles from wall time at the reported clock.
     double wave_instr_per_simd = ninstr * wps;   // instructions issued on one SIMD
     printf("  wps=%d: %7.3f ms %5.2f ns/instr/SIMD %5.2f cyc/instr/SIMD", wps, ms, ms * 1e6 / wave_instr_per_simd, (double)mx / wave_instr_per_simd);
@@ -120,7 +136,7 @@ int main() {
   printf("device: %s  CUs=%d  clock=%d kHz  arch=%s\n", p.name, p.multiProcessorCount, p.clockRate, p.gcnArchName);
   int ncu = p.multiProcessorCount;
   uint32_t* out; unsigned long long* cyc;
-  CK(hipMalloc(&out, (size_t)ncu * 8 * 256 * 4)); CK(hipMalloc(&cyc, (size_t)ncu * 8 * 8));
+  CK(hipMalloc(&out, (size_t)ncu * 16 * 256 * 4)); CK(hipMalloc(&cyc, (size_t)ncu * 16 * 8));
   printf("ns/instr/SIMD x clock(GHz) = cycles per wave64 instruction on one SIMD\n");
   run<FMA_F32>(out, cyc, ncu);
   run<PK_FMA_F32>(out, cyc, ncu);
@@ -137,6 +153,17 @@ int main() {
   run<MUL_HI_U32>(out, cyc, ncu);
   run<MAD_U64_U32>(out, cyc, ncu);
   run<MAD_I64_I32>(out, cyc, ncu);
+  run<MAD_U64_SGPR>(out, cyc, ncu);
+  run<MAD_U64_ALT>(out, cyc, ncu);
+  run<MAD_AND_MIX>(out, cyc, ncu);
+  run<MAD_SHIFT_MIX>(out, cyc, ncu);
+  run<MAD_DEP10>(out, cyc, ncu);
+  run<MAD_DEP10_SHIFT_AND>(out, cyc, ncu);
+  run<MAD_2X10>(out, cyc, ncu);
+  run<MAD_DEP40>(out, cyc, ncu);
+  run<MAD10_AND10>(out, cyc, ncu);
+  run<AND20>(out, cyc, ncu);
+  run<MAD10_SHL10>(out, cyc, ncu);
   run<MAD_MIX_ADDC>(out, cyc, ncu);
   run<DOT4_U8>(out, cyc, ncu);
   run<DOT2_U16>(out, cyc, ncu);
