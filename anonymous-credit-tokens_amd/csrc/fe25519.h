@@ -1,7 +1,7 @@
 // fe25519.h — GF(2^255-19) for gfx950 lanes: 10 unsigned limbs in radix 2^25.5 (26/25 bits
 // alternating), one field element per lane, every column of a product one chain of
-// v_mad_u64_u32 (measured on MI355X: 4.7 cyc per wave64 issue, the same class as an add-with-carry,
-// so the representation minimises instruction count, not multiplies).
+// v_mad_u64_u32 (measured on MI355X: one per 4.06 cycles per SIMD in blocks of dependent ones, the cost of any other
+// VALU instruction in this mix, so the representation minimises instruction count, not multiplies).
 //
 // Replaces, for the device path, the field arithmetic the reference takes from curve25519-dalek
 // 4.1.3 (not in /root/reference; call sites /root/reference/src/lib.rs:465-1239 via
