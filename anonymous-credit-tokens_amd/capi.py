@@ -347,6 +347,13 @@ class Engine:
     def request_dev(self, n: int, d_pre: int, d_rng: int, d_out: int):
         self._ck(self.lib.act_request_batch(self.ctx, n, MEM_DEVICE, d_pre, d_rng, d_out))
 
+    def pre_issuance_random_dev(self, n: int, d_rng: int, d_out: int):
+        self._ck(self.lib.act_pre_issuance_random_batch(self.ctx, n, MEM_DEVICE, d_rng, d_out))
+
+    def issuance_to_credit_token_dev(self, n: int, d_pre: int, w: bytes, d_req: int, d_resp: int, d_tok: int, d_status: int):
+        pw, kw = _in(w, 32)
+        self._ck(self.lib.act_issuance_to_credit_token_batch(self.ctx, n, MEM_DEVICE, d_pre, pw, d_req, d_resp, d_tok, d_status))
+
     # ---- profiling ---------------------------------------------------------------------------------
     def prof_enable(self, on: bool = True):
         self._ck(self.lib.act_prof_enable(self.ctx, 1 if on else 0))
@@ -438,6 +445,11 @@ class Node:
         ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n)
         self._ck(self.lib.act_node_verify_spend_batch(self.nd, n, ps, p0, st.ctypes.data, kp.ctypes.data if want_kprime else None))
         return (st.tobytes(), kp.tobytes()) if want_kprime else st.tobytes()
+
+    def verify_spend_ptr(self, sk: bytes, n: int, p_proofs: int, p_status: int, p_kprime: int = 0):
+        """Raw HOST pointers (pageable or pinned): the call a Rust caller's slices turn into."""
+        ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_node_verify_spend_batch(self.nd, n, ps, p_proofs, p_status, p_kprime or None))
 
     def refund(self, sk: bytes, proofs: bytes, rng: bytes, rng_mode: int = RNG_PER_LANE):
         n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,6 +21,14 @@
 using namespace act;
 
 extern "C" void act_host_b3_xof64_x16(const uint8_t* msgs, size_t stride, uint32_t len, uint32_t* xof);   // host_hash.cpp
+
+// HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues per device (default 4).  A context owns two
+// streams; a process that holds two contexts on one GPU next to the streams of its framework (measured: bench.py's engine +
+// a node handle + torch's stream) runs out, two streams of one context land on the same hardware queue, and that context's
+// two-chunk pipeline silently runs its chunks one after the other (415 k instead of 466 k verifies/s from host memory).  The
+// library therefore asks for 8 queues unless the caller has set the variable; this only takes effect if it happens before the
+// HIP runtime initialises (a process that initialises HIP before loading this library sets it itself: bench.py does).
+__attribute__((constructor)) static void act_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 namespace {
 
@@ -31,10 +40,11 @@ const uint8_t kGeneratorEnc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x7
 
 enum ProfId { PK_SPEND_PREP, PK_SPEND_BITS, PK_SPEND_ENC, PK_SPEND_TAIL, PK_HASH_SPEND, PK_SPEND_FINISH, PK_SIGN_A, PK_HASH_SMALL, PK_SIGN_B,
               PK_ISSUE_A, PK_ISSUE_CHECK, PK_REQUEST_A, PK_REQUEST_B, PK_PROVE_HEAD, PK_PROVE_BITS, PK_PROVE_ENC, PK_PROVE_TAIL, PK_PROVE_RESP,
-              PK_CLIENT, PK_COUNT };
+              PK_CLIENT, PK_COPY_H2D, PK_COPY_D2H, PK_COUNT };
 const char* const kProfNames[PK_COUNT] = {"k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail", "k_hash_xof(spend)", "k_spend_finish",
                                           "k_sign_a", "k_hash_xof(small)", "k_sign_b", "k_issue_a", "k_issue_check", "k_request_a",
-                                          "k_request_b", "k_prove_head", "k_prove_bits", "k_prove_enc", "k_prove_tail", "k_prove_resp", "k_client_verify"};
+                                          "k_request_b", "k_prove_head", "k_prove_bits", "k_prove_enc", "k_prove_tail", "k_prove_resp", "k_client_verify",
+                                          "copy_h2d(bulk)", "copy_d2h(transcripts)"};
 
 struct PendingProf { int id; hipEvent_t e0, e1; uint64_t lanes; };
 
@@ -68,7 +78,8 @@ struct act_ctx {
   int host_threads = 0;
   std::string err;
   Slot slots[2];
-  uint32_t* d_tables[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::mutex mu;                       // every batch entry point holds it: calls on one context are serialised, whatever thread they come from
+  uint32_t* d_tables[4] = {nullptr, nullptr, nullptr, nullptr};     // shared with the other contexts of this device (table cache below)
   int fb_bits[4] = {0, 0, 0, 0};        // window width of each base's table
   uint32_t* d_half_h1 = nullptr;
   uint32_t* d_tables_ct = nullptr;     // ACT_CT_SECRET_TABLES builds only
@@ -116,6 +127,8 @@ int prof_collect(act_ctx* c, Slot& sl) {
     if (c->prof_base) {
       float t0 = 0; HIPCK(c, hipEventElapsedTime(&t0, c->prof_base, p.e0));
       c->prof_iv[p.id].emplace_back(t0, t0 + ms);
+      static FILE* const tl = [] { const char* f = getenv("ACT_TIMELINE_FILE"); return f ? fopen(f, "a") : (FILE*)nullptr; }();     // diagnostics: one line per launch / copy
+      if (tl) { fprintf(tl, "%s,%d,%.3f,%.3f,%llu\n", kProfNames[p.id], (int)(&sl - c->slots), t0, t0 + ms, (unsigned long long)p.lanes); fflush(tl); }
     }
     hipEventDestroy(p.e0); hipEventDestroy(p.e1);
   }
@@ -139,7 +152,9 @@ int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
 int dev_in(act_ctx* c, Slot& sl, int slot, int mem, const uint8_t* p, size_t bytes, const uint8_t** out) {
   if (mem == ACT_MEM_DEVICE || bytes == 0) { *out = p; return ACT_OK; }
   int rc = stage_reserve(c, sl, slot, bytes); if (rc) return rc;
-  HIPCK(c, hipMemcpyAsync(sl.d_stage[slot], p, bytes, hipMemcpyHostToDevice, sl.stream));
+  hipError_t ce = hipSuccess;
+  rc = prof_launch(c, sl, PK_COPY_H2D, bytes, [&] { ce = hipMemcpyAsync(sl.d_stage[slot], p, bytes, hipMemcpyHostToDevice, sl.stream); }); if (rc) return rc;
+  HIPCK(c, ce);
   sl.d_stage_dirty[slot] = std::max(sl.d_stage_dirty[slot], bytes);
   *out = sl.d_stage[slot];
   return ACT_OK;
@@ -243,7 +258,12 @@ int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_
   for (int k = 0; k < HASH_PIECES; k++) {
     size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
     if (!sl.h_ev[k]) HIPCK(c, hipEventCreateWithFlags(&sl.h_ev[k], hipEventDisableTiming));
-    if (i1 > i0) HIPCK(c, hipMemcpyAsync(sl.h_tr + i0 * stride, d_msgs + i0 * stride, (i1 - i0) * stride, hipMemcpyDeviceToHost, sl.stream));
+    if (i1 > i0) {
+      hipError_t ce = hipSuccess;
+      int rc = prof_launch(c, sl, PK_COPY_D2H, (i1 - i0) * stride, [&] { ce = hipMemcpyAsync(sl.h_tr + i0 * stride, d_msgs + i0 * stride, (i1 - i0) * stride, hipMemcpyDeviceToHost, sl.stream); });
+      if (rc) return rc;
+      HIPCK(c, ce);
+    }
     HIPCK(c, hipEventRecord(sl.h_ev[k], sl.stream));
   }
   return ACT_OK;
@@ -306,6 +326,50 @@ int set_pubkey(act_ctx* c, const uint8_t w[32]) {
   return ACT_OK;
 }
 
+
+// ---- fixed-base tables shared between the contexts of one device --------------------------------------------------
+// A table is a pure function of (base, window width): contexts with the same Params on the same GPU (the entries of a node
+// handle that list a device twice, a verifier context beside a prover context) use one copy.  At 24-bit windows that is
+// 23.6 GB and 0.9 s of construction per base saved for every context after the first.  Reference counted; the last context
+// to go frees it.  One lock per device, held across construction, so contexts on different GPUs build concurrently and a
+// second context on the same GPU waits for the first's table instead of building its own.
+struct SharedTable { uint8_t enc[32]; int bits; uint32_t* p; int refs; };
+struct DeviceTables { std::mutex mu; std::vector<SharedTable> tabs; };
+DeviceTables g_tables[64];
+
+// returns the table (building it on `s` from the decoded base at d_ext if no context of this device has it yet); nullptr =
+// the allocation failed (the caller falls back to a narrower width)
+uint32_t* table_acquire(int device, const uint8_t enc[32], int bits, const uint32_t* d_ext, hipStream_t s, bool* built) {
+  DeviceTables& dt = g_tables[device & 63];
+  std::lock_guard<std::mutex> lk(dt.mu);
+  for (SharedTable& t : dt.tabs)
+    if (t.bits == bits && memcmp(t.enc, enc, 32) == 0) { t.refs++; if (built) *built = false; return t.p; }
+  uint32_t* p = nullptr;
+  if (hipMalloc(&p, fb_table_words((uint32_t)bits) * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  launch_build_table(d_ext, p, (uint32_t)bits, s);
+  if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  SharedTable t{}; memcpy(t.enc, enc, 32); t.bits = bits; t.p = p; t.refs = 1;
+  dt.tabs.push_back(t);
+  if (built) *built = true;
+  return p;
+}
+void table_release(int device, uint32_t* p) {
+  if (!p) return;
+  DeviceTables& dt = g_tables[device & 63];
+  std::lock_guard<std::mutex> lk(dt.mu);
+  for (size_t i = 0; i < dt.tabs.size(); i++)
+    if (dt.tabs[i].p == p) {
+      if (--dt.tabs[i].refs == 0) { (void)hipFree(p); dt.tabs.erase(dt.tabs.begin() + i); }
+      return;
+    }
+}
+bool table_cached(int device, const uint8_t enc[32], int bits) {
+  DeviceTables& dt = g_tables[device & 63];
+  std::lock_guard<std::mutex> lk(dt.mu);
+  for (SharedTable& t : dt.tabs) if (t.bits == bits && memcmp(t.enc, enc, 32) == 0) return true;
+  return false;
+}
+
 int workspace_alloc(act_ctx* c) {
   const SpendTranscript st{c->L};
   size_t B = c->max_batch;
@@ -357,6 +421,23 @@ int finish_call(act_ctx* c, size_t n) {
   }
   return sync_all(c);
 }
+
+// Every entry point that runs kernels owns one of these from its first line: it serialises the callers of a context (the
+// Rust binding keeps the handle inside `Params`, which safe code may share between threads) and runs finish_call on EVERY
+// exit -- a failed call must not leave tokens, rng bytes, nonces or key-dependent buckets behind any more than a
+// successful one does.  On the failure path the wipe is best effort and the first error is the one reported.
+struct Call {
+  act_ctx* c; size_t n; std::unique_lock<std::mutex> lk; bool finished = false;
+  Call(act_ctx* c_, size_t n_) : c(c_), n(n_), lk(c_->mu) {}
+  int finish() { finished = true; return finish_call(c, n); }
+  ~Call() {
+    if (finished) return;
+    const std::string first = c->err;
+    (void)hipSetDevice(c->device);
+    (void)finish_call(c, n);
+    if (!first.empty()) c->err = first;
+  }
+};
 
 int from_uniform_on_device(int device, const uint8_t* in64, int n, uint8_t* out_enc) {
   int ndev = 0;
@@ -494,22 +575,36 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   HIPCK(c, hipMemcpyAsync(ok, d_ok, 16, hipMemcpyDeviceToHost, s0));
   HIPCK(c, hipStreamSynchronize(s0));
   if (!(ok[0] && ok[1] && ok[2] && ok[3])) { c->err = "h1/h2/h3 is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
-  // window widths: 16 bits everywhere by default (128 MiB per base); in contexts sized for throughput the two bases the
+  // Window widths: 16 bits everywhere by default (128 MiB per base).  In contexts sized for throughput the two bases the
   // range kernel multiplies (h1, h3: 48 of its table additions per proof-bit) get 24-bit windows, 23.6 GB each of the 288 GB
+  // -- but only when the device has that much to spare: free memory after this context's workspace must cover the tables
+  // that are not already shared on this device plus a reserve for what is allocated later (staging buffers of host-memory
+  // callers grow on demand: up to ~7 GB for a 65536-lane prover chunk).  ACT_FB_WIDE_BITS=16 turns the wide tables off,
+  // ACT_FB_WIDE_BITS=<n> picks another width, ACT_FB_ALL_WIDE=1 widens g and h2 as well (prover-heavy deployments).
   {
-    static const int wide_env = [] { const char* e = getenv("ACT_FB_WIDE_BITS"); return e ? atoi(e) : 0; }();          // tuning knobs
-    static const bool all_wide = getenv("ACT_FB_ALL_WIDE") != nullptr;                                                 // also g, h2 (prover-heavy deployments)
+    static const int wide_env = [] { const char* e = getenv("ACT_FB_WIDE_BITS"); return e ? atoi(e) : 0; }();
+    static const bool all_wide = getenv("ACT_FB_ALL_WIDE") != nullptr;
     int wide = wide_env ? wide_env : (c->max_batch >= 32768 ? 24 : FB_WBITS);
     if (wide < 4 || wide > 24) wide = FB_WBITS;
     for (int b = 0; b < 4; b++) c->fb_bits[b] = (b == BASE_H1 || b == BASE_H3 || all_wide) ? wide : FB_WBITS;
+    if (wide > FB_WBITS) {
+      size_t need = 0, free_b = 0, total_b = 0;
+      for (int b = 0; b < 4; b++)
+        if (c->fb_bits[b] > FB_WBITS && !table_cached(device, enc + 32 * b, c->fb_bits[b])) need += fb_table_words((uint32_t)c->fb_bits[b]) * 4;
+      const size_t reserve = (size_t)16 << 30;
+      if (need && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + reserve)) {
+        (void)hipGetLastError();
+        for (int b = 0; b < 4; b++) c->fb_bits[b] = FB_WBITS;
+      }
+    }
   }
   for (int b = 0; b < 4; b++) {
-    if (c->fb_bits[b] > FB_WBITS && hipMalloc(&c->d_tables[b], fb_table_words((uint32_t)c->fb_bits[b]) * 4) != hipSuccess) {
-      (void)hipGetLastError(); c->d_tables[b] = nullptr;
-      c->fb_bits[b] = FB_WBITS;                 // no room for the wide table (a GPU shared with other contexts): the default width
+    c->d_tables[b] = table_acquire(device, enc + 32 * b, c->fb_bits[b], d_ext + b * GE_WORDS, s0, nullptr);
+    if (!c->d_tables[b] && c->fb_bits[b] > FB_WBITS) {           // no room after all (another process took it meanwhile): the default width
+      c->fb_bits[b] = FB_WBITS;
+      c->d_tables[b] = table_acquire(device, enc + 32 * b, FB_WBITS, d_ext + b * GE_WORDS, s0, nullptr);
     }
-    if (!c->d_tables[b]) HIPCK(c, hipMalloc(&c->d_tables[b], fb_table_words((uint32_t)c->fb_bits[b]) * 4));
-    launch_build_table(d_ext + b * GE_WORDS, c->d_tables[b], (uint32_t)c->fb_bits[b], s0);
+    if (!c->d_tables[b]) { c->err = "fixed-base table allocation failed"; return ACT_ERR_HIP; }
     c->P.tab[b] = FbTab{c->d_tables[b], (uint32_t)c->fb_bits[b], (uint32_t)b};
   }
 #if defined(ACT_CT_SECRET_TABLES)
@@ -556,7 +651,7 @@ void act_ctx_destroy(act_ctx* c) {
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->prof_base) (void)hipEventDestroy(c->prof_base);
-  for (uint32_t* t : c->d_tables) if (t) (void)hipFree(t);
+  for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
@@ -583,6 +678,7 @@ size_t act_spend_transcript_bytes(const act_ctx* c) { return SpendTranscript{c->
 
 int act_private_key_random(act_ctx* c, const uint8_t rng[64], uint8_t out_sk[64]) {
   if (!c || !rng || !out_sk) return ACT_ERR_ARG;
+  Call call(c, 0);
   HIPCK(c, hipSetDevice(c->device));
   Slot& sl = c->slots[0];
   int rc = stage_reserve(c, sl, 0, 128); if (rc) return rc;
@@ -590,10 +686,11 @@ int act_private_key_random(act_ctx* c, const uint8_t rng[64], uint8_t out_sk[64]
   launch_keygen(c->P, sl.d_stage[0], 1, sl.d_stage[0] + 64, sl.stream);
   HIPCK(c, hipMemcpyAsync(out_sk, sl.d_stage[0] + 64, 64, hipMemcpyDeviceToHost, sl.stream));
   sl.d_stage_dirty[0] = std::max<size_t>(sl.d_stage_dirty[0], 128);
-  return finish_call(c, 0);
+  return call.finish();
 }
 int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* rng, uint8_t* out_pre) {
   if (!c || (n && (!rng || !out_pre))) return ACT_ERR_ARG;
+  Call call(c, 0);
   HIPCK(c, hipSetDevice(c->device));
   Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
@@ -605,11 +702,12 @@ int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* 
     if ((rc = dev_out_end(c, sl, mem, out_pre + off * 64, d_out, (size_t)m * 64))) return rc;
     HIPCK(c, hipStreamSynchronize(sl.stream));
   }
-  return finish_call(c, 0);
+  return call.finish();
 }
 
 int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
   if (!c || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
+  Call call(c, 0);
   HIPCK(c, hipSetDevice(c->device));
   Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
@@ -624,13 +722,14 @@ int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const u
     if ((rc = dev_out_end(c, sl, mem, out_req + off * 128, a.out, (size_t)m * 128))) return rc;
     if ((rc = sync_all(c))) return rc;
   }
-  return finish_call(c, 0);
+  return call.finish();
 }
 
 int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
                     int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!c || !sk || (n && (!req || !camt || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
   size_t cursor = 0, chunk = 0;
@@ -654,7 +753,7 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
     if ((rc = dev_out_end(c, sl, mem, out_resp + off * 160, d_out, (size_t)m * 160))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
   }
-  return finish_call(c, n);
+  return call.finish();
 }
 
 // The two halves of issue / refund as separate calls, for callers that must see every verdict before any rng is assigned:
@@ -662,6 +761,7 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
 // counting the accepted lanes of the shards in front, and only then signing.
 int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uint8_t* status) {
   if (!c || (n && (!req || !status))) return ACT_ERR_ARG;
+  Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc; size_t chunk = 0;
   for (size_t off = 0; off < n; off += c->max_batch, chunk++) {
@@ -675,11 +775,12 @@ int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uin
     if ((rc = prof_launch(c, sl, PK_ISSUE_CHECK, m, [&] { launch_issue_check(a, sl.stream); }))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
   }
-  return finish_call(c, n);
+  return call.finish();
 }
 // signs the lanes whose status_in is 0; `point` = IssuanceRequest records (label RESPOND, with amounts) or enc(K') (label REFUND)
 static int sign_only_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t sk[64], const uint8_t* point, size_t point_stride,
                            const uint8_t* camt, const uint8_t* status_in, const uint8_t* rng, int rng_mode, uint8_t* out, uint8_t* status) {
+  Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
   const size_t rec = label == LABEL_RESPOND ? 160 : 128;
@@ -701,7 +802,7 @@ static int sign_only_batch(act_ctx* c, size_t n, int mem, int label, const uint8
     if ((rc = dev_out_end(c, sl, mem, out + off * rec, d_out, (size_t)m * rec))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
   }
-  return finish_call(c, n);
+  return call.finish();
 }
 int act_issue_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* status_in,
                          const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
@@ -720,6 +821,7 @@ int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], c
 // the host touches chunk i again.
 static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
                        int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime) {
+  Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
   const size_t pb = ProofLayout{c->L}.bytes();
@@ -729,16 +831,34 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   // kernels' best size), short ones are cut finer so that there is something to pipeline
   const size_t host_chunk = host_chunk_env ? host_chunk_env : (n >= 8 * c->max_batch ? c->max_batch : (size_t)16384);
   const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
-  const size_t nchunks = (n + chunk_len - 1) / chunk_len;
+  static const int stagger_env = [] { const char* e = getenv("ACT_STAGGER"); return e ? atoi(e) : -1; }();      // tuning knob: force on / off
+  const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (mem == ACT_MEM_HOST || c->tr_mode == ACT_TRANSCRIPT_HOST);
+  // Chunk schedule.  Full-size chunks are the kernels' best size, but whenever a call moves data over PCIe the pipeline has a
+  // head (nothing computes until the first chunk's proofs have arrived and its per-proof kernel has run) and a tail (the
+  // last chunk's transcripts travel to the host, are hashed and come back with nothing left to overlap): measured 44 ms and
+  // ~60 ms of a 2.2 s call with 65 536-proof chunks.  Such calls therefore open and close with quarter- and half-size chunks.
+  std::vector<std::pair<size_t, size_t>> sched;          // (offset, lanes)
+  {
+    static const bool taper_off = getenv("ACT_NO_TAPER") != nullptr;
+    std::vector<size_t> head, tail;
+    size_t left = n;
+    if (stagger && !taper_off && chunk_len >= 4096 && n >= 4 * chunk_len) {
+      head = {chunk_len / 4, chunk_len / 2}; tail = {chunk_len / 2, chunk_len / 4};
+      left -= chunk_len / 4 * 2 + chunk_len / 2 * 2;
+    }
+    size_t off = 0;
+    for (size_t l : head) { sched.emplace_back(off, l); off += l; }
+    while (left) { size_t l = std::min(chunk_len, left); sched.emplace_back(off, l); off += l; left -= l; }
+    for (size_t l : tail) { sched.emplace_back(off, l); off += l; }
+  }
+  const size_t nchunks = sched.size();
   SpendChunk chunks[2];
   size_t cursor = 0;
   const size_t depth = (size_t)c->depth;
-  static const int stagger_env = [] { const char* e = getenv("ACT_STAGGER"); return e ? atoi(e) : -1; }();      // tuning knob: force on / off
-  const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (mem == ACT_MEM_HOST || c->tr_mode == ACT_TRANSCRIPT_HOST);
   c->last_bits_ev = nullptr;
   auto stage1 = [&](size_t i) -> int {
     Slot& sl = c->slots[i % depth]; SpendChunk& ch = chunks[i % depth];
-    ch = SpendChunk{}; ch.off = i * chunk_len; ch.m = (uint32_t)std::min(chunk_len, n - ch.off);
+    ch = SpendChunk{}; ch.off = sched[i].first; ch.m = (uint32_t)sched[i].second;
     ch.stagger = stagger;
     int r;
     if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
@@ -767,7 +887,7 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
     if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
   }
   for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
-  return finish_call(c, n);
+  return call.finish();
 }
 
 int act_verify_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
@@ -784,6 +904,7 @@ int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const 
 int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng,
                           uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
   if (!c || (n && (!token || !s || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+  Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   const size_t pb = ProofLayout{c->L}.bytes(), rb = act_prove_rng_bytes(c);
   const SpendTranscript st{c->L};
@@ -826,11 +947,12 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
     if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
   }
   for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
-  return finish_call(c, n);
+  return call.finish();
 }
 
 static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                         const uint8_t* resp, const uint8_t* proofs, uint8_t* out_token, uint8_t* status) {
+  Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_pubkey(c, w); if (rc) return rc;
   const bool issuance = label == LABEL_RESPOND;
@@ -857,7 +979,7 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
     if ((rc = sync_all(c))) return rc;
   }
-  return finish_call(c, n);
+  return call.finish();
 }
 int act_issuance_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                                        const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
@@ -914,6 +1036,7 @@ int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
 
 int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* points, const uint8_t* scalars, uint8_t* out, uint8_t* status) {
   if (!c || (n && (!points || !scalars || !out || !status))) return ACT_ERR_ARG;
+  Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
@@ -927,7 +1050,7 @@ int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* poi
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
     HIPCK(c, hipStreamSynchronize(sl.stream));
   }
-  return finish_call(c, n);
+  return call.finish();
 }
 
 // Test hook: bytes that are not zero in the context's secret-bearing buffers (what finish_call wipes), read back to the host.

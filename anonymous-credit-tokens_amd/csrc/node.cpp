@@ -7,7 +7,9 @@
 // every shard signs from its own offset into the stream -- byte for byte what one loop over one generator produces.
 // Plain host C++ over the C ABI: nothing here touches a device.
 #include <algorithm>
+#include <sys/random.h>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -18,6 +20,7 @@ struct act_node {
   std::vector<int> devices;
   int L = 0;
   std::string err;
+  std::mutex mu;      // every act_node_*_batch call holds it: a handle shared between host threads is used by one at a time
 };
 
 namespace {
@@ -65,17 +68,23 @@ int act_node_create(const uint8_t h[96], int L, const int* devices, int n_device
   act_node* nd = new act_node();
   *out = nd;      // returned even on failure so that act_node_last_error() can be read; the caller destroys it
   nd->L = L;
-  // contexts are created one after the other: table construction saturates a GPU anyway, and a failure leaves a clean prefix
-  for (int k = 0; k < n_devices; k++) {
-    act_ctx* c = nullptr;
-    int rc = act_ctx_create(h, L, devices[k], max_batch, &c);
-    if (rc) {
-      nd->err = "device " + std::to_string(devices[k]) + ": " + (c ? act_last_error(c) : "context creation failed");
-      if (c) act_ctx_destroy(c);
-      return rc;
-    }
-    nd->ctx.push_back(c); nd->devices.push_back(devices[k]);
+  // One thread per entry: contexts on different GPUs are built at the same time (a throughput-sized context spends ~2 s
+  // constructing 47 GB of fixed-base tables); entries that name the same GPU share that GPU's tables (engine.hip table
+  // cache), so the second one waits for the first one's tables instead of building its own.
+  std::vector<act_ctx*> made(n_devices, nullptr);
+  std::vector<int> rcs(n_devices, ACT_OK);
+  std::vector<std::thread> th;
+  for (int k = 1; k < n_devices; k++) th.emplace_back([&, k] { rcs[k] = act_ctx_create(h, L, devices[k], max_batch, &made[k]); });
+  rcs[0] = act_ctx_create(h, L, devices[0], max_batch, &made[0]);
+  for (auto& t : th) t.join();
+  int bad = -1;
+  for (int k = 0; k < n_devices; k++) if (rcs[k] && bad < 0) bad = k;
+  if (bad >= 0) {
+    nd->err = "device " + std::to_string(devices[bad]) + ": " + (made[bad] ? act_last_error(made[bad]) : "context creation failed");
+    for (act_ctx* c : made) if (c) act_ctx_destroy(c);
+    return rcs[bad];
   }
+  for (int k = 0; k < n_devices; k++) { nd->ctx.push_back(made[k]); nd->devices.push_back(devices[k]); }
   return ACT_OK;
 }
 void act_node_destroy(act_node* nd) {
@@ -99,6 +108,7 @@ int act_node_set_host_threads(act_node* nd, int per_gpu) {
 
 int act_node_request_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
   if (!nd || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   return run(nd, n, [&](size_t k, Shard s) {
     return act_request_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(pre, s.off, 64), at(rng, s.off, 128), at(out_req, s.off, 128));
   });
@@ -107,6 +117,7 @@ int act_node_request_batch(act_node* nd, size_t n, const uint8_t* pre, const uin
 int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* req, const uint8_t* c, const uint8_t* rng,
                          int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!nd || !sk || (n && (!req || !c || !rng || !out_resp || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
     return run(nd, n, [&](size_t k, Shard s) {
       return act_issue_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(req, s.off, 128), at(c, s.off, 32),
@@ -127,11 +138,13 @@ int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uin
 // by exactly 128 bytes per accepted lane, as the sequential loop would: INTEGRATION.md).
 int act_node_issue_check_batch(act_node* nd, size_t n, const uint8_t* req, uint8_t* status) {
   if (!nd || (n && (!req || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   return run(nd, n, [&](size_t k, Shard s) { return act_issue_check_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(req, s.off, 128), status + s.off); });
 }
 int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* req, const uint8_t* c, const uint8_t* status_in,
                               const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!nd || !sk || (n && (!req || !c || !status_in || !rng || !out_resp || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
   const std::vector<uint8_t> checked(status_in, status_in + n);
@@ -143,6 +156,7 @@ int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], cons
 int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
                                int rng_mode, uint8_t* out_refund, uint8_t* status) {
   if (!nd || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
   const std::vector<uint8_t> checked(status_in, status_in + n);
@@ -155,6 +169,7 @@ int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], con
 int act_node_issuance_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                                             const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
   if (!nd || !w || (n && (!pre || !req || !resp || !out_token || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   return run(nd, n, [&](size_t k, Shard s) {
     return act_issuance_to_credit_token_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(pre, s.off, 64), w, at(req, s.off, 128), at(resp, s.off, 160),
                                               at(out_token, s.off, 160), status + s.off);
@@ -164,6 +179,7 @@ int act_node_issuance_to_credit_token_batch(act_node* nd, size_t n, const uint8_
 int act_node_prove_spend_batch(act_node* nd, size_t n, const uint8_t* token, const uint8_t* s_, const uint8_t* rng, uint8_t* out_proof,
                                uint8_t* out_prerefund, uint8_t* status) {
   if (!nd || (n && (!token || !s_ || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]), rb = act_prove_rng_bytes(nd->ctx[0]);
   return run(nd, n, [&](size_t k, Shard s) {
     return act_prove_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(token, s.off, 160), at(s_, s.off, 32), at(rng, s.off, rb), at(out_proof, s.off, pb),
@@ -173,6 +189,7 @@ int act_node_prove_spend_batch(act_node* nd, size_t n, const uint8_t* token, con
 
 int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!nd || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   return run(nd, n, [&](size_t k, Shard s) {
     return act_verify_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(proof, s.off, pb), status + s.off, at(out_kprime, s.off, 32));
@@ -182,6 +199,7 @@ int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], co
 int act_node_refund_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
                           uint8_t* out_refund, uint8_t* status) {
   if (!nd || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
     return run(nd, n, [&](size_t k, Shard s) {
@@ -207,6 +225,7 @@ int act_node_refund_batch(act_node* nd, size_t n, const uint8_t sk[64], const ui
 int act_node_refund_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* prerefund, const uint8_t* proof, const uint8_t* refund,
                                           const uint8_t w[32], uint8_t* out_token, uint8_t* status) {
   if (!nd || !w || (n && (!prerefund || !proof || !refund || !out_token || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   return run(nd, n, [&](size_t k, Shard s) {
     return act_refund_to_credit_token_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(prerefund, s.off, 96), at(proof, s.off, pb), at(refund, s.off, 128), w,
@@ -227,6 +246,7 @@ struct act_node_nullifier_set {
   std::vector<int> devices;
   uint64_t route_key[2] = {0, 0};
   std::string err;
+  std::mutex mu;
 };
 
 namespace {
@@ -243,10 +263,23 @@ void reduce_mod_l(const uint8_t in[32], uint64_t out[4]) {
   }
   memcpy(out, v, 32);
 }
-uint64_t route_hash(const uint64_t k[4], const uint64_t key[2]) {     // keyed mix (the per-GPU tables use their own SipHash keys)
-  uint64_t h = key[0];
-  for (int i = 0; i < 4; i++) { h ^= k[i] + key[1]; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29; }
-  return h;
+// Owner of a key = SipHash-1-3 of the reduced scalar under the set's 128-bit routing key (the same construction the per-GPU
+// tables use for their slots, nullifier_impl.inc null_hash, each under its own key).  Clients choose their nullifiers: with
+// an unkeyed or weakly mixed owner function they could aim every spend at one GPU and exhaust that GPU's capacity.
+uint64_t route_hash(const uint64_t k[4], const uint64_t key[2]) {
+  uint64_t v0 = key[0] ^ 0x736f6d6570736575ull, v1 = key[1] ^ 0x646f72616e646f6dull, v2 = key[0] ^ 0x6c7967656e657261ull, v3 = key[1] ^ 0x7465646279746573ull;
+  auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+  auto round = [&]() {
+    v0 += v1; v1 = rotl(v1, 13); v1 ^= v0; v0 = rotl(v0, 32);
+    v2 += v3; v3 = rotl(v3, 16); v3 ^= v2;
+    v0 += v3; v3 = rotl(v3, 21); v3 ^= v0;
+    v2 += v1; v1 = rotl(v1, 17); v1 ^= v2; v2 = rotl(v2, 32);
+  };
+  for (int i = 0; i < 4; i++) { v3 ^= k[i]; round(); v0 ^= k[i]; }
+  const uint64_t last = (uint64_t)32 << 56;
+  v3 ^= last; round(); v0 ^= last;
+  v2 ^= 0xff; round(); round(); round();
+  return v0 ^ v1 ^ v2 ^ v3;
 }
 }  // namespace
 
@@ -256,6 +289,14 @@ int act_node_nullifier_set_create(const int* devices, int n_devices, size_t capa
   act_node_nullifier_set* ns = new act_node_nullifier_set();
   *out = ns;
   if (salt) memcpy(ns->route_key, salt, 16);
+  else {                                                       // no caller-supplied key: 16 bytes from the OS, or no set at all
+    size_t got = 0;
+    while (got < 16) {
+      ssize_t r = getrandom(reinterpret_cast<uint8_t*>(ns->route_key) + got, 16 - got, 0);
+      if (r <= 0) { ns->err = "getrandom failed: no routing key"; return ACT_ERR_ARG; }
+      got += (size_t)r;
+    }
+  }
   for (int k = 0; k < n_devices; k++) {
     act_nullifier_set* s = nullptr;
     int rc = act_nullifier_set_create(devices[k], capacity_per_device, nullptr, &s);     // every table draws its own slot-hash key
@@ -279,6 +320,7 @@ const char* act_node_nullifier_set_last_error(const act_node_nullifier_set* ns) 
 int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t n, const uint8_t* nullifiers, size_t stride, const uint8_t* skip_mask,
                                               uint8_t* out_spent) {
   if (!ns || (n && (!nullifiers || !out_spent)) || stride < 32) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> lock(ns->mu);
   const size_t parts = ns->sets.size();
   std::vector<std::vector<uint32_t>> lanes(parts);
   std::vector<std::vector<uint8_t>> keys(parts), spent(parts);
@@ -299,10 +341,20 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t
   for (size_t p = 1; p < parts; p++) th.emplace_back(work, p);
   work(0);
   for (auto& t : th) t.join();
+  // Every device answers for its own keys.  If one of them failed, the others have still inserted theirs: their lanes get
+  // their (final) answers, the failed device's lanes get ACT_NULLIFIER_UNDETERMINED, and the call reports the error --
+  // a caller that retries must resubmit only the undetermined lanes, or the lanes already inserted would come back "spent".
+  int first_rc = ACT_OK;
+  ns->err.clear();
   for (size_t p = 0; p < parts; p++) {
-    if (rc[p]) { ns->err = "device " + std::to_string(ns->devices[p]) + ": " + act_nullifier_set_last_error(ns->sets[p]); return rc[p]; }
-    for (size_t j = 0; j < lanes[p].size(); j++) out_spent[lanes[p][j]] = spent[p][j];
+    if (rc[p]) {
+      if (!first_rc) first_rc = rc[p];
+      ns->err += (ns->err.empty() ? "device " : "; device ") + std::to_string(ns->devices[p]) + ": " + act_nullifier_set_last_error(ns->sets[p]);
+      for (size_t j = 0; j < lanes[p].size(); j++) out_spent[lanes[p][j]] = ACT_NULLIFIER_UNDETERMINED;
+    } else {
+      for (size_t j = 0; j < lanes[p].size(); j++) out_spent[lanes[p][j]] = spent[p][j];
+    }
   }
-  return ACT_OK;
+  return first_rc;
 }
 }  // extern "C"

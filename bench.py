@@ -1,24 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — spend-proof verifies/sec (whole node), batch 2^20 per GPU, L = 128 (BASELINE.json metric).
+"""bench.py — spend-proof verifies/sec (whole node), batch 2^20, L = 128 (BASELINE.json metric).
 
 A step = one pass of the hot path (PrivateKey::refund up to the challenge check, src/lib.rs:787-844) over one batch of
 2^20 synthetic spend proofs that are already resident in HBM when the timed region starts, transcripts hashed by the
-device BLAKE3 kernel (byte-identical to the host path).  That is `value`.  One process per GPU; ranks shard independent
-batches (weak scaling, no data-path collective — torch.distributed/RCCL is used only for the barrier and the
-max-over-ranks reduction of the timing).
+device BLAKE3 kernel (byte-identical to the host path).  That is `value`.  **Every proof of the batch is distinct**: the
+engine's own prover makes 2^20 of them on the device before the timed region (c uniform in [0, 2^L), s uniform in [0, c]:
+SURVEY.md 8d config 3), so no launch holds a proof twice and the scalar-addressed look-ups into the 47 GB fixed-base tables
+are as cold as real traffic makes them; 1 lane in 1024 is tampered.  One process per GPU; ranks shard independent batches with
+no data-path collective — torch.distributed/RCCL is used only for the barrier and the max-over-ranks reduction of the timing.
 
-At N = 1 the same process also measures and prints, inside the one JSON line:
-  extra.host_transcript_hbm      the library's default / north-star contract mode: transcripts hashed on host threads
-  extra.host_transcript_hostmem  ... with the proofs in pinned HOST memory and statuses returned to host memory
-                                 (ACT_MEM_HOST, what a Rust caller passes): the PCIe-inclusive rate, never `value`
-  extra.refund                   verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
-  extra.verify_L64               BASELINE config 2: 2^16 verifies at L = 64
-  roofline                       HBM view the contract asks for (algorithmic bytes / k_spend_bits busy time) ...
-  roofline.alu                   ... and the roofline that actually binds: 64-bit multiply-accumulates per second against
-                                 a v_mad_u64_u32 micro-kernel timed in this run on this GPU; the multiply-accumulates
-                                 per verify are counted, not estimated (the kernels' own lane bodies executed on the
-                                 host with counting field operations, tests/hostcheck)
-  cpu_baseline                   the C oracle (a port of the reference algorithm) on this box's host cores
+Scaling: the default line is WEAK scaling (2^20 proofs per rank).  At N > 1 the same run also times the metric as
+BASELINE.json words it — ONE 2^20 batch over the whole node, 2^20 / N proofs per rank — and prints it as `strong`
+(`--scaling strong` swaps which of the two is `value`).
+
+The one JSON line carries
+  roofline             the binding roofline of the dominant kernel, k_spend_bits: 64-bit integer multiply-accumulates per second
+                       against a v_mad_u64_u32 micro-kernel timed in this run on this GPU; the multiply-accumulates per verify
+                       are counted, not estimated (the kernels' own lane bodies executed on the host with counting field
+                       operations, tests/hostcheck).  roofline.hbm is the HBM view the contract also asks for (not binding).
+  cpu_baseline         the C oracle (a port of the reference algorithm) on this box's host cores; it also re-verifies the
+                       tampered lanes of the first chunk and its whole sample against the GPU's statuses
+and at N = 1
+  extra.tiled_4096                 the round-1/2 input (4 096 distinct proofs tiled x256): what tiling flatters
+  extra.host_transcript_hbm*       the library's default / north-star contract mode: transcripts hashed on host threads
+  extra.host_transcript_hostmem    ... with the proofs in pinned HOST memory and statuses returned to host memory
+  extra.node_host_path             2^20 proofs through act_node_verify_spend_batch (devices = [0]) from PAGEABLE and from
+                                   pinned host memory: the path the Rust binding takes (PCIe-inclusive, never `value`)
+  extra.refund                     verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
+  extra.verify_L64                 BASELINE config 2: 2^16 verifies at L = 64
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -35,12 +44,17 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps a process's streams onto 4 hardware queues per device by default; this process holds two engine contexts (2 streams
+# each) beside torch's streams, and with 4 queues the node context's two streams share one (its chunks then run one after the
+# other: 415 k instead of 466 k verifies/s on extra.node_host_path).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ELL = 2**252 + 27742317777372353535851937790883648493
 CSRC = os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc")
 # sources that determine k_spend_bits: PMC summaries under profiles/ are only cited when they were taken from these bytes
 KERNEL_SOURCES = ["fe25519.h", "fe25519_gen.inc", "fe25519_consts.inc", "sc25519.h", "ge25519.h", "msm.h", "kernels.h", "spend_lanes.h",
                   "k_spend_verify.hip"]
+MAD_PER_MUL, MAD_PER_SQ = 100, 55         # fe25519.h: a product is 10 columns x 10 v_mad_u64_u32, a square 55
 
 
 def proof_bytes(L):
@@ -63,8 +77,7 @@ def kernel_source_sha16():
 
 
 def make_inputs(eng, sk, distinct):
-    """`distinct` valid spend proofs made by the engine itself (request -> issue -> token -> prove_spend):
-    bench Params, c uniform in [20,1000), s uniform in [1,c-1] (benches/benchmark.rs:131,147-154)."""
+    """`distinct` valid spend proofs through the host-memory entry points (small counts: the CPU-baseline config, tests)."""
     import random
     r = random.Random(20240101)
     pre = eng.pre_issuance_random(shake("bench-pre", 128 * distinct))
@@ -80,6 +93,55 @@ def make_inputs(eng, sk, distinct):
     return proofs
 
 
+def make_distinct_proofs_on_device(eng, capi, torch, np, sk, n, L, seed, chunk=None):
+    """n DISTINCT valid spend proofs, resident in HBM, made by the engine itself on the device: per chunk
+    PreIssuance::random -> request -> issue -> to_credit_token -> prove_spend, all with device-memory pointers and rng bytes
+    drawn on the device (torch.randint; 33 536 B per proof would be 35 GB over PCIe otherwise).  Credits c uniform in
+    [0, 2^L), charges s uniform in [0, c], drawn on the host with Python integers.
+    Returns (proofs [n, PB] uint8 cuda tensor, seconds spent in prove_spend)."""
+    import random
+    r = random.Random(20240101 + 7919 * seed)
+    PB = proof_bytes(L)
+    chunk = chunk or 65536
+    cs = [r.getrandbits(L) for _ in range(n)]
+    ss = [r.randrange(c + 1) for c in cs]
+    c_host = np.frombuffer(b"".join(c.to_bytes(32, "little") for c in cs), np.uint8).reshape(n, 32)
+    s_host = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in ss), np.uint8).reshape(n, 32)
+    dev = torch.empty((n, PB), dtype=torch.uint8, device="cuda")
+    g = torch.Generator(device="cuda"); g.manual_seed(20240101 + seed)
+    rnd = lambda *shape: torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
+    buf = lambda m, w: torch.empty((m, w), dtype=torch.uint8, device="cuda")
+    t_prove = 0.0
+    for off in range(0, n, chunk):
+        m = min(chunk, n - off)
+        d_c = torch.from_numpy(c_host[off:off + m].copy()).cuda(); d_s = torch.from_numpy(s_host[off:off + m].copy()).cuda()
+        r_pre, r_rq, r_ir, r_pr = rnd(m, 128), rnd(m, 128), rnd(m, 128), rnd(m, eng.prove_rng_bytes)
+        pre, req, resp, tok, prer = buf(m, 64), buf(m, 128), buf(m, 160), buf(m, 160), buf(m, 96)
+        st = torch.empty(m, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()          # the engine works on its own streams
+        eng.pre_issuance_random_dev(m, r_pre.data_ptr(), pre.data_ptr())
+        eng.request_dev(m, pre.data_ptr(), r_rq.data_ptr(), req.data_ptr())
+        eng.issue_dev(sk, m, req.data_ptr(), d_c.data_ptr(), r_ir.data_ptr(), capi.RNG_PER_LANE, resp.data_ptr(), st.data_ptr())
+        assert int(st.sum()) == 0
+        eng.issuance_to_credit_token_dev(m, pre.data_ptr(), sk[32:], req.data_ptr(), resp.data_ptr(), tok.data_ptr(), st.data_ptr())
+        assert int(st.sum()) == 0
+        t = time.perf_counter()
+        eng.prove_spend_dev(m, tok.data_ptr(), d_s.data_ptr(), r_pr.data_ptr(), dev[off:off + m].data_ptr(), prer.data_ptr(), st.data_ptr())
+        t_prove += time.perf_counter() - t
+        assert int(st.sum()) == 0
+        del r_pr
+    return dev, t_prove
+
+
+def tamper(torch, dev, n):
+    """1 lane in 1024: flipped charge bit (-> InvalidClientSpendProof, 7) or A' = identity (-> IdentityPointError, 6)."""
+    idx = torch.arange(513, n, 1024, device="cuda")
+    dev[idx[0::2], 32] ^= 1
+    dev[idx[1::2], 64:96] = 0
+    expect = torch.zeros(n, dtype=torch.uint8, device="cuda"); expect[idx[0::2]] = 7; expect[idx[1::2]] = 6
+    return expect, idx
+
+
 def usable_cores():
     """Host threads this process may actually use: CPU affinity capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -92,35 +154,71 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(proofs_host, h, sk, L, seconds_target=12.0):
+def mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def prebuild_cpu_side(want_cpu_baseline):
+    """Everything that spawns a compiler, done BEFORE the process touches the GPU (a child process started by a process that
+    has initialised HIP — under rocprofv3 one that carries the profiler's preload — is the pattern to stay away from on this
+    pool): the instrumented host build of the lane bodies (field-operation counts) and the -march=native C oracle."""
+    paths = {}
+    src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
+    out = os.path.join("/tmp", "libhostcheck_bench_%d.so" % os.getpid())
+    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src], check=True)
+    paths["hostcheck"] = out
+    if want_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c
+        native = os.path.join("/tmp", "libact_oracle_native_%d.so" % os.getpid())
+        try:
+            oracle_c.build(native_out=native)
+            paths["oracle"] = native
+        except Exception:
+            oracle_c.build()
+            paths["oracle"] = None
+    return paths
+
+
+def cpu_baseline(paths, proofs_host, expect_host, extra_lanes_host, extra_expect, h, sk, L, seconds_target=12.0):
     """The C oracle (a restatement of the reference algorithm with the reference's operation structure — NOT the
-    Rust crate, which cannot be built here) timed on this box's host cores on a bounded sample of the same proofs."""
+    Rust crate, which cannot be built here) timed on this box's host cores on a bounded sample of the bench's own proofs
+    (lanes 0 .. n-1 of the batch, tampered lanes included).  Its statuses must equal the GPU's (`expect`), which also makes
+    it the SURVEY.md 8d diff of "the first lanes + the tampered lanes" against the CPU backend."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_c
     pb = proof_bytes(L)
-    native = os.path.join("/tmp", "libact_oracle_native_%d.so" % os.getpid())
-    try:
-        oracle_c.build(native_out=native)
-        o = oracle_c.Oracle(native)
-    except Exception:
-        o = oracle_c.Oracle()
+    o = oracle_c.Oracle(paths.get("oracle")) if paths.get("oracle") else oracle_c.Oracle()
     ctx = o.ctx(h, L)
     cores = usable_cores()
+    avail = len(proofs_host) // pb
     t = time.perf_counter(); st = ctx.verify_spend_batch(sk, proofs_host[:pb * 8], 1); t1 = (time.perf_counter() - t) / 8
-    assert st == bytes(8)
-    n = max(cores, min(len(proofs_host) // pb, int(seconds_target / t1 * cores * 0.6)))
-    n = min(n, len(proofs_host) // pb)
+    assert st == bytes(expect_host[:8])
+    n = min(avail, max(cores, int(seconds_target / t1 * cores * 0.6)))
     t = time.perf_counter(); st = ctx.verify_spend_batch(sk, proofs_host[:pb * n], cores); dt = time.perf_counter() - t
-    assert st == bytes(n)
+    assert st == bytes(expect_host[:n]), "oracle and GPU statuses differ on the baseline sample"
+    tampered_checked = sum(1 for v in expect_host[:n] if v)
+    if extra_lanes_host:
+        st = ctx.verify_spend_batch(sk, extra_lanes_host, cores)
+        assert st == bytes(extra_expect), "oracle and GPU statuses differ on the tampered lanes"
+        tampered_checked += len(extra_expect)
     per_fn = config1_round_trip(ctx, L)
-    try:
-        os.unlink(native)
-    except OSError:
-        pass
+    if paths.get("oracle"):
+        try:
+            os.unlink(paths["oracle"])
+        except OSError:
+            pass
     return {"value": n / dt, "unit": "verifies/s", "cores": cores, "kind": "port", "config1_single_round_trip_ms": per_fn,
-            "sample": "%d of the bench's own L=%d proofs, C oracle (-O3 -march=native), %d threads, %.1f s; 1 thread: %.2f verifies/s"
-                      % (n, L, cores, dt, 1.0 / t1),
-            "single_thread_value": 1.0 / t1}
+            "sample": "lanes 0..%d of the bench's own L=%d batch (tampered lanes included), C oracle (-O3 -march=native), %d threads, %.1f s; "
+                      "1 thread: %.2f verifies/s; statuses equal to the GPU's on the sample and on %d tampered lanes"
+                      % (n - 1, L, cores, dt, 1.0 / t1, tampered_checked),
+            "single_thread_value": 1.0 / t1, "lanes_checked_against_gpu": n + len(extra_expect), "tampered_lanes_checked": tampered_checked}
 
 
 def config1_round_trip(ctx, L, reps=6):
@@ -150,21 +248,18 @@ def config1_round_trip(ctx, L, reps=6):
     return {k: round(1e3 * v / reps, 3) for k, v in acc.items()}
 
 
-def count_field_ops(h, L, sk, proofs_host, fb_bits, sample=4):
+def count_field_ops(hc_path, h, L, sk, proofs_host, fb_bits, sample=4):
     """Exact field-operation counts of one verify: the spend kernels' own lane bodies (csrc/spend_lanes.h) executed on the
-    host, with counting fe_mul / fe_sq, by the instrumented test build tests/hostcheck (built here with g++).  A count of
-    operations, not a computation of results: statuses come from the GPU.  fb_bits = the context's table window widths
+    host, with counting fe_mul / fe_sq, by the instrumented test build tests/hostcheck (built by prebuild_cpu_side).  A count
+    of operations, not a computation of results: statuses come from the GPU.  fb_bits = the context's table window widths
     (g, h1, h2, h3): a fixed-base product is ceil(253 / bits) mixed additions of 7 multiplications."""
-    src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
-    out = os.path.join("/tmp", "libhostcheck_bench_%d.so" % os.getpid())
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src], check=True)
-    hc = ctypes.CDLL(out)
+    hc = ctypes.CDLL(hc_path)
     pb = proof_bytes(L); n = sample
     tb = 184 + 40 * (6 + 3 * L)
     tr = ctypes.create_string_buffer(n * tb); st = ctypes.create_string_buffer(n); kp = ctypes.create_string_buffer(32 * n)
     c = (ctypes.c_uint64 * 25)()
     ok = hc.hc_spend_verify(h, L, sk, n, proofs_host[:pb * n], tr, st, kp, c)
-    os.unlink(out)
+    os.unlink(hc_path)
     assert ok == 1 and st.raw == bytes(n)
     windows = [-(-253 // b) for b in fb_bits]
     per = {}
@@ -196,7 +291,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--range-bits", type=int, default=128, help="L; 128 is the crate's width and the metric's")
-    ap.add_argument("--distinct", type=int, default=4096)
+    ap.add_argument("--distinct", type=int, default=0, help="0 = every proof of the batch distinct (default); k > 0 = k distinct proofs tiled (the round-1/2 input)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which of the two N > 1 measurements is `value` (both are printed)")
     ap.add_argument("--max-batch", type=int, default=65536)
     ap.add_argument("--extra-log2", type=int, default=18, help="proofs per extra measurement (contract mode, refund)")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="chunks in flight; 1 for profiling runs (rocprofv3 per-kernel durations then do not overlap)")
@@ -208,11 +304,13 @@ def main():
     args = ap.parse_args()
     L = args.range_bits
     PB = proof_bytes(L)
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    paths = prebuild_cpu_side(want_cpu) if rank == 0 else {}
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
     if args.force_device >= 0:
@@ -231,19 +329,18 @@ def main():
     eng = capi.Engine(h, L, device=local, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
     eng.set_pipeline_depth(args.pipeline_depth)
     sk = eng.private_key_random(shake("bench-sk", 64))
-    distinct = min(args.distinct, n)
-    proofs = make_inputs(eng, sk, distinct)
-    host = np.frombuffer(proofs, np.uint8).reshape(distinct, PB)
-    dev = torch.from_numpy(host.copy()).cuda().repeat(n // distinct, 1).contiguous()      # distinct proofs tiled
-    # 1 lane in 1024 tampered: flipped charge bit (-> InvalidClientSpendProof) or A' = identity (-> IdentityPointError)
-    idx = torch.arange(513, n, 1024, device="cuda")
-    dev[idx[0::2], 32] ^= 1
-    dev[idx[1::2], 64:96] = 0
-    expect = torch.zeros(n, dtype=torch.uint8, device="cuda"); expect[idx[0::2]] = 7; expect[idx[1::2]] = 6
+    t_gen = time.perf_counter()
+    if args.distinct and args.distinct < n:
+        distinct = args.distinct
+        first, t_prove = make_distinct_proofs_on_device(eng, capi, torch, np, sk, distinct, L, rank, args.max_batch)
+        dev = first.repeat(n // distinct, 1).contiguous(); del first
+    else:
+        distinct = n
+        dev, t_prove = make_distinct_proofs_on_device(eng, capi, torch, np, sk, n, L, rank, args.max_batch)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    expect, idx = tamper(torch, dev, n)
     status = torch.zeros(n, dtype=torch.uint8, device="cuda")
-
-    def step():
-        eng.verify_spend_dev(sk, n, dev.data_ptr(), status.data_ptr())
 
     def barrier():
         torch.cuda.synchronize()
@@ -251,23 +348,40 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.cuda.synchronize()      # the engine runs on its own streams: inputs written by torch must be complete first
-    for _ in range(args.warmup):
-        step()
-    eng.prof_reset(); eng.prof_enable(True)        # HIP events on the engine's own streams (torch events cannot see them)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    eng.prof_enable(False)
+    def timed_region(m, steps, warmup):
+        """EXACTLY `steps` passes over the first m proofs of this rank's batch between barriers; max over ranks."""
+        def step():
+            eng.verify_spend_dev(sk, m, dev.data_ptr(), status.data_ptr())
+        torch.cuda.synchronize()      # the engine runs on its own streams: inputs written by torch must be complete first
+        for _ in range(warmup):
+            step()
+        eng.prof_reset(); eng.prof_enable(True)        # HIP events on the engine's own streams (torch events cannot see them)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        eng.prof_enable(False)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert torch.equal(status[:m], expect[:m]), "verification statuses wrong"
+        return elapsed, eng.prof()
+
+    # weak scaling: every rank its own 2^batch_log2 proofs;  strong scaling: ONE batch of that size over the whole node
+    weak_elapsed, weak_prof = timed_region(n, args.steps, args.warmup)
+    strong = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.equal(status, expect), "verification statuses wrong"
-    prof = eng.prof()
+        n_s = n // world
+        status.zero_()
+        s_elapsed, s_prof = timed_region(n_s, args.steps, args.warmup)
+        strong = {"value": world * n_s * args.steps / s_elapsed, "unit": "verifies/s", "ms_per_step": 1e3 * s_elapsed / args.steps, "batch_total": world * n_s,
+                  "batch_per_gpu": n_s, "launch_chunks_per_gpu": -(-n_s // args.max_batch), "scaling": "strong",
+                  "what": "BASELINE.json's metric as worded: ONE 2^%d batch over the whole node, contiguous shards of 2^%d / %d proofs per rank, no collective"
+                          % (args.batch_log2, args.batch_log2, world)}
+    elapsed, prof = weak_elapsed, weak_prof
 
     if rank == 0:
         value = world * n * args.steps / elapsed
@@ -279,34 +393,65 @@ def main():
         launch_s = bits["busy_ms"] / 1e3 / max(1, bits["launches"])
         proofs_per_launch = bits["lanes"] / max(1, bits["launches"]) / L
         algo_bytes = PB + 1
-        achieved = algo_bytes * proofs_per_launch / launch_s / 1e9 if launch_s else 0.0
+        hbm_achieved = algo_bytes * proofs_per_launch / launch_s / 1e9 if launch_s else 0.0
         kernel_ms = {k: {"busy": round(v["busy_ms"] / args.steps, 3), "sum_of_launches": round(v["ms"] / args.steps, 3)} for k, v in prof.items()}
         assert bits["busy_ms"] / args.steps <= ms_per_step * 1.001, "kernel busy time exceeds the step time"
 
+        data = ("synthetic: 2^%d DISTINCT valid L=%d proofs per GPU made by the engine's own prover on the device (c uniform in [0,2^%d), s uniform in [0,c]), "
+                "1/1024 lanes tampered; device transcripts" % (args.batch_log2, L, L)) if distinct == n else \
+               ("synthetic: %d distinct valid L=%d proofs made by the engine's own prover, tiled to 2^%d per GPU, 1/1024 lanes tampered; device transcripts"
+                % (distinct, L, args.batch_log2))
         out = {
             "metric": "spend-proof verifies/sec (whole node), batch=2^20", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs / u64 accumulators (integer)",
-            "data": "synthetic: %d distinct valid L=%d proofs made by the engine's own prover, tiled to 2^%d per GPU, 1/1024 lanes tampered; device transcripts"
-                    % (distinct, L, args.batch_log2),
+            "data": data,
             "config": {"workload": "configs[1] scaled to the metric batch: 2^%d spend-proof verifies per GPU, L=%d%s, inputs resident in HBM"
                                    % (args.batch_log2, L, " (the crate's width)" if L == 128 else ""),
-                       "batch_per_gpu": n, "range_bits": L, "lanes_per_launch": args.max_batch, "chunks_in_flight": args.pipeline_depth, "transcript": "device BLAKE3",
+                       "batch_per_gpu": n, "distinct_proofs_per_gpu": distinct, "range_bits": L, "lanes_per_launch": args.max_batch,
+                       "chunks_in_flight": args.pipeline_depth, "transcript": "device BLAKE3",
                        "fixed_base_window_bits_g_h1_h2_h3": eng.fixed_base_bits(),
-                       "sharding": "independent batches per rank, no collective"},
+                       "sharding": "independent batches per rank, no collective",
+                       "input_generation_s": round(t_gen, 2), "prove_spend_proofs_per_s": round(distinct / t_prove) if t_prove else None},
         }
-        roof = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
-                "kernel": "k_spend_bits", "avg_launch_ms": 1e3 * launch_s, "launches_per_step": launches_per_step,
+        if strong:
+            out["strong"] = strong
+            if args.scaling == "strong":          # the metric as BASELINE.json words it becomes the headline; the weak figures stay alongside
+                out["weak"] = {"value": value, "ms_per_step": ms_per_step, "batch_per_gpu": n, "scaling": "weak"}
+                out["value"], out["ms_per_step"], out["scaling"] = strong["value"], strong["ms_per_step"], "strong"
+                out["config"]["batch_per_gpu"] = strong["batch_per_gpu"]
+                out["config"]["sharding"] = "one batch cut into contiguous shards, one per rank, no collective"
+        sha = kernel_source_sha16()
+        # ---- the binding roofline: measured peak of the multiply-accumulate instruction, counted work per verify --------
+        proofs_host = dev[:4].cpu().numpy().tobytes()
+        peak_mad, probe_ms = capi.ubench_mad(local)
+        ops = count_field_ops(paths["hostcheck"], h, L, sk, proofs_host, eng.fixed_base_bits())
+        fe_mul = sum(v["fe_mul"] for v in ops.values()); fe_sq = sum(v["fe_sq"] for v in ops.values())
+        mad_per_verify = MAD_PER_MUL * fe_mul + MAD_PER_SQ * fe_sq
+        bits_mad_per_proof = MAD_PER_MUL * ops["k_spend_bits"]["fe_mul"] + MAD_PER_SQ * ops["k_spend_bits"]["fe_sq"]
+        bits_rate = bits_mad_per_proof * proofs_per_launch / launch_s if launch_s else 0.0
+        roof = {"bound": "valu-int-mad", "kernel": "k_spend_bits",
+                "achieved": bits_rate, "peak": peak_mad, "unit": "lane multiply-accumulates (v_mad_u64_u32) per second", "frac": bits_rate / peak_mad,
+                "traffic": None,
+                "avg_launch_ms": 1e3 * launch_s, "launches_per_step": launches_per_step,
                 "avg_launch_ms_x_launches_per_step": 1e3 * launch_s * launches_per_step,
-                "proofs_per_launch": proofs_per_launch, "algorithmic_bytes_per_verify": algo_bytes,
+                "proofs_per_launch": proofs_per_launch,
+                "algorithmic_mad_per_proof_in_this_kernel": bits_mad_per_proof, "mad_per_verify_whole_path": mad_per_verify,
+                "whole_path": {"achieved": value / world * mad_per_verify, "frac": value / world * mad_per_verify / peak_mad,
+                               "what": "all kernels of the path: verifies/s per GPU x multiply-accumulates per verify"},
+                "fe_mul_per_verify": fe_mul, "fe_sq_per_verify": fe_sq, "per_kernel_field_ops_per_verify": ops, "probe_ms": probe_ms,
                 "timing": "HIP events on the engine's streams over the timed region; avg_launch_ms = (time during which k_spend_bits was executing) / launches "
                           "— two chunks' launches overlap on two streams, each launch's own start-to-end duration is kernel_ms_per_step.sum_of_launches",
-                "note": "not HBM bound: 16.8 KB in per verify against ~43 M 64-bit multiply-accumulates (roofline.alu is the binding view); "
-                        "PMC traffic is dominated by the per-lane Pippenger buckets cycling through L2 / Infinity Cache"}
-        sha = kernel_source_sha16()
+                "how": "peak: act_ubench_mad_u64_u32 (8 register-resident accumulators per lane advanced by blocks of 10 dependent multiply-accumulates, "
+                       "8 waves per SIMD, ~0.3 s so that the clock settles) timed in this process on this GPU; work: fe_mul / fe_sq executed by the kernels' "
+                       "own lane bodies, counted on the host (tests/hostcheck), x %d / %d multiply-accumulates each" % (MAD_PER_MUL, MAD_PER_SQ),
+                "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": 8000.0, "unit": "GB/s", "frac": hbm_achieved / 8000.0,
+                        "algorithmic_bytes_per_verify": algo_bytes,
+                        "note": "the view the contract template asks for; not binding: 16.8 KB in per verify against ~40 M 64-bit multiply-accumulates"}}
         t = newest_matching_pmc("pmc_hbm_traffic", proofs_per_launch, sha, L)
         if t:
             roof["traffic"] = t[1]["hbm_bytes_per_launch_fetch_x2"]; roof["traffic_source"] = t[0]
+            roof["traffic_unit"] = "bytes per launch at the L2's memory side (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): per-lane Pippenger buckets cycling through L2 / Infinity Cache"
         else:
             roof["traffic_source"] = "none: no profiles/*_pmc_hbm_traffic.json was collected from these kernel sources (sha %s) at L = %d" % (sha, L)
         v = newest_matching_pmc("pmc_valu", proofs_per_launch, sha, L)
@@ -319,26 +464,14 @@ def main():
         out["kernel_ms_per_step"] = kernel_ms
         out["kernel_source_sha16"] = sha
 
-        if world == 1:
-            # ---- the ALU roofline: measured peak of the multiply-accumulate instruction, counted work per verify -------
-            peak_mad, probe_ms = capi.ubench_mad(local)
-            ops = count_field_ops(h, L, sk, proofs, eng.fixed_base_bits())
-            fe_mul = sum(v["fe_mul"] for v in ops.values()); fe_sq = sum(v["fe_sq"] for v in ops.values())
-            mad_per_verify = 100 * fe_mul + 55 * fe_sq          # fe25519.h: a product is 10 columns x 10 v_mad_u64_u32, a square 55
-            bits_mad = (100 * ops["k_spend_bits"]["fe_mul"] + 55 * ops["k_spend_bits"]["fe_sq"]) * proofs_per_launch
-            roof["alu"] = {"fe_mul_per_verify": fe_mul, "fe_sq_per_verify": fe_sq, "mad_per_verify": mad_per_verify,
-                           "achieved_mad_per_s": value * mad_per_verify, "peak_mad_per_s": peak_mad, "frac": value * mad_per_verify / peak_mad,
-                           "k_spend_bits_frac": bits_mad / launch_s / peak_mad if launch_s else None,
-                           "unit": "lane multiply-accumulates (v_mad_u64_u32) per second", "probe_ms": probe_ms,
-                           "per_kernel_field_ops_per_verify": ops,
-                           "how": "peak: act_ubench_mad_u64_u32 (8 register-resident accumulators per lane advanced by blocks of 10 dependent multiply-accumulates, 8 waves per SIMD, ~0.3 s so that the clock settles) timed in this process; "
-                                  "work: fe_mul / fe_sq executed by the kernels' own lane bodies, counted on the host (tests/hostcheck), x 100 / 55 "
-                                  "multiply-accumulates each; k_spend_bits_frac uses that kernel's busy time alone"}
-
         if world == 1 and not args.no_extras:
-            out["extra"] = extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(proofs, h, sk, L)
+            out["extra"] = extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinct)
+        if want_cpu:
+            # the oracle's sample = the first lanes of the batch; plus every tampered lane of the first launch chunk
+            first_chunk = idx[idx < min(n, args.max_batch)]
+            sample_lanes = min(n, 16384)
+            out["cpu_baseline"] = cpu_baseline(paths, dev[:sample_lanes].cpu().numpy().tobytes(), expect[:sample_lanes].cpu().numpy().tobytes(),
+                                               dev[first_chunk].cpu().numpy().tobytes(), expect[first_chunk].cpu().numpy().tobytes(), h, sk, L)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
@@ -353,25 +486,37 @@ def timed(fn, sync):
     return time.perf_counter() - t
 
 
-def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB):
-    """Rates the north-star contract and SURVEY.md 8d ask for beside the headline, each over 2^extra_log2 proofs, N = 1 only."""
-    m = min(1 << args.extra_log2, dev.shape[0])
+def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinct):
+    """Rates the north-star contract and SURVEY.md 8d ask for beside the headline, N = 1 only."""
+    n = dev.shape[0]
+    m = min(1 << args.extra_log2, n)
     sync = torch.cuda.synchronize
     ex = {"proofs_each": m}
     st = torch.zeros(m, dtype=torch.uint8, device="cuda")
+    # (0) what tiling flatters: the round-1/2 input, 4 096 distinct proofs x256 (every 65 536-proof launch holds each proof 16
+    #     times, so the scalar-addressed reads of the 24-bit tables hit in L2 / Infinity Cache)
+    if distinct == n and n >= 8192:
+        clean = torch.nonzero(expect[:8192] == 0).flatten()[:4096]          # untampered lanes only: tamper() is applied to the tiled copy afresh
+        tiled = dev[clean].repeat(n // 4096, 1).contiguous()
+        t_exp, _ = tamper(torch, tiled, n)
+        stf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        sync()
+        dt = timed(lambda: eng.verify_spend_dev(sk, n, tiled.data_ptr(), stf.data_ptr()), sync)
+        assert torch.equal(stf, t_exp)
+        ex["tiled_4096"] = {"value": n / dt, "unit": "verifies/s", "proofs": n, "what": "the same call on 4 096 distinct proofs tiled x%d (one step after a warm-up step)" % (n // 4096)}
+        del tiled, stf
     # (1) host transcripts (library default, src/transcript.rs stays on the host), inputs in HBM
     eng.set_transcript_mode(capi.TRANSCRIPT_HOST)
     dt = timed(lambda: eng.verify_spend_dev(sk, m, dev.data_ptr(), st.data_ptr()), sync)
     assert torch.equal(st, expect[:m])
     ex["host_transcript_hbm"] = {"value": m / dt, "unit": "verifies/s", "what": "ACT_TRANSCRIPT_HOST, proofs and statuses in HBM (ACT_MEM_DEVICE)"}
-    nfull = dev.shape[0]
-    if nfull > m:                         # the same at the metric batch: pipeline fill and drain amortised over 16 chunks
-        stf = torch.zeros(nfull, dtype=torch.uint8, device="cuda")
-        dt = timed(lambda: eng.verify_spend_dev(sk, nfull, dev.data_ptr(), stf.data_ptr()), sync)
+    if n > m:                         # the same at the metric batch: pipeline fill and drain amortised over 16 chunks
+        stf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dt = timed(lambda: eng.verify_spend_dev(sk, n, dev.data_ptr(), stf.data_ptr()), sync)
         assert torch.equal(stf, expect)
-        ex["host_transcript_hbm_metric_batch"] = {"value": nfull / dt, "unit": "verifies/s", "proofs": nfull,
+        ex["host_transcript_hbm_metric_batch"] = {"value": n / dt, "unit": "verifies/s", "proofs": n,
                                                   "what": "ACT_TRANSCRIPT_HOST over the whole 2^%d batch, proofs in HBM" % args.batch_log2}
-    # (2) ... with proofs in pinned host memory and statuses back in host memory: what a Rust caller's slices are
+    # (2) ... with proofs in pinned host memory and statuses back in host memory
     hp = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); hp.copy_(dev[:m]); sync()
     hs = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
     dt = timed(lambda: eng.verify_spend_ptr(sk, m, capi.MEM_HOST, hp.data_ptr(), hs.data_ptr()), sync)
@@ -384,7 +529,10 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB):
     ex["device_transcript_hostmem"] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9,
                                        "what": "ACT_TRANSCRIPT_DEVICE + ACT_MEM_HOST (pinned)"}
     del hp
-    # (3) refund = verify + sign (src/lib.rs:787-868), per-lane rng resident in HBM
+    # (3) the path the Rust binding takes: act_node_verify_spend_batch over devices = [this GPU], proofs and statuses in ordinary
+    #     host memory.  The node's context shares this device's fixed-base tables with the bench's engine (engine.hip table cache).
+    ex["node_host_path"] = node_host_path(args, capi, torch, np, sk, dev, expect, h, local, L, PB)
+    # (4) refund = verify + sign (src/lib.rs:787-868), per-lane rng resident in HBM
     g = torch.Generator(device="cuda"); g.manual_seed(7)
     rng = torch.randint(0, 256, (m, 128), dtype=torch.uint8, device="cuda", generator=g)
     rf = torch.zeros((m, 128), dtype=torch.uint8, device="cuda")
@@ -393,20 +541,54 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB):
     assert torch.equal(st, expect[:m])
     assert bool((rf[expect[:m] != 0] == 0).all()) and bool((rf[expect[:m] == 0].any(dim=1)).all())
     ex["refund"] = {"value": m / dt, "unit": "refunds/s", "what": "verify + BBS re-sign, device transcripts, HBM-resident, ACT_RNG_PER_LANE"}
-    # (4) BASELINE config 2: 2^16 verifies at L = 64
+    # (5) BASELINE config 2: 2^16 DISTINCT verifies at L = 64
     if L == 128:
         e64 = capi.Engine(h, 64, device=local, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
-        d64 = 1024
-        p64 = make_inputs(e64, sk, d64)
         n64 = 1 << 16
-        dev64 = torch.from_numpy(np.frombuffer(p64, np.uint8).reshape(d64, proof_bytes(64)).copy()).cuda().repeat(n64 // d64, 1).contiguous()
+        dev64, _ = make_distinct_proofs_on_device(e64, capi, torch, np, sk, n64, 64, 64, args.max_batch)
         st64 = torch.zeros(n64, dtype=torch.uint8, device="cuda")
         sync()
         dt = timed(lambda: e64.verify_spend_dev(sk, n64, dev64.data_ptr(), st64.data_ptr()), sync)
         assert int(st64.sum()) == 0
-        ex["verify_L64"] = {"value": n64 / dt, "unit": "verifies/s", "what": "BASELINE configs[1]: 2^16 spend-proof verifies, 64-bit range, one launch chunk, device transcripts"}
+        ex["verify_L64"] = {"value": n64 / dt, "unit": "verifies/s", "what": "BASELINE configs[1]: 2^16 distinct spend-proof verifies, 64-bit range, one launch chunk, device transcripts"}
         e64.close()
     return ex
+
+
+def node_host_path(args, capi, torch, np, sk, dev, expect, h, local, L, PB):
+    n = dev.shape[0]
+    # two host copies of the batch (pinned + pageable): scale the batch down on a box without the memory for it
+    need_gb = 2 * n * PB / 1e9 + 8
+    m = n
+    while m > 4096 and 2 * m * PB / 1e9 + 8 > mem_available_gb():
+        m //= 2
+    sync = torch.cuda.synchronize
+    res = {"proofs": m, "host_mem_available_gb": round(mem_available_gb(), 1)}
+    if m < n:
+        res["note"] = "batch scaled down from 2^%d: %.0f GB of host memory needed for a pinned and a pageable copy" % (args.batch_log2, need_gb)
+    node = capi.Node(h, L, devices=(local,), max_batch=args.max_batch, transcript=capi.TRANSCRIPT_HOST)
+    try:
+        exp_host = expect[:m].cpu().numpy()
+        pinned = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); pinned.copy_(dev[:m]); sync()
+        st_pin = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
+        for mode, key in ((capi.TRANSCRIPT_HOST, "pinned_host_transcripts"), (capi.TRANSCRIPT_DEVICE, "pinned_device_transcripts")):
+            node.set_transcript_mode(mode)
+            dt = timed(lambda: node.verify_spend_ptr(sk, m, pinned.data_ptr(), st_pin.data_ptr()), sync)
+            assert np.array_equal(st_pin.numpy(), exp_host)
+            res[key] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9}
+        pageable = np.empty((m, PB), np.uint8); pageable[:] = pinned.numpy()
+        del pinned
+        st_pg = np.zeros(m, np.uint8)
+        for mode, key in ((capi.TRANSCRIPT_HOST, "pageable_host_transcripts"), (capi.TRANSCRIPT_DEVICE, "pageable_device_transcripts")):
+            node.set_transcript_mode(mode)
+            dt = timed(lambda: node.verify_spend_ptr(sk, m, pageable.ctypes.data, st_pg.ctypes.data), sync)
+            assert np.array_equal(st_pg, exp_host)
+            res[key] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9}
+        res["what"] = ("act_node_verify_spend_batch(devices=[%d]) over host pointers: pageable = an ordinary allocation (a Rust Vec), pinned = page-locked; "
+                       "host transcripts = the library default (src/transcript.rs on host threads), %d usable host threads" % (local, usable_cores()))
+    finally:
+        node.close()
+    return res
 
 
 if __name__ == "__main__":

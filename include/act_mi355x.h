@@ -44,9 +44,10 @@
  * Memory: every bulk pointer of one call is either host memory (ACT_MEM_HOST) or memory of the
  * context's GPU (ACT_MEM_DEVICE); `sk` is always host memory.  The engine works on its own HIP streams:
  * device-memory inputs must be complete (the producing stream synchronised) before a call, and outputs are
- * complete when the call returns.  A context is bound to one GPU,
- * owns its streams and workspace, and may be used by one host thread at a time; contexts on
- * different GPUs run concurrently (batches shard across GPUs with no collective).
+ * complete when the call returns.  A context is bound to one GPU and owns its streams and workspace; every batch entry
+ * point takes the context's lock, so a context shared between host threads serves them one at a time; different contexts
+ * (e.g. one per GPU) run concurrently (batches shard across GPUs with no collective).  Contexts of one process on the
+ * same GPU with the same Params share one set of fixed-base tables.
  * There is no CPU fallback: without a HIP device every entry point fails.
  */
 #ifndef ACT_MI355X_H
@@ -170,8 +171,10 @@ int act_refund_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64],
  * pointers are host memory.  ACT_RNG_SEQUENTIAL stays exact across shards -- the bytes of one sequential loop over one
  * generator (src/lib.rs:638-643, 842-846 draw only for accepted lanes): all shards are checked first, the host counts
  * the accepted lanes in front of every shard, then all shards sign from their offsets into the stream; refund carries
- * only enc(K') between the two phases.  ACT_RNG_PER_LANE needs no such barrier and is one pass.  A node handle may be
- * used by one host thread at a time. */
+ * only enc(K') between the two phases.  ACT_RNG_PER_LANE needs no such barrier and is one pass.  A node handle (like a
+ * context) may be shared between host threads: every *_batch call takes the handle's lock, so concurrent callers are
+ * served one after the other.  act_node_create builds the contexts concurrently (one thread per entry); entries that name
+ * the same device share that device's fixed-base tables. */
 typedef struct act_node act_node;
 int act_node_create(const uint8_t h[96], int L, const int *devices, int n_devices, size_t max_batch, act_node **out);
 void act_node_destroy(act_node *node);
@@ -249,7 +252,14 @@ int act_nullifier_check_and_insert_batch(act_nullifier_set *set, size_t n, int m
 /* The same set spread over the GPUs of a node: one set per entry of devices[], a nullifier owned by exactly one of them
  * (keyed hash of the reduced scalar), so a batch keeps the sequential meaning above in lane order.  The host buckets the
  * keys by owner (stable), every GPU checks-and-inserts its bucket from its own thread, answers are scattered back:
- * 33 bytes per spend over PCIe, no peer traffic.  Host memory only.  `salt` (16 bytes, nullable) keys the routing. */
+ * 33 bytes per spend over PCIe, no peer traffic.  Host memory only.  `salt` (16 bytes) keys the routing (SipHash-1-3 of the
+ * reduced scalar, so that clients, who choose their nullifiers, cannot aim them at one GPU); NULL = 16 bytes from the OS
+ * (getrandom), and creation fails if that fails.  A handle may be shared between host threads (calls are serialised).
+ * Failure of one device: the other devices have checked and inserted their keys all the same, so the call fills in their
+ * answers (final), marks the lanes owned by the failed device ACT_NULLIFIER_UNDETERMINED in out_spent, and returns the error;
+ * only the undetermined lanes may be resubmitted -- a blind retry of the whole batch would report the honest spends that
+ * were already inserted as double spends. */
+#define ACT_NULLIFIER_UNDETERMINED 2
 typedef struct act_node_nullifier_set act_node_nullifier_set;
 int act_node_nullifier_set_create(const int *devices, int n_devices, size_t capacity_per_device, const uint8_t salt[16],
                                   act_node_nullifier_set **out);

@@ -124,3 +124,14 @@ def test_bench_two_ranks_on_one_device():
     assert d["config"]["batch_per_gpu"] == 4096
     assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]      # whole-job aggregate over both ranks
     assert d["roofline"]["avg_launch_ms"] * d["roofline"]["launches_per_step"] <= d["ms_per_step"] * 1.001
+    assert d["roofline"]["bound"] == "valu-int-mad" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["hbm"]["bound"] == "hbm"
+    # the metric as BASELINE.json words it: ONE batch over the whole node (strong scaling), 4096 / 2 proofs per rank
+    s = d["strong"]
+    assert s["batch_total"] == 4096 and s["batch_per_gpu"] == 2048 and s["scaling"] == "strong"
+    assert abs(s["value"] - 4096 * 2 / (s["ms_per_step"] * 2 / 1e3)) < 1e-6 * s["value"]
+    # --scaling strong swaps which of the two is `value`
+    r = subprocess.run(cmd + ["--scaling", "strong"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 2048 and d["weak"]["batch_per_gpu"] == 4096
+    assert d["value"] == d["strong"]["value"]
