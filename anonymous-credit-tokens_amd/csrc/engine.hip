@@ -378,7 +378,7 @@ int workspace_alloc(act_ctx* c) {
     HIPCK(c, hipMalloc(&sl.d_tr, B * st.stride()));
     HIPCK(c, hipMalloc(&sl.d_coords, B * (size_t)c->L * NIELS_WORDS * 4));
     HIPCK(c, hipMalloc(&sl.d_d01, B * 3 * GE_WORDS * 4));
-    HIPCK(c, hipMalloc(&sl.d_buckets, B * (size_t)std::max(c->L, 2) * BUCKET_WORDS * 4));   // >= 2 bucket sets per proof for chain_b
+    HIPCK(c, hipMalloc(&sl.d_buckets, B * (size_t)std::max(c->L, PREP_BUCKET_SETS) * BUCKET_WORDS * 4));   // >= 3 bucket sets per proof for the per-proof kernels
     HIPCK(c, hipMalloc(&sl.d_xa, B * GE_WORDS * 4));
     HIPCK(c, hipMalloc(&sl.d_flags, B * 4));
     HIPCK(c, hipMalloc(&sl.d_xof, B * 64));
@@ -393,7 +393,7 @@ int workspace_alloc(act_ctx* c) {
     // returned to that state by every call (finish_call)
     HIPCK(c, hipMemsetAsync(sl.d_state, 0, B * 24 * 4, sl.stream));
     HIPCK(c, hipMemsetAsync(sl.d_d01, 0, B * 3 * GE_WORDS * 4, sl.stream));
-    HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, B * 2 * BUCKET_WORDS * 4, sl.stream));
+    HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, B * PREP_BUCKET_SETS * BUCKET_WORDS * 4, sl.stream));
   }
   return ACT_OK;
 }
@@ -416,7 +416,7 @@ int finish_call(act_ctx* c, size_t n) {
     if (lanes) {
       HIPCK(c, hipMemsetAsync(sl.d_state, 0, lanes * 24 * 4, sl.stream));
       HIPCK(c, hipMemsetAsync(sl.d_d01, 0, lanes * 3 * GE_WORDS * 4, sl.stream));
-      HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, lanes * 2 * BUCKET_WORDS * 4, sl.stream));
+      HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, lanes * PREP_BUCKET_SETS * BUCKET_WORDS * 4, sl.stream));
     }
   }
   return sync_all(c);
@@ -1063,7 +1063,7 @@ int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
     for (int i = 0; i < 6; i++) if (sl.d_stage[i]) regions.emplace_back(sl.d_stage[i], sl.d_stage_cap[i]);
     regions.emplace_back(sl.d_state, c->max_batch * 24 * 4);
     regions.emplace_back(sl.d_d01, c->max_batch * 3 * GE_WORDS * 4);
-    regions.emplace_back(sl.d_buckets, c->max_batch * 2 * BUCKET_WORDS * 4);
+    regions.emplace_back(sl.d_buckets, c->max_batch * PREP_BUCKET_SETS * BUCKET_WORDS * 4);
   }
   for (auto& r : regions) total += r.second;
   if (total > ((size_t)1 << 28)) { c->err = "act_debug_secret_residue: context too large to read back (use a small max_batch)"; return ACT_ERR_ARG; }

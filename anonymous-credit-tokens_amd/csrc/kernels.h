@@ -76,6 +76,8 @@ struct SpendTranscript {
   ACT_HDC size_t stride() const { return (bytes() + 15u) & ~(size_t)15u; }
 };
 
+constexpr int PREP_BUCKET_SETS = 3;      // bucket sets per proof that k_spend_prep's three roles use side by side: d_buckets holds max(L, 3) per proof
+
 struct SpendArgs {
   DevParams P;
   DevKey K;
@@ -85,8 +87,8 @@ struct SpendArgs {
   uint32_t tr_stride;
   uint32_t* coords;          // n * L * NIELS_WORDS : affine Niels of every decoded Com_j
   uint32_t* d01;             // n * 2 * GE_WORDS    : w00*h2, w01*h2
-  uint32_t* buckets;         // n * max(L, 2) * BUCKET_WORDS: per-lane Pippenger buckets of k_spend_bits (msm.h chain_bu); the
-                             // per-proof kernels use the first 2 * BUCKET_WORDS of every 2 * BUCKET_WORDS stride (chain_b)
+  uint32_t* buckets;         // n * max(L, 3) * BUCKET_WORDS: per-lane Pippenger buckets of k_spend_bits (msm.h chain_bu); the
+                             // per-proof kernels use PREP_BUCKET_SETS sets per proof (chain_b / chain_s)
   uint32_t* xa;              // n * GE_WORDS        : X_A = g + K'
   uint32_t* flags;           // n
   const uint32_t* xof;       // n * 16              : BLAKE3 XOF words of the transcript

@@ -5,12 +5,12 @@
 // inside the __global__ wrappers of k_spend_verify.hip; there is no CPU compute path in libact_mi355x.so.
 //
 // PrivateKey::refund up to the challenge check, /root/reference/src/lib.rs:787-844:
-//   spend_prep_lane   lane = proof          A', B_bar checks (:787), A1, A2 (:791-799), w00*h2 / w01*h2 (:806,808)
+//   spend_prep_*      3 lanes per proof     A', B_bar checks (:787), A1, A2 (:791-799), w00*h2 / w01*h2 (:806,808)
 //   spend_bits_lane   lane = (proof, bit)   C'_j0 / 2, C'_j1 / 2 (:800-817): decode Com_j, two fixed-base sums, one shared
 //                                           doubling chain over -Com_j (msm.h chain_bu); every scalar halved mod l
 //   spend_enc_lane    lane = 32 half-points encodings of C'_j0, C'_j1 = 2 * (half-point) by batched double-and-compress:
 //                                           one field inversion per 32 encodings instead of one inverse square root each
-//   spend_tail_lane   lane = proof          K' by Horner over the decoded Com_j (:819-824), Com, C (:825-829), X_A (:848)
+//   spend_tail_*      3 lanes per proof     K' by Horner over the decoded Com_j (:819-824), Com, C (:825-829), X_A (:848)
 //   spend_finish_lane lane = proof          challenge = XOF mod l ?= gamma (:842-844) -> status
 //
 // Algebraic regrouping that leaves every encoded point (hence every transcript byte) unchanged:
@@ -23,61 +23,92 @@
 
 namespace act {
 
+// the independent pieces of a per-proof kernel are separate FUNCTIONS on the device (own register allocation each), not one inlined live range
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ACT_PIECES_NOINLINE)
+#define ACT_PIECE __device__ __attribute__((noinline))
+#else
+#define ACT_PIECE ACT_HD
+#endif
+
 constexpr int ENC_BATCH = 32;   // half-points per lane of k_spend_enc
 
-ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
+// ---- k_spend_prep: three independent pieces per proof ---------------------------------------------------------------
+//   piece A  decode A' (identity check :787), transcript k | A',  A1a = (e_bar - x gamma) A'          buckets set 0
+//   piece B  decode B_bar, transcript B_bar,  A1b = r2_bar B_bar,  A2b = r3_bar B_bar  (one chain)    buckets sets 1, 2
+//   piece C  transcript prefix, A2f = c_bar h1 + r_bar h3 - gamma g - (gamma k) h2, w00/2 h2, w01/2 h2, gamma's NAF digits
+//   then     A1 = A1a + A1b, A2 = A2f + A2b, encoded.
+// One lane runs the three pieces in sequence (spend_prep_lane).  Measured alternatives (same-box A/B): the
+// pieces on three wavefronts of one block meeting in LDS (105 instead of 303 spilled VGPRs, 3 waves per SIMD-slot instead of 1)
+// was 30 % SLOWER -- 65 536 proofs already put one wavefront on every SIMD, the kernel is bound by issue slots, and three roles
+// of unequal length need two rounds of blocks; the pieces as non-inlined functions (-DACT_PIECES_NOINLINE: 2 spilled VGPRs in the
+// kernel, each piece with its own register allocation) ran at the same speed as the inlined form: the spills are not the cost.
+ACT_PIECE ge spend_prep_role_a(const SpendArgs& a, uint32_t p, uint32_t& flags) {
   const ProofLayout pl{a.P.L};
   const SpendTranscript st{a.P.L};
   const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
-  uint8_t* tr = a.tr + (size_t)p * a.tr_stride;
-  uint32_t flags = 0;
-
-  uint32_t wk[8], wa[8], wb[8];
-  load8(wk, rec + 32 * pl.k()); load8(wa, rec + 32 * pl.a_prime()); load8(wb, rec + 32 * pl.b_bar());
-  ge A, B;
+  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
+  uint32_t wk[8], wa[8];
+  load8(wk, rec + 32 * pl.k()); load8(wa, rec + 32 * pl.a_prime());
+  ge A;
   if (!ristretto_decode(A, wa)) flags |= FLAG_UNDECODABLE;
-  if (!ristretto_decode(B, wb)) flags |= FLAG_UNDECODABLE;
   if (ristretto_is_identity(A)) flags |= FLAG_IDENTITY;                       // src/lib.rs:787-789
-
   sc k = sc_from_words(wk);
-  sc gamma = load_sc(rec + 32 * pl.gamma());
-  sc e_bar = load_sc(rec + 32 * pl.e_bar()), r2_bar = load_sc(rec + 32 * pl.r2_bar()), r3_bar = load_sc(rec + 32 * pl.r3_bar());
+  tr_put_aligned(el + 40 * st.el_k(), k.v);                                   // Scalar::as_bytes of the reduced k
+  tr_put_aligned(el + 40 * st.el_a_prime(), wa);                              // compress(decompress(x)) == x for canonical x
+  sc gamma = load_sc(rec + 32 * pl.gamma()), e_bar = load_sc(rec + 32 * pl.e_bar());
+  ge acc[1] = {ge_identity()};
+  sc sa[1] = {sc_sub(e_bar, sc_mul(a.K.x, gamma))};
+  chain_s<1>(acc, A, sa, a.buckets + (size_t)p * PREP_BUCKET_SETS * BUCKET_WORDS);      // the scalar depends on the issuer's x
+  return acc[0];
+}
+ACT_PIECE void spend_prep_role_b(const SpendArgs& a, uint32_t p, uint32_t& flags, ge& a1b, ge& a2b) {
+  const ProofLayout pl{a.P.L};
+  const SpendTranscript st{a.P.L};
+  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
+  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
+  uint32_t wb[8];
+  load8(wb, rec + 32 * pl.b_bar());
+  ge B;
+  if (!ristretto_decode(B, wb)) flags |= FLAG_UNDECODABLE;
+  tr_put_aligned(el + 40 * st.el_b_bar(), wb);
+  ge acc[2] = {ge_identity(), ge_identity()};
+  sc sb[2] = {load_sc(rec + 32 * pl.r2_bar()), load_sc(rec + 32 * pl.r3_bar())};
+  chain_b<2>(acc, B, sb, a.buckets + ((size_t)p * PREP_BUCKET_SETS + 1) * BUCKET_WORDS);
+  a1b = acc[0]; a2b = acc[1];
+}
+ACT_PIECE ge spend_prep_role_c(const SpendArgs& a, uint32_t p) {
+  const ProofLayout pl{a.P.L};
+  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
+  tr_put_prefix(a.tr + (size_t)p * a.tr_stride, a.P, LABEL_SPEND);
+  sc k = load_sc(rec + 32 * pl.k()), gamma = load_sc(rec + 32 * pl.gamma());
   sc c_bar = load_sc(rec + 32 * pl.c_bar()), r_bar = load_sc(rec + 32 * pl.r_bar());
   sc w00 = load_sc(rec + 32 * pl.w00()), w01 = load_sc(rec + 32 * pl.w01());
   sc ngamma = sc_neg(gamma);
-
-  // transcript: prefix, k, A', B_bar (compress(decompress(x)) == x for canonical x)
-  tr_put_prefix(tr, a.P, LABEL_SPEND);
-  uint8_t* el = tr + 184;
-  tr_put_aligned(el + 40 * st.el_k(), k.v);                                   // Scalar::as_bytes of the reduced k
-  tr_put_aligned(el + 40 * st.el_a_prime(), wa);
-  tr_put_aligned(el + 40 * st.el_b_bar(), wb);
-
-  // A2's fixed part and the two h2 terms of bit 0
-  ge acc[2];
-  acc[1] = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], c_bar);
-  acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_H3], r_bar);
-  acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_G], ngamma);
-  acc[1] = fixed_base_acc(acc[1], a.P.tab[BASE_H2], sc_mul(ngamma, k));
+  ge f = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], c_bar);
+  f = fixed_base_acc(f, a.P.tab[BASE_H3], r_bar);
+  f = fixed_base_acc(f, a.P.tab[BASE_G], ngamma);
+  f = fixed_base_acc(f, a.P.tab[BASE_H2], sc_mul(ngamma, k));
   ge d0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w00));     // the bits kernel works on C'/2 (k_spend_enc)
   ge d1 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w01));
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS, d0);
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS, d1);
-  {                                                                            // the proof-wide challenge's digit string for k_spend_bits (msm.h naf3_recode)
-    naf3_recode(a.naf + (size_t)p * NAF_WORDS, sc_half(gamma));
-  }
-
-  // A1 = (e_bar - x gamma) A' + r2_bar B_bar ; A2 += r3_bar B_bar
-  acc[0] = ge_identity();
-  sc sa[1] = {sc_sub(e_bar, sc_mul(a.K.x, gamma))};
-  uint32_t* pbk = a.buckets + (size_t)p * 2 * BUCKET_WORDS;      // free until k_spend_bits runs
-  chain_s<1>(acc, A, sa, pbk);                                   // the scalar depends on the issuer's x
-  sc sb[2] = {r2_bar, r3_bar};
-  chain_b<2>(acc, B, sb, pbk);
-
+  naf3_recode(a.naf + (size_t)p * NAF_WORDS, sc_half(gamma));                 // the proof-wide challenge's digit string for k_spend_bits (msm.h)
+  return f;
+}
+ACT_PIECE void spend_prep_put(const SpendArgs& a, uint32_t p, int element, const ge& pt) {
   uint32_t enc[8];
-  ristretto_encode(enc, acc[0]); tr_put_aligned(el + 40 * st.el_a1(), enc);
-  ristretto_encode(enc, acc[1]); tr_put_aligned(el + 40 * st.el_a2(), enc);
+  ristretto_encode(enc, pt);
+  tr_put_aligned(a.tr + (size_t)p * a.tr_stride + 184 + 40 * element, enc);
+}
+ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
+  const SpendTranscript st{a.P.L};
+  uint32_t flags = 0;
+  ge a1a = spend_prep_role_a(a, p, flags);
+  ge a1b, a2b;
+  spend_prep_role_b(a, p, flags, a1b, a2b);
+  ge a2f = spend_prep_role_c(a, p);
+  spend_prep_put(a, p, st.el_a1(), ge_add(a1a, a1b));
+  spend_prep_put(a, p, st.el_a2(), ge_add(a2f, a2b));
   a.flags[p] = flags;     // bits kernel ORs its decode failures in afterwards (same stream)
 }
 
@@ -144,34 +175,48 @@ ACT_HD void spend_enc_lane(const SpendArgs& a, uint64_t q0) {
       });
 }
 
-ACT_HD void spend_tail_lane(const SpendArgs& a, uint32_t p) {
+// ---- k_spend_tail ---------------------------------------------------------------------------------------------------------
+//   K' = sum_j 2^j Com_j by Horner over the decoded points (src/lib.rs:819-824: the reference does 128 separate mults)
+//   F  = (-c_bar - gamma s) h1 + k_bar h2 + s_bar h3;  C = F - gamma K' (:825-829), encoded;  X_A = g + K' (:848), enc(K') if asked for.
+// (spend_tail_horner takes a sub-range and a shift so that K' can be cut into independent runs: the three-wavefront form of this
+// kernel -- lo / hi halves of the Horner run and F on three wavefronts of a block, DESIGN.md section 8 -- measured slower.)
+ACT_HD ge spend_tail_horner(const SpendArgs& a, uint32_t p, int j_lo, int j_hi, int shift) {
   const int L = a.P.L;
-  const ProofLayout pl{L};
-  const SpendTranscript st{L};
-  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
-  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
-
-  // K' = sum_j 2^j Com_j by Horner (the reference does 128 separate mults, src/lib.rs:819-824)
   ge kp = ge_identity();
-  for (int j = L - 1; j >= 0; j--) {
+  for (int j = j_hi - 1; j >= j_lo; j--) {
     kp = ge_double(kp);
     kp = ge_madd(kp, niels_load(a.coords + ((size_t)p * L + j) * NIELS_WORDS));
   }
+  for (int i = 0; i < shift; i++) kp = ge_double(kp);
+  return kp;
+}
+ACT_HD ge spend_tail_fixed(const SpendArgs& a, uint32_t p) {
+  const ProofLayout pl{a.P.L};
+  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
   sc gamma = load_sc(rec + 32 * pl.gamma());
   sc s = load_sc(rec + 32 * pl.s()), c_bar = load_sc(rec + 32 * pl.c_bar());
   sc k_bar = load_sc(rec + 32 * pl.k_bar()), s_bar = load_sc(rec + 32 * pl.s_bar());
-  sc ngamma = sc_neg(gamma);
-  ge acc[1];
-  acc[0] = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], sc_sub(sc_mul(ngamma, s), c_bar));   // -c_bar - gamma s
-  acc[0] = fixed_base_acc(acc[0], a.P.tab[BASE_H2], k_bar);
-  acc[0] = fixed_base_acc(acc[0], a.P.tab[BASE_H3], s_bar);
-  sc sk_[1] = {ngamma};
-  chain_b<1>(acc, kp, sk_, a.buckets + (size_t)p * 2 * BUCKET_WORDS);      // the half-points were consumed by k_spend_enc
+  ge f = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], sc_sub(sc_mul(sc_neg(gamma), s), c_bar));   // -c_bar - gamma s
+  f = fixed_base_acc(f, a.P.tab[BASE_H2], k_bar);
+  return fixed_base_acc(f, a.P.tab[BASE_H3], s_bar);
+}
+ACT_HD void spend_tail_c(const SpendArgs& a, uint32_t p, const ge& kp, const ge& f) {
+  const ProofLayout pl{a.P.L};
+  const SpendTranscript st{a.P.L};
+  ge acc[1] = {f};
+  sc sk_[1] = {sc_neg(load_sc(a.proofs + (size_t)p * pl.bytes() + 32 * pl.gamma()))};
+  chain_b<1>(acc, kp, sk_, a.buckets + (size_t)p * PREP_BUCKET_SETS * BUCKET_WORDS);      // the half-points were consumed by k_spend_enc
   uint32_t enc[8];
-  ristretto_encode(enc, acc[0]); tr_put_aligned(el + 40 * st.el_c(), enc);
-  ge xa = ge_add(kp, ge_basepoint());                                         // X_A = g + K' (src/lib.rs:848)
-  ge_store(a.xa + (size_t)p * GE_WORDS, xa);
-  if (a.kprime_enc) { ristretto_encode(enc, kp); store8(a.kprime_enc + (size_t)p * 32, enc); }
+  ristretto_encode(enc, acc[0]); tr_put_aligned(a.tr + (size_t)p * a.tr_stride + 184 + 40 * st.el_c(), enc);
+}
+ACT_HD void spend_tail_xa(const SpendArgs& a, uint32_t p, const ge& kp) {
+  ge_store(a.xa + (size_t)p * GE_WORDS, ge_add(kp, ge_basepoint()));                 // X_A = g + K' (src/lib.rs:848)
+  if (a.kprime_enc) { uint32_t enc[8]; ristretto_encode(enc, kp); store8(a.kprime_enc + (size_t)p * 32, enc); }
+}
+ACT_HD void spend_tail_lane(const SpendArgs& a, uint32_t p) {
+  ge kp = spend_tail_horner(a, p, 0, a.P.L, 0);
+  spend_tail_c(a, p, kp, spend_tail_fixed(a, p));
+  spend_tail_xa(a, p, kp);
 }
 
 ACT_HD void spend_finish_lane(const SpendArgs& a, uint32_t p) {

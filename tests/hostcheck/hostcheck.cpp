@@ -212,7 +212,7 @@ extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint3
   { uint32_t w[8]; ld(w, sk); a.K.x = sc_from_words(w); ld(w, sk + 32); if (!ristretto_decode(a.K.w, w)) return 0; }
   const SpendTranscript st{L}; const ProofLayout pl{L};
   std::vector<uint8_t> tr((size_t)n * st.stride(), 0), status(n, 0), kp((size_t)n * 32, 0);
-  std::vector<uint32_t> coords((size_t)n * L * NIELS_WORDS), d01((size_t)n * 2 * GE_WORDS), buckets((size_t)n * (L < 2 ? 2 : L) * BUCKET_WORDS),
+  std::vector<uint32_t> coords((size_t)n * L * NIELS_WORDS), d01((size_t)n * 2 * GE_WORDS), buckets((size_t)n * (L < PREP_BUCKET_SETS ? PREP_BUCKET_SETS : L) * BUCKET_WORDS),
       xa((size_t)n * GE_WORDS), flags(n, 0), xof((size_t)n * 16), naf((size_t)n * NAF_WORDS), dig((size_t)n * L * 8);
   a.proofs = proofs; a.n = n; a.tr = tr.data(); a.tr_stride = (uint32_t)st.stride(); a.coords = coords.data(); a.d01 = d01.data();
   a.buckets = buckets.data(); a.xa = xa.data(); a.flags = flags.data(); a.xof = xof.data(); a.status = status.data(); a.kprime_enc = kp.data(); a.naf = naf.data(); a.dig = dig.data();
