@@ -22,7 +22,8 @@ EXPORTS = [
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
     "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32",
-    "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch",
+    "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch", "act_verify_spend_cbor_batch",
+    "act_node_verify_spend_cbor_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
     "act_nullifier_check_and_insert_batch",
     "act_issue_check_batch", "act_issue_sign_batch", "act_refund_sign_batch",
@@ -100,6 +101,8 @@ def load() -> C.CDLL:
         getattr(lib, f).restype = sz
     lib.act_cbor_encode_batch.argtypes = [vp, i32, sz, i32, u8p, u8p]
     lib.act_cbor_decode_batch.argtypes = [vp, i32, sz, i32, u8p, vp, u8p, u8p]
+    lib.act_verify_spend_cbor_batch.argtypes = [vp, sz, i32, u8p, u8p, vp, u8p, u8p]
+    lib.act_node_verify_spend_cbor_batch.argtypes = [vp, sz, u8p, u8p, vp, u8p, u8p]
     lib.act_nullifier_set_create.argtypes = [i32, sz, u8p, C.POINTER(vp)]
     lib.act_nullifier_set_destroy.argtypes = [vp]
     lib.act_nullifier_set_destroy.restype = None
@@ -322,6 +325,20 @@ class Engine:
         out = np.zeros(rb * n, np.uint8); st = np.zeros(n, np.uint8); p0, k0 = _in(blob)
         self._ck(self.lib.act_cbor_decode_batch(self.ctx, t, n, MEM_HOST, p0, offs.ctypes.data, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
+
+    def verify_spend_cbor(self, sk: bytes, messages: list, want_kprime: bool = False):
+        """CBOR SpendProof messages (byte strings of any length) -> statuses: from_cbor + refund's verification in one pass."""
+        n = len(messages)
+        offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(m) for m in messages], dtype=np.uint64)
+        blob = b"".join(messages) + b"\0"
+        st = np.zeros(n, np.uint8); kp = np.zeros(32 * n, np.uint8) if want_kprime else None
+        ps, ks = _in(sk, 64); p0, k0 = _in(blob)
+        self._ck(self.lib.act_verify_spend_cbor_batch(self.ctx, n, MEM_HOST, ps, p0, offs.ctypes.data, st.ctypes.data, kp.ctypes.data if want_kprime else None))
+        return (st.tobytes(), kp.tobytes()) if want_kprime else st.tobytes()
+
+    def verify_spend_cbor_ptr(self, sk: bytes, n: int, mem: int, p_cbor: int, p_offsets: int, p_status: int, p_kprime: int = 0):
+        ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_verify_spend_cbor_batch(self.ctx, n, mem, ps, p_cbor, p_offsets or None, p_status, p_kprime or None))
 
     # ---- device-memory batch calls (raw device pointers) -----------------------------------------
     def verify_spend_dev(self, sk: bytes, n: int, d_proofs: int, d_status: int, d_kprime: int = 0):

@@ -57,9 +57,11 @@ struct Slot {
   hipStream_t stream = nullptr;
   uint8_t *d_tr = nullptr, *d_trs = nullptr, *d_status = nullptr;
   uint32_t *d_buckets = nullptr, *d_coords = nullptr, *d_d01 = nullptr, *d_xa = nullptr, *d_flags = nullptr, *d_xof = nullptr, *d_state = nullptr, *d_slot = nullptr, *d_naf = nullptr, *d_dig = nullptr;
-  uint8_t* d_stage[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // staging for host-memory callers (grow-only)
-  size_t d_stage_cap[6] = {0, 0, 0, 0, 0, 0};
-  size_t d_stage_dirty[6] = {0, 0, 0, 0, 0, 0};     // bytes written since the last wipe (finish_call)
+  static constexpr int N_STAGE = 9;
+  uint8_t* d_stage[N_STAGE] = {};   // staging for host-memory callers (grow-only); 5 = key decoding scratch, 6 = records unframed from wire bytes, 7 = their offsets, 8 = CBOR layout tables
+  size_t d_stage_cap[N_STAGE] = {};
+  size_t d_stage_dirty[N_STAGE] = {};     // bytes written since the last wipe (finish_call)
+  std::vector<uint64_t> h_rel;            // message offsets of the chunk in flight, relative to its first byte (act_verify_spend_cbor_batch)
   uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
   uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
   hipEvent_t h_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per returned piece (HASH_PIECES)
@@ -83,6 +85,8 @@ struct act_ctx {
   int fb_bits[4] = {0, 0, 0, 0};        // window width of each base's table
   uint32_t* d_half_h1 = nullptr;
   uint32_t* d_tables_ct = nullptr;     // ACT_CT_SECRET_TABLES builds only
+  void* wire_layout = nullptr;         // the running wire-bytes call's CborDev (cbor_impl.inc)
+  uint8_t* d_wire_flags = nullptr; size_t d_wire_flags_cap = 0;     // per message of a wire-bytes call: 0x80 = not the canonical encoding (cbor_impl.inc)
   // key cache
   uint8_t sk_cached[64]{}; bool sk_valid = false; DevKey key{};
   uint8_t w_cached[32]{}; bool w_valid = false; ge w_pub{};
@@ -137,7 +141,8 @@ int prof_collect(act_ctx* c, Slot& sl) {
 }
 
 int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
-  if (bytes <= sl.d_stage_cap[slot]) return ACT_OK;
+  // whatever a call reserves it is about to write: the extent is wiped when the call ends (finish_call), secret or not
+  if (bytes <= sl.d_stage_cap[slot]) { sl.d_stage_dirty[slot] = std::max(sl.d_stage_dirty[slot], bytes); return ACT_OK; }
   HIPCK(c, hipStreamSynchronize(sl.stream));
   if (sl.d_stage[slot]) {
     if (sl.d_stage_dirty[slot]) HIPCK(c, hipMemset(sl.d_stage[slot], 0, sl.d_stage_dirty[slot]));     // never hand secrets back to the allocator
@@ -145,7 +150,7 @@ int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
   }
   sl.d_stage[slot] = nullptr; sl.d_stage_cap[slot] = 0; sl.d_stage_dirty[slot] = 0;
   HIPCK(c, hipMalloc(&sl.d_stage[slot], bytes));
-  sl.d_stage_cap[slot] = bytes;
+  sl.d_stage_cap[slot] = bytes; sl.d_stage_dirty[slot] = bytes;
   return ACT_OK;
 }
 // device view of `bytes` of caller memory: the pointer itself (device memory) or a staged H2D copy
@@ -411,7 +416,7 @@ int sync_all(act_ctx* c) {
 int finish_call(act_ctx* c, size_t n) {
   const size_t lanes = std::min(n, c->max_batch);
   for (Slot& sl : c->slots) {
-    for (int i = 0; i < 6; i++)
+    for (int i = 0; i < Slot::N_STAGE; i++)
       if (sl.d_stage_dirty[i]) { HIPCK(c, hipMemsetAsync(sl.d_stage[i], 0, sl.d_stage_dirty[i], sl.stream)); sl.d_stage_dirty[i] = 0; }
     if (lanes) {
       HIPCK(c, hipMemsetAsync(sl.d_state, 0, lanes * 24 * 4, sl.stream));
@@ -643,7 +648,7 @@ void act_ctx_destroy(act_ctx* c) {
     if (sl.d_d01) (void)hipMemset(sl.d_d01, 0, c->max_batch * 3 * GE_WORDS * 4);
     void* ptrs[] = {sl.d_buckets, sl.d_tr, sl.d_trs, sl.d_status, sl.d_coords, sl.d_d01, sl.d_xa, sl.d_flags, sl.d_xof, sl.d_state, sl.d_slot, sl.d_naf, sl.d_dig};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (int i = 0; i < 6; i++) if (sl.d_stage[i]) { (void)hipMemset(sl.d_stage[i], 0, sl.d_stage_cap[i]); (void)hipFree(sl.d_stage[i]); }   // staging may hold secrets
+    for (int i = 0; i < Slot::N_STAGE; i++) if (sl.d_stage[i]) { (void)hipMemset(sl.d_stage[i], 0, sl.d_stage_cap[i]); (void)hipFree(sl.d_stage[i]); }   // staging may hold secrets
     if (sl.h_tr) (void)hipHostFree(sl.h_tr);
     if (sl.h_xof) (void)hipHostFree(sl.h_xof);
     for (hipEvent_t& e : sl.h_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -654,6 +659,7 @@ void act_ctx_destroy(act_ctx* c) {
   for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
+  if (c->d_wire_flags) (void)hipFree(c->d_wire_flags);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
   delete c;
 }
@@ -817,12 +823,15 @@ int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], c
   return sign_only_batch(c, n, mem, LABEL_REFUND, sk, kprime, 32, nullptr, status_in, rng, rng_mode, out_refund, status);
 }
 
+// Proofs that arrive as CBOR wire bytes (act_verify_spend_cbor_batch, cbor_impl.inc): every chunk's messages are copied /
+// read where they are and unframed into raw records by a kernel on the chunk's own stream, in front of k_spend_prep.
+struct WireSrc { const uint8_t* cbor; const uint64_t* offsets; size_t msg_len; };
+static int wire_unframe_chunk(act_ctx* c, Slot& sl, const WireSrc& w, int mem, size_t off, uint32_t m, const uint8_t** d_records);     // cbor_impl.inc
+
 // verify (sign == false) or refund (sign == true), two-slot software pipeline: stage 1 of chunk i+1 is enqueued before
-// the host touches chunk i again.
-static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
-                       int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime) {
-  Call call(c, n);
-  HIPCK(c, hipSetDevice(c->device));
+// the host touches chunk i again.  The caller holds the context (Call).
+static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
+                              int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime, const WireSrc* wire = nullptr) {
   int rc = set_key(c, sk); if (rc) return rc;
   const size_t pb = ProofLayout{c->L}.bytes();
   static const size_t host_chunk_env = [] { const char* e = getenv("ACT_HOST_CHUNK"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning knob
@@ -861,7 +870,8 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
     ch = SpendChunk{}; ch.off = sched[i].first; ch.m = (uint32_t)sched[i].second;
     ch.stagger = stagger;
     int r;
-    if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
+    if (wire) { if ((r = wire_unframe_chunk(c, sl, *wire, mem, ch.off, ch.m, &ch.d_proofs))) return r; }
+    else if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
     if (out_kprime && (r = dev_out_begin(c, sl, 2, mem, out_kprime + ch.off * 32, (size_t)ch.m * 32, &ch.d_kprime))) return r;
     if (sign && (r = dev_out_begin(c, sl, 4, mem, out_refund + ch.off * 128, (size_t)ch.m * 128, &ch.d_out))) return r;
     return spend_stage1(c, sl, ch);
@@ -887,7 +897,15 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
     if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
   }
   for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
-  return call.finish();
+  return sync_all(c);
+}
+
+static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
+                       int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime) {
+  Call call(c, n);
+  HIPCK(c, hipSetDevice(c->device));
+  int rc = spend_batch_locked(c, n, mem, sk, proof, sign, rng, rng_mode, out_refund, status, out_kprime);
+  return rc ? rc : call.finish();
 }
 
 int act_verify_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
@@ -1060,7 +1078,7 @@ int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
   size_t total = 0, nz = 0;
   std::vector<std::pair<const void*, size_t>> regions;
   for (Slot& sl : c->slots) {
-    for (int i = 0; i < 6; i++) if (sl.d_stage[i]) regions.emplace_back(sl.d_stage[i], sl.d_stage_cap[i]);
+    for (int i = 0; i < Slot::N_STAGE; i++) if (sl.d_stage[i]) regions.emplace_back(sl.d_stage[i], sl.d_stage_cap[i]);
     regions.emplace_back(sl.d_state, c->max_batch * 24 * 4);
     regions.emplace_back(sl.d_d01, c->max_batch * 3 * GE_WORDS * 4);
     regions.emplace_back(sl.d_buckets, c->max_batch * PREP_BUCKET_SETS * BUCKET_WORDS * 4);

@@ -88,10 +88,12 @@ void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipS
 
 // PrivateKey::random (src/lib.rs:188-194): x <- 64 rng bytes; w = x * g
 __global__ void __launch_bounds__(64) k_keygen(DevParams P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk) {
+  ACT_SECRET_FB(fb, P);
+  fb.stage(BASE_G);
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   sc x = load_wide(rng64 + (size_t)i * 64);
-  ge w = fixed_base_acc_s(ge_identity(), ACT_FB_S(P, BASE_G), x);
+  ge w = fb.mul(ge_identity(), BASE_G, x);
   uint32_t e[8]; ristretto_encode(e, w);
   store_sc(out_sk + (size_t)i * 64, x); store8(out_sk + (size_t)i * 64 + 32, e);
 }

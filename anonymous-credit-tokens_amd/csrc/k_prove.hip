@@ -45,39 +45,50 @@ struct RngView {   // draw index -> 64-byte slot
 __device__ __forceinline__ size_t rng_bytes(int L) { return 64u * (4u * (size_t)L + 12u); }
 
 __global__ void __launch_bounds__(64, 2) k_prove_head(ProveArgs a) {
+  ACT_SECRET_FB(fb, a.P);
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= a.n) return;
+  const bool live = p < a.n;
   const int L = a.P.L;
   const ProofLayout pl{L}; const SpendTranscript st{L};
-  const uint8_t* tok = a.tok + (size_t)p * 160;
+  RngView rv{a.rng + (size_t)(live ? p : 0) * rng_bytes(L), L};
+  ge acc[2] = {ge_identity(), ge_identity()};
+  sc k = sc_zero(), s = sc_zero(), r1 = sc_zero(), r1c = sc_zero(), r1k = sc_zero(), r1r = sc_zero();
+  sc c_prime = sc_zero(), r_prime = sc_zero(), r2_prime = sc_zero(), r3_prime = sc_zero(), k_star = sc_zero();
+  if (live) {
+    const uint8_t* tok = a.tok + (size_t)p * 160;
+    uint32_t wa[8]; load8(wa, tok);
+    ge A; a.flags[p] = ristretto_decode(A, wa) ? 0u : FLAG_UNDECODABLE;
+    k = load_sc(tok + 64); sc r = load_sc(tok + 96), c = load_sc(tok + 128); s = load_sc(a.s + (size_t)p * 32);
+    r1 = rv.r1(); sc r2 = rv.r2(); c_prime = rv.c_prime(); r_prime = rv.r_prime();
+    sc e_prime = rv.e_prime(); r2_prime = rv.r2_prime(); r3_prime = rv.r3_prime(); k_star = rv.k_star();
+    sc r1r2 = sc_mul(r1, r2);
+    // A' = (r1 r2) A and the A-part of A1 = e' A' share A's doubling chain
+    sc sa[2] = {r1r2, sc_mul(e_prime, r1r2)};
+    chain_s<2>(acc, A, sa, a.half + (size_t)p * 2 * BUCKET_WORDS);       // the half-point area is not in use yet
+    r1c = sc_mul(r1, c); r1k = sc_mul(r1, k); r1r = sc_mul(r1, r);
+  }
+  // B_bar = r1 g + (r1 c) h1 + (r1 k) h2 + (r1 r) h3;  A1 = e' A' + r2' B_bar;  A2 = r3' B_bar + c' h1 + r' h3 -- the twelve products
+  // (and the three h2 terms of bit 0, src/lib.rs:1001, 1025-1035, at half scale like everything k_prove_bits computes) grouped
+  // by base: the ct build stages one base's table in LDS at a time
+  ge bbar = ge_identity(), a1 = acc[1], a2 = ge_identity();
+  fb.stage(BASE_G);
+  if (live) { bbar = fb.mul(bbar, BASE_G, r1); a1 = fb.mul(a1, BASE_G, sc_mul(r2_prime, r1)); a2 = fb.mul(a2, BASE_G, sc_mul(r3_prime, r1)); }
+  fb.stage(BASE_H1);
+  if (live) { bbar = fb.mul(bbar, BASE_H1, r1c); a1 = fb.mul(a1, BASE_H1, sc_mul(r2_prime, r1c)); a2 = fb.mul(a2, BASE_H1, sc_muladd(r3_prime, r1c, c_prime)); }
+  fb.stage(BASE_H2);
+  if (live) {
+    bbar = fb.mul(bbar, BASE_H2, r1k); a1 = fb.mul(a1, BASE_H2, sc_mul(r2_prime, r1k)); a2 = fb.mul(a2, BASE_H2, sc_mul(r3_prime, r1k));
+    uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
+    ge_store(d3, fb.mul(ge_identity(), BASE_H2, sc_half(k_star)));
+    ge_store(d3 + GE_WORDS, fb.mul(ge_identity(), BASE_H2, sc_half(rv.k0_prime())));
+    ge_store(d3 + 2 * GE_WORDS, fb.mul(ge_identity(), BASE_H2, sc_half(sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star)))));
+  }
+  fb.stage(BASE_H3);
+  if (!live) return;
+  bbar = fb.mul(bbar, BASE_H3, r1r); a1 = fb.mul(a1, BASE_H3, sc_mul(r2_prime, r1r)); a2 = fb.mul(a2, BASE_H3, sc_muladd(r3_prime, r1r, r_prime));
+
   uint8_t* rec = a.proof + (size_t)p * pl.bytes();
   uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
-  RngView rv{a.rng + (size_t)p * rng_bytes(L), L};
-
-  uint32_t wa[8]; load8(wa, tok);
-  ge A; a.flags[p] = ristretto_decode(A, wa) ? 0u : FLAG_UNDECODABLE;
-  sc k = load_sc(tok + 64), r = load_sc(tok + 96), c = load_sc(tok + 128), s = load_sc(a.s + (size_t)p * 32);
-  sc r1 = rv.r1(), r2 = rv.r2(), c_prime = rv.c_prime(), r_prime = rv.r_prime();
-  sc e_prime = rv.e_prime(), r2_prime = rv.r2_prime(), r3_prime = rv.r3_prime();
-  sc r1r2 = sc_mul(r1, r2);
-  // A' = (r1 r2) A and the A-part of A1 = e' A' share A's doubling chain
-  ge acc[2] = {ge_identity(), ge_identity()};
-  sc sa[2] = {r1r2, sc_mul(e_prime, r1r2)};
-  chain_s<2>(acc, A, sa, a.half + (size_t)p * 2 * BUCKET_WORDS);       // the half-point area is not in use yet
-  sc r1c = sc_mul(r1, c), r1k = sc_mul(r1, k), r1r = sc_mul(r1, r);
-  ge bbar = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), r1);
-  bbar = fixed_base_acc_s(bbar, ACT_FB_S(a.P, BASE_H1), r1c);
-  bbar = fixed_base_acc_s(bbar, ACT_FB_S(a.P, BASE_H2), r1k);
-  bbar = fixed_base_acc_s(bbar, ACT_FB_S(a.P, BASE_H3), r1r);
-  ge a1 = fixed_base_acc_s(acc[1], ACT_FB_S(a.P, BASE_G), sc_mul(r2_prime, r1));
-  a1 = fixed_base_acc_s(a1, ACT_FB_S(a.P, BASE_H1), sc_mul(r2_prime, r1c));
-  a1 = fixed_base_acc_s(a1, ACT_FB_S(a.P, BASE_H2), sc_mul(r2_prime, r1k));
-  a1 = fixed_base_acc_s(a1, ACT_FB_S(a.P, BASE_H3), sc_mul(r2_prime, r1r));
-  ge a2 = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), sc_mul(r3_prime, r1));
-  a2 = fixed_base_acc_s(a2, ACT_FB_S(a.P, BASE_H1), sc_muladd(r3_prime, r1c, c_prime));
-  a2 = fixed_base_acc_s(a2, ACT_FB_S(a.P, BASE_H2), sc_mul(r3_prime, r1k));
-  a2 = fixed_base_acc_s(a2, ACT_FB_S(a.P, BASE_H3), sc_muladd(r3_prime, r1r, r_prime));
-
   tr_put_prefix(a.tr + (size_t)p * a.tr_stride, a.P, LABEL_SPEND);
   uint32_t enc[8];
   tr_put_aligned(el + 40 * st.el_k(), k.v);
@@ -86,33 +97,38 @@ __global__ void __launch_bounds__(64, 2) k_prove_head(ProveArgs a) {
   ristretto_encode(enc, bbar); tr_put_aligned(el + 40 * st.el_b_bar(), enc); store8(rec + 32 * pl.b_bar(), enc);
   ristretto_encode(enc, a1); tr_put_aligned(el + 40 * st.el_a1(), enc);
   ristretto_encode(enc, a2); tr_put_aligned(el + 40 * st.el_a2(), enc);
-
-  // bit-0 extras over h2 (src/lib.rs:1001, 1025-1035)
-  sc k_star = rv.k_star();
-  uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
-  // at half scale, like everything k_prove_bits computes
-  ge_store(d3, fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), sc_half(k_star)));
-  ge_store(d3 + GE_WORDS, fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), sc_half(rv.k0_prime())));
-  ge_store(d3 + 2 * GE_WORDS, fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), sc_half(sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star)))));
   sc r3 = sc_invert(r1);                                                      // :992
   uint32_t* stt = a.state + (size_t)p * 24;
   for (int i = 0; i < 8; i++) stt[i] = r3.v[i];
 }
 
 __global__ void __launch_bounds__(256, 2) k_prove_bits(ProveArgs a) {
+  ACT_SECRET_FB_LDS(fb, a.P);
   const int L = a.P.L;
   uint32_t gid = blockIdx.x * 256 + threadIdx.x;
   uint32_t p = gid / (uint32_t)L, j = gid % (uint32_t)L;
-  if (p >= a.n) return;
-  const uint8_t* tok = a.tok + (size_t)p * 160;
-  RngView rv{a.rng + (size_t)p * rng_bytes(L), L};
-
-  sc m = sc_sub(load_sc(tok + 128), load_sc(a.s + (size_t)p * 32));           // c - s (:996)
-  uint32_t bit = (m.v[j >> 5] >> (j & 31)) & 1u;                              // bits_of (:902-915)
-  sc s_j = rv.s_i(j), s_jp = rv.s_i_prime(j), g_j = rv.gamma_i(j), z_j = rv.z(j);
-
+  const bool live = p < a.n;
+  RngView rv{a.rng + (size_t)(live ? p : 0) * rng_bytes(L), L};
+  uint32_t bit = 0;
+  sc s_j = sc_zero(), s_jp = sc_zero(), g_j = sc_zero(), z_j = sc_zero();
+  if (live) {
+    const uint8_t* tok = a.tok + (size_t)p * 160;
+    sc m = sc_sub(load_sc(tok + 128), load_sc(a.s + (size_t)p * 32));         // c - s (:996)
+    bit = (m.v[j >> 5] >> (j & 31)) & 1u;                                     // bits_of (:902-915)
+    s_j = rv.s_i(j); s_jp = rv.s_i_prime(j); g_j = rv.gamma_i(j); z_j = rv.z(j);
+  }
   // Half scale throughout (k_prove_enc encodes the doubles): Com_j / 2 = i_j (h1 / 2) + (s_j / 2) h3 (+ (k* / 2) h2)
-  ge com = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H3), sc_half(s_j));
+  // real branch: s'_j h3 (+ k0' h2);  simulated: (z_j - gamma_j s_j) h3 -/+ gamma_j h1 (+ (w0 - gamma_0 k*) h2)
+  ge com = ge_identity(), real = ge_identity(), sim = ge_identity();
+  fb.stage(BASE_H3);
+  if (live) {
+    com = fb.mul(com, BASE_H3, sc_half(s_j));
+    real = fb.mul(real, BASE_H3, sc_half(s_jp));
+    sim = fb.mul(sim, BASE_H3, sc_half(sc_sub(z_j, sc_mul(g_j, s_j))));
+  }
+  fb.stage(BASE_H1);
+  if (!live) return;
+  sim = fb.mul(sim, BASE_H1, sc_half(bit ? sc_neg(g_j) : g_j));
 #if defined(ACT_CT_SECRET_TABLES)
   {                                                                                // both entries read, the bit picks with masks
     const ge_niels e0 = niels_load(a.P.half_h1), e1 = niels_load(a.P.half_h1 + NIELS_WORDS);
@@ -123,11 +139,6 @@ __global__ void __launch_bounds__(256, 2) k_prove_bits(ProveArgs a) {
 #else
   com = ge_madd(com, niels_load(a.P.half_h1 + (size_t)bit * NIELS_WORDS));        // entry 0 = identity, entry 1 = h1 / 2
 #endif
-  // real branch: s'_j h3 (+ k0' h2);  simulated: (z_j - gamma_j s_j) h3 -/+ gamma_j h1 (+ (w0 - gamma_0 k*) h2)
-  ge real = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H3), sc_half(s_jp));
-  ge sim = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H3), sc_half(sc_sub(z_j, sc_mul(g_j, s_j))));
-  sc gh1 = sc_half(bit ? sc_neg(g_j) : g_j);
-  sim = fixed_base_acc_s(sim, ACT_FB_S(a.P, BASE_H1), gh1);
   if (j == 0) {
     const uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
     com = ge_add(com, ge_load(d3)); real = ge_add(real, ge_load(d3 + GE_WORDS)); sim = ge_add(sim, ge_load(d3 + 2 * GE_WORDS));
@@ -163,17 +174,23 @@ __global__ void __launch_bounds__(256, 2) k_prove_enc(ProveArgs a) {
 }
 
 __global__ void __launch_bounds__(64, 2) k_prove_tail(ProveArgs a) {
+  ACT_SECRET_FB(fb, a.P);
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= a.n) return;
+  const bool live = p < a.n;
   const int L = a.P.L;
   const SpendTranscript st{L};
-  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
-  RngView rv{a.rng + (size_t)p * rng_bytes(L), L};
+  RngView rv{a.rng + (size_t)(live ? p : 0) * rng_bytes(L), L};
+  ge cc = ge_identity();                                                      // C = -c' h1 + k' h2 + s' h3 (:1059)
+  fb.stage(BASE_H1);
+  if (live) cc = fb.mul(cc, BASE_H1, sc_neg(rv.c_prime()));
+  fb.stage(BASE_H2);
+  if (live) cc = fb.mul(cc, BASE_H2, rv.k_prime());
+  fb.stage(BASE_H3);
+  if (!live) return;
+  cc = fb.mul(cc, BASE_H3, rv.s_prime());
   sc rstar = sc_zero();                                                       // r* = sum s_j 2^j (:1052-1056), Horner
   for (int j = L - 1; j >= 0; j--) rstar = sc_add(sc_add(rstar, rstar), rv.s_i(j));
-  ge cc = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H1), sc_neg(rv.c_prime()));   // :1059
-  cc = fixed_base_acc_s(cc, ACT_FB_S(a.P, BASE_H2), rv.k_prime());
-  cc = fixed_base_acc_s(cc, ACT_FB_S(a.P, BASE_H3), rv.s_prime());
+  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
   uint32_t enc[8]; ristretto_encode(enc, cc); tr_put_aligned(el + 40 * st.el_c(), enc);
   uint32_t* stt = a.state + (size_t)p * 24;
   for (int i = 0; i < 8; i++) stt[8 + i] = rstar.v[i];

@@ -9,6 +9,8 @@ namespace act {
 // ---- sign, phase A: e, alpha <- rng;  A = (e+x)^-1 X_A;  X_g = e g + w;  Y_A = alpha A;  Y_g = alpha g --------
 // A and Y_A share X_A's doubling chain: Y_A = (alpha (e+x)^-1) X_A.
 __global__ void __launch_bounds__(64, 2) k_sign_a(SignArgs a) {
+  ACT_SECRET_FB(fb, a.P);
+  fb.stage(BASE_G);                                               // before any lane leaves (kernels.h SecretFb)
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= a.n) return;
   if (a.status[p] != 0) return;                                   // rng is drawn only after verification (:638-643, :842-846)
@@ -19,8 +21,8 @@ __global__ void __launch_bounds__(64, 2) k_sign_a(SignArgs a) {
   ge acc[2] = {ge_identity(), ge_identity()};
   sc s[2] = {inv, sc_mul(alpha, inv)};
   chain_s<2>(acc, xa, s, a.pbk + (size_t)p * 2 * BUCKET_WORDS);                                           // acc[0] = A, acc[1] = Y_A (:650 / :853)
-  ge xg = ge_add(fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), e), a.K.w);     // :646 / :851
-  ge yg = fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_G), alpha);                 // :651 / :854
+  ge xg = ge_add(fb.mul(ge_identity(), BASE_G, e), a.K.w);        // :646 / :851
+  ge yg = fb.mul(ge_identity(), BASE_G, alpha);                   // :651 / :854
 
   // transcript: prefix | [c] | e | A | X_A | X_g | Y_A | Y_g   (:654-657 / :856-859)
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
@@ -111,12 +113,21 @@ void launch_issue_check(const IssueArgs& a, hipStream_t s) { if (a.n) hipLaunchK
 
 // ---- PreIssuance::request (:463-487) ---------------------------------------------------------------------
 __global__ void __launch_bounds__(64, 2) k_request_a(RequestArgs a) {
+  ACT_SECRET_FB(fb, a.P);
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= a.n) return;
-  sc r = load_sc(a.pre + (size_t)p * 64), k = load_sc(a.pre + (size_t)p * 64 + 32);
-  sc kp = load_wide(a.rng + (size_t)p * 128), rp = load_wide(a.rng + (size_t)p * 128 + 64);      // :468-469
-  ge big_k = fixed_base_acc_s(fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), k), ACT_FB_S(a.P, BASE_H3), r);     // :465
-  ge k1 = fixed_base_acc_s(fixed_base_acc_s(ge_identity(), ACT_FB_S(a.P, BASE_H2), kp), ACT_FB_S(a.P, BASE_H3), rp);      // :470
+  const bool live = p < a.n;
+  sc r = sc_zero(), k = sc_zero(), kp = sc_zero(), rp = sc_zero();
+  if (live) {
+    r = load_sc(a.pre + (size_t)p * 64); k = load_sc(a.pre + (size_t)p * 64 + 32);
+    kp = load_wide(a.rng + (size_t)p * 128); rp = load_wide(a.rng + (size_t)p * 128 + 64);        // :468-469
+  }
+  // K = k h2 + r h3 (:465), K1 = k' h2 + r' h3 (:470): the products grouped by base (one staged table at a time in the ct build)
+  ge big_k = ge_identity(), k1 = ge_identity();
+  fb.stage(BASE_H2);
+  if (live) { big_k = fb.mul(big_k, BASE_H2, k); k1 = fb.mul(k1, BASE_H2, kp); }
+  fb.stage(BASE_H3);
+  if (!live) return;
+  big_k = fb.mul(big_k, BASE_H3, r); k1 = fb.mul(k1, BASE_H3, rp);
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
   tr_put_prefix(tr, a.P, LABEL_REQUEST);
   uint8_t* el = tr + a.P.prefix_len[LABEL_REQUEST];

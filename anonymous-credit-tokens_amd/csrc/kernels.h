@@ -225,6 +225,50 @@ void launch_client_a(const ClientArgs& a, hipStream_t s);
 void launch_client_b(const ClientArgs& a, hipStream_t s);
 #endif
 
+// ---- fixed-base products of SECRET scalars (msm.h "secret scalars") ---------------------------------------------------------
+// Kernel code writes   ACT_SECRET_FB(fb, a.P);  fb.stage(BASE_G);  x = fb.mul(acc, BASE_G, e);
+// Default build: stage() is nothing and mul() is fixed_base_acc on the context's wide tables (addressed look-ups).
+// ACT_CT_SECRET_TABLES build: mul() scans all eight entries of every window of the base's 64 KiB CT table.
+//   ACT_SECRET_FB      the scan reads the table where it lies in global memory.  Every lane of a wavefront reads the same
+//                      addresses, so a window is 8 x 128 B per WAVEFRONT through L2, not per lane: for the 64-thread blocks of
+//                      the per-proof kernels that is the same traffic as staging would be, without the barriers.
+//   ACT_SECRET_FB_LDS  (k_prove_bits: 256-thread blocks, three products per staged base) the block copies the table into
+//                      64 KiB of LDS first -- stage(base) holds the block's barriers and a block-strided copy, so EVERY thread
+//                      of the block must call it, before any early exit -- and the scan is broadcast ds_read_b128.
+// Measured on one MI355X (profiles/r03_b_other_configs_1gpu*.json): staging in LDS everywhere made `request` slower (0.27x ->
+// 0.15x of the default build: 128 KiB copied per 64 lanes for four products) and prove_spend 3 % faster; the cost of the ct build's
+// fixed-base products is their 64 additions per product (the default build's 24- / 16-bit windows need 11 / 16), not the scan.
+#if defined(__HIPCC__)
+#if defined(ACT_CT_SECRET_TABLES)
+struct SecretFb {
+  const DevParams& P;
+  __device__ __forceinline__ void stage(int) {}
+  __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_ct(acc, P.tab_ct[base], s); }
+};
+struct SecretFbLds {
+  uint32_t* lds; const DevParams& P;
+  __device__ __forceinline__ void stage(int base) {
+    __syncthreads();                                                           // the previous base's readers are done
+    const uint4* src = reinterpret_cast<const uint4*>(P.tab_ct[base]);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (uint32_t i = threadIdx.x; i < (uint32_t)(CT_TABLE_WORDS / 4); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+  }
+  __device__ __forceinline__ ge mul(const ge& acc, int, const sc& s) const { return fixed_base_acc_ct(acc, lds, s); }
+};
+#define ACT_SECRET_FB(name, P) SecretFb name{P}
+#define ACT_SECRET_FB_LDS(name, P) __shared__ uint32_t name##_lds_[CT_TABLE_WORDS]; SecretFbLds name{name##_lds_, P}
+#else
+struct SecretFb {
+  const DevParams& P;
+  __device__ __forceinline__ void stage(int) {}
+  __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc(acc, P.tab[base], s); }
+};
+#define ACT_SECRET_FB(name, P) SecretFb name{P}
+#define ACT_SECRET_FB_LDS(name, P) SecretFb name{P}
+#endif
+#endif
+
 // ---- record / transcript access helpers (uint4 / uint2 accesses on the device; memcpy in the g++ test build) ----
 ACT_HD void load8(uint32_t w[8], const uint8_t* p) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -453,10 +453,7 @@ ACT_HD void chain_bu(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc&
 // doubling chain (the bucket half of chain_bu, for the per-proof kernels): 64 bucket additions + a 14-addition
 // combine per scalar and one cached conversion per four doublings, instead of chain<NACC>'s 127 digit additions
 // and two cached conversions per two doublings.  `bk`: NACC * BUCKET_WORDS words owned by this lane.
-// CT = true (chain_s under ACT_CT_SECRET_TABLES): the bucket a digit selects is not an address -- all nine buckets of the
-// scalar are read, the addressed one is picked with masks, and all nine are written back, so the memory trace is the same
-// for every scalar (the reference scans its lookup tables with `subtle`, /root/reference/src/lib.rs:98).
-template <int NACC, bool CT = false>
+template <int NACC>
 ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
   const ge id = ge_identity();
   for (int b = 0; b < NACC * BUCKETS; b++) bucket_store(bk + b * GE_WORDS, id);
@@ -473,16 +470,8 @@ ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
       carry[a] = v > 8u ? 1u : 0u;
       bool neg = v > 8u;
       uint32_t mag = neg ? 16u - v : v;        // 0..8; bucket 0 absorbs the zero digits
-      if (!CT) {
-        uint32_t* slot = bk + ((size_t)a * BUCKETS + mag) * GE_WORDS;
-        bucket_store(slot, ge_add_cached(bucket_load(slot), ge_cached_cneg(c, neg)));
-      } else {
-        uint32_t* row = bk + (size_t)a * BUCKET_WORDS;
-        ge B = ge_identity();
-        for (uint32_t v = 0; v < (uint32_t)BUCKETS; v++) B = ge_select_m(B, bucket_load(row + v * GE_WORDS), fe_mask(v == mag));
-        B = ge_add_cached(B, ge_cached_cneg(c, neg));
-        for (uint32_t v = 0; v < (uint32_t)BUCKETS; v++) bucket_store(row + v * GE_WORDS, ge_select_m(bucket_load(row + v * GE_WORDS), B, fe_mask(v == mag)));
-      }
+      uint32_t* slot = bk + ((size_t)a * BUCKETS + mag) * GE_WORDS;
+      bucket_store(slot, ge_add_cached(bucket_load(slot), ge_cached_cneg(c, neg)));
     }
     if (step == 63) break;
     P = ge_double_opt(P, false); P = ge_double_opt(P, false); P = ge_double_opt(P, false);
@@ -501,16 +490,23 @@ ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
 }
 
 // ---- secret scalars --------------------------------------------------------------------------------------------
-// fixed_base_acc_s / chain_s are what the prover, the signer, key generation and the x-dependent product of the verifier
-// call.  By default they are fixed_base_acc / chain_b: table entries and buckets are addressed by scalar digits, so the
-// memory-access pattern depends on secrets (the instruction stream does not).  Built with -DACT_CT_SECRET_TABLES (make ct ->
-// libact_mi355x_ct.so) neither does the access pattern, to the standard the reference sets with `subtle`
-// (/root/reference/src/lib.rs:98, 1025-1118) and dalek's table scans: fixed-base products use signed radix-16 windows over
-// small tables (64 windows x 8 entries x 128 B = 64 KiB per base) whose eight entries are ALL read and masked, and the
-// Pippenger buckets are all read and all written back every step (chain_b<NACC, true>).  Cost: DESIGN.md section 4.
-#if defined(ACT_CT_SECRET_TABLES)
+// What the prover, the signer, key generation and the x-dependent product of the verifier call (through SecretFb in kernels.h
+// and chain_s here).  By default they are fixed_base_acc / chain_b: table entries and buckets are addressed by scalar digits,
+// so the memory-access pattern depends on secrets (the instruction stream does not).  Built with -DACT_CT_SECRET_TABLES
+// (make ct -> libact_mi355x_ct.so) neither does the access pattern, to the standard the reference sets with `subtle`
+// (/root/reference/src/lib.rs:98, 1025-1118) and dalek's table scans:
+//   fixed-base products   signed radix-16 windows over a small table of the base (64 windows x 8 entries x 128 B = 64 KiB)
+//                         that the BLOCK first stages in LDS (ct_stage); every lane then reads all eight entries of a window --
+//                         the same LDS addresses in every lane: broadcast reads, no bank conflicts -- and keeps one with masks.
+//                         Round 2 scanned the table in global memory: 8 x 128 B per window per lane through L2, 64 KiB per
+//                         product per lane, which made the all-fixed-base functions run at a quarter of the default build.
+//   variable-base chains  chain_ct: radix-4 digits on the shared doubling chain, EVERY digit addition executed (a zero digit adds
+//                         the identity, picked with masks), everything in registers: no buckets, so nothing to address.  Round 2
+//                         read and rewrote all nine Pippenger buckets of a scalar at every step (369 KB of traffic per
+//                         signature); this form costs 1.36x the default chain's multiplications and no memory traffic.
 constexpr int CT_WINDOWS = 64, CT_ENTRIES = 8;
-constexpr size_t CT_TABLE_WORDS = (size_t)CT_WINDOWS * CT_ENTRIES * NIELS_WORDS;       // T[pos][e-1] = e * 16^pos * B, e = 1..8
+constexpr size_t CT_TABLE_WORDS = (size_t)CT_WINDOWS * CT_ENTRIES * NIELS_WORDS;       // T[pos][e-1] = e * 16^pos * B, e = 1..8: 64 KiB
+// acc += s * B; `table` = B's CT table (in LDS on the device: SecretFb::stage)
 ACT_HD ge fixed_base_acc_ct(ge acc, const uint32_t* table, const sc& s) {
   uint32_t t[8];
   radix16_bias(t, s);                                  // nibble - 8 = signed digit in [-8, 7]
@@ -535,13 +531,37 @@ ACT_HD ge fixed_base_acc_ct(ge acc, const uint32_t* table, const sc& s) {
   }
   return acc;
 }
-#define ACT_FB_S(P, base) ((P).tab_ct[base])
-ACT_HD ge fixed_base_acc_s(ge acc, const uint32_t* table_ct, const sc& s) { return fixed_base_acc_ct(acc, table_ct, s); }
-template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t* bk) { chain_b<NACC, true>(acc, N, s, bk); }
+// acc[a] += s[a] * N with no secret-dependent address and no secret-dependent branch: chain<NACC> with every addition executed
+template <int NACC>
+ACT_HD void chain_ct(ge* acc, const ge& N, const sc* s) {
+  uint32_t w[NACC][8], carry[NACC];
+  for (int a = 0; a < NACC; a++) { carry[a] = 0; for (int i = 0; i < 8; i++) w[a][i] = s[a].v[i]; }
+  ge_cached idc; idc.YpX = fe_one(); idc.YmX = fe_one(); idc.Z = fe_one(); idc.T2d = fe_zero();
+  ge P = N;
+#pragma unroll 1
+  for (int step = 0; step < 127; step++) {
+    ge_cached c1 = ge_to_cached(P);
+    ge Q = ge_double(P);
+    ge_cached c2 = ge_to_cached(Q);
+    if (step < 126) P = ge_double(Q);
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+      digit4 d = next_digit4(w[a], carry[a]);
+      const uint32_t m2 = fe_mask(d.two), mz = fe_mask(!d.nonzero);
+      ge_cached q;
+      q.YpX = fe_select_m(c1.YpX, c2.YpX, m2); q.YmX = fe_select_m(c1.YmX, c2.YmX, m2);
+      q.Z = fe_select_m(c1.Z, c2.Z, m2); q.T2d = fe_select_m(c1.T2d, c2.T2d, m2);
+      q = ge_cached_cneg(q, d.neg);
+      q.YpX = fe_select_m(q.YpX, idc.YpX, mz); q.YmX = fe_select_m(q.YmX, idc.YmX, mz);
+      q.Z = fe_select_m(q.Z, idc.Z, mz); q.T2d = fe_select_m(q.T2d, idc.T2d, mz);
+      acc[a] = ge_add_cached(acc[a], q);
+    }
+  }
+}
+#if defined(ACT_CT_SECRET_TABLES)
+template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t*) { chain_ct<NACC>(acc, N, s); }
 #else
-#define ACT_FB_S(P, base) ((P).tab[base])
-ACT_HD ge fixed_base_acc_s(ge acc, const FbTab& table, const sc& s) { return fixed_base_acc(acc, table, s); }
-template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t* bk) { chain_b<NACC, false>(acc, N, s, bk); }
+template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t* bk) { chain_b<NACC>(acc, N, s, bk); }
 #endif
 
 // ---- batched double-and-compress (ge25519.h dc_*): one field inversion per E encodings ----------------------

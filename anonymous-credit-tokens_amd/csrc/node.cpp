@@ -196,6 +196,18 @@ int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], co
   });
 }
 
+// wire bytes: shard k takes messages [n k / N, n (k+1) / N); offsets are absolute into `cbor`, so every shard gets the same base
+int act_node_verify_spend_cbor_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* cbor, const uint64_t* offsets, uint8_t* status,
+                                     uint8_t* out_kprime) {
+  if (!nd || !sk || (n && (!cbor || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  const size_t ml = act_cbor_size(nd->ctx[0], ACT_CBOR_SPEND_PROOF);
+  return run(nd, n, [&](size_t k, Shard s) {
+    return act_verify_spend_cbor_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, offsets ? cbor : cbor + s.off * ml, offsets ? offsets + s.off : nullptr,
+                                       status + s.off, at(out_kprime, s.off, 32));
+  });
+}
+
 int act_node_refund_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
                           uint8_t* out_refund, uint8_t* status) {
   if (!nd || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;

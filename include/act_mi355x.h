@@ -231,6 +231,23 @@ int act_cbor_encode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8
 int act_cbor_decode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8_t *cbor, const uint64_t *offsets,
                           uint8_t *out_records, uint8_t *status);
 
+/* Wire bytes in, verdict out: SpendProof::from_cbor (src/cbor.rs:236-408) + PrivateKey::refund up to the challenge check
+ * (src/lib.rs:787-844) as ONE pass over n CBOR messages (delimited like act_cbor_decode_batch's: offsets[0..n] in host memory, or
+ * NULL for canonical-size messages back to back).  Every chunk is unframed on the GPU in front of its verification kernels, and
+ * each of a proof's 130 points is decoded once -- act_cbor_decode_batch followed by act_verify_spend_batch decodes them twice and
+ * moves the records through the caller's memory in between.  status[i]: 0 / 6 / 7 as act_verify_spend_batch;
+ * 255 = a point that is not a canonical Ristretto encoding (from_cbor's CborError::InvalidValue);
+ * ACT_STATUS_CBOR_MALFORMED = not well-formed CBOR (CborError::Ciborium); ACT_STATUS_CBOR_STRUCTURE = CborError::InvalidStructure
+ * (not a map, missing field, wrong shape or length).  Accept / reject agrees with from_cbor followed by refund; a message that is
+ * wrong in two ways may report the other of its two errors.  Non-canonical but valid encodings take a host reader and a second,
+ * small verification call.  out_kprime (nullable) as in act_verify_spend_batch. */
+#define ACT_STATUS_CBOR_MALFORMED 254
+#define ACT_STATUS_CBOR_STRUCTURE 253
+int act_verify_spend_cbor_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
+                                uint8_t *status, uint8_t *out_kprime);
+int act_node_verify_spend_cbor_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
+                                     uint8_t *status, uint8_t *out_kprime);
+
 /* Nullifier set: the double-spend database the crate leaves to the caller (src/lib.rs:741-745; `HashSet<Scalar>` with
  * "is_spent? reject : insert" per spend in src/tests.rs:29-50, examples/act.rs:10-30), as a hash set in one GPU's HBM.
  * act_nullifier_check_and_insert_batch has the meaning of that loop run over the batch in lane order: out_spent[i] = 1

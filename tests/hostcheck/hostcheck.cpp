@@ -128,6 +128,34 @@ extern "C" int hc_chain_b2(const uint8_t* pt, const uint8_t* s0, const uint8_t* 
   ristretto_encode(r, acc[0]); st(o0, r); ristretto_encode(r, acc[1]); st(o1, r);
   return 1;
 }
+// the address-free form the ct build uses for secret scalars (msm.h chain_ct: every digit addition executed, no buckets)
+extern "C" int hc_chain_ct2(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
+  uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
+  ge acc[2] = {ge_identity(), ge_identity()};
+  sc s[2] = {sc_in(s0), sc_in(s1)};
+  chain_ct<2>(acc, p, s);
+  ristretto_encode(r, acc[0]); st(o0, r); ristretto_encode(r, acc[1]); st(o1, r);
+  return 1;
+}
+// fixed_base_acc_ct over a CT table of `pt` built here (T[pos][e-1] = e * 16^pos * pt, the recurrence of k_build_table_ct)
+extern "C" int hc_fixed_base_ct(const uint8_t* pt, const uint8_t* s0, uint8_t* o0) {
+  uint32_t w[8], r[8]; ld(w, pt); ge b; if (!ristretto_decode(b, w)) return 0;
+  std::vector<uint32_t> tab(CT_TABLE_WORDS);
+  for (int pos = 0; pos < CT_WINDOWS; pos++) {
+    ge acc = ge_identity();
+    const ge_cached bc = ge_to_cached(b);
+    for (int e = 1; e <= CT_ENTRIES; e++) {
+      acc = ge_add_cached(acc, bc);
+      fe zi = fe_invert(acc.Z);
+      ge af; af.X = fe_mul(acc.X, zi); af.Y = fe_mul(acc.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
+      niels_store(tab.data() + ((size_t)pos * CT_ENTRIES + (e - 1)) * NIELS_WORDS, niels_from_affine(af));
+    }
+    for (int i = 0; i < 4; i++) b = ge_double(b);
+  }
+  ge out = fixed_base_acc_ct(ge_identity(), tab.data(), sc_in(s0));
+  ristretto_encode(r, out); st(o0, r);
+  return 1;
+}
 extern "C" int hc_chain_bu(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
   uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
   ge al = ge_identity(), au = ge_identity();

@@ -68,6 +68,16 @@ int act_verify_spend_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint
   for (size_t i = 0; i < n; i++) { status[i] = (proof[kPB * i] & 1) ? 7 : 0; if (kp) { memset(kp + 32 * i, 0, 32); if (!status[i]) memcpy(kp + 32 * i, proof + kPB * i, 8); } }
   return ACT_OK;
 }
+size_t act_cbor_size(const act_ctx*, int) { return kPB + 3; }       // mock wire message: 3 framing bytes + the record
+int act_verify_spend_cbor_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* cbor, const uint64_t* offsets, uint8_t* status, uint8_t* kp) {
+  c->lanes += n;
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t* m = cbor + (offsets ? offsets[i] : i * (kPB + 3)) + 3;
+    status[i] = (m[0] & 1) ? 7 : 0;
+    if (kp) { memset(kp + 32 * i, 0, 32); if (!status[i]) memcpy(kp + 32 * i, m, 8); }
+  }
+  return ACT_OK;
+}
 int act_refund_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* proof, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status) {
   return sign_like(c, n, proof, kPB, nullptr, 7, rng, mode, out, 128, status);
 }

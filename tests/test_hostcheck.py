@@ -94,7 +94,7 @@ def test_group_and_msm_shapes(hostcheck):
     # digit-recoding corner cases of the radix-4 chain
     e = bytes.fromhex(g["generator_multiples"][1])
     for s in (0, 1, 2, 3, 4, m.ELL - 1, (1 << 252) + 5, (1 << 252) - 1, int("3" * 60, 16) % m.ELL, int("2" * 63, 16) % m.ELL):
-        for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_bu_pre", "hc_chain_b2"):      # radix-4 / radix-4, radix-4 / NAF, buckets / NAF (twice), buckets / buckets
+        for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_bu_pre", "hc_chain_b2", "hc_chain_ct2"):      # radix-4 / radix-4, radix-4 / NAF, buckets / NAF (twice), buckets / buckets, the ct build's address-free form
             ok, o0, o1 = call(hc, fn, e, m.sc_bytes(s), m.sc_bytes(m.ELL - 1 - s), nout=2)
             assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, s)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, m.ELL - 1 - s)), (fn, s)
     # width-3 NAF recoding of the wave-uniform scalar (msm.h naf3_next): runs of 1s, alternating digits, carries
@@ -106,7 +106,7 @@ def test_group_and_msm_shapes(hostcheck):
         for fn in ("hc_chain_bu", "hc_chain_bu_pre"):
             ok, o0, o1 = call(hc, fn, e, m.sc_bytes(9), su.to_bytes(32, "little"), nout=2)
             assert o0 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, 9)) and o1 == m.ristretto_encode(m.pt_mul(m.BASEPOINT, su)), (fn, hex(su))
-    for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_bu_pre", "hc_chain_b2"):   # identity base
+    for fn in ("hc_chain2", "hc_chain2u", "hc_chain_bu", "hc_chain_bu_pre", "hc_chain_b2", "hc_chain_ct2"):   # identity base
         ok, o0, o1 = call(hc, fn, bytes(32), m.sc_bytes(5), m.sc_bytes(m.ELL - 7), nout=2)
         assert o0 == bytes(32) and o1 == bytes(32), fn
 

@@ -105,6 +105,17 @@ def test_other_entry_points_slice_consistently(lib):
     for i in range(n):
         assert t2.raw[160 * i:160 * i + 8] == prer.raw[96 * i:96 * i + 8] and t2.raw[160 * i + 8:160 * i + 16] == refund[128 * i:128 * i + 8]
         assert t2.raw[160 * i + 159] == proof.raw[PB * i]
+    # wire bytes: offsets are absolute into the one buffer; without offsets the messages are canonical-size and back to back
+    ML = PB + 3
+    msgs = b"".join(b"\xa1\x01\x58" + proof.raw[PB * i:PB * (i + 1)] for i in range(n))
+    offs = (C.c_uint64 * (n + 1))(*[ML * i for i in range(n + 1)])
+    want_st = bytes(7 if proof.raw[PB * i] & 1 else 0 for i in range(n))
+    for o in (offs, None):
+        st2 = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
+        assert lib.act_node_verify_spend_cbor_batch(nd, C.c_size_t(n), bytes(64), msgs, o, st2, kp) == 0
+        assert st2.raw == want_st
+        for i in range(n):
+            assert kp.raw[32 * i:32 * i + 8] == (proof.raw[PB * i:PB * i + 8] if want_st[i] == 0 else bytes(8))
     lib.act_node_destroy(nd)
 
 

@@ -100,7 +100,7 @@ def test_device_headers_primitives(hostcheck):
     for i, v in enumerate(sms):
         w = sms[(i + 1) % len(sms)]
         # every variable-base chain shape of msm.h on the same base: s0 * P and s1 * P
-        for fn in ("hc_chain_b2", "hc_chain_bu", "hc_chain2u") if i % 4 == 0 else ("hc_chain_b2", "hc_chain_bu"):
+        for fn in ("hc_chain_b2", "hc_chain_bu", "hc_chain2u", "hc_chain_ct2") if i % 4 == 0 else ("hc_chain_b2", "hc_chain_bu"):
             ok, o0, o1 = _hc(hc, fn, hx(v["point"]), hx(v["scalar"]), hx(w["scalar"]), nout=2)
             assert ok and o0.hex() == v["out"], (fn, i)
         if i % 16 == 0:
@@ -110,6 +110,9 @@ def test_device_headers_primitives(hostcheck):
     gen_enc = next(v["out"] for v in gen if i_le(hx(v["scalar"])) == 1)
     for v in gen[:8]:                                                            # fixed-base windows (table rebuilt per call: keep it short)
         ok, o0 = _hc(hc, "hc_fixed_base", hx(gen_enc), hx(v["scalar"]))
+        assert ok and o0.hex() == v["out"]
+    for v in gen[:24]:                                                           # the ct build's scanned radix-16 tables
+        ok, o0 = _hc(hc, "hc_fixed_base_ct", hx(gen_enc), hx(v["scalar"]))
         assert ok and o0.hex() == v["out"]
     for v in gen[8:]:
         ok, o0, o1 = _hc(hc, "hc_chain_b2", hx(gen_enc), hx(v["scalar"]), hx(v["scalar"]), nout=2)
