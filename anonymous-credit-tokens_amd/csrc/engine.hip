@@ -84,7 +84,7 @@ struct act_ctx {
   uint32_t* d_tables[4] = {nullptr, nullptr, nullptr, nullptr};     // shared with the other contexts of this device (table cache below)
   int fb_bits[4] = {0, 0, 0, 0};        // window width of each base's table
   uint32_t* d_half_h1 = nullptr;
-  uint32_t* d_tables_ct = nullptr;     // ACT_CT_SECRET_TABLES builds only
+  uint32_t* d_tables_ct = nullptr;     // the four scanned tables (msm.h fixed_base_acc_ct)
   void* wire_layout = nullptr;         // the running wire-bytes call's CborDev (cbor_impl.inc)
   uint8_t* d_wire_flags = nullptr; size_t d_wire_flags_cap = 0;     // per message of a wire-bytes call: 0x80 = not the canonical encoding (cbor_impl.inc)
   // key cache
@@ -612,13 +612,13 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
     if (!c->d_tables[b]) { c->err = "fixed-base table allocation failed"; return ACT_ERR_HIP; }
     c->P.tab[b] = FbTab{c->d_tables[b], (uint32_t)c->fb_bits[b], (uint32_t)b};
   }
-#if defined(ACT_CT_SECRET_TABLES)
+  // the small scanned tables (64 KiB per base): the ISSUER's secrets (signing nonces, x) use them in every build, the client's
+  // (prover, request) in the ct build (msm.h "secret scalars")
   HIPCK(c, hipMalloc(&c->d_tables_ct, (size_t)4 * CT_TABLE_WORDS * 4));
   for (int b = 0; b < 4; b++) {
     launch_build_table_ct(d_ext + b * GE_WORDS, c->d_tables_ct + (size_t)b * CT_TABLE_WORDS, s0);
     c->P.tab_ct[b] = c->d_tables_ct + (size_t)b * CT_TABLE_WORDS;
   }
-#endif
   HIPCK(c, hipMalloc(&c->d_half_h1, (size_t)2 * NIELS_WORDS * 4));
   launch_half_point_table(c->P.tab[BASE_H1], c->d_half_h1, s0);
   c->P.half_h1 = c->d_half_h1;

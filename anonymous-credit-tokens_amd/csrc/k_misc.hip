@@ -28,7 +28,6 @@ void launch_build_table(const uint32_t* base_ext, uint32_t* table, uint32_t wbit
   hipLaunchKernelGGL(k_build_table, dim3((lanes + 255) / 256), dim3(256), 0, s, base_ext, table, wbits);
 }
 
-#if defined(ACT_CT_SECRET_TABLES)
 // T[pos][e-1] = e * 16^pos * B, e = 1..8, as affine Niels: the small tables the secret-scalar products scan in full (msm.h)
 __global__ void __launch_bounds__(64) k_build_table_ct(const uint32_t* base_ext, uint32_t* table) {
   uint32_t gid = blockIdx.x * 64 + threadIdx.x;
@@ -49,7 +48,6 @@ __global__ void __launch_bounds__(64) k_build_table_ct(const uint32_t* base_ext,
 void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_t s) {
   hipLaunchKernelGGL(k_build_table_ct, dim3((CT_WINDOWS * CT_ENTRIES + 63) / 64), dim3(64), 0, s, base_ext, table);
 }
-#endif
 
 // out[0] = identity, out[1] = B / 2 as affine Niels, B the base of `table`: the prover works at half scale (k_prove.hip)
 __global__ void k_half_point_table(FbTab table, uint32_t* out) {
@@ -88,8 +86,7 @@ void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipS
 
 // PrivateKey::random (src/lib.rs:188-194): x <- 64 rng bytes; w = x * g
 __global__ void __launch_bounds__(64) k_keygen(DevParams P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk) {
-  ACT_SECRET_FB(fb, P);
-  fb.stage(BASE_G);
+  IssuerFb fb{P};                                                 // the issuer's key never addresses memory, in either build
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   sc x = load_wide(rng64 + (size_t)i * 64);

@@ -9,8 +9,7 @@ namespace act {
 // ---- sign, phase A: e, alpha <- rng;  A = (e+x)^-1 X_A;  X_g = e g + w;  Y_A = alpha A;  Y_g = alpha g --------
 // A and Y_A share X_A's doubling chain: Y_A = (alpha (e+x)^-1) X_A.
 __global__ void __launch_bounds__(64, 2) k_sign_a(SignArgs a) {
-  ACT_SECRET_FB(fb, a.P);
-  fb.stage(BASE_G);                                               // before any lane leaves (kernels.h SecretFb)
+  IssuerFb fb{a.P};                                               // nonces and key: scanned tables, register-only chain, in either build
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= a.n) return;
   if (a.status[p] != 0) return;                                   // rng is drawn only after verification (:638-643, :842-846)
@@ -20,7 +19,7 @@ __global__ void __launch_bounds__(64, 2) k_sign_a(SignArgs a) {
   ge xa = ge_load(a.xa + (size_t)p * GE_WORDS);
   ge acc[2] = {ge_identity(), ge_identity()};
   sc s[2] = {inv, sc_mul(alpha, inv)};
-  chain_s<2>(acc, xa, s, a.pbk + (size_t)p * 2 * BUCKET_WORDS);                                           // acc[0] = A, acc[1] = Y_A (:650 / :853)
+  chain_ct<2>(acc, xa, s);                                                                                // acc[0] = A, acc[1] = Y_A (:650 / :853)
   ge xg = ge_add(fb.mul(ge_identity(), BASE_G, e), a.K.w);        // :646 / :851
   ge yg = fb.mul(ge_identity(), BASE_G, alpha);                   // :651 / :854
 

@@ -30,9 +30,7 @@ constexpr int SMALL_TR_STRIDE = 512;      // request 266 B, respond 466 B, refun
 struct DevParams {
   FbTab tab[4];                           // position-specific fixed-base tables of g, h1, h2, h3 with their window widths (msm.h)
   const uint32_t* half_h1;                // two affine-Niels entries: identity, h1 / 2 (the prover's bit term at half scale)
-#if defined(ACT_CT_SECRET_TABLES)
   const uint32_t* tab_ct[4];              // small tables the secret-scalar products scan in full (msm.h fixed_base_acc_ct)
-#endif
   uint32_t prefix[4][PREFIX_WORDS];       // Transcript::new(params, label) bytes, zero padded
   uint32_t prefix_len[4];
   int L;                                  // range-proof width (src/lib.rs:116)
@@ -190,9 +188,7 @@ struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n;
 #if defined(__HIPCC__)
 // launchers (defined in the .hip files)
 void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, uint32_t wbits, hipStream_t s);
-#if defined(ACT_CT_SECRET_TABLES)
 void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_t s);
-#endif
 void launch_half_point_table(FbTab table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
 void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s);
 void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s);
@@ -227,18 +223,25 @@ void launch_client_b(const ClientArgs& a, hipStream_t s);
 
 // ---- fixed-base products of SECRET scalars (msm.h "secret scalars") ---------------------------------------------------------
 // Kernel code writes   ACT_SECRET_FB(fb, a.P);  fb.stage(BASE_G);  x = fb.mul(acc, BASE_G, e);
-// Default build: stage() is nothing and mul() is fixed_base_acc on the context's wide tables (addressed look-ups).
-// ACT_CT_SECRET_TABLES build: mul() scans all eight entries of every window of the base's 64 KiB CT table.
-//   ACT_SECRET_FB      the scan reads the table where it lies in global memory.  Every lane of a wavefront reads the same
-//                      addresses, so a window is 8 x 128 B per WAVEFRONT through L2, not per lane: for the 64-thread blocks of
-//                      the per-proof kernels that is the same traffic as staging would be, without the barriers.
-//   ACT_SECRET_FB_LDS  (k_prove_bits: 256-thread blocks, three products per staged base) the block copies the table into
-//                      64 KiB of LDS first -- stage(base) holds the block's barriers and a block-strided copy, so EVERY thread
-//                      of the block must call it, before any early exit -- and the scan is broadcast ds_read_b128.
-// Measured on one MI355X (profiles/r03_b_other_configs_1gpu*.json): staging in LDS everywhere made `request` slower (0.27x ->
-// 0.15x of the default build: 128 KiB copied per 64 lanes for four products) and prove_spend 3 % faster; the cost of the ct build's
-// fixed-base products is their 64 additions per product (the default build's 24- / 16-bit windows need 11 / 16), not the scan.
+//   IssuerFb           the issuer's secrets (signing nonces e, alpha; key generation): in EVERY build mul() scans all eight entries
+//                      of every window of the base's 64 KiB table (fixed_base_acc_ct).  The scan reads the table where it lies in
+//                      global memory; every lane of a wavefront reads the same addresses, so a window is 8 x 128 B per WAVEFRONT
+//                      through L2, not per lane.
+//   ACT_SECRET_FB      the client's secrets in the per-proof kernels (prover head / tail, request).  Default build: stage() is
+//                      nothing and mul() is fixed_base_acc on the context's wide tables (addressed look-ups); ct build: the scan
+//                      above.
+//   ACT_SECRET_FB_LDS  the same for k_prove_bits (256-thread blocks, three products per staged base): in the ct build the block
+//                      copies the table into 64 KiB of LDS first -- stage(base) holds the block's barriers and a block-strided
+//                      copy, so EVERY thread of the block must call it, before any early exit -- and scans it with broadcast
+//                      ds_read_b128.
+// Measured on one MI355X (profiles/r03_b_other_configs_1gpu*.json): staging in LDS in the 64-thread kernels made `request` slower
+// (0.27x -> 0.15x of the default build: 128 KiB copied per 64 lanes for four products) and prove_spend 3 % faster; the cost of the ct
+// build's fixed-base products is their 64 additions per product (the default build's 24- / 16-bit windows need 11 / 16), not the scan.
 #if defined(__HIPCC__)
+struct IssuerFb {
+  const DevParams& P;
+  __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_ct(acc, P.tab_ct[base], s); }
+};
 #if defined(ACT_CT_SECRET_TABLES)
 struct SecretFb {
   const DevParams& P;

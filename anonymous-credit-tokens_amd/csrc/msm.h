@@ -490,11 +490,14 @@ ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
 }
 
 // ---- secret scalars --------------------------------------------------------------------------------------------
-// What the prover, the signer, key generation and the x-dependent product of the verifier call (through SecretFb in kernels.h
-// and chain_s here).  By default they are fixed_base_acc / chain_b: table entries and buckets are addressed by scalar digits,
-// so the memory-access pattern depends on secrets (the instruction stream does not).  Built with -DACT_CT_SECRET_TABLES
-// (make ct -> libact_mi355x_ct.so) neither does the access pattern, to the standard the reference sets with `subtle`
-// (/root/reference/src/lib.rs:98, 1025-1118) and dalek's table scans:
+// The reference is constant-time in its table accesses (`subtle`, /root/reference/src/lib.rs:98, 1025-1118; dalek's table scans).
+// Here, in EVERY build, the ISSUER's secrets -- the key x (the verifier's (e_bar - x gamma) A', the signer's (e + x)^-1) and the
+// signing nonces e, alpha -- never select a memory address: their chains are chain_ct and their fixed-base products scan
+// (IssuerFb in kernels.h).  Measured cost against addressed look-ups: verify 1.00x, refund 0.99x, issue 0.88x.
+// The CLIENT's secrets (prover: SecretFb in kernels.h and chain_s here; request) use fixed_base_acc / chain_b in the default build --
+// table entries and buckets addressed by scalar digits, so the memory-access pattern depends on them (the instruction stream does
+// not) -- and the address-free forms when built with -DACT_CT_SECRET_TABLES (make ct -> libact_mi355x_ct.so): prove_spend 0.26x,
+// request 0.26x of the default build, because a scanned table cannot be wider than a few entries per window:
 //   fixed-base products   signed radix-16 windows over a small table of the base (64 windows x 8 entries x 128 B = 64 KiB)
 //                         that the BLOCK first stages in LDS (ct_stage); every lane then reads all eight entries of a window --
 //                         the same LDS addresses in every lane: broadcast reads, no bank conflicts -- and keeps one with masks.

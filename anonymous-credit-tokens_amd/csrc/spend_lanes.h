@@ -33,7 +33,7 @@ namespace act {
 constexpr int ENC_BATCH = 32;   // half-points per lane of k_spend_enc
 
 // ---- k_spend_prep: three independent pieces per proof ---------------------------------------------------------------
-//   piece A  decode A' (identity check :787), transcript k | A',  A1a = (e_bar - x gamma) A'          buckets set 0
+//   piece A  decode A' (identity check :787), transcript k | A',  A1a = (e_bar - x gamma) A'          register-only chain (msm.h chain_ct)
 //   piece B  decode B_bar, transcript B_bar,  A1b = r2_bar B_bar,  A2b = r3_bar B_bar  (one chain)    buckets sets 1, 2
 //   piece C  transcript prefix, A2f = c_bar h1 + r_bar h3 - gamma g - (gamma k) h2, w00/2 h2, w01/2 h2, gamma's NAF digits
 //   then     A1 = A1a + A1b, A2 = A2f + A2b, encoded.
@@ -58,7 +58,7 @@ ACT_PIECE ge spend_prep_role_a(const SpendArgs& a, uint32_t p, uint32_t& flags) 
   sc gamma = load_sc(rec + 32 * pl.gamma()), e_bar = load_sc(rec + 32 * pl.e_bar());
   ge acc[1] = {ge_identity()};
   sc sa[1] = {sc_sub(e_bar, sc_mul(a.K.x, gamma))};
-  chain_s<1>(acc, A, sa, a.buckets + (size_t)p * PREP_BUCKET_SETS * BUCKET_WORDS);      // the scalar depends on the issuer's x
+  chain_ct<1>(acc, A, sa);                                 // the scalar depends on the issuer's x: no digit of it ever selects an address (msm.h)
   return acc[0];
 }
 ACT_PIECE void spend_prep_role_b(const SpendArgs& a, uint32_t p, uint32_t& flags, ge& a1b, ge& a2b) {

@@ -112,10 +112,15 @@ int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);   /* host BLAKE3 worke
  * host-transcript mode, its host hashing) or 1 (strictly one after the other: profiling runs whose per-kernel durations
  * must not overlap) */
 int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
-/* 1 if this library was built with -DACT_CT_SECRET_TABLES (libact_mi355x_ct.so): table entries and Pippenger buckets selected
- * by digits of SECRET scalars (prover, signer, key generation, the verifier's x-dependent product) are read / written in
- * full and picked with masks, so the memory-access pattern is independent of secrets, as the reference's use of `subtle`
- * and dalek's table scans are (src/lib.rs:98, 1025-1118).  0 = default build: addressed look-ups. */
+/* Secrets and memory addresses.  The reference is constant-time in its table accesses (`subtle`, src/lib.rs:98, 1025-1118;
+ * dalek's table scans).  In EVERY build of this library the ISSUER's secrets -- the private key x and the signing nonces, i.e.
+ * everything act_issue_* / act_refund_* / act_verify_spend_* / act_private_key_random compute with -- never select a memory
+ * address: variable-base products run a register-only chain that executes every digit addition, fixed-base products scan all
+ * entries of small tables and pick with masks.  The CLIENT's secrets (act_prove_spend_batch, act_request_batch: tokens, blinding
+ * factors, the prover's rng) use scalar-addressed tables in the default build and the same address-free forms in
+ * libact_mi355x_ct.so (make ct, -DACT_CT_SECRET_TABLES), which returns 1 here; same bytes either way.  Cost of the ct build on one
+ * MI355X: prove_spend 0.26x, request 0.26x of the default build; every issuer-side call within 1 %.  A deployment that runs the
+ * client side on a GPU it shares with parties it does not trust loads the ct build; an issuer can load either. */
 int act_build_has_ct_secret_tables(void);
 /* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
  * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 when max_batch >= 32768 (23.6 GB per base) */

@@ -270,6 +270,7 @@ def test_config4_2_19_issue_and_refund_per_gpu_sequential_rng(oracle, bench_para
         assert not resp[exp_issue != 0].any() and resp[exp_issue == 0].any(axis=1).all()
         slot = _accepted_index(st.tobytes())
         lanes = _sample_lanes(n, parts, st.tobytes(), 8192, 41)
+        n_issue_checked = len(lanes)
         acc = [i for i in lanes if exp_issue[i] == 0]
         st_o, resp_o = octx.issue_batch(sk, reqs[acc].tobytes(), camt[acc].tobytes(), rng_i[slot[acc]].tobytes(), 8)
         assert st_o == bytes(len(acc)) and resp_o == resp[acc].tobytes(), "issue: node != oracle on the sequential slices"
@@ -295,6 +296,6 @@ def test_config4_2_19_issue_and_refund_per_gpu_sequential_rng(oracle, bench_para
         node.close()
     note_rate("config4_per_gpu_2^19_issue_refund_sequential_rng", {
         "issues_per_s": n / dt_issue, "refunds_per_s": n / dt_refund, "ms_issue": 1e3 * dt_issue, "ms_refund": 1e3 * dt_refund,
-        "rejected_lanes": int(len(bad)), "oracle_checked_issue_lanes": len(lanes), "note":
+        "rejected_lanes": int(len(bad)), "oracle_checked_issue_lanes": n_issue_checked, "oracle_checked_refund_lanes": len(lanes), "note":
         "one act_node_issue_batch and one act_node_refund_batch of 2^19 lanes from pageable host memory, node = two contexts on one GPU, "
         "ACT_RNG_SEQUENTIAL (two-phase: check on all shards, host prefix count, sign), device transcripts"})
