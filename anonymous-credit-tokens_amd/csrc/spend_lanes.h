@@ -144,7 +144,11 @@ ACT_HD void spend_bits_lane(const SpendArgs& a, uint32_t gid, uint32_t* lds_wave
   acc_u = fixed_base_acc(acc_u, a.P.tab[BASE_H1], g1);
   if (j == 0) acc_u = ge_add(acc_u, ge_load(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS));      // + w01 h2 (:808)
   ge acc_l = ge_identity();
+#if defined(ACT_ABLATE_BUCKET_FOOTPRINT)      // measurement build only: all lanes' buckets folded onto 8 MiB so that the bucket
+  uint32_t* bk = a.buckets + (size_t)(gid % ACT_ABLATE_BUCKET_FOOTPRINT) * BUCKET_WORDS;      // traffic hits in L2; results are garbage
+#else
   uint32_t* bk = a.buckets + (size_t)gid * BUCKET_WORDS;
+#endif
   uint32_t* dg = a.dig + (size_t)gid * 8;
   { uint32_t t[8]; radix16_bias(t, g0); for (int i = 0; i < 8; i++) dg[i] = t[i]; }
   // Com_j in E[4] <=> its encoding is all zero (or it did not decode: the proof is rejected anyway): D = G = identity
