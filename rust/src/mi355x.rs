@@ -47,14 +47,40 @@ extern "C" {
                                              w: *const u8, out_token: *mut u8, status: *mut u8) -> c_int;
 }
 
-/// All GPUs of the node behind one handle (contiguous shards, no collective).  `Params` owns one lazily:
-/// add `#[cfg(feature = "mi355x")] gpu: OnceLock<Gpu>` to `Params` (src/lib.rs:222-229) and `Params::gpu()` below.
+/// All GPUs of the node behind one handle (contiguous shards, no collective).
+///
+/// How `Params` (src/lib.rs:222-229, `#[derive(Clone)]`) carries it: add the field
+/// `#[cfg(feature = "mi355x")] gpu: GpuSlot` and nothing else -- `GpuSlot` below is `Clone` (a clone starts EMPTY and builds its own
+/// handle on first use, so `#[derive(Clone)]` on `Params` keeps compiling and clones never share engine state), `Default`, `Send`
+/// and `Sync`.
+///
+/// Threads: safe Rust may call `request` / `issue` / `refund` on one `&Params` from many threads at once.  The library serialises
+/// them itself -- every `act_node_*_batch` call takes the node handle's lock and every context entry point the context's
+/// (include/act_mi355x.h, "A node handle ... may be shared between host threads") -- so concurrent callers are served one after
+/// the other and never observe each other's staging buffers, cached key or error string.  That is why `Gpu` may be `Sync`; the
+/// guarantee lives in the library, not in a promise by the caller.
 pub struct Gpu(*mut ActNode);
+// SAFETY: the handle is only ever passed to act_node_* entry points, each of which locks it (csrc/node.cpp `node_lock`);
+// act_node_destroy runs from Drop, i.e. with exclusive access.
 unsafe impl Send for Gpu {}
-unsafe impl Sync for Gpu {} // the engine serialises nothing: callers must not share one Gpu between threads concurrently
+unsafe impl Sync for Gpu {}
 impl Drop for Gpu {
     fn drop(&mut self) {
         unsafe { act_node_destroy(self.0) }
+    }
+}
+
+/// The `Params` field: a lazily built `Gpu` that does not get in the way of `#[derive(Clone)]`.
+#[derive(Default)]
+pub struct GpuSlot(OnceLock<Gpu>);
+impl Clone for GpuSlot {
+    fn clone(&self) -> Self {
+        GpuSlot(OnceLock::new()) // a cloned Params builds its own node handle on first use
+    }
+}
+impl std::fmt::Debug for GpuSlot {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        f.write_str(if self.0.get().is_some() { "GpuSlot(ready)" } else { "GpuSlot(empty)" })
     }
 }
 
@@ -68,8 +94,12 @@ impl Gpu {
         let devices: Vec<c_int> = std::env::var("ACT_MI355X_DEVICES")
             .map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect())
             .unwrap_or_else(|_| vec![0]);
+        // ACT_MI355X_MAX_BATCH: records per internal launch.  Unset = the library default (65 536: 29 GB of workspace per GPU and,
+        // where the device has the memory to spare, 47 GB of 24-bit fixed-base tables built in ~2 s, all GPUs concurrently);
+        // a service that only ever sees small batches sets e.g. 4096 (1.8 GB, 16-bit tables, 0.02 s).
+        let max_batch: usize = std::env::var("ACT_MI355X_MAX_BATCH").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
         let mut node = std::ptr::null_mut();
-        let rc = unsafe { act_node_create(h.as_ptr(), L as c_int, devices.as_ptr(), devices.len() as c_int, 0, &mut node) };
+        let rc = unsafe { act_node_create(h.as_ptr(), L as c_int, devices.as_ptr(), devices.len() as c_int, max_batch, &mut node) };
         if rc != 0 {
             let msg = if node.is_null() { String::new() } else { unsafe { CStr::from_ptr(act_node_last_error(node)) }.to_string_lossy().into_owned() };
             panic!("act_node_create failed ({rc}): {msg}"); // infrastructure failure, not a protocol error
@@ -86,7 +116,7 @@ impl Gpu {
 
 impl Params {
     pub(crate) fn gpu(&self) -> &Gpu {
-        self.gpu.get_or_init(|| Gpu::new(self))
+        self.gpu.0.get_or_init(|| Gpu::new(self))
     }
 }
 
