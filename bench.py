@@ -450,8 +450,13 @@ def main():
                         "note": "the view the contract template asks for; not binding: 16.8 KB in per verify against ~40 M 64-bit multiply-accumulates"}}
         t = newest_matching_pmc("pmc_hbm_traffic", proofs_per_launch, sha, L)
         if t:
-            roof["traffic"] = t[1]["hbm_bytes_per_launch_fetch_x2"]; roof["traffic_source"] = t[0]
-            roof["traffic_unit"] = "bytes per launch at the L2's memory side (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE): per-lane Pippenger buckets cycling through L2 / Infinity Cache"
+            j = t[1]
+            roof["traffic"] = j.get("hbm_bytes_per_launch_calibrated", j["hbm_bytes_per_launch_fetch_x2"]); roof["traffic_source"] = t[0]
+            roof["traffic_unit"] = ("bytes per launch at the L2's memory side: 1.25 x FETCH_SIZE + WRITE_SIZE, the factor calibrated on a known byte count in the kernel's own "
+                                    "access pattern (profiles/r03_calib_fetch.txt) as MI355X_MICROARCH.md prescribes for anything but wide streaming reads; "
+                                    "dominated by the per-lane Pippenger buckets cycling through L2 / Infinity Cache")
+            roof["traffic_other_corrections"] = {"uncorrected": j["hbm_bytes_per_launch_uncorrected"], "fetch_x2_as_for_streaming_reads": j["hbm_bytes_per_launch_fetch_x2"]}
+            roof["traffic_over_algorithmic_bytes"] = roof["traffic"] / (algo_bytes * proofs_per_launch)
         else:
             roof["traffic_source"] = "none: no profiles/*_pmc_hbm_traffic.json was collected from these kernel sources (sha %s) at L = %d" % (sha, L)
         v = newest_matching_pmc("pmc_valu", proofs_per_launch, sha, L)
