@@ -170,9 +170,16 @@ def prebuild_cpu_side(want_cpu_baseline):
     pool): the instrumented host build of the lane bodies (field-operation counts) and the -march=native C oracle."""
     paths = {}
     src = os.path.join(ROOT, "tests", "hostcheck", "hostcheck.cpp")
-    out = os.path.join("/tmp", "libhostcheck_bench_%d.so" % os.getpid())
-    subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src], check=True)
-    paths["hostcheck"] = out
+    # the in-tree build of the CPU test suite (tests/conftest.py `hostcheck`) is reused when it is newer than every source it is made
+    # from -- it travels to the GPU box with the snapshot, and a profiled run then starts no compiler at all
+    intree = os.path.join(ROOT, "tests", "hostcheck", "libhostcheck.so")
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    if os.path.exists(intree) and all(os.path.getmtime(d) <= os.path.getmtime(intree) for d in deps):
+        paths["hostcheck"] = intree
+    else:
+        out = os.path.join("/tmp", "libhostcheck_bench_%d.so" % os.getpid())
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", "-o", out, src], check=True)
+        paths["hostcheck"] = out
     if want_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_c
@@ -259,7 +266,8 @@ def count_field_ops(hc_path, h, L, sk, proofs_host, fb_bits, sample=4):
     tr = ctypes.create_string_buffer(n * tb); st = ctypes.create_string_buffer(n); kp = ctypes.create_string_buffer(32 * n)
     c = (ctypes.c_uint64 * 25)()
     ok = hc.hc_spend_verify(h, L, sk, n, proofs_host[:pb * n], tr, st, kp, c)
-    os.unlink(hc_path)
+    if hc_path.startswith("/tmp/"):
+        os.unlink(hc_path)
     assert ok == 1 and st.raw == bytes(n)
     windows = [-(-253 // b) for b in fb_bits]
     per = {}
