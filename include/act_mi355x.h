@@ -98,7 +98,9 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
  * RistrettoBasepointTables of src/lib.rs:222-229) + the range-proof width L (src/lib.rs:116; 128 is the
  * crate's value, 1..128 accepted) + one GPU.  max_batch bounds the records per internal launch and
  * thereby the workspace: about 220 KB per record at L = 128 (1.7 KB per range-proof bit), times two
- * pipeline slots, plus the fixed-base tables (0.5 GB; 48 GB from max_batch 32768 up, where h1 and h3 get 24-bit windows).
+ * pipeline slots, plus the fixed-base tables, which the contexts of a process on one GPU with the same Params share: 0.5 GB with
+ * 16-bit windows; from max_batch 32768 up h1 and h3 get 24-bit windows (47 GB, built in about 2 s, +3 % verifies/s) provided at
+ * least 16 GB of the device would stay free afterwards (otherwise, or with ACT_FB_WIDE_BITS=16 in the environment, 16 bits).
  * 0 = default = 65536 (29 GB of workspace at L = 128), from which size on the
  * throughput of every entry point is flat; 16384 costs about 5 % of the verify rate and two thirds
  * of the issue/request rate.  Batches of any length are accepted and processed in such chunks.  max_batch > 2^22 is
@@ -107,7 +109,7 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
 int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act_ctx **out);
 void act_ctx_destroy(act_ctx *ctx);
 int act_ctx_set_transcript_mode(act_ctx *ctx, int mode);    /* default ACT_TRANSCRIPT_HOST */
-int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);   /* host BLAKE3 workers; 0 = hardware concurrency */
+int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);   /* host BLAKE3 workers; 0 = the CPUs the process may use (affinity, cgroup quota) */
 /* chunks in flight per call: 2 (default; chunk i+1's kernels overlap chunk i's low-occupancy head / tail kernels and, in
  * host-transcript mode, its host hashing) or 1 (strictly one after the other: profiling runs whose per-kernel durations
  * must not overlap) */
@@ -123,7 +125,7 @@ int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
  * client side on a GPU it shares with parties it does not trust loads the ct build; an issuer can load either. */
 int act_build_has_ct_secret_tables(void);
 /* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
- * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 when max_batch >= 32768 (23.6 GB per base) */
+ * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 when max_batch >= 32768 and the device has the memory (see above) */
 int act_ctx_fixed_base_bits(const act_ctx *ctx, int base);
 const char *act_last_error(const act_ctx *ctx);
 size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
