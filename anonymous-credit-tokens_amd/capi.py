@@ -23,7 +23,7 @@ EXPORTS = [
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
     "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch", "act_verify_spend_cbor_batch",
-    "act_node_verify_spend_cbor_batch",
+    "act_node_verify_spend_cbor_batch", "act_redeem_batch", "act_node_redeem_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
     "act_nullifier_check_and_insert_batch",
     "act_issue_check_batch", "act_issue_sign_batch", "act_refund_sign_batch",
@@ -103,6 +103,8 @@ def load() -> C.CDLL:
     lib.act_cbor_decode_batch.argtypes = [vp, i32, sz, i32, u8p, vp, u8p, u8p]
     lib.act_verify_spend_cbor_batch.argtypes = [vp, sz, i32, u8p, u8p, vp, u8p, u8p]
     lib.act_node_verify_spend_cbor_batch.argtypes = [vp, sz, u8p, u8p, vp, u8p, u8p]
+    lib.act_redeem_batch.argtypes = [vp, vp, sz, i32, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_node_redeem_batch.argtypes = [vp, vp, sz, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_nullifier_set_create.argtypes = [i32, sz, u8p, C.POINTER(vp)]
     lib.act_nullifier_set_destroy.argtypes = [vp]
     lib.act_nullifier_set_destroy.restype = None
@@ -326,6 +328,17 @@ class Engine:
         self._ck(self.lib.act_cbor_decode_batch(self.ctx, t, n, MEM_HOST, p0, offs.ctypes.data, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
 
+    def redeem(self, nullifier_set, sk: bytes, proofs: bytes, rng: bytes, rng_mode: int = RNG_PER_LANE):
+        """verify -> nullifier check-and-insert -> sign: statuses (3 = DoubleSpendError) and refunds."""
+        n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
+        self._ck(self.lib.act_redeem_batch(self.ctx, nullifier_set.h, n, MEM_HOST, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def redeem_dev(self, nullifier_set, sk: bytes, n: int, d_proofs: int, d_rng: int, rng_mode: int, d_out: int, d_status: int):
+        ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_redeem_batch(self.ctx, nullifier_set.h, n, MEM_DEVICE, ps, d_proofs, d_rng, rng_mode, d_out, d_status))
+
     def verify_spend_cbor(self, sk: bytes, messages: list, want_kprime: bool = False):
         """CBOR SpendProof messages (byte strings of any length) -> statuses: from_cbor + refund's verification in one pass."""
         n = len(messages)
@@ -472,6 +485,12 @@ class Node:
         n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
         ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
         self._ck(self.lib.act_node_refund_batch(self.nd, n, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def redeem(self, nullifier_set, sk: bytes, proofs: bytes, rng: bytes, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
+        self._ck(self.lib.act_node_redeem_batch(self.nd, nullifier_set.h, n, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
 
     def refund_sign(self, sk: bytes, kprime: bytes, status_in: bytes, rng: bytes, rng_mode: int = RNG_SEQUENTIAL):

@@ -370,3 +370,21 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t
   return first_rc;
 }
 }  // extern "C"
+
+// The issuer's whole redemption step over the GPUs of a node (act_redeem_batch's meaning, include/act_mi355x.h): verification on
+// every shard, the node-level nullifier set over the whole batch in lane order (verdicts as skip mask), then the signatures --
+// ACT_RNG_SEQUENTIAL draws only for lanes that are signed, from one stream, exactly as the sequential loop would.
+extern "C" int act_node_redeem_batch(act_node* nd, act_node_nullifier_set* set, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng,
+                                     int rng_mode, uint8_t* out_refund, uint8_t* status) {
+  if (!nd || !set || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  if (n == 0) return ACT_OK;
+  const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
+  std::vector<uint8_t> kprime(n * 32), verdict(n), spent(n);
+  int rc = act_node_verify_spend_batch(nd, n, sk, proof, verdict.data(), kprime.data());
+  if (rc) return rc;
+  rc = act_node_nullifier_check_and_insert_batch(set, n, proof, pb, verdict.data(), spent.data());
+  if (rc) { nd->err = std::string("nullifier set: ") + act_node_nullifier_set_last_error(set); return rc; }
+  for (size_t i = 0; i < n; i++) if (verdict[i] == 0 && spent[i]) verdict[i] = ACT_STATUS_DOUBLE_SPEND;
+  return act_node_refund_sign_batch(nd, n, sk, kprime.data(), verdict.data(), rng, rng_mode, out_refund, status);
+}

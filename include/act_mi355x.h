@@ -293,6 +293,22 @@ const char *act_node_nullifier_set_last_error(const act_node_nullifier_set *set)
 int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set *set, size_t n, const uint8_t *nullifiers, size_t stride,
                                               const uint8_t *skip_mask, uint8_t *out_spent);
 
+/* The issuer's whole redemption step -- verify, look the nullifier up, record it, sign the refund (examples/act.rs:62-73; the
+ * NullifierDb loops of src/tests.rs) -- as one call with the result of the loop
+ *     for i in 0..n:  refund(proof_i)'s checks fail (src/lib.rs:787-844)  -> status[i] = that error; nothing recorded, no rng drawn
+ *                     nullifier_i already in the set, or spent by an earlier accepted lane of this batch
+ *                                                                        -> status[i] = ACT_STATUS_DOUBLE_SPEND; no rng drawn
+ *                     otherwise: recorded, signed (src/lib.rs:846-868)    -> status[i] = 0, out_refund[i]
+ * Verification comes first, so a proof that does not verify cannot burn a nullifier (the crate's example marks the nullifier
+ * before calling refund and unwraps: same result for valid proofs).  rng / rng_mode as in act_refund_batch: ACT_RNG_SEQUENTIAL hands
+ * consecutive 128-byte slices to the lanes that are SIGNED.  The set must live on the context's device.  The node form runs the
+ * verification and the signatures on all GPUs and the look-up through the node-level set.  The three steps take their handles'
+ * locks one after the other: concurrent callers interleave between steps, never inside one. */
+int act_redeem_batch(act_ctx *ctx, act_nullifier_set *set, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof,
+                     const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
+int act_node_redeem_batch(act_node *node, act_node_nullifier_set *set, size_t n, const uint8_t sk[64], const uint8_t *proof,
+                          const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
+
 /* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
 int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *out, size_t *n_copied);

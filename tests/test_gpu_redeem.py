@@ -1,0 +1,114 @@
+"""act_redeem_batch / act_node_redeem_batch: the issuer's whole redemption step (verify -> nullifier look-up and record -> sign) must
+equal the sequential loop a server built on the crate runs (examples/act.rs:62-73 with verification first): statuses incl.
+DoubleSpendError, refund bytes under ACT_RNG_SEQUENTIAL (one rng stream, drawn from only by lanes that are signed), and the set's
+contents afterwards -- checked against the C oracle + a Python set, from host memory, from device memory, and over a node handle."""
+import numpy as np
+import pytest
+
+from conftest import ELL, shake, scb
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(eng, sk, n, tag):
+    pre = eng.pre_issuance_random(shake(tag + "-pre", 128 * n)); req = eng.request(pre, shake(tag + "-rq", 128 * n))
+    st, resp = eng.issue(sk, req, b"".join(scb(30 + i) for i in range(n)), shake(tag + "-ir", 128 * n))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i % 20) for i in range(n)), shake(tag + "-pr", eng.prove_rng_bytes * n))
+    assert st == bytes(n)
+    pb = eng.proof_bytes
+    return [proofs[pb * i:pb * i + pb] for i in range(n)]
+
+
+def _sequential_loop(octx, sk, proofs, rng, spent):
+    """the reference loop: verification, then the nullifier database, then the signature with the next 128 rng bytes"""
+    st_out, rf_out, cur = [], [], 0
+    for p in proofs:
+        st, _ = octx.verify_spend(sk, p)
+        k = int.from_bytes(p[:32], "little") % ELL                 # HashSet<Scalar>: the reduced scalar
+        if st == 0 and k in spent:
+            st = 3                                                 # Error::DoubleSpendError
+        if st:
+            st_out.append(st); rf_out.append(bytes(128)); continue
+        spent.add(k)
+        s2, rf = octx.refund(sk, p, rng[128 * cur:128 * cur + 128]); cur += 1
+        assert s2 == 0
+        st_out.append(0); rf_out.append(rf)
+    return bytes(st_out), b"".join(rf_out), cur
+
+
+def _batches(eng, sk, L):
+    good = _make(eng, sk, 12, "rd%d" % L)
+    t = [bytearray(p) for p in good]
+    t[2][32] ^= 1                                                   # charge           -> 7, nullifier NOT recorded
+    t[5][64:96] = bytes(32)                                         # A' = identity     -> 6
+    t[7][32 * (4 + 1):32 * (4 + 2)] = b"\xff" * 32                  # Com_1 undecodable -> 255
+    first = [bytes(x) for x in t] + [good[0], good[3]]             # lanes 12, 13 repeat lanes 0, 3 inside the batch -> 3
+    alias = bytearray(good[4]); alias[0:32] = (int.from_bytes(good[4][:32], "little") + ELL).to_bytes(32, "little")
+    second = [good[2], bytes(alias), good[9]] + _make(eng, sk, 3, "rd%d-b" % L)    # the honest form of lane 2 is still spendable;
+    return first, second                                            # k + l and lane 9 were recorded by the first batch -> 3
+
+
+@pytest.mark.parametrize("L", [8, 128])
+def test_redeem_equals_the_sequential_loop(engine_factory, oracle, bench_params, L):
+    import torch
+    from act_amd import capi
+    eng = engine_factory(bench_params, L, max_batch=5, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("rd-sk", 64))
+    octx = oracle.ctx(bench_params, L)
+    first, second = _batches(eng, sk, L)
+    rng = shake("rd-rng%d" % L, 128 * 32)
+    # oracle: one database across both batches
+    db = set()
+    want1 = _sequential_loop(octx, sk, first, rng, db)
+    want2 = _sequential_loop(octx, sk, second, rng[128 * want1[2]:], db)
+    assert list(want1[0]) == [0, 0, 7, 0, 0, 6, 0, 255, 0, 0, 0, 0, 3, 3] and list(want2[0]) == [0, 3, 3, 0, 0, 0]
+    # host memory
+    ns = capi.NullifierSet(1000)
+    st1, rf1 = eng.redeem(ns, sk, b"".join(first), rng, capi.RNG_SEQUENTIAL)
+    assert (st1, rf1) == want1[:2] and len(ns) == 9
+    st2, rf2 = eng.redeem(ns, sk, b"".join(second), rng[128 * want1[2]:], capi.RNG_SEQUENTIAL)
+    assert (st2, rf2) == want2[:2] and len(ns) == 13 == len(db)
+    ns.close()
+    # device memory
+    ns = capi.NullifierSet(1000)
+    d = lambda b: torch.from_numpy(np.frombuffer(b, np.uint8).copy()).cuda()
+    for batch, want, r in ((first, want1, rng), (second, want2, rng[128 * want1[2]:])):
+        n = len(batch)
+        d_p, d_r = d(b"".join(batch)), d(r)
+        d_o = torch.full((n * 128,), 7, dtype=torch.uint8, device="cuda"); d_s = torch.full((n,), 99, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        eng.redeem_dev(ns, sk, n, d_p.data_ptr(), d_r.data_ptr(), capi.RNG_SEQUENTIAL, d_o.data_ptr(), d_s.data_ptr())
+        assert d_s.cpu().numpy().tobytes() == want[0] and d_o.cpu().numpy().tobytes() == want[1]
+    assert len(ns) == 13
+    ns.close()
+    # per-lane rng: lane i signs with slice i
+    ns = capi.NullifierSet(1000)
+    st, rf = eng.redeem(ns, sk, b"".join(first), rng, capi.RNG_PER_LANE)
+    assert st == want1[0]
+    for i, p in enumerate(first):
+        if st[i] == 0:
+            assert octx.refund(sk, p, rng[128 * i:128 * i + 128]) == (0, rf[128 * i:128 * i + 128])
+    ns.close()
+    assert eng.secret_residue() == 0
+
+
+def test_redeem_over_a_node(engine_factory, oracle, bench_params):
+    from act_amd import capi
+    L = 8
+    eng = engine_factory(bench_params, L, max_batch=5, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("rd-sk", 64))
+    octx = oracle.ctx(bench_params, L)
+    first, second = _batches(eng, sk, L)
+    rng = shake("rdn-rng", 128 * 32)
+    db = set()
+    want1 = _sequential_loop(octx, sk, first, rng, db)
+    want2 = _sequential_loop(octx, sk, second, rng[128 * want1[2]:], db)
+    node = capi.Node(bench_params, L, devices=(0, 0, 0), max_batch=3, transcript=capi.TRANSCRIPT_DEVICE)
+    ns = capi.NodeNullifierSet(1000, devices=(0, 0))
+    try:
+        assert node.redeem(ns, sk, b"".join(first), rng) == want1[:2]
+        assert node.redeem(ns, sk, b"".join(second), rng[128 * want1[2]:]) == want2[:2]
+        assert len(ns) == len(db)
+    finally:
+        ns.close(); node.close()

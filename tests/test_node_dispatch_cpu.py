@@ -116,6 +116,31 @@ def test_other_entry_points_slice_consistently(lib):
         assert st2.raw == want_st
         for i in range(n):
             assert kp.raw[32 * i:32 * i + 8] == (proof.raw[PB * i:PB * i + 8] if want_st[i] == 0 else bytes(8))
+    # the redemption step: verdicts from every shard, the node-level set over the whole batch in lane order, then the signatures
+    # with ACT_RNG_SEQUENTIAL slices handed only to lanes that are signed
+    ns = C.c_void_p()
+    devs2 = (C.c_int * 2)(0, 1)
+    assert lib.act_node_nullifier_set_create(devs2, 2, C.c_size_t(10 * n + 16), None, C.byref(ns)) == 0
+    recs = bytearray(proof.raw)
+    if n >= 4:
+        recs[PB * 3:PB * 4] = recs[PB * 1:PB * 2]                       # lane 3 repeats lane 1: a double spend if lane 1 is accepted
+    recs = bytes(recs)
+    rrng = records(n, 128, 9)
+    out = C.create_string_buffer(128 * n); st3 = C.create_string_buffer(n)
+    assert lib.act_node_redeem_batch(nd, ns, C.c_size_t(n), bytes(64), recs, rrng, 1, out, st3) == 0
+    cur, seen = 0, set()
+    for i in range(n):
+        rec = recs[PB * i:PB * (i + 1)]
+        want = 7 if rec[0] & 1 else (3 if rec[:32] in seen else 0)
+        assert st3.raw[i] == want, (i, st3.raw[i], want)
+        if want == 0:
+            seen.add(rec[:32])
+            assert out.raw[128 * i:128 * i + 8] == rec[:8] and out.raw[128 * i + 8:128 * i + 16] == rrng[128 * cur:128 * cur + 8]
+            cur += 1
+        else:
+            assert out.raw[128 * i:128 * (i + 1)] == bytes(128)
+    assert lib.act_node_nullifier_set_len(ns) == len(seen)
+    lib.act_node_nullifier_set_destroy(ns)
     lib.act_node_destroy(nd)
 
 

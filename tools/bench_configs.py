@@ -78,6 +78,14 @@ def main():
         dt = timed(lambda: eng.refund_dev(sk, n, d_proof.data_ptr(), d_rr.data_ptr(), capi.RNG_PER_LANE, d_out.data_ptr(), d_st.data_ptr()), 1)
         assert int((d_st == 0).sum()) == n
         out["config4_refund_L128_2^%d" % a.refund_log2] = {"refunds_per_s": n / dt, "ms": 1e3 * dt}
+        # the whole redemption step: verify -> nullifier look-up and record -> sign (act_redeem_batch).  The proofs are tiled, so
+        # all but the first copy of each are double spends: the look-up and the record are exercised, 1 / (n / D) of the lanes are signed
+        ns = capi.NullifierSet(2 * n)
+        t0 = time.perf_counter(); eng.redeem_dev(ns, sk, n, d_proof.data_ptr(), d_rr.data_ptr(), capi.RNG_PER_LANE, d_out.data_ptr(), d_st.data_ptr())
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        assert int((d_st == 0).sum()) == D and int((d_st == 3).sum()) == n - D and len(ns) == D
+        out["redeem_L128_2^%d" % a.refund_log2] = {"redemptions_per_s": n / dt, "ms": 1e3 * dt, "signed": D, "double_spends": n - D}
+        ns.close()
         del d_proof, d_pre
         n = 1 << a.issue_log2
         d_req = dev_bytes(req, D).repeat(n // D, 1).contiguous(); d_c = dev_bytes(b"".join(scb(c) for c in cs), D).repeat(n // D, 1).contiguous()
