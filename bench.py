@@ -309,6 +309,7 @@ def main():
     # test hooks: exercise the N>1 control path on a box with one GPU (RCCL refuses two ranks on one device)
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-device", type=int, default=-1)
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank (exercises the RCCL rendezvous / barrier / all-reduce path on a one-GPU box)")
     args = ap.parse_args()
     L = args.range_bits
     PB = proof_bytes(L)
@@ -324,8 +325,9 @@ def main():
     if args.force_device >= 0:
         local = args.force_device
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29677")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
@@ -352,7 +354,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -371,7 +373,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         eng.prof_enable(False)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -488,7 +490,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -135,3 +135,19 @@ def test_bench_two_ranks_on_one_device():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 2048 and d["weak"]["batch_per_gpu"] == 4096
     assert d["value"] == d["strong"]["value"]
+
+
+def test_bench_rccl_path_with_one_rank():
+    """bench.py's RCCL calls (init_process_group("nccl", device_id=...), barrier, all_reduce MAX of the timing, destroy) on the one GPU a
+    test box has: one rank under torch.distributed.run with --force-dist.  The two-rank test above uses gloo because RCCL refuses two
+    ranks on one device; this one makes sure the nccl branch itself runs."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29673",
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch-log2", "12", "--max-batch", "1024",
+           "--force-dist", "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["distinct_proofs_per_gpu"] == 4096 and d["value"] > 0
