@@ -9,4 +9,4 @@ set over the GPUs of a node.
 from . import capi  # noqa: F401
 from .capi import Engine, NullifierSet, ActError, load, build, LIB_PATH  # noqa: F401
 from .api import (Params, PrivateKey, PublicKey, PreIssuance, IssuanceRequest, IssuanceResponse,  # noqa: F401
-                  CreditToken, SpendProof, PreRefund, Refund, Error, L)
+                  CreditToken, SpendProof, PreRefund, Refund, Error, CborError, NullifierDb, L)

@@ -36,6 +36,39 @@ class Error(Exception):
         self.name = self.NAMES.get(code, str(code))
 
 
+class CborError(Exception):
+    """Mirror of `enum CborError` (src/cbor.rs:30-37): Ciborium (malformed CBOR), InvalidStructure, InvalidValue."""
+    NAMES = {1: "Ciborium", 2: "InvalidStructure", 3: "InvalidValue"}
+
+    def __init__(self, code: int):
+        super().__init__(self.NAMES.get(code, f"status {code}"))
+        self.code = code
+        self.name = self.NAMES.get(code, str(code))
+
+
+class _Cbor:
+    """to_cbor / from_cbor of the crate's wire and state types (src/cbor.rs:94-695) through the batch codec of the engine:
+    deterministic RFC 8949 encoding with integer keys; from_cbor accepts what ciborium accepts, reduces scalars mod l and rejects
+    points that are not canonical Ristretto encodings."""
+    CBOR_TYPE = None
+
+    def to_cbor(self, params: "Params" = None) -> bytes:
+        nbits = getattr(self, "nbits", L)
+        return _codec_engine(params, nbits).cbor_encode(self.CBOR_TYPE, self.record)[0]
+
+    @classmethod
+    def from_cbor(cls, data: bytes, params: "Params" = None, nbits: int = L):
+        st, rec = _codec_engine(params, nbits).cbor_decode(cls.CBOR_TYPE, [bytes(data)])
+        if st[0]:
+            raise CborError(st[0])
+        return cls(rec, nbits) if cls.CBOR_TYPE == "SpendProof" else cls(rec)
+
+
+def _codec_engine(params, nbits):
+    # the codec does not depend on the Params; any context of the right range width will do
+    return (params or Params.new("act", "keygen", "default", "1970-01-01")).engine(nbits)
+
+
 class OsRng:
     """CryptoRngCore stand-in backed by os.urandom."""
 
@@ -116,12 +149,17 @@ class Params:
         return not self.__eq__(other)
 
 
-class PublicKey:
+class PublicKey(_Cbor):
+    CBOR_TYPE = "PublicKey"
+
     def __init__(self, w: bytes):
         self.w = bytes(w)
+        self.record = self.w
 
 
-class PrivateKey:
+class PrivateKey(_Cbor):
+    CBOR_TYPE = "PrivateKey"
+
     def __init__(self, record: bytes):
         assert len(record) == 64
         self.record = bytes(record)
@@ -159,12 +197,23 @@ class PrivateKey:
             raise res[0]
         return res
 
+    def redeem_batch(self, params: Params, db: "NullifierDb", proofs: Sequence["SpendProof"], rng) -> List["Refund"]:
+        """The server loop of examples/act.rs:62-73 as one call: verify, look the nullifier up, record it, sign.  Entry i is a
+        Refund, or Error (DoubleSpendError for a nullifier already recorded / spent by an earlier accepted proof of the batch)."""
+        nbits = proofs[0].nbits if proofs else L
+        e = params.engine(nbits)
+        pb = b"".join(p.record for p in proofs)
+        st, out = _draw_accepting(rng, len(proofs), lambda rb, mode: e.redeem(db.set, self.record, pb, rb, mode))
+        return [Refund(out[128 * i:128 * i + 128]) if st[i] == 0 else Error(st[i]) for i in range(len(proofs))]
+
     def verify_spend_batch(self, params: Params, proofs: Sequence["SpendProof"]) -> bytes:
         nbits = proofs[0].nbits if proofs else L
         return params.engine(nbits).verify_spend(self.record, b"".join(p.record for p in proofs))
 
 
-class PreIssuance:
+class PreIssuance(_Cbor):
+    CBOR_TYPE = "PreIssuance"
+
     def __init__(self, record: bytes):
         assert len(record) == 64
         self.record = bytes(record)   # r | k
@@ -184,19 +233,25 @@ class PreIssuance:
         return CreditToken(out)
 
 
-class IssuanceRequest:
+class IssuanceRequest(_Cbor):
+    CBOR_TYPE = "IssuanceRequest"
+
     def __init__(self, record: bytes):
         assert len(record) == 128
         self.record = bytes(record)   # K | gamma | k_bar | r_bar
 
 
-class IssuanceResponse:
+class IssuanceResponse(_Cbor):
+    CBOR_TYPE = "IssuanceResponse"
+
     def __init__(self, record: bytes):
         assert len(record) == 160
         self.record = bytes(record)   # A | e | gamma | z | c
 
 
-class CreditToken:
+class CreditToken(_Cbor):
+    CBOR_TYPE = "CreditToken"
+
     def __init__(self, record: bytes):
         assert len(record) == 160
         self.record = bytes(record)   # a | e | k | r | c
@@ -218,7 +273,9 @@ class CreditToken:
         return self.record == other.record
 
 
-class SpendProof:
+class SpendProof(_Cbor):
+    CBOR_TYPE = "SpendProof"
+
     def __init__(self, record: bytes, nbits: int = L):
         assert len(record) == 32 * (14 + 4 * nbits)
         self.record, self.nbits = bytes(record), nbits
@@ -230,7 +287,9 @@ class SpendProof:
         return self.record[32:64]
 
 
-class PreRefund:
+class PreRefund(_Cbor):
+    CBOR_TYPE = "PreRefund"
+
     def __init__(self, record: bytes):
         assert len(record) == 96
         self.record = bytes(record)   # r | k | m
@@ -242,10 +301,33 @@ class PreRefund:
         return CreditToken(out)
 
 
-class Refund:
+class Refund(_Cbor):
+    CBOR_TYPE = "Refund"
+
     def __init__(self, record: bytes):
         assert len(record) == 128
         self.record = bytes(record)   # A* | e | gamma | z
 
     def __eq__(self, other):
         return self.record == other.record
+
+
+class NullifierDb:
+    """The double-spend database the crate leaves to the caller (src/lib.rs:741-745; `NullifierDb` of src/tests.rs:29-50), as a
+    hash set in the GPU's memory.  The tests' `if is_spent(k) { reject } else { record_spent(k) }` pair is one atomic call here,
+    `spend(k)` (there is no read-only query: a look-up that does not record is how double spends slip through concurrent
+    callers); whole batches go through PrivateKey.redeem_batch.  Keys are compared as scalars (k and k + l are one nullifier)."""
+
+    def __init__(self, capacity: int = 1 << 20, device: int = 0):
+        self.set = capi.NullifierSet(capacity, device)
+
+    def spend(self, nullifier: bytes) -> bool:
+        """record `nullifier`; True if it was fresh, False if it had been spent before (DoubleSpendError)"""
+        return self.set.check_and_insert(bytes(nullifier))[0] == 0
+
+    def spend_batch(self, nullifiers: Sequence[bytes]) -> List[bool]:
+        """the same for a list, with the meaning of the loop in list order (a repeat inside the list is a double spend)"""
+        return [b == 0 for b in self.set.check_and_insert(b"".join(bytes(k) for k in nullifiers))] if nullifiers else []
+
+    def __len__(self):
+        return len(self.set)

@@ -143,3 +143,55 @@ def test_sequential_rng_is_consumed_only_by_accepted_lanes(env):   # src/lib.rs:
     out = sk.issue_batch(params, reqs, [5, 6, 7], stream)
     assert isinstance(out[1], api.Error) and not isinstance(out[0], api.Error)
     assert stream.pos == pos + 2 * 128                     # two accepted lanes drew 2 scalars each
+
+
+def test_cbor_round_trips_of_every_type(env):             # src/tests.rs:1450-1496, 1776-1860, 2216-2233
+    """prop_cbor_round_trip_* and prop_cbor_encoding_canonical, restated: to_cbor / from_cbor of the nine wire and state types
+    through the API mirror; encoding twice and re-encoding the decoded value give the same bytes; CborError on broken input."""
+    api, params, rng, sk = env
+    pre = api.PreIssuance.random(rng, params)
+    req = pre.request(params, rng)
+    resp = sk.issue(params, req, 33, rng)
+    tok = pre.to_credit_token(params, sk.public(), req, resp)
+    proof, prerefund = tok.prove_spend(params, 11, rng)
+    refund = sk.refund(params, proof, rng)
+    for v in (req, resp, tok, proof, prerefund, refund, pre, sk, sk.public()):
+        b1, b2 = v.to_cbor(), v.to_cbor()
+        assert b1 == b2                                                  # canonical: encoding twice
+        back = type(v).from_cbor(b1)
+        assert back.record == v.record and back.to_cbor() == b1          # decode and re-encode
+        assert type(v).from_cbor(b1 + b"trailing").record == v.record    # ciborium reads one item
+    assert len(proof.to_cbor()) == 18036                                 # SURVEY.md Appendix C
+    with pytest.raises(api.CborError) as e:
+        api.CreditToken.from_cbor(tok.to_cbor()[:-1])
+    assert e.value.name == "Ciborium"
+    with pytest.raises(api.CborError) as e:
+        api.CreditToken.from_cbor(b"\x80")
+    assert e.value.name == "InvalidStructure"
+    bad = bytearray(tok.to_cbor()); bad[4:36] = b"\x01" + bytes(31)      # field 1 (A): not a Ristretto encoding
+    with pytest.raises(api.CborError) as e:
+        api.CreditToken.from_cbor(bytes(bad))
+    assert e.value.name == "InvalidValue"
+    # a token that went through CBOR spends like the original (src/tests.rs:1470-1483 uses the round-tripped token)
+    tok2 = api.CreditToken.from_cbor(tok.to_cbor())
+    p2, _ = tok2.prove_spend(params, 3, rng)
+    sk.refund(params, p2, rng)
+
+
+def test_redeem_batch_and_nullifier_db(env):              # examples/act.rs:62-73; NullifierDb of src/tests.rs:29-50, :127-207
+    """The server loop as one call: double spends come back as DoubleSpendError, fresh spends as refunds the client accepts."""
+    api, params, rng, sk = env
+    db = api.NullifierDb(1 << 10)
+    toks = [issue_token(api, params, rng, sk, 50) for _ in range(4)]
+    spends = [t.prove_spend(params, 7, rng) for t in toks]
+    proofs = [p for p, _ in spends] + [toks[1].prove_spend(params, 9, rng)[0]]      # the last one re-spends token 1
+    res = sk.redeem_batch(params, db, proofs, rng)
+    assert [isinstance(r, api.Refund) for r in res] == [True, True, True, True, False]
+    assert isinstance(res[4], api.Error) and res[4].name == "DoubleSpendError" and len(db) == 4
+    for (proof, prerefund), refund in zip(spends, res):
+        new = prerefund.to_credit_token(params, proof, refund, sk.public())
+        assert api.scalar_to_u128(new.credits()) == 43
+    # the same nullifiers again, one at a time: all spent; a fresh one is not
+    assert db.spend_batch([p.nullifier() for p in proofs[:4]]) == [False] * 4
+    fresh = issue_token(api, params, rng, sk, 5)
+    assert db.spend(fresh.nullifier()) is True and db.spend(fresh.nullifier()) is False and len(db) == 5
