@@ -89,6 +89,8 @@ def test_redeem_equals_the_sequential_loop(engine_factory, oracle, bench_params,
     for i, p in enumerate(first):
         if st[i] == 0:
             assert octx.refund(sk, p, rng[128 * i:128 * i + 128]) == (0, rf[128 * i:128 * i + 128])
+    # empty batch; a set on a context's own device only
+    assert eng.redeem(ns, sk, b"", b"") == (b"", b"") and len(ns) == 9
     ns.close()
     assert eng.secret_residue() == 0
 
