@@ -5,8 +5,8 @@
 // How a group element is computed does not change its canonical 32-byte encoding, so the
 // kernels are free to use different addition chains than the reference.
 //
-// Operand-size discipline of fe25519.h is annotated per formula: [g] = fits the 19x-premultiplied
-// operand (<= 1.68*2^27), [f] = needs the wide operand slot (<= 1.5*2^28).
+// Operand-size discipline of fe25519.h is annotated per formula: {k} = limbs at most k times a tight element's (phi <= k);
+// a product needs phi * gamma <= 12.
 #pragma once
 #include "fe25519.h"
 #include "sc25519.h"
@@ -14,7 +14,7 @@
 namespace act {
 
 struct ge { fe X, Y, Z, T; };                 // extended; all coordinates tight
-struct ge_cached { fe YpX, YmX, Z, T2d; };    // "projective Niels": YpX, YmX loose [g]; Z, T2d tight
+struct ge_cached { fe YpX, YmX, Z, T2d; };    // "projective Niels": YpX {2}, YmX {3}; Z, T2d tight
 struct ge_niels { fe ypx, ymx, xy2d; };       // affine Niels (Z = 1); tight
 
 ACT_HD ge ge_identity() { ge p; p.X = fe_zero(); p.Y = fe_one(); p.Z = fe_one(); p.T = fe_zero(); return p; }
@@ -24,8 +24,8 @@ ACT_HD ge ge_neg(const ge& p) { ge r; r.X = fe_carry(fe_neg(p.X)); r.Y = p.Y; r.
 
 ACT_HD ge_cached ge_to_cached(const ge& p) {
   ge_cached c;
-  c.YpX = fe_add(p.Y, p.X);          // <= 2^27            [g]
-  c.YmX = fe_sub(p.Y, p.X);          // <= 1.5 * 2^27      [g]
+  c.YpX = fe_add(p.Y, p.X);          // {2}
+  c.YmX = fe_sub(p.Y, p.X);          // {3}
   c.Z = p.Z;
   c.T2d = fe_mul(p.T, fe_d2());
   return c;
@@ -35,7 +35,7 @@ ACT_HD ge_cached ge_cached_cneg(const ge_cached& c, bool neg) {
   ge_cached r = c;
   uint32_t m = fe_mask(neg);
   fe_cswap_m(r.YpX, r.YmX, m);
-  r.T2d = fe_select_m(c.T2d, fe_neg(c.T2d), m);   // <= 2^27 [g]
+  r.T2d = fe_select_m(c.T2d, fe_neg(c.T2d), m);   // {2}
   return r;
 }
 ACT_HD ge ge_select_m(const ge& a, const ge& b, uint32_t m) {      // m all-ones: b, all-zeros: a
@@ -49,12 +49,12 @@ ACT_HD ge_niels ge_niels_cneg(const ge_niels& c, bool neg) {
   return r;
 }
 
-// completed point (cx : cz) x (cy : ct) -> extended.  Operand classes: cx [g], cy [g], cz [g], ct [f]
+// completed point (cx : cz) x (cy : ct) -> extended.  ct * cx, cy * cz, ct * cz, cy * cx must each fit the product budget
 template <bool WITH_T = true>
 ACT_HD ge ge_from_completed(const fe& cx, const fe& cy, const fe& cz, const fe& ct) {
   ge r;
-  // operand order: fe_mul doubles the odd limbs of its first and 19-folds its second operand; each of ct, cy is a first
-  // operand twice and each of cx, cz a second operand twice, so those preparations are shared
+  // operand order: fe_mul doubles limbs 1, 4, 7 of both operands; each operand appears twice on the same side, so the
+  // compiler shares those preparations
   r.X = fe_mul(ct, cx);
   r.Y = fe_mul(cy, cz);
   r.Z = fe_mul(ct, cz);
@@ -65,16 +65,16 @@ ACT_HD ge ge_from_completed(const fe& cx, const fe& cy, const fe& cz, const fe& 
 // p + q, q cached.  8M.
 template <bool WITH_T = true>
 ACT_HD ge ge_add_cached(const ge& p, const ge_cached& q) {
-  fe ypx = fe_add(p.Y, p.X);                 // [g] 2^27
-  fe ymx = fe_sub(p.Y, p.X);                 // [g] 1.5*2^27
-  fe pp = fe_mul(ypx, q.YpX);
-  fe mm = fe_mul(ymx, q.YmX);
-  fe tt2d = fe_mul(p.T, q.T2d);
-  fe zz2 = fe_dbl(fe_mul(p.Z, q.Z));         // 2^27
-  fe cx = fe_sub(pp, mm);                    // [g] 1.5*2^27
-  fe cy = fe_add(pp, mm);                    // [g] 2^27
-  fe cz = fe_add(zz2, tt2d);                 // [g] 1.5*2^27
-  fe ct = fe_sub(zz2, tt2d);                 // [f] 2^28
+  fe ypx = fe_add(p.Y, p.X);                 // {2}
+  fe ymx = fe_sub(p.Y, p.X);                 // {3}
+  fe pp = fe_mul(ypx, q.YpX);                // 2 * 2
+  fe mm = fe_mul(ymx, q.YmX);                // 3 * 3
+  fe tt2d = fe_mul(p.T, q.T2d);              // 1 * 2
+  fe zz2 = fe_dbl(fe_mul(p.Z, q.Z));         // {2}
+  fe cx = fe_sub(pp, mm);                    // {3}
+  fe cy = fe_add(pp, mm);                    // {2}
+  fe cz = fe_add(zz2, tt2d);                 // {3}
+  fe ct = fe_sub(zz2, tt2d);                 // {4}: ct * cx = ct * cz = 12
   return ge_from_completed<WITH_T>(cx, cy, cz, ct);
 }
 // p + q, q affine Niels.  7M.
@@ -99,11 +99,11 @@ ACT_HD ge ge_madd(const ge& p, const ge_niels& q) {
 // With q - p in E[4] (q = p, or q = p + a point of order 2 or 4) both B-A and D-C (or B+A) vanish and the result is
 // (0,0,0,0); everywhere else it is the sum (p = identity included when q is not in E[4]).  msm.h chain_bu_pre uses it only
 // where q - p in E[4] is impossible for ANY digit string (proof there) and keeps the complete formulas everywhere else.
-struct ge_ded { fe YpX, YmX, Z, T; };          // YpX, YmX loose [g]; Z, T tight
+struct ge_ded { fe YpX, YmX, Z, T; };          // YpX {2}, YmX {3}; Z, T tight
 ACT_HD ge_ded ge_to_ded(const ge& p) {
   ge_ded c;
-  c.YpX = fe_add(p.Y, p.X);          // <= 2^27            [g]
-  c.YmX = fe_sub(p.Y, p.X);          // <= 1.5 * 2^27      [g]
+  c.YpX = fe_add(p.Y, p.X);          // {2}
+  c.YmX = fe_sub(p.Y, p.X);          // {3}
   c.Z = p.Z; c.T = p.T;
   return c;
 }
@@ -111,19 +111,19 @@ ACT_HD ge_ded ge_ded_cneg(const ge_ded& c, bool neg) {
   ge_ded r = c;
   uint32_t m = fe_mask(neg);
   fe_cswap_m(r.YpX, r.YmX, m);
-  r.T = fe_select_m(c.T, fe_neg(c.T), m);         // <= 2^27 [g]
+  r.T = fe_select_m(c.T, fe_neg(c.T), m);         // {2}
   return r;
 }
 ACT_HD ge ge_add_ded(const ge& p, const ge_ded& q) {
-  fe A = fe_mul(fe_sub(p.Y, p.X), q.YpX);
-  fe B = fe_mul(fe_add(p.Y, p.X), q.YmX);
-  fe C = fe_mul(fe_dbl(p.Z), q.T);               // [f] 2^27 x [g] 2^27
+  fe A = fe_mul(fe_sub(p.Y, p.X), q.YpX);        // 3 * 2
+  fe B = fe_mul(fe_add(p.Y, p.X), q.YmX);        // 2 * 3
+  fe C = fe_mul(fe_dbl(p.Z), q.T);               // 2 * 2
   fe D = fe_mul(fe_dbl(p.T), q.Z);
-  fe E = fe_add(D, C);                           // 2^27
-  fe F = fe_sub(B, A);                           // 1.5 * 2^27
-  fe G = fe_add(B, A);                           // 2^27
-  fe H = fe_sub(D, C);                           // 1.5 * 2^27
-  ge r;                                          // E, G are first operands twice and F, H second operands twice (shared preparation)
+  fe E = fe_add(D, C);                           // {2}
+  fe F = fe_sub(B, A);                           // {3}
+  fe G = fe_add(B, A);                           // {2}
+  fe H = fe_sub(D, C);                           // {3}
+  ge r;                                          // every product 2 * 3
   r.X = fe_mul(E, F);
   r.Y = fe_mul(G, H);
   r.Z = fe_mul(G, F);
@@ -140,8 +140,8 @@ ACT_HD ge ge_double_opt(const ge& p, bool with_t) {
   fe xpy2 = fe_sq(fe_add(p.X, p.Y));
   fe yypxx = fe_add(yy, xx);
   fe yymxx = fe_sub(yy, xx);
-  fe cx = fe_carry(fe_sub4(xpy2, yypxx));
-  fe ct = fe_sub4(zz2, yymxx);
+  fe cx = fe_sub4(xpy2, yypxx);
+  fe ct = fe_carry(fe_sub4(zz2, yymxx));      // operand sizes: ge_double below
   ge r;
   r.X = fe_mul(ct, cx);
   r.Y = fe_mul(yypxx, yymxx);
@@ -154,12 +154,13 @@ ACT_HD ge ge_double_opt(const ge& p, bool with_t) {
 template <bool WITH_T = true>
 ACT_HD ge ge_double(const ge& p) {
   fe xx = fe_sq(p.X), yy = fe_sq(p.Y);
-  fe zz2 = fe_dbl(fe_sq(p.Z));               // 2^27
-  fe xpy2 = fe_sq(fe_add(p.X, p.Y));         // sq operand 2^27 [g]
-  fe yypxx = fe_add(yy, xx);                 // cy [g] 2^27
-  fe yymxx = fe_sub(yy, xx);                 // cz [g] 1.5*2^27
-  fe cx = fe_carry(fe_sub4(xpy2, yypxx));    // tight
-  fe ct = fe_sub4(zz2, yymxx);               // [f] 1.5*2^28
+  fe zz2 = fe_dbl(fe_sq(p.Z));               // {2}
+  fe xpy2 = fe_sq(fe_add(p.X, p.Y));         // sq operand {2}
+  fe yypxx = fe_add(yy, xx);                 // cy {2}
+  fe yymxx = fe_sub(yy, xx);                 // cz {3}
+  fe cx = fe_sub4(xpy2, yypxx);              // {5}
+  fe ct = fe_carry(fe_sub4(zz2, yymxx));     // {6} -> tight: the one carry of a doubling (ct * cz would be 18; with ct tight
+                                             // the largest product is cy * cx = 10)
   return ge_from_completed<WITH_T>(cx, yypxx, yymxx, ct);
 }
 
@@ -178,8 +179,8 @@ ACT_HD void ristretto_encode(uint32_t out[8], const ge& p) {
   fe x = fe_select(p.X, iy, rotate);
   fe y = fe_select(p.Y, ix, rotate);
   fe den = fe_select(d2, ench, rotate);
-  y = fe_cneg(y, fe_is_negative(fe_mul(x, zinv)));          // <= 2^27
-  fe s = fe_mul(fe_sub4(p.Z, y), den);                       // f = Z - y (<= 1.25*2^28)
+  y = fe_cneg(y, fe_is_negative(fe_mul(x, zinv)));          // {2}
+  fe s = fe_mul(fe_sub4(p.Z, y), den);                       // Z - y {5}
   fe_to_words(out, fe_abs(s));
 }
 // ---- double-and-compress: the encoding of 2Q from Q with a field INVERSION instead of an inverse square root, so that a
@@ -188,7 +189,7 @@ ACT_HD void ristretto_encode(uint32_t out[8], const ge& p) {
 // l; the representatives may then differ from C' by 4-torsion, which Ristretto encodings do not see) and encodes 2Q.
 //   e = 2XY, f = Z^2 + dT^2, g = Y^2 + X^2, h = Z^2 - dT^2;  inv = 1 / ((e g)(f h)), or 0 when that product is 0
 //   (2Q in the identity class: the encoding is then 32 zero bytes, which is what the formulas give with inv = 0).
-struct dc_efgh { fe e, f, g, h; };       // e tight; f, g, h loose [g]
+struct dc_efgh { fe e, f, g, h; };       // e tight; f, g {2}; h {3}
 ACT_HD dc_efgh dc_prepare(const ge& q) {
   dc_efgh s;
   fe xx = fe_sq(q.X), yy = fe_sq(q.Y), zz = fe_sq(q.Z);
@@ -209,13 +210,13 @@ ACT_HD fe dc_product(fe& eg, fe& fh, bool& is_zero, const dc_efgh& s) {
 ACT_HD void dc_finish(uint32_t out[8], const dc_efgh& s, const fe& eg, const fe& fh, const fe& inv) {
   fe zinv = fe_mul(eg, inv), tinv = fe_mul(fh, inv);
   bool neg1 = fe_is_negative(fe_mul(eg, zinv));
-  fe e = fe_select(s.e, s.g, neg1);                                  // [g]
+  fe e = fe_select(s.e, s.g, neg1);                                  // {2}
   fe g = fe_carry(fe_select(s.g, fe_neg(s.e), neg1));                // tight
   fe h = fe_carry(fe_select(s.h, fe_mul(s.f, fe_sqrt_m1()), neg1));  // tight
   fe magic = fe_select(fe_invsqrt_a_minus_d(), fe_sqrt_m1(), neg1);
   bool neg2 = fe_is_negative(fe_mul(fe_mul(h, e), zinv));
-  g = fe_cneg(g, neg2);                                              // <= 2^27
-  fe r = fe_mul(fe_sub4(h, g), fe_mul(magic, fe_mul(tinv, g)));      // f = h - g (<= 1.25*2^28)
+  g = fe_cneg(g, neg2);                                              // {2}
+  fe r = fe_mul(fe_sub4(h, g), fe_mul(magic, fe_mul(tinv, g)));      // h - g {5}
   fe_to_words(out, fe_abs(r));
 }
 // RFC 9496 4.3.1; returns false for non-canonical / negative / non-square / t negative / y == 0
@@ -226,11 +227,11 @@ ACT_HD bool ristretto_decode(ge& p, const uint32_t in[8]) {
   for (int i = 0; i < 8; i++) canonical = canonical && (chk[i] == in[i]);
   bool ok = canonical && !(in[0] & 1u);
   fe ss = fe_sq(s);
-  fe u1 = fe_sub(fe_one(), ss);                              // [g] 2^27
-  fe u2 = fe_add(fe_one(), ss);                              // [g]
+  fe u1 = fe_sub(fe_one(), ss);                              // {3}
+  fe u2 = fe_add(fe_one(), ss);                              // {2}
   fe u2s = fe_sq(u2);
   fe du1s = fe_mul(fe_sq(u1), fe_d());
-  fe v = fe_sub(fe_neg(du1s), u2s);                          // [f] 2^28 : -(d*u1^2) - u2^2
+  fe v = fe_sub(fe_neg(du1s), u2s);                          // {4}: -(d*u1^2) - u2^2
   fe inv;
   bool was_square = fe_invsqrt(inv, fe_mul(v, u2s));
   fe dx = fe_mul(inv, u2);

@@ -27,30 +27,26 @@ namespace act {
 constexpr int FB_WBITS = ACT_FB_WBITS;                      // window width in bits
 constexpr int FB_WINDOWS = (253 + FB_WBITS - 1) / FB_WBITS;  // scalars are canonical: < l < 2^253
 constexpr int FB_ENTRIES = 1 << FB_WBITS;
-constexpr int NIELS_WORDS = 32;         // 30 used (ypx, ymx, xy2d), padded to 128 B = one L2 line
+constexpr int NIELS_WORDS = 32;         // 27 used (ypx, ymx, xy2d), padded to 128 B = one L2 line
 constexpr size_t FB_TABLE_WORDS = (size_t)FB_WINDOWS * FB_ENTRIES * NIELS_WORDS;   // 128 MiB per base at 16 bits
 
 ACT_HD ge_niels niels_load(const uint32_t* p) {
   ge_niels n;
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5], a6 = q[6], a7 = q[7];
-  n.ypx.v[0] = a0.x; n.ypx.v[1] = a0.y; n.ypx.v[2] = a0.z; n.ypx.v[3] = a0.w;
-  n.ypx.v[4] = a1.x; n.ypx.v[5] = a1.y; n.ypx.v[6] = a1.z; n.ypx.v[7] = a1.w;
-  n.ypx.v[8] = a2.x; n.ypx.v[9] = a2.y; n.ymx.v[0] = a2.z; n.ymx.v[1] = a2.w;
-  n.ymx.v[2] = a3.x; n.ymx.v[3] = a3.y; n.ymx.v[4] = a3.z; n.ymx.v[5] = a3.w;
-  n.ymx.v[6] = a4.x; n.ymx.v[7] = a4.y; n.ymx.v[8] = a4.z; n.ymx.v[9] = a4.w;
-  n.xy2d.v[0] = a5.x; n.xy2d.v[1] = a5.y; n.xy2d.v[2] = a5.z; n.xy2d.v[3] = a5.w;
-  n.xy2d.v[4] = a6.x; n.xy2d.v[5] = a6.y; n.xy2d.v[6] = a6.z; n.xy2d.v[7] = a6.w;
-  n.xy2d.v[8] = a7.x; n.xy2d.v[9] = a7.y;
+  uint4 a[7];
+  for (int i = 0; i < 7; i++) a[i] = q[i];
+  uint32_t w[28];
+  for (int i = 0; i < 7; i++) { w[4 * i] = a[i].x; w[4 * i + 1] = a[i].y; w[4 * i + 2] = a[i].z; w[4 * i + 3] = a[i].w; }
+  for (int i = 0; i < FE_LIMBS; i++) { n.ypx.v[i] = w[i]; n.ymx.v[i] = w[FE_LIMBS + i]; n.xy2d.v[i] = w[2 * FE_LIMBS + i]; }
 #else
-  for (int i = 0; i < 10; i++) { n.ypx.v[i] = p[i]; n.ymx.v[i] = p[10 + i]; n.xy2d.v[i] = p[20 + i]; }
+  for (int i = 0; i < FE_LIMBS; i++) { n.ypx.v[i] = p[i]; n.ymx.v[i] = p[FE_LIMBS + i]; n.xy2d.v[i] = p[2 * FE_LIMBS + i]; }
 #endif
   return n;
 }
 ACT_HD void niels_store(uint32_t* p, const ge_niels& n) {
-  for (int i = 0; i < 10; i++) { p[i] = n.ypx.v[i]; p[10 + i] = n.ymx.v[i]; p[20 + i] = n.xy2d.v[i]; }
-  p[30] = 0; p[31] = 0;
+  for (int i = 0; i < FE_LIMBS; i++) { p[i] = n.ypx.v[i]; p[FE_LIMBS + i] = n.ymx.v[i]; p[2 * FE_LIMBS + i] = n.xy2d.v[i]; }
+  for (int i = 3 * FE_LIMBS; i < NIELS_WORDS; i++) p[i] = 0;
 }
 // affine Niels form of an extended point with Z == 1 (x, y, t = xy all tight)
 ACT_HD ge_niels niels_from_affine(const ge& p) {
@@ -60,15 +56,17 @@ ACT_HD ge_niels niels_from_affine(const ge& p) {
   n.xy2d = fe_mul(p.T, fe_d2());
   return n;
 }
-ACT_HD void ge_store(uint32_t* p, const ge& g) {
-  for (int i = 0; i < 10; i++) { p[i] = g.X.v[i]; p[10 + i] = g.Y.v[i]; p[20 + i] = g.Z.v[i]; p[30 + i] = g.T.v[i]; }
+constexpr int GE_WORDS = 4 * FE_LIMBS;    // 36 words = 144 B = nine 16-byte pieces
+ACT_HD void ge_words(uint32_t w[GE_WORDS], const ge& g) {
+  for (int i = 0; i < FE_LIMBS; i++) { w[i] = g.X.v[i]; w[FE_LIMBS + i] = g.Y.v[i]; w[2 * FE_LIMBS + i] = g.Z.v[i]; w[3 * FE_LIMBS + i] = g.T.v[i]; }
 }
-ACT_HD ge ge_load(const uint32_t* p) {
+ACT_HD ge ge_of_words(const uint32_t w[GE_WORDS]) {
   ge g;
-  for (int i = 0; i < 10; i++) { g.X.v[i] = p[i]; g.Y.v[i] = p[10 + i]; g.Z.v[i] = p[20 + i]; g.T.v[i] = p[30 + i]; }
+  for (int i = 0; i < FE_LIMBS; i++) { g.X.v[i] = w[i]; g.Y.v[i] = w[FE_LIMBS + i]; g.Z.v[i] = w[2 * FE_LIMBS + i]; g.T.v[i] = w[3 * FE_LIMBS + i]; }
   return g;
 }
-constexpr int GE_WORDS = 40;
+ACT_HD void ge_store(uint32_t* p, const ge& g) { ge_words(p, g); }
+ACT_HD ge ge_load(const uint32_t* p) { return ge_of_words(p); }
 
 // A fixed-base table and its window width.  The width is a property of the table, chosen per base when a context is created
 // (engine.hip): 16 bits by default; the two bases of the range kernel (h1, h3) get 24-bit windows -- 11 instead of 16 table
@@ -208,61 +206,57 @@ ACT_HD void chain2u(ge& acc_l, ge& acc_u, const ge& N, const sc& s_l, const sc& 
 // ---- chain_bu: bucketed per-lane accumulator + wave-uniform NAF accumulator on one doubling chain ----------
 // acc_u += s_u * N as in chain2u.  The per-lane scalar s_l is recoded in signed radix 16 (digits in [-8, 8]) and
 // handled Pippenger-style: every fourth chain point P_i = 16^i N is added, with the digit's sign, into bucket
-// |digit| of the lane (9 extended points per lane in global memory, AoS so a lane's bucket is 160 contiguous
+// |digit| of the lane (9 extended points per lane in global memory, AoS so a lane's bucket is 144 contiguous
 // bytes; bucket 0 absorbs the zero digits so no lane ever sits out or selects).  Afterwards
 // s_l * N = sum_v v * B_v by running sums: 64 + 14 additions instead of 127, one cached conversion per four
 // doublings instead of four, and T is computed only for chain points that are actually added (the NAF
-// positions are wave-uniform, so that is a uniform branch).  Working set: 1440 B per lane, re-touched every
+// positions are wave-uniform, so that is a uniform branch).  Working set: 1296 B per lane, re-touched every
 // step -> served by L2 / Infinity Cache.
 constexpr int BUCKETS = 9;
-constexpr int BUCKET_WORDS = BUCKETS * GE_WORDS;     // 360 words = 1440 B per lane
+constexpr int BUCKET_WORDS = BUCKETS * GE_WORDS;     // 324 words = 1296 B per lane
 
+constexpr int GE_PIECES = GE_WORDS / 4;     // 16-byte pieces of an extended point
 ACT_HD ge bucket_load(const uint32_t* p) {
-  ge g;
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a[10];
-  for (int i = 0; i < 10; i++) a[i] = q[i];
-  uint32_t w[40];
-  for (int i = 0; i < 10; i++) { w[4 * i] = a[i].x; w[4 * i + 1] = a[i].y; w[4 * i + 2] = a[i].z; w[4 * i + 3] = a[i].w; }
-  for (int i = 0; i < 10; i++) { g.X.v[i] = w[i]; g.Y.v[i] = w[10 + i]; g.Z.v[i] = w[20 + i]; g.T.v[i] = w[30 + i]; }
+  uint4 a[GE_PIECES];
+  for (int i = 0; i < GE_PIECES; i++) a[i] = q[i];
+  uint32_t w[GE_WORDS];
+  for (int i = 0; i < GE_PIECES; i++) { w[4 * i] = a[i].x; w[4 * i + 1] = a[i].y; w[4 * i + 2] = a[i].z; w[4 * i + 3] = a[i].w; }
+  return ge_of_words(w);
 #else
-  g = ge_load(p);
+  return ge_load(p);
 #endif
-  return g;
 }
 ACT_HD void bucket_store(uint32_t* p, const ge& g) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t w[40];
-  for (int i = 0; i < 10; i++) { w[i] = g.X.v[i]; w[10 + i] = g.Y.v[i]; w[20 + i] = g.Z.v[i]; w[30 + i] = g.T.v[i]; }
+  uint32_t w[GE_WORDS];
+  ge_words(w, g);
   uint4* q = reinterpret_cast<uint4*>(p);
-  for (int i = 0; i < 10; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  for (int i = 0; i < GE_PIECES; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 #else
   ge_store(p, g);
 #endif
 }
-// `bk`: this lane's BUCKET_WORDS words.  Returns s_l * N in acc_l (overwritten), adds s_u * N to acc_u.
-constexpr int GE_LDS_WORDS_PER_WAVE = 10 * 64 * 4;   // one extended point per lane of a wavefront
+constexpr int GE_LDS_WORDS_PER_WAVE = GE_PIECES * 64 * 4;   // one extended point per lane of a wavefront
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // home of an extended point in LDS: [piece][lane][4 words], so the ds_read/write_b128 are conflict-free
 __device__ __forceinline__ void ge_to_lds(uint32_t* lds_wave, const ge& g) {
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t w[40];
-  for (int i = 0; i < 10; i++) { w[i] = g.X.v[i]; w[10 + i] = g.Y.v[i]; w[20 + i] = g.Z.v[i]; w[30 + i] = g.T.v[i]; }
-  for (int k = 0; k < 10; k++)
+  uint32_t w[GE_WORDS];
+  ge_words(w, g);
+  for (int k = 0; k < GE_PIECES; k++)
     *reinterpret_cast<uint4*>(lds_wave + (k * 64 + lane) * 4) = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
 }
 __device__ __forceinline__ ge ge_from_lds(const uint32_t* lds_wave) {
   const uint32_t lane = threadIdx.x & 63u;
-  uint32_t w[40];
-  for (int k = 0; k < 10; k++) {
+  uint32_t w[GE_WORDS];
+  for (int k = 0; k < GE_PIECES; k++) {
     const uint4 q = *reinterpret_cast<const uint4*>(lds_wave + (k * 64 + lane) * 4);
     w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w;
   }
-  ge g;
-  for (int i = 0; i < 10; i++) { g.X.v[i] = w[i]; g.Y.v[i] = w[10 + i]; g.Z.v[i] = w[20 + i]; g.T.v[i] = w[30 + i]; }
-  return g;
+  return ge_of_words(w);
 }
 #endif
 
@@ -271,7 +265,7 @@ __device__ __forceinline__ ge ge_from_lds(const uint32_t* lds_wave) {
 // The wave-uniform scalar is recoded in width-3 NAF with two accumulators, U1 for digits +-1 and U3 for digits +-3
 // (acc_u += U1 + U3 + 2*U3 at the end: ~63 + 3 additions instead of ~84 with plain NAF).  On the device both live in
 // LDS between their additions -- one addition site per position, its operand picked by address -- which also takes
-// the 40 accumulator registers out of the loop's live set.
+// the 36 accumulator registers out of the loop's live set.
 // Digit strings of chain_bu, recoded once instead of inside the chain loop (where the 9-word NAF state with its 64-bit
 // carries and the 8-word radix-16 state would sit in the loop's VGPR set):
 //   naf3_recode   the wave-uniform scalar -> 64 words, word `step` = the width-3-NAF digits of chain positions 4*step .. 4*step+3

@@ -32,10 +32,10 @@ int hc_fe_sqrt_ratio(const uint8_t* u, const uint8_t* v, uint8_t* o) { fe r; boo
 // stress: a chain of lazily-reduced operations at the extreme of the allowed operand classes
 void hc_fe_stress(const uint8_t* a, const uint8_t* b, uint8_t* o) {
   fe x = fe_in(a), y = fe_in(b);
-  fe s = fe_sub(x, y), t = fe_add(x, y);                // [g]-class operands
-  fe f = fe_sub4(fe_dbl(x), fe_sub(y, x));              // [f]-class: 2x - (y - x)
-  fe r = fe_mul(f, s);                                  // (3x - y)(x - y)
-  r = fe_mul(fe_sub(fe_dbl(r), t), fe_sq(s));           // (2r - (x+y)) (x-y)^2
+  fe s = fe_sub(x, y), t = fe_add(x, y);                // {3}, {2}
+  fe f = fe_sub(fe_dbl(x), y);                          // {4}: 2x - y
+  fe r = fe_mul(f, s);                                  // (2x - y)(x - y): the whole product budget, 4 * 3
+  r = fe_mul(fe_sub4(fe_dbl(r), t), fe_sq(s));          // (2r - (x+y)) (x-y)^2: {6} * tight, square of a {3}
   fe_out(o, r);
 }
 

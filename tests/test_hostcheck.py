@@ -32,7 +32,7 @@ def test_field(hostcheck):
         assert fi(call(hc, "hc_fe_add", le(a), le(b))[1]) == (a + b) % P
         assert fi(call(hc, "hc_fe_sub", le(a), le(b))[1]) == (a - b) % P
         x, y = a % P, b % P
-        exp = ((3 * x - y) * (x - y)) % P
+        exp = ((2 * x - y) * (x - y)) % P
         exp = ((2 * exp - (x + y)) * (x - y) ** 2) % P
         assert fi(call(hc, "hc_fe_stress", le(a), le(b))[1]) == exp
         if i < 40 and a % P:
@@ -244,6 +244,9 @@ def test_limb_bounds_hold(hostcheck):
     test_dedicated_addition_never_exceptional(hostcheck)
     bd = (C.c_uint64 * 6)()
     hostcheck.hc_bounds(bd)
-    lim = [1.68 * 2**27, 1.68 * 2**26, 1.5 * 2**28, 1.5 * 2**27, 2**27 - 38, 2**26 - 2]
+    # units of 2^-16: product budget phi*gamma (mul), phi^2 (sq) <= 12.5 (a column holds 5 * 2^58 * budget < 2^64);
+    # subtrahend / (2p resp. 4p) limb-wise <= 1; no element anywhere reaches phi = 7.5 (limbs stay below 2^32 through a carry)
+    lim = [12.5, 12.5, 1.0, 1.0, 7.5]
+    print('limb bounds (units of 2^-16):', [round(v / 65536, 4) for v in bd])
     for v, l in zip(bd, lim):
-        assert 0 < v <= l
+        assert 0 < v <= l * 2**16, (list(bd), lim)

@@ -82,3 +82,15 @@ def test_ragged_and_small_widths(hostcheck, oracle, bench_params):
             if so in (0, 7):                       # the reference returns before building a transcript when A' is the identity
                 assert trs[i] == tro, (L, i)
         assert list(st) == [0, 7, 6, 7]
+
+
+def test_lane_bodies_stay_inside_the_limb_budget(hostcheck, oracle, bench_params):
+    """The verifier's lane bodies, run through the instrumented host build: every product inside the column budget of
+    fe25519.h (12.5), every subtrahend below its 2p / 4p offset."""
+    import ctypes as C
+    hostcheck.hc_bounds_reset()
+    test_ragged_and_small_widths(hostcheck, oracle, bench_params)
+    bd = (C.c_uint64 * 6)()
+    hostcheck.hc_bounds(bd)
+    for v, l in zip(bd, [12.5, 12.5, 1.0, 1.0, 7.5]):
+        assert 0 < v <= l * 2**16, list(bd)
