@@ -572,7 +572,7 @@ template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint3
 #endif
 
 // ---- batched double-and-compress (ge25519.h dc_*): one field inversion per E encodings ----------------------
-// Encodes 2*Q_i for `count` <= E points.  `slot(i)` -> the 40 words of point i (X|Y|Z|T); they are overwritten with
+// Encodes 2*Q_i for `count` <= E points.  `slot(i)` -> the GE_WORDS words of point i (X|Y|Z|T); they are overwritten with
 // e|f|g|h between the two passes.  `emit(i, words)` receives the encodings, last point first.
 template <int E, typename Slot, typename Emit>
 ACT_HD void dc_encode_batch(int count, Slot slot, Emit emit) {

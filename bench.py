@@ -54,7 +54,7 @@ CSRC = os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc")
 # sources that determine k_spend_bits: PMC summaries under profiles/ are only cited when they were taken from these bytes
 KERNEL_SOURCES = ["fe25519.h", "fe25519_gen.inc", "fe25519_consts.inc", "sc25519.h", "ge25519.h", "msm.h", "kernels.h", "spend_lanes.h",
                   "k_spend_verify.hip"]
-MAD_PER_MUL, MAD_PER_SQ = 100, 55         # fe25519.h: a product is 10 columns x 10 v_mad_u64_u32, a square 55
+MAD_PER_MUL, MAD_PER_SQ = 97, 61          # fe25519.h / tools/gen_fe_mul.py: 81 (45) limb products + 7 carries of the high half + 9 folds by 19, all v_mad_u64_u32
 
 
 def proof_bytes(L):
@@ -462,8 +462,8 @@ def main():
         if t:
             j = t[1]
             roof["traffic"] = j.get("hbm_bytes_per_launch_calibrated", j["hbm_bytes_per_launch_fetch_x2"]); roof["traffic_source"] = t[0]
-            roof["traffic_unit"] = ("bytes per launch at the L2's memory side: 1.25 x FETCH_SIZE + WRITE_SIZE, the factor calibrated on a known byte count in the kernel's own "
-                                    "access pattern (profiles/r03_calib_fetch.txt) as MI355X_MICROARCH.md prescribes for anything but wide streaming reads; "
+            roof["traffic_unit"] = ("bytes per launch at the L2's memory side: 1.125 x FETCH_SIZE + 0.90 x WRITE_SIZE, the factors calibrated on a known byte count in the kernel's own "
+                                    "access pattern (profiles/r03_calib_fetch_144.txt) as MI355X_MICROARCH.md prescribes for anything but wide streaming reads; "
                                     "dominated by the per-lane Pippenger buckets cycling through L2 / Infinity Cache")
             roof["traffic_other_corrections"] = {"uncorrected": j["hbm_bytes_per_launch_uncorrected"], "fetch_x2_as_for_streaming_reads": j["hbm_bytes_per_launch_fetch_x2"]}
             roof["traffic_over_algorithmic_bytes"] = roof["traffic"] / (algo_bytes * proofs_per_launch)

@@ -33,9 +33,11 @@ json.dump(valu, open("gpurun_out/%s_pmc_valu.json" % tag, "w"), indent=1)
 f, w = tot["FETCH_SIZE"] * 1024, tot["WRITE_SIZE"] * 1024
 json.dump({"kernel": "k_spend_bits", "kernel_source_sha16": SHA, "range_bits": 128, "proofs_per_launch": NB, "FETCH_SIZE_KB": tot["FETCH_SIZE"], "WRITE_SIZE_KB": tot["WRITE_SIZE"],
            "hbm_bytes_per_launch_uncorrected": f + w, "hbm_bytes_per_launch_fetch_x2": 2 * f + w,
-           # calibrated on a known byte count in THIS access pattern (tools/calib_fetch.hip, profiles/r03_calib_fetch.txt: one 160-byte
-           # entry per lane as ten dwordx4 at a 1 440-byte lane stride): FETCH_SIZE reports 0.80 of the bytes read, WRITE_SIZE all of them
-           "fetch_calibration_factor": 1.25, "hbm_bytes_per_launch_calibrated": 1.25 * f + w,
+           # calibrated on a known byte count in THIS access pattern (tools/calib_fetch.hip, profiles/r03_calib_fetch_144.txt: one
+           # 144-byte entry per lane as nine dwordx4 at a 1 296-byte lane stride): FETCH_SIZE reports 128 B per lane (0.889 of the
+           # bytes asked for; the two 128-byte lines an entry straddles would be 256 B = 2 x FETCH_SIZE), WRITE_SIZE 160 B per
+           # lane (32-byte sectors: 1.11 x the bytes written)
+           "fetch_calibration_factor": 1.125, "write_calibration_factor": 0.90, "hbm_bytes_per_launch_calibrated": 1.125 * f + 0.90 * w,
            "note": "separate --pmc passes (tools/pmc_profile.sh, NB=%d); gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), both figures given; includes the per-lane Pippenger bucket and scratch traffic, counted at the L2's memory side (Infinity-Cache hits are not excluded)" % NB},
           open("gpurun_out/%s_pmc_hbm_traffic.json" % tag, "w"), indent=1)
 print(json.dumps({k: v for k, v in valu.items() if k != "raw"}))
