@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(64, 2) k_spend_prep(SpendArgs a) {
 // UNIFORM: L is a multiple of 64, so a wavefront holds bits of ONE proof and reads that proof's challenge digits into SGPRs
 template <bool UNIFORM>
 __global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
-  __shared__ uint32_t u_lds[(ACT_BITS_BLOCK / 64) * 2 * GE_LDS_WORDS_PER_WAVE];            // 20 KiB per wavefront
+  __shared__ uint32_t u_lds[(ACT_BITS_BLOCK / 64) * 2 * GE_LDS_WORDS_PER_WAVE];            // 18 KiB per wavefront
   spend_bits_lane<UNIFORM>(a, blockIdx.x * ACT_BITS_BLOCK + threadIdx.x, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
 }
 
