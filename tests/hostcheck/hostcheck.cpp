@@ -39,6 +39,13 @@ void hc_fe_stress(const uint8_t* a, const uint8_t* b, uint8_t* o) {
   fe_out(o, r);
 }
 
+// products / squares / carries of operands given limb by limb (9 words each): the extremes of the column budget, which no
+// 32-byte input reaches.  out = canonical bytes; the operands' limb sizes go through the same ACT_FE_BOUNDS bookkeeping.
+void hc_fe_mul_limbs(const uint32_t* a, const uint32_t* b, uint8_t* o) { fe x, y; for (int i = 0; i < FE_LIMBS; i++) { x.v[i] = a[i]; y.v[i] = b[i]; } fe_out(o, fe_mul(x, y)); }
+void hc_fe_sq_limbs(const uint32_t* a, uint8_t* o) { fe x; for (int i = 0; i < FE_LIMBS; i++) x.v[i] = a[i]; fe_out(o, fe_sq(x)); }
+void hc_fe_carry_limbs(const uint32_t* a, uint32_t* limbs_out, uint8_t* o) { fe x; for (int i = 0; i < FE_LIMBS; i++) x.v[i] = a[i]; fe c = fe_carry(x); for (int i = 0; i < FE_LIMBS; i++) limbs_out[i] = c.v[i]; fe_out(o, c); }
+void hc_fe_mul_out_limbs(const uint32_t* a, const uint32_t* b, uint32_t* limbs_out) { fe x, y; for (int i = 0; i < FE_LIMBS; i++) { x.v[i] = a[i]; y.v[i] = b[i]; } fe c = fe_mul(x, y); for (int i = 0; i < FE_LIMBS; i++) limbs_out[i] = c.v[i]; }
+
 void hc_sc_reduce_wide(const uint8_t* a, uint8_t* o) { uint32_t w[16]; memcpy(w, a, 64); sc_out(o, sc_from_wide_words(w)); }
 void hc_sc_from_bytes(const uint8_t* a, uint8_t* o) { sc_out(o, sc_in(a)); }
 void hc_sc_muladd(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* o) { sc_out(o, sc_muladd(sc_in(a), sc_in(b), sc_in(c))); }

@@ -42,6 +42,54 @@ def test_field(hostcheck):
             assert bool(ok) == ok2 and fi(r) == r2
 
 
+POS = [-(-85 * i // 3) for i in range(10)]
+WID = [POS[i + 1] - POS[i] for i in range(9)]
+
+
+def test_field_at_the_column_budget(hostcheck):
+    """fe_mul / fe_sq on operands whose EVERY limb sits at the top of its size class (phi * gamma up to the 12.5 the header allows,
+    squares up to phi = 3.5): a 64-bit column that overflowed would give a wrong product.  Also: outputs are tight, and fe_carry
+    brings any element below phi = 7.5 back to tight."""
+    import random
+    hc = hostcheck
+    r = random.Random(9)
+    val = lambda limbs: sum(l << POS[i] for i, l in enumerate(limbs))
+    arr = lambda limbs: (C.c_uint32 * 9)(*limbs)
+    fi = lambda x: int.from_bytes(x, "little")
+    tight_max = [(1 << w) + ((1 << 12) if i == 1 else 0) for i, w in enumerate(WID)]
+
+    def operand(phi, kind):
+        top = [min(int(phi * (1 << w)), (1 << 32) - 1) for w in WID]
+        if kind == "max":
+            return top
+        if kind == "alt":
+            return [t if i % 2 else t // 3 for i, t in enumerate(top)]
+        return [r.randrange(t // 2, t + 1) for t in top]
+
+    pairs = [(1, 1), (2, 2), (3, 3), (4, 3), (3, 4), (6, 2), (2, 6), (7.4, 1.68), (1.68, 7.4), (5, 2.5), (3.5, 3.5)]   # every operand below phi = 7.5
+    for pa, pb in pairs:
+        for kind in ("max", "alt", "rnd", "rnd"):
+            a, b = operand(pa, kind), operand(pb, kind)
+            out = C.create_string_buffer(32)
+            hc.hc_fe_mul_limbs(arr(a), arr(b), out)
+            assert fi(out.raw) == val(a) * val(b) % P, (pa, pb, kind)
+            lo = (C.c_uint32 * 9)()
+            hc.hc_fe_mul_out_limbs(arr(a), arr(b), lo)
+            assert all(l <= t for l, t in zip(lo, tight_max)), (pa, pb, kind, list(lo))
+    for phi in (1, 2, 3, 3.5):
+        for kind in ("max", "alt", "rnd", "rnd"):
+            a = operand(phi, kind)
+            out = C.create_string_buffer(32)
+            hc.hc_fe_sq_limbs(arr(a), out)
+            assert fi(out.raw) == val(a) ** 2 % P, (phi, kind)
+    for phi in (1, 2, 5, 6, 7.4):
+        for kind in ("max", "alt", "rnd"):
+            a = operand(phi, kind)
+            lo, out = (C.c_uint32 * 9)(), C.create_string_buffer(32)
+            hc.hc_fe_carry_limbs(arr(a), lo, out)
+            assert fi(out.raw) == val(a) % P and all(l <= t for l, t in zip(lo, tight_max)), (phi, kind, list(lo))
+
+
 def test_scalars(hostcheck):
     hc = hostcheck
     for v in load_golden("primitives.json")["sc_from_wide"]:
@@ -238,6 +286,7 @@ def test_dedicated_addition_chain_agrees_with_the_complete_one_on_structured_dig
 
 def test_limb_bounds_hold(hostcheck):
     """Every operand recorded by the instrumented host build stays inside its class (fe25519.h header comment)."""
+    hostcheck.hc_bounds_reset()
     test_field(hostcheck)
     test_group_and_msm_shapes(hostcheck)
     test_batched_double_and_compress(hostcheck)
