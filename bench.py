@@ -55,6 +55,7 @@ CSRC = os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc")
 KERNEL_SOURCES = ["fe25519.h", "fe25519_gen.inc", "fe25519_consts.inc", "sc25519.h", "ge25519.h", "msm.h", "kernels.h", "spend_lanes.h",
                   "k_spend_verify.hip"]
 MAD_PER_MUL, MAD_PER_SQ = 97, 61          # fe25519.h / tools/gen_fe_mul.py: 81 (45) limb products + 7 carries of the high half + 9 folds by 19, all v_mad_u64_u32
+LIMB_PRODUCTS_PER_MUL, LIMB_PRODUCTS_PER_SQ = 81, 45   # the part of those no 9-limb representation can avoid
 
 
 def proof_bytes(L):
@@ -453,6 +454,8 @@ def main():
                 "avg_launch_ms_x_launches_per_step": 1e3 * launch_s * launches_per_step,
                 "proofs_per_launch": proofs_per_launch,
                 "algorithmic_mad_per_proof_in_this_kernel": bits_mad_per_proof, "mad_per_verify_whole_path": mad_per_verify,
+                "frac_counting_limb_products_only": (LIMB_PRODUCTS_PER_MUL * ops["k_spend_bits"]["fe_mul"] + LIMB_PRODUCTS_PER_SQ * ops["k_spend_bits"]["fe_sq"])
+                                                    * proofs_per_launch / launch_s / peak_mad if launch_s else 0.0,
                 "whole_path": {"achieved": value / world * mad_per_verify, "frac": value / world * mad_per_verify / peak_mad,
                                "what": "all kernels of the path: verifies/s per GPU x multiply-accumulates per verify"},
                 "fe_mul_per_verify": fe_mul, "fe_sq_per_verify": fe_sq, "per_kernel_field_ops_per_verify": ops, "probe_ms": probe_ms,
