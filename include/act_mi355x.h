@@ -97,11 +97,11 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
 /* A context = Params (h1,h2,h3 with their device-resident fixed-base tables, cf. the three
  * RistrettoBasepointTables of src/lib.rs:222-229) + the range-proof width L (src/lib.rs:116; 128 is the
  * crate's value, 1..128 accepted) + one GPU.  max_batch bounds the records per internal launch and
- * thereby the workspace: about 220 KB per record at L = 128 (1.7 KB per range-proof bit), times two
+ * thereby the workspace: about 200 KB per record at L = 128 (1.6 KB per range-proof bit), times two
  * pipeline slots, plus the fixed-base tables, which the contexts of a process on one GPU with the same Params share: 0.5 GB with
  * 16-bit windows; from max_batch 32768 up h1 and h3 get 24-bit windows (47 GB, built in about 2 s, +3 % verifies/s) provided at
  * least 16 GB of the device would stay free afterwards (otherwise, or with ACT_FB_WIDE_BITS=16 in the environment, 16 bits).
- * 0 = default = 65536 (29 GB of workspace at L = 128), from which size on the
+ * 0 = default = 65536 (27 GB of workspace at L = 128), from which size on the
  * throughput of every entry point is flat; 16384 costs about 5 % of the verify rate and two thirds
  * of the issue/request rate.  Batches of any length are accepted and processed in such chunks.  max_batch > 2^22 is
  * refused (ACT_ERR_ARG).  On failure *out still receives a context whose only use is act_last_error() and
