@@ -299,3 +299,23 @@ def test_limb_bounds_hold(hostcheck):
     print('limb bounds (units of 2^-16):', [round(v / 65536, 4) for v in bd])
     for v, l in zip(bd, lim):
         assert 0 < v <= l * 2**16, (list(bd), lim)
+
+
+def test_generated_field_sources_are_current():
+    """csrc/fe25519_gen.inc and fe25519_consts.inc are what tools/gen_fe_mul.py / gen_fe_consts.py print (no hand edits, no stale
+    output), and the constants are the right numbers: each ACT_FE_CONST row, read back through the 9-limb positions, equals the
+    value gen_fe_consts.py derives it from."""
+    import subprocess, sys, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "anonymous-credit-tokens_amd", "csrc")
+    for tool, inc in (("gen_fe_mul.py", "fe25519_gen.inc"), ("gen_fe_consts.py", "fe25519_consts.inc")):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", tool)], capture_output=True, text=True, check=True).stdout
+        assert out == open(os.path.join(csrc, inc)).read(), inc
+    rows = dict((m.group(1), [int(x.rstrip("u"), 16) for x in m.group(2).split(", ")])
+                for m in re.finditer(r"ACT_FE_CONST\((\w+), ([^)]*)\)", open(os.path.join(csrc, "fe25519_consts.inc")).read()))
+    val = lambda limbs: sum(l << POS[i] for i, l in enumerate(limbs))
+    d = (-121665 * pow(121666, P - 2, P)) % P
+    sqrt_m1 = pow(2, (P - 1) // 4, P)
+    assert val(rows["fe_d"]) == d and val(rows["fe_d2"]) == 2 * d % P
+    assert val(rows["fe_sqrt_m1"]) in (sqrt_m1, P - sqrt_m1) and val(rows["fe_sqrt_m1"]) ** 2 % P == P - 1
+    assert all(len(v) == 9 and all(l < (1 << WID[i]) for i, l in enumerate(v)) for v in rows.values())
