@@ -553,6 +553,18 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     ex["device_transcript_hostmem"] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9,
                                        "what": "ACT_TRANSCRIPT_DEVICE + ACT_MEM_HOST (pinned)"}
     del hp
+    # (2b) latency of small calls (a service answering single redemptions): proofs and statuses in pinned host memory, device transcripts
+    lat = {}
+    hs1 = torch.zeros(4096, dtype=torch.uint8, pin_memory=True); hp1 = torch.empty((4096, PB), dtype=torch.uint8, pin_memory=True); hp1.copy_(dev[:4096]); sync()
+    for k in (1, 64, 4096):
+        ts = []
+        for _ in range(7):
+            t0 = time.perf_counter(); eng.verify_spend_ptr(sk, k, capi.MEM_HOST, hp1.data_ptr(), hs1.data_ptr()); ts.append(time.perf_counter() - t0)
+        assert torch.equal(hs1[:k], expect[:k].cpu())
+        lat["%d" % k] = round(1e3 * sorted(ts)[len(ts) // 2], 3)
+    ex["call_latency_ms"] = {"proofs_per_call": lat, "what": "median wall time of act_verify_spend_batch over 1 / 64 / 4 096 proofs in pinned host memory (device transcripts): "
+                             "one proof is two wavefronts of the range kernel, i.e. the chain's serial depth"}
+    del hp1
     # (3) the path the Rust binding takes: act_node_verify_spend_batch over devices = [this GPU], proofs and statuses in ordinary
     #     host memory.  The node's context shares this device's fixed-base tables with the bench's engine (engine.hip table cache).
     ex["node_host_path"] = node_host_path(args, capi, torch, np, sk, dev, expect, h, local, L, PB)
