@@ -17,11 +17,11 @@ _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_ctx_set_pipeline_depth", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
-    "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32",
+    "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32", "act_ubench_random_read",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch", "act_verify_spend_cbor_batch",
     "act_node_verify_spend_cbor_batch", "act_redeem_batch", "act_node_redeem_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
@@ -77,6 +77,12 @@ def load() -> C.CDLL:
     lib.act_ctx_set_transcript_mode.argtypes = [vp, i32]
     lib.act_ctx_set_host_threads.argtypes = [vp, i32]
     lib.act_ctx_set_pipeline_depth.argtypes = [vp, i32]
+    lib.act_host_usable_cpus.argtypes = []
+    lib.act_host_hash_many.argtypes = [u8p, sz, C.c_uint32, sz, i32, u8p]
+    lib.act_host_hash_many.restype = None
+    lib.act_host_pool_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    lib.act_host_pool_stats.restype = None
+    lib.act_ctx_streams_overlap.argtypes = [vp]
     lib.act_build_has_ct_secret_tables.argtypes = []
     lib.act_ctx_fixed_base_bits.argtypes = [vp, i32]
     lib.act_last_error.argtypes = [vp]
@@ -121,6 +127,7 @@ def load() -> C.CDLL:
     lib.act_prof_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.act_prof_get_busy.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.act_ubench_mad_u64_u32.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.act_ubench_random_read.argtypes = [i32, sz, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.act_issue_check_batch.argtypes = [vp, sz, i32, u8p, u8p]
     lib.act_issue_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_refund_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
@@ -183,12 +190,39 @@ def params_random(rng: bytes, device: int = 0) -> bytes:
     return out.tobytes()
 
 
+def host_usable_cpus() -> int:
+    return load().act_host_usable_cpus()
+
+
+def host_pool_stats() -> dict:
+    j, t, n = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+    load().act_host_pool_stats(C.byref(j), C.byref(t), C.byref(n))
+    return {"jobs": j.value, "threads_created": t.value, "pool_size": n.value}
+
+
+def host_hash_many(msgs, stride: int, length: int, n: int, max_threads: int = 0) -> bytes:
+    """BLAKE3 XOF (64 B) of n messages at `stride` through the process-wide worker pool (pure host code)."""
+    out = np.zeros(64 * n, np.uint8)
+    p, keep = _in(msgs)
+    load().act_host_hash_many(p, stride, length, n, max_threads, out.ctypes.data)
+    return out.tobytes()
+
+
 def ubench_mad(device: int = 0):
     """(lane-MADs per second, probe ms) of the v_mad_u64_u32 roofline probe."""
     r, ms = C.c_double(0), C.c_double(0)
     rc = load().act_ubench_mad_u64_u32(device, C.byref(r), C.byref(ms))
     if rc:
         raise ActError(f"act_ubench_mad_u64_u32 failed: {_ERRS.get(rc, rc)}")
+    return r.value, ms.value
+
+
+def ubench_random_read(device: int = 0, gib: int = 0):
+    """(GB/s of 128-byte random reads, probe ms): the memory-side roofline of the scalar-addressed fixed-base tables."""
+    r, ms = C.c_double(0), C.c_double(0)
+    rc = load().act_ubench_random_read(device, gib, C.byref(r), C.byref(ms))
+    if rc:
+        raise ActError(f"act_ubench_random_read failed: {_ERRS.get(rc, rc)}")
     return r.value, ms.value
 
 
@@ -240,6 +274,13 @@ class Engine:
 
     def set_pipeline_depth(self, depth: int):
         self._ck(self.lib.act_ctx_set_pipeline_depth(self.ctx, depth))
+
+    def set_host_threads(self, n: int):
+        self._ck(self.lib.act_ctx_set_host_threads(self.ctx, n))
+
+    def streams_overlap(self) -> int:
+        """1 = the two pipeline streams run side by side, 0 = they share a hardware queue, -1 = not measured."""
+        return self.lib.act_ctx_streams_overlap(self.ctx)
 
     # ---- host-memory batch calls ----------------------------------------------------------------
     def private_key_random(self, rng: bytes) -> bytes:
@@ -445,6 +486,12 @@ class Node:
 
     def set_transcript_mode(self, mode: int):
         self._ck(self.lib.act_node_set_transcript_mode(self.nd, mode))
+
+    def set_host_threads(self, per_gpu: int):
+        self._ck(self.lib.act_node_set_host_threads(self.nd, per_gpu))
+
+    def streams_overlap(self) -> list:
+        return [self.lib.act_ctx_streams_overlap(self.lib.act_node_ctx(self.nd, k)) for k in range(self.device_count())]
 
     def request(self, pre: bytes, rng: bytes) -> bytes:
         n = len(pre) // 64; out = np.zeros(128 * n, np.uint8)

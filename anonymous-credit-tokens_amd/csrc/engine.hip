@@ -3,7 +3,6 @@
 // reference's src/transcript.rs does) and the C ABI of include/act_mi355x.h.
 // There is no CPU compute path here: the host only moves bytes and (optionally) hashes them.
 #include <algorithm>
-#include <sched.h>
 #include <sys/random.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -20,15 +19,7 @@
 
 using namespace act;
 
-extern "C" void act_host_b3_xof64_x16(const uint8_t* msgs, size_t stride, uint32_t len, uint32_t* xof);   // host_hash.cpp
-
-// HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues per device (default 4).  A context owns two
-// streams; a process that holds two contexts on one GPU next to the streams of its framework (measured: bench.py's engine +
-// a node handle + torch's stream) runs out, two streams of one context land on the same hardware queue, and that context's
-// two-chunk pipeline silently runs its chunks one after the other (415 k instead of 466 k verifies/s from host memory).  The
-// library therefore asks for 8 queues unless the caller has set the variable; this only takes effect if it happens before the
-// HIP runtime initialises (a process that initialises HIP before loading this library sets it itself: bench.py does).
-__attribute__((constructor)) static void act_env_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+extern "C" void act_host_hash_many(const uint8_t* msgs, size_t stride, uint32_t len, size_t n, int max_threads, uint32_t* xof);   // host_pool.cpp
 
 namespace {
 
@@ -78,6 +69,7 @@ struct act_ctx {
   int tr_mode = ACT_TRANSCRIPT_HOST;
   int depth = 2;                       // chunks in flight (act_ctx_set_pipeline_depth): 2 = both slots, 1 = strictly one after the other
   int host_threads = 0;
+  int streams_overlap = -1;            // 1 = the two slots' streams run side by side (measured at creation), 0 = they share a hardware queue
   std::string err;
   Slot slots[2];
   std::mutex mu;                       // every batch entry point holds it: calls on one context are serialised, whatever thread they come from
@@ -192,49 +184,10 @@ void host_xof64(const std::vector<uint8_t>& msg, uint8_t out[64]) {
   memcpy(out, o, 64);
 }
 
-// CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a 16-CPU container on a
-// 256-thread host reports hardware_concurrency() = 256; hashing with that many threads runs at half the rate of 16)
-int usable_cpus() {
-  int n = (int)std::thread::hardware_concurrency();
-  cpu_set_t set;
-  if (sched_getaffinity(0, sizeof(set), &set) == 0) { int k = CPU_COUNT(&set); if (k > 0 && (n < 1 || k < n)) n = k; }
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                      // cgroup v2: "<quota|max> <period>"
-    char q[32]; long period = 0;
-    if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
-      long k = (atol(q) + period - 1) / period; if (k > 0 && k < n) n = (int)k;
-    }
-    fclose(f);
-  } else {
-    long quota = -1, period = 0;                                              // cgroup v1
-    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
-    if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
-    if (quota > 0 && period > 0) { long k = (quota + period - 1) / period; if (k > 0 && k < n) n = (int)k; }
-  }
-  return n < 1 ? 1 : n;
-}
-int n_host_threads(const act_ctx* c) {
-  static const int usable = usable_cpus();
-  int t = c->host_threads > 0 ? c->host_threads : usable;
-  return t < 1 ? 1 : t;
-}
-// hash n messages of `len` bytes at `stride` (host memory) into xof[n][16] on host threads: groups of sixteen through
-// the SIMD routine of host_hash.cpp (one message per 32-bit lane), the remainder through the scalar routine
+// hash n messages of `len` bytes at `stride` (host memory) into xof[n][16] on this call's share of the process-wide worker pool
+// (host_pool.cpp): groups of sixteen through the SIMD routine of host_hash.cpp, the remainder through the scalar routine
 void host_hash_many(const act_ctx* c, const uint8_t* msgs, size_t stride, uint32_t len, size_t n, uint32_t* xof) {
-  int nt = (int)std::min<size_t>((size_t)n_host_threads(c), n ? (n + 63) / 64 : 1);
-  std::atomic<size_t> next{0};
-  auto work = [&]() {
-    for (;;) {
-      size_t i0 = next.fetch_add(64);
-      if (i0 >= n) break;
-      size_t i1 = std::min(n, i0 + 64), i = i0;
-      for (; i + 16 <= i1; i += 16) act_host_b3_xof64_x16(msgs + i * stride, stride, len, xof + i * 16);
-      for (; i < i1; i++) b3_hash_xof64(xof + i * 16, reinterpret_cast<const uint32_t*>(msgs + i * stride), len);
-    }
-  };
-  if (nt <= 1) { work(); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < nt; t++) th.emplace_back(work);
-  for (auto& t : th) t.join();
+  act_host_hash_many(msgs, stride, len, n, c->host_threads, xof);
 }
 
 // transcript hashing step, split so that callers can overlap the host part with other slots' GPU work:
@@ -402,6 +355,55 @@ int workspace_alloc(act_ctx* c) {
   }
   return ACT_OK;
 }
+// Do the two slots' streams run side by side?  HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues per
+// device and priority (default 4); a process that holds several contexts next to the streams of its framework (measured: bench.py's
+// engine + a node handle + torch) runs out, both streams of a context land on one queue, and its two-chunk pipeline silently
+// runs its chunks one after the other (415 k instead of 466 k verifies/s from host memory).  Round 3 set GPU_MAX_HW_QUEUES from a
+// library constructor -- a setenv in somebody else's process, racy against getenv in a multi-threaded host and without effect
+// once HIP is initialised.  Now the context MEASURES it: one idle wavefront of `ticks` on each stream, started together, takes
+// one `ticks` side by side and two on a shared queue.
+int streams_overlap_probe(act_ctx* c, int* overlap) {
+  hipStream_t s0 = c->slots[0].stream, s1 = c->slots[1].stream;
+  hipEvent_t e0, e1, e2;
+  HIPCK(c, hipEventCreate(&e0)); HIPCK(c, hipEventCreate(&e1)); HIPCK(c, hipEventCreate(&e2));
+  const uint32_t ticks = 30000;                   // 0.3 ms of the 100 MHz counter
+  launch_spin(1, s0); launch_spin(1, s1);         // code load
+  HIPCK(c, hipStreamSynchronize(s0)); HIPCK(c, hipStreamSynchronize(s1));
+  HIPCK(c, hipEventRecord(e0, s0));
+  HIPCK(c, hipStreamWaitEvent(s1, e0, 0));
+  launch_spin(ticks, s0); launch_spin(ticks, s1);
+  HIPCK(c, hipEventRecord(e1, s0)); HIPCK(c, hipEventRecord(e2, s1));
+  HIPCK(c, hipEventSynchronize(e1)); HIPCK(c, hipEventSynchronize(e2));
+  float t1 = 0, t2 = 0;
+  HIPCK(c, hipEventElapsedTime(&t1, e0, e1)); HIPCK(c, hipEventElapsedTime(&t2, e0, e2));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  *overlap = std::max(t1, t2) < 1.6f * (ticks / 1e5f) ? 1 : 0;
+  return ACT_OK;
+}
+// ... and if they share a queue, slot 1 moves to a stream of another priority: the runtime keeps a separate set of hardware queues
+// per priority, so the two cannot alias whatever else the process has created.  What is left is reported by
+// act_ctx_streams_overlap() and documented for the embedding process (GPU_MAX_HW_QUEUES).
+int streams_settle(act_ctx* c) {
+  static const bool skip = getenv("ACT_NO_STREAM_PROBE") != nullptr;
+  if (skip) { c->streams_overlap = -1; return ACT_OK; }
+  int ov = 0, rc = streams_overlap_probe(c, &ov); if (rc) return rc;
+  if (!ov) {
+    int least = 0, greatest = 0;
+    HIPCK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    for (int prio : {greatest, least}) {
+      if (ov || least == greatest) break;
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) { (void)hipGetLastError(); continue; }
+      HIPCK(c, hipStreamSynchronize(c->slots[1].stream));
+      HIPCK(c, hipStreamDestroy(c->slots[1].stream));
+      c->slots[1].stream = s;
+      if ((rc = streams_overlap_probe(c, &ov))) return rc;
+    }
+  }
+  c->streams_overlap = ov;
+  return ACT_OK;
+}
+
 int sync_all(act_ctx* c) {
   for (Slot& sl : c->slots) { HIPCK(c, hipStreamSynchronize(sl.stream)); int rc = prof_collect(c, sl); if (rc) return rc; }
   return ACT_OK;
@@ -569,6 +571,7 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   memcpy(c->henc, h, 96);
   HIPCK(c, hipSetDevice(device));
   int rc = workspace_alloc(c); if (rc) return rc;
+  if ((rc = streams_settle(c))) return rc;
   hipStream_t s0 = c->slots[0].stream;
   // decode g, h1, h2, h3 and build their fixed-base tables
   uint8_t enc[128]; memcpy(enc, kGeneratorEnc, 32); memcpy(enc + 32, h, 96);
@@ -667,6 +670,7 @@ int act_ctx_set_transcript_mode(act_ctx* c, int mode) {
   if (!c || (mode != ACT_TRANSCRIPT_HOST && mode != ACT_TRANSCRIPT_DEVICE)) return ACT_ERR_ARG;
   c->tr_mode = mode; return ACT_OK;
 }
+int act_ctx_streams_overlap(const act_ctx* c) { return c ? c->streams_overlap : -1; }
 int act_ctx_fixed_base_bits(const act_ctx* c, int base) { return (c && base >= 0 && base < 4) ? c->fb_bits[base] : 0; }
 int act_build_has_ct_secret_tables(void) {
 #if defined(ACT_CT_SECRET_TABLES)
@@ -677,7 +681,14 @@ int act_build_has_ct_secret_tables(void) {
 }
 int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
 int act_ctx_set_host_threads(act_ctx* c, int n) { if (!c || n < 0) return ACT_ERR_ARG; c->host_threads = n; return ACT_OK; }
-const char* act_last_error(const act_ctx* c) { return c ? c->err.c_str() : "null context"; }
+// copied under the context's lock into a buffer of the calling thread (another thread's failing call may rewrite c->err at any
+// moment); valid until this thread's next act_last_error call
+const char* act_last_error(const act_ctx* c) {
+  if (!c) return "null context";
+  thread_local std::string mine;
+  { std::lock_guard<std::mutex> lk(const_cast<act_ctx*>(c)->mu); mine = c->err; }
+  return mine.c_str();
+}
 size_t act_spend_proof_bytes(const act_ctx* c) { return ProofLayout{c->L}.bytes(); }
 size_t act_prove_rng_bytes(const act_ctx* c) { return 64u * (4u * (size_t)c->L + 12u); }
 size_t act_spend_transcript_bytes(const act_ctx* c) { return SpendTranscript{c->L}.bytes(); }
@@ -1012,6 +1023,7 @@ int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_
 
 int act_debug_last_spend_transcripts(act_ctx* c, size_t max_lanes, uint8_t* out, size_t* n_copied) {
   if (!c || !out || !n_copied) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
   HIPCK(c, hipSetDevice(c->device));
   const SpendTranscript st{c->L};
   Slot& sl = c->slots[c->last_spend_slot];
@@ -1052,6 +1064,36 @@ int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
   return ACT_OK;
 }
 
+// 128-byte random-read micro-benchmark (k_misc.hip k_ubench_random_read): the memory-side roofline of the scalar-addressed
+// fixed-base tables.  `gib` GiB of device memory are allocated for the probe and freed again (0 = 16).
+int act_ubench_random_read(int device, size_t gib, double* gbytes_per_s, double* ms) {
+  if (!gbytes_per_s) return ACT_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
+  const size_t bytes = (gib ? gib : 16) << 30;
+  const uint64_t lines = bytes / 128;
+  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = 2048;
+  uint32_t *buf = nullptr, *out = nullptr; hipEvent_t e0, e1; hipStream_t st;
+  if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
+  if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return ACT_ERR_HIP; }
+  int rc = ACT_OK; float t = 0;
+  if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(buf); (void)hipFree(out); return ACT_ERR_HIP; }
+  (void)hipMemsetAsync(buf, 0x5a, bytes, st);                                  // touch every page
+  launch_ubench_random_read(buf, lines, blocks, 64, out, st);                  // warm-up
+  (void)hipEventRecord(e0, st);
+  launch_ubench_random_read(buf, lines, blocks, iters, out, st);
+  (void)hipEventRecord(e1, st);
+  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = ACT_ERR_HIP;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(buf); (void)hipFree(out);
+  if (rc) { (void)hipGetLastError(); return rc; }
+  *gbytes_per_s = (double)blocks * 256.0 * iters * 128.0 / (t * 1e-3) / 1e9;     // a 128-byte line per read (112 bytes of it used, as the tables' entries)
+  if (ms) *ms = t;
+  return ACT_OK;
+}
+
 int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* points, const uint8_t* scalars, uint8_t* out, uint8_t* status) {
   if (!c || (n && (!points || !scalars || !out || !status))) return ACT_ERR_ARG;
   Call call(c, n);
@@ -1074,6 +1116,7 @@ int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* poi
 // Test hook: bytes that are not zero in the context's secret-bearing buffers (what finish_call wipes), read back to the host.
 int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
   if (!c || !nonzero_bytes) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
   HIPCK(c, hipSetDevice(c->device));
   size_t total = 0, nz = 0;
   std::vector<std::pair<const void*, size_t>> regions;
@@ -1097,6 +1140,7 @@ int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
 
 int act_prof_enable(act_ctx* c, int on) {
   if (!c) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
   c->prof_on = on != 0;
   if (c->prof_on && !c->prof_base) {
     HIPCK(c, hipSetDevice(c->device));

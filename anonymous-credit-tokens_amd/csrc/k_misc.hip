@@ -152,6 +152,37 @@ __global__ void __launch_bounds__(256) k_ubench_mad(uint32_t* out, uint32_t iter
 }
 void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream_t s) { hipLaunchKernelGGL(k_ubench_mad, dim3(blocks), dim3(256), 0, s, out, iters); }
 
+// Random-read roofline probe: what the scalar-addressed look-ups into the wide fixed-base tables (msm.h fixed_base_acc: one 128-byte
+// affine-Niels entry per window, 112 bytes of it read as seven 16-byte loads, every entry on a different line of a 23.6 GB table)
+// can get from HBM at best.  Every lane reads `iters` pseudo-random lines of `lines` (xorshift per lane, so no two lanes share a
+// line more than by chance), four independent reads in flight per lane as fixed_base_acc's software pipeline has two.
+__global__ void __launch_bounds__(256) k_ubench_random_read(const uint4* buf, uint64_t lines, uint32_t iters, uint32_t* out) {
+  uint64_t x = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (uint32_t it = 0; it < iters; it += 4) {
+    const uint4* q[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; q[k] = buf + (x % lines) * 8; }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int i = 0; i < 7; i++) { const uint4 v = q[k][i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+void launch_ubench_random_read(const uint32_t* buf, uint64_t lines, uint32_t blocks, uint32_t iters, uint32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_ubench_random_read, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(buf), lines, iters, out);
+}
+
+// One wavefront that does nothing for `ticks` of the 100 MHz constant-rate counter (s_memrealtime).  act_ctx_create runs one on each
+// of the context's two streams at the same time to learn whether the HIP runtime gave them different hardware queues (engine.hip
+// streams_overlap): two of these take one `ticks` when the streams run side by side and two when they share a queue.
+__global__ void __launch_bounds__(64) k_spin(uint32_t ticks) {
+  const uint64_t t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+void launch_spin(uint32_t ticks, hipStream_t s) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, ticks); }
+
 // out[i] = base + i: the rng slice index of lane i in ACT_RNG_PER_LANE mode (no host round trip, so a chunk's launches stay asynchronous)
 __global__ void __launch_bounds__(256) k_iota(uint32_t* out, uint32_t n, uint32_t base) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;

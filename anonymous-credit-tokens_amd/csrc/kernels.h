@@ -196,6 +196,8 @@ void launch_keygen(const DevParams& P, const uint8_t* rng64, uint32_t n, uint8_t
 void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hipStream_t s);
 void launch_hash(const HashArgs& a, hipStream_t s);
 void launch_iota(uint32_t* out, uint32_t n, uint32_t base, hipStream_t s);
+void launch_spin(uint32_t ticks_100mhz, hipStream_t s);
+void launch_ubench_random_read(const uint32_t* buf, uint64_t lines, uint32_t blocks, uint32_t iters, uint32_t* out, hipStream_t s);
 constexpr int UBENCH_MADS_PER_ITER = 80;    // 8 chains x 10 dependent multiply-accumulates (k_misc.hip k_ubench_mad)
 void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream_t s);
 void launch_debug_scalarmult(const uint8_t* pts, const uint8_t* scs, uint32_t n, uint32_t* pbk, uint8_t* out, uint8_t* status, hipStream_t s);

@@ -32,8 +32,9 @@ std::vector<Shard> cut(size_t n, size_t parts) {
   return s;
 }
 // fn(k, shard) on one thread per GPU; first failure wins and is reported with its device
+// (the caller holds nd->mu: nd->err is only ever written under it)
 template <class F>
-int run(act_node* nd, size_t n, F fn) {
+int run(act_node* nd, size_t n, F fn, std::vector<int>* shard_rc = nullptr) {
   const size_t parts = nd->ctx.size();
   const std::vector<Shard> sh = cut(n, parts);
   std::vector<int> rc(parts, ACT_OK);
@@ -41,6 +42,7 @@ int run(act_node* nd, size_t n, F fn) {
   for (size_t k = 1; k < parts; k++) th.emplace_back([&, k] { rc[k] = fn(k, sh[k]); });
   rc[0] = fn(0, sh[0]);
   for (auto& t : th) t.join();
+  if (shard_rc) *shard_rc = rc;
   for (size_t k = 0; k < parts; k++)
     if (rc[k]) { nd->err = "device " + std::to_string(nd->devices[k]) + ": " + act_last_error(nd->ctx[k]); return rc[k]; }
   return ACT_OK;
@@ -94,7 +96,14 @@ void act_node_destroy(act_node* nd) {
 }
 int act_node_device_count(const act_node* nd) { return nd ? (int)nd->ctx.size() : 0; }
 act_ctx* act_node_ctx(act_node* nd, int k) { return (nd && k >= 0 && k < (int)nd->ctx.size()) ? nd->ctx[k] : nullptr; }
-const char* act_node_last_error(const act_node* nd) { return nd ? nd->err.c_str() : "null node"; }
+// the text is copied under the handle's lock into a buffer of the calling thread: another thread's failing call can rewrite
+// nd->err at any moment, a pointer into it could dangle.  Valid until this thread's next act_node_last_error call.
+const char* act_node_last_error(const act_node* nd) {
+  if (!nd) return "null node";
+  thread_local std::string mine;
+  { std::lock_guard<std::mutex> lk(const_cast<act_node*>(nd)->mu); mine = nd->err; }
+  return mine.c_str();
+}
 int act_node_set_transcript_mode(act_node* nd, int mode) {
   if (!nd) return ACT_ERR_ARG;
   for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_transcript_mode(c, mode); if (rc) return rc; }
@@ -153,17 +162,21 @@ int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], cons
                                 rng + (rng_mode == ACT_RNG_PER_LANE ? s.off : base[k]) * 128, rng_mode, at(out_resp, s.off, 160), status + s.off);
   });
 }
-int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
-                               int rng_mode, uint8_t* out_refund, uint8_t* status) {
-  if (!nd || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> node_lock(nd->mu);
-  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+static int refund_sign_locked(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
+                              int rng_mode, uint8_t* out_refund, uint8_t* status, std::vector<int>* shard_rc) {
   const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
   const std::vector<uint8_t> checked(status_in, status_in + n);
   return run(nd, n, [&](size_t k, Shard s) {
     return act_refund_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(kprime, s.off, 32), checked.data() + s.off,
                                  rng + (rng_mode == ACT_RNG_PER_LANE ? s.off : base[k]) * 128, rng_mode, at(out_refund, s.off, 128), status + s.off);
-  });
+  }, shard_rc);
+}
+int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
+                               int rng_mode, uint8_t* out_refund, uint8_t* status) {
+  if (!nd || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  return refund_sign_locked(nd, n, sk, kprime, status_in, rng, rng_mode, out_refund, status, nullptr);
 }
 
 int act_node_issuance_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
@@ -327,7 +340,12 @@ size_t act_node_nullifier_set_len(const act_node_nullifier_set* ns) {
   if (ns) for (act_nullifier_set* s : ns->sets) n += act_nullifier_set_len(s);
   return n;
 }
-const char* act_node_nullifier_set_last_error(const act_node_nullifier_set* ns) { return ns ? ns->err.c_str() : "null set"; }
+const char* act_node_nullifier_set_last_error(const act_node_nullifier_set* ns) {
+  if (!ns) return "null set";
+  thread_local std::string mine;
+  { std::lock_guard<std::mutex> lk(const_cast<act_node_nullifier_set*>(ns)->mu); mine = ns->err; }
+  return mine.c_str();
+}
 
 int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t n, const uint8_t* nullifiers, size_t stride, const uint8_t* skip_mask,
                                               uint8_t* out_spent) {
@@ -374,6 +392,10 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t
 // The issuer's whole redemption step over the GPUs of a node (act_redeem_batch's meaning, include/act_mi355x.h): verification on
 // every shard, the node-level nullifier set over the whole batch in lane order (verdicts as skip mask), then the signatures --
 // ACT_RNG_SEQUENTIAL draws only for lanes that are signed, from one stream, exactly as the sequential loop would.
+// Failures after verification never lose a decision (same contract as act_redeem_batch): a device of the nullifier set that
+// fails leaves ITS lanes ACT_STATUS_NULLIFIER_UNDETERMINED (not recorded, not signed) while every other lane is finished; a GPU
+// that fails while signing leaves the lanes of ITS shard that were to be signed ACT_STATUS_RECORDED_UNSIGNED (nullifier recorded,
+// refund owed); status[] and out_refund[] are complete for all other lanes and the error code says that something was left over.
 extern "C" int act_node_redeem_batch(act_node* nd, act_node_nullifier_set* set, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng,
                                      int rng_mode, uint8_t* out_refund, uint8_t* status) {
   if (!nd || !set || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
@@ -383,8 +405,21 @@ extern "C" int act_node_redeem_batch(act_node* nd, act_node_nullifier_set* set, 
   std::vector<uint8_t> kprime(n * 32), verdict(n), spent(n);
   int rc = act_node_verify_spend_batch(nd, n, sk, proof, verdict.data(), kprime.data());
   if (rc) return rc;
-  rc = act_node_nullifier_check_and_insert_batch(set, n, proof, pb, verdict.data(), spent.data());
-  if (rc) { nd->err = std::string("nullifier set: ") + act_node_nullifier_set_last_error(set); return rc; }
-  for (size_t i = 0; i < n; i++) if (verdict[i] == 0 && spent[i]) verdict[i] = ACT_STATUS_DOUBLE_SPEND;
-  return act_node_refund_sign_batch(nd, n, sk, kprime.data(), verdict.data(), rng, rng_mode, out_refund, status);
+  const int rc_null = act_node_nullifier_check_and_insert_batch(set, n, proof, pb, verdict.data(), spent.data());
+  for (size_t i = 0; i < n; i++)
+    if (verdict[i] == 0 && spent[i]) verdict[i] = spent[i] == 1 ? ACT_STATUS_DOUBLE_SPEND : ACT_STATUS_NULLIFIER_UNDETERMINED;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  std::vector<int> shard_rc;
+  const int rc_sign = refund_sign_locked(nd, n, sk, kprime.data(), verdict.data(), rng, rng_mode, out_refund, status, &shard_rc);
+  if (rc_sign) {
+    const std::vector<Shard> sh = cut(n, nd->ctx.size());
+    for (size_t k = 0; k < sh.size(); k++) {
+      if (!shard_rc[k]) continue;
+      for (size_t i = sh[k].off; i < sh[k].off + sh[k].m; i++) status[i] = verdict[i] == 0 ? ACT_STATUS_RECORDED_UNSIGNED : verdict[i];
+      memset(out_refund + sh[k].off * 128, 0, sh[k].m * 128);
+    }
+    return rc_sign;
+  }
+  if (rc_null) nd->err = std::string("nullifier set: ") + act_node_nullifier_set_last_error(set);
+  return rc_null;
 }

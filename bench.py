@@ -1,35 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — spend-proof verifies/sec (whole node), batch 2^20, L = 128 (BASELINE.json metric).
 
-A step = one pass of the hot path (PrivateKey::refund up to the challenge check, src/lib.rs:787-844) over one batch of
-2^20 synthetic spend proofs that are already resident in HBM when the timed region starts, transcripts hashed by the
-device BLAKE3 kernel (byte-identical to the host path).  That is `value`.  **Every proof of the batch is distinct**: the
-engine's own prover makes 2^20 of them on the device before the timed region (c uniform in [0, 2^L), s uniform in [0, c]:
-SURVEY.md 8d config 3), so no launch holds a proof twice and the scalar-addressed look-ups into the 47 GB fixed-base tables
-are as cold as real traffic makes them; 1 lane in 1024 is tampered.  One process per GPU; ranks shard independent batches with
-no data-path collective — torch.distributed/RCCL is used only for the barrier and the max-over-ranks reduction of the timing.
+A step = one pass of the hot path (PrivateKey::refund up to the challenge check, src/lib.rs:787-844) over one batch of 2^20
+synthetic spend proofs that are already resident in HBM when the timed region starts, in the library's default / north-star
+contract mode: every Fiat-Shamir transcript is hashed on the HOST (src/transcript.rs stays on the host; the engine's shared
+worker pool, csrc/host_pool.cpp), so each step moves 15.8 KB of pre-image per proof device -> host and 64 B back.  That is
+`value`.  (The bench contract forbids a PCIe-inclusive INPUT path as `value`; the same batch from ordinary host memory through
+act_node_verify_spend_batch -- what the Rust binding calls -- is the top-level `host_memory_path`, and the device-BLAKE3 figure
+that was the headline until round 3 is `extra.hbm_device_transcripts`.)  **Every proof of the batch is distinct**: the engine's
+own prover makes 2^20 of them on the device before the timed region (c uniform in [0, 2^L), s uniform in [0, c]: SURVEY.md 8d
+config 3); 1 lane in 1024 is tampered.
 
-Scaling: the default line is WEAK scaling (2^20 proofs per rank).  At N > 1 the same run also times the metric as
-BASELINE.json words it — ONE 2^20 batch over the whole node, 2^20 / N proofs per rank — and prints it as `strong`
-(`--scaling strong` swaps which of the two is `value`).
+N GPUs: `python bench.py --gpus N` starts N ranks ITSELF (a child `python -m torch.distributed.run --nproc-per-node N`, spawned
+before this process imports torch or touches HIP) unless it already runs under a launcher (WORLD_SIZE set); every rank asserts
+WORLD_SIZE == --gpus.  One process per GPU; ranks shard with no data-path collective -- torch.distributed/RCCL is used only for
+the barrier and the max-over-ranks reduction of the timing.  At N > 1 `value` is the metric as BASELINE.json words it, STRONG
+scaling: ONE 2^20 batch over the whole node, contiguous shards of 2^20 / N proofs per rank (`--scaling weak` swaps in 2^20 per
+rank; both are always printed).  Each rank's host hashing takes usable CPUs / N workers.  `node_multi` = the product's own
+multi-GPU path: ONE process, one act_node handle over all N devices, one 2^20 batch from host memory (rank 0, the other ranks idle).
 
 The one JSON line carries
   roofline             the binding roofline of the dominant kernel, k_spend_bits: 64-bit integer multiply-accumulates per second
                        against a v_mad_u64_u32 micro-kernel timed in this run on this GPU; the multiply-accumulates per verify
                        are counted, not estimated (the kernels' own lane bodies executed on the host with counting field
                        operations, tests/hostcheck).  roofline.hbm is the HBM view the contract also asks for (not binding).
+  roofline_prover      the same for k_prove_bits (BASELINE configs[2]), from the proof generation in front of the timed region
   cpu_baseline         the C oracle (a port of the reference algorithm) on this box's host cores; it also re-verifies the
                        tampered lanes of the first chunk and its whole sample against the GPU's statuses
+  host_memory_path     2^20 proofs through act_node_verify_spend_batch(devices = [this GPU]) from PAGEABLE and from pinned host
+                       memory, host transcripts: the path the Rust binding takes (PCIe-inclusive, never `value`)
 and at N = 1
+  extra.hbm_device_transcripts     the round-1..3 headline: device BLAKE3, nothing crosses PCIe inside a step
   extra.tiled_4096                 the round-1/2 input (4 096 distinct proofs tiled x256): what tiling flatters
-  extra.host_transcript_hbm*       the library's default / north-star contract mode: transcripts hashed on host threads
-  extra.host_transcript_hostmem    ... with the proofs in pinned HOST memory and statuses returned to host memory
-  extra.node_host_path             2^20 proofs through act_node_verify_spend_batch (devices = [0]) from PAGEABLE and from
-                                   pinned host memory: the path the Rust binding takes (PCIe-inclusive, never `value`)
+  extra.call_latency_ms            one call over 1 / 64 / 4 096 proofs (the crate's call shape is one proof per call)
   extra.refund                     verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
   extra.verify_L64                 BASELINE config 2: 2^16 verifies at L = 64
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8                      # starts 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -299,7 +307,7 @@ def newest_matching_pmc(kind, proofs_per_launch, sha, L=128):
     return best
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -307,23 +315,67 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--range-bits", type=int, default=128, help="L; 128 is the crate's width and the metric's")
     ap.add_argument("--distinct", type=int, default=0, help="0 = every proof of the batch distinct (default); k > 0 = k distinct proofs tiled (the round-1/2 input)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="which of the two N > 1 measurements is `value` (both are printed)")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
+                    help="which of the two N > 1 measurements is `value` (both are printed); auto = strong, the metric as BASELINE.json words it")
+    ap.add_argument("--transcript", choices=("host", "device"), default="host",
+                    help="where the timed region hashes its transcripts: host = the library default / north-star contract (src/transcript.rs on the host)")
     ap.add_argument("--max-batch", type=int, default=65536)
-    ap.add_argument("--extra-log2", type=int, default=18, help="proofs per extra measurement (contract mode, refund)")
+    ap.add_argument("--extra-log2", type=int, default=18, help="proofs per extra measurement (refund, host-memory variants)")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="chunks in flight; 1 for profiling runs (rocprofv3 per-kernel durations then do not overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-node-multi", action="store_true", help="skip the one-process act_node measurement over all N devices")
     # test hooks: exercise the N>1 control path on a box with one GPU (RCCL refuses two ranks on one device)
     ap.add_argument("--dist-backend", default="nccl")
     ap.add_argument("--force-device", type=int, default=-1)
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank (exercises the RCCL rendezvous / barrier / all-reduce path on a one-GPU box)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD process (torch.distributed.run), before this
+    process has imported torch or touched HIP (a process that has initialised the GPU must not exec or fork GPU users on this
+    pool), relay the one JSON line of rank 0 and the exit code.  Checks that the line really is an N-GPU measurement."""
+    import socket
+    with socket.socket() as sk_:
+        sk_.bind(("127.0.0.1", 0)); port = sk_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # RCCL on this pool: dmabuf IPC only
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for l in proc.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        else:
+            print(l, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print("bench.py: the %d-rank run failed (exit code %d)%s" % (args.gpus, proc.returncode, "" if line else ", no JSON line"), file=sys.stderr)
+        raise SystemExit(proc.returncode or 1)
+    got = json.loads(line).get("n_gpus")
+    if got != args.gpus:
+        print("bench.py: asked for %d GPUs, the ranks measured %r" % (args.gpus, got), file=sys.stderr)
+        raise SystemExit(1)
+    print(line)
+    raise SystemExit(0)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     L = args.range_bits
     PB = proof_bytes(L)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE = %d: every rank must be one of the N GPUs the line reports" % (args.gpus, world))
     want_cpu = world == 1 and not args.no_cpu_baseline
     paths = prebuild_cpu_side(want_cpu) if rank == 0 else {}
 
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -331,22 +383,35 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU fallback")
     if args.force_device >= 0:
         local = args.force_device
+    elif world > 1 and torch.cuda.device_count() < local_world:
+        raise SystemExit("bench.py: %d ranks on this node but %d visible GPUs" % (local_world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_dist
+    ctl = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29677")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+        # control-plane group on the CPU: ranks that wait while rank 0 measures `node_multi` must not sit in an RCCL barrier
+        # kernel that polls on their GPU
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
 
     from act_amd import capi
     n = 1 << args.batch_log2
+    tr_mode = capi.TRANSCRIPT_HOST if args.transcript == "host" else capi.TRANSCRIPT_DEVICE
+    # host BLAKE3 workers of this rank: an equal share of the CPUs the node gives its ranks (the ranks are separate processes, each
+    # with its own pool; inside one process the contexts share one pool, csrc/host_pool.cpp)
+    host_threads = max(1, usable_cores() // max(1, local_world))
     h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01", device=local)    # benches/benchmark.rs:9-16
     eng = capi.Engine(h, L, device=local, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
     eng.set_pipeline_depth(args.pipeline_depth)
+    if world > 1:
+        eng.set_host_threads(host_threads)
     sk = eng.private_key_random(shake("bench-sk", 64))
     t_gen = time.perf_counter()
+    eng.prof_reset(); eng.prof_enable(True)
     if args.distinct and args.distinct < n:
         distinct = args.distinct
         first, t_prove = make_distinct_proofs_on_device(eng, capi, torch, np, sk, distinct, L, rank, args.max_batch)
@@ -355,9 +420,12 @@ def main():
         distinct = n
         dev, t_prove = make_distinct_proofs_on_device(eng, capi, torch, np, sk, n, L, rank, args.max_batch)
     torch.cuda.synchronize()
+    eng.prof_enable(False)
+    prover_prof = eng.prof()
     t_gen = time.perf_counter() - t_gen
     expect, idx = tamper(torch, dev, n)
     status = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    eng.set_transcript_mode(tr_mode)
 
     def barrier():
         torch.cuda.synchronize()
@@ -387,7 +455,9 @@ def main():
         assert os.environ.get("ACT_BENCH_NO_CHECK") or torch.equal(status[:m], expect[:m]), "verification statuses wrong"
         return elapsed, eng.prof()
 
-    # weak scaling: every rank its own 2^batch_log2 proofs;  strong scaling: ONE batch of that size over the whole node
+    # N = 1: one region.  N > 1: strong scaling = ONE batch of 2^batch_log2 over the whole node (the metric as BASELINE.json words
+    # it) and weak scaling = every rank its own 2^batch_log2 proofs; --scaling picks which is `value`, both are printed.
+    scaling = "weak" if world == 1 else ("strong" if args.scaling == "auto" else args.scaling)
     weak_elapsed, weak_prof = timed_region(n, args.steps, args.warmup)
     strong = None
     if world > 1:
@@ -398,10 +468,14 @@ def main():
                   "batch_per_gpu": n_s, "launch_chunks_per_gpu": -(-n_s // args.max_batch), "scaling": "strong",
                   "what": "BASELINE.json's metric as worded: ONE 2^%d batch over the whole node, contiguous shards of 2^%d / %d proofs per rank, no collective"
                           % (args.batch_log2, args.batch_log2, world)}
-    elapsed, prof = weak_elapsed, weak_prof
+    if scaling == "strong":
+        elapsed, prof, n_rank = s_elapsed, s_prof, n_s
+    else:
+        elapsed, prof, n_rank = weak_elapsed, weak_prof, n
 
+    out = None
     if rank == 0:
-        value = world * n * args.steps / elapsed
+        value = world * n_rank * args.steps / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
         bits = prof.get("k_spend_bits", {"ms": 0.0, "busy_ms": 0.0, "launches": 1, "lanes": 0})
         launches_per_step = bits["launches"] / args.steps
@@ -414,30 +488,34 @@ def main():
         kernel_ms = {k: {"busy": round(v["busy_ms"] / args.steps, 3), "sum_of_launches": round(v["ms"] / args.steps, 3)} for k, v in prof.items()}
         assert bits["busy_ms"] / args.steps <= ms_per_step * 1.001, "kernel busy time exceeds the step time"
 
+        tr_name = "host BLAKE3 (src/transcript.rs)" if args.transcript == "host" else "device BLAKE3"
         data = ("synthetic: 2^%d DISTINCT valid L=%d proofs per GPU made by the engine's own prover on the device (c uniform in [0,2^%d), s uniform in [0,c]), "
-                "1/1024 lanes tampered; device transcripts" % (args.batch_log2, L, L)) if distinct == n else \
-               ("synthetic: %d distinct valid L=%d proofs made by the engine's own prover, tiled to 2^%d per GPU, 1/1024 lanes tampered; device transcripts"
-                % (distinct, L, args.batch_log2))
+                "1/1024 lanes tampered; %s" % (args.batch_log2, L, L, tr_name)) if distinct == n else \
+               ("synthetic: %d distinct valid L=%d proofs made by the engine's own prover, tiled to 2^%d per GPU, 1/1024 lanes tampered; %s"
+                % (distinct, L, args.batch_log2, tr_name))
+        workload = ("configs[1] scaled to the metric batch: %s, L=%d%s, inputs resident in HBM, transcripts hashed on the host (the library default; "
+                    "pre-images device -> host, challenges back)" if args.transcript == "host" else
+                    "configs[1] scaled to the metric batch: %s, L=%d%s, inputs resident in HBM, transcripts hashed by the device BLAKE3 kernel") % (
+                        ("2^%d spend-proof verifies per GPU" % args.batch_log2) if scaling == "weak" else
+                        ("ONE batch of 2^%d spend-proof verifies over %d GPUs (2^%d / %d per rank)" % (args.batch_log2, world, args.batch_log2, world)),
+                        L, " (the crate's width)" if L == 128 else "")
         out = {
             "metric": "spend-proof verifies/sec (whole node), batch=2^20", "value": value, "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs / u64 accumulators (integer)",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32 limbs / u64 accumulators (integer)",
             "data": data,
-            "config": {"workload": "configs[1] scaled to the metric batch: 2^%d spend-proof verifies per GPU, L=%d%s, inputs resident in HBM"
-                                   % (args.batch_log2, L, " (the crate's width)" if L == 128 else ""),
-                       "batch_per_gpu": n, "distinct_proofs_per_gpu": distinct, "range_bits": L, "lanes_per_launch": args.max_batch,
-                       "chunks_in_flight": args.pipeline_depth, "transcript": "device BLAKE3",
+            "config": {"workload": workload,
+                       "batch_per_gpu": n_rank, "batch_total": world * n_rank, "distinct_proofs_per_gpu": distinct, "range_bits": L, "lanes_per_launch": args.max_batch,
+                       "chunks_in_flight": args.pipeline_depth, "transcript": tr_name,
+                       "host_hash_threads_per_rank": host_threads if world > 1 else usable_cores(), "streams_overlap": eng.streams_overlap(),
                        "fixed_base_window_bits_g_h1_h2_h3": eng.fixed_base_bits(),
-                       "sharding": "independent batches per rank, no collective",
+                       "sharding": ("one batch cut into contiguous shards, one per rank, no collective" if scaling == "strong" else "independent batches per rank, no collective"),
                        "input_generation_s": round(t_gen, 2), "prove_spend_proofs_per_s": round(distinct / t_prove) if t_prove else None},
         }
         if strong:
             out["strong"] = strong
-            if args.scaling == "strong":          # the metric as BASELINE.json words it becomes the headline; the weak figures stay alongside
-                out["weak"] = {"value": value, "ms_per_step": ms_per_step, "batch_per_gpu": n, "scaling": "weak"}
-                out["value"], out["ms_per_step"], out["scaling"] = strong["value"], strong["ms_per_step"], "strong"
-                out["config"]["batch_per_gpu"] = strong["batch_per_gpu"]
-                out["config"]["sharding"] = "one batch cut into contiguous shards, one per rank, no collective"
+            out["weak"] = {"value": world * n * args.steps / weak_elapsed, "unit": "verifies/s", "ms_per_step": 1e3 * weak_elapsed / args.steps, "batch_per_gpu": n,
+                           "scaling": "weak", "what": "every rank its own 2^%d proofs" % args.batch_log2}
         sha = kernel_source_sha16()
         # ---- the binding roofline: measured peak of the multiply-accumulate instruction, counted work per verify --------
         proofs_host = dev[:4].cpu().numpy().tobytes()
@@ -487,7 +565,24 @@ def main():
         out["roofline"] = roof
         out["kernel_ms_per_step"] = kernel_ms
         out["kernel_source_sha16"] = sha
+        try:
+            out["roofline_prover"] = prover_roofline(paths["hostcheck"], prover_prof, peak_mad, h, L, eng, distinct, t_prove, args.max_batch)
+        except Exception as e:          # an accessory measurement must never cost the line
+            out["roofline_prover"] = {"error": repr(e)}
 
+    # ---- the product's own multi-GPU path: ONE process, one node handle over all N devices, one batch from host memory ----------
+    # (rank 0; the other ranks wait on the CPU-side control group with their GPUs idle)
+    if rank == 0 and not args.no_node_multi:
+        devices = tuple(range(world)) if args.force_device < 0 else (args.force_device,) * world
+        try:
+            res = node_host_path(args, capi, torch, np, sk, dev, expect, h, devices, L, PB)
+        except Exception as e:
+            res = {"error": repr(e)}
+        out["host_memory_path" if world == 1 else "node_multi"] = res
+    if ctl is not None:
+        dist.barrier(group=ctl)
+
+    if rank == 0:
         if world == 1 and not args.no_extras:
             out["extra"] = extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinct)
         if want_cpu:
@@ -499,8 +594,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
+        sys.stdout.flush()
     if use_dist:
-        dist.barrier()
+        dist.barrier(group=ctl)
         dist.destroy_process_group()
 
 
@@ -517,29 +613,31 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     sync = torch.cuda.synchronize
     ex = {"proofs_each": m}
     st = torch.zeros(m, dtype=torch.uint8, device="cuda")
-    # (0) what tiling flatters: the round-1/2 input, 4 096 distinct proofs x256 (every 65 536-proof launch holds each proof 16
-    #     times, so the scalar-addressed reads of the 24-bit tables hit in L2 / Infinity Cache)
+    stf = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    # (0) the round-1..3 headline: the same batch with the transcripts hashed by the device BLAKE3 kernel (nothing crosses PCIe)
+    eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
+    sync()
+    dt = timed(lambda: eng.verify_spend_dev(sk, n, dev.data_ptr(), stf.data_ptr()), sync)
+    assert torch.equal(stf, expect)
+    ex["hbm_device_transcripts"] = {"value": n / dt, "unit": "verifies/s", "proofs": n,
+                                    "what": "ACT_TRANSCRIPT_DEVICE over the whole 2^%d batch, proofs in HBM: byte-identical transcripts hashed on the GPU (one step after a warm-up step)" % args.batch_log2}
+    # (0b) what tiling flatters: the round-1/2 input, 4 096 distinct proofs x256 (every 65 536-proof launch holds each proof 16
+    #      times, so the scalar-addressed reads of the 24-bit tables hit in L2 / Infinity Cache)
     if distinct == n and n >= 8192:
         clean = torch.nonzero(expect[:8192] == 0).flatten()[:4096]          # untampered lanes only: tamper() is applied to the tiled copy afresh
         tiled = dev[clean].repeat(n // 4096, 1).contiguous()
         t_exp, _ = tamper(torch, tiled, n)
-        stf = torch.zeros(n, dtype=torch.uint8, device="cuda")
         sync()
         dt = timed(lambda: eng.verify_spend_dev(sk, n, tiled.data_ptr(), stf.data_ptr()), sync)
         assert torch.equal(stf, t_exp)
-        ex["tiled_4096"] = {"value": n / dt, "unit": "verifies/s", "proofs": n, "what": "the same call on 4 096 distinct proofs tiled x%d (one step after a warm-up step)" % (n // 4096)}
-        del tiled, stf
-    # (1) host transcripts (library default, src/transcript.rs stays on the host), inputs in HBM
+        ex["tiled_4096"] = {"value": n / dt, "unit": "verifies/s", "proofs": n, "what": "device transcripts, 4 096 distinct proofs tiled x%d (one step after a warm-up step)" % (n // 4096)}
+        del tiled
+    del stf
+    # (1) host transcripts on a quarter-size batch: pipeline fill and drain are a larger share
     eng.set_transcript_mode(capi.TRANSCRIPT_HOST)
     dt = timed(lambda: eng.verify_spend_dev(sk, m, dev.data_ptr(), st.data_ptr()), sync)
     assert torch.equal(st, expect[:m])
-    ex["host_transcript_hbm"] = {"value": m / dt, "unit": "verifies/s", "what": "ACT_TRANSCRIPT_HOST, proofs and statuses in HBM (ACT_MEM_DEVICE)"}
-    if n > m:                         # the same at the metric batch: pipeline fill and drain amortised over 16 chunks
-        stf = torch.zeros(n, dtype=torch.uint8, device="cuda")
-        dt = timed(lambda: eng.verify_spend_dev(sk, n, dev.data_ptr(), stf.data_ptr()), sync)
-        assert torch.equal(stf, expect)
-        ex["host_transcript_hbm_metric_batch"] = {"value": n / dt, "unit": "verifies/s", "proofs": n,
-                                                  "what": "ACT_TRANSCRIPT_HOST over the whole 2^%d batch, proofs in HBM" % args.batch_log2}
+    ex["host_transcript_hbm"] = {"value": m / dt, "unit": "verifies/s", "what": "ACT_TRANSCRIPT_HOST, 2^%d proofs and statuses in HBM (ACT_MEM_DEVICE)" % args.extra_log2}
     # (2) ... with proofs in pinned host memory and statuses back in host memory
     hp = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); hp.copy_(dev[:m]); sync()
     hs = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
@@ -553,21 +651,27 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     ex["device_transcript_hostmem"] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9,
                                        "what": "ACT_TRANSCRIPT_DEVICE + ACT_MEM_HOST (pinned)"}
     del hp
-    # (2b) latency of small calls (a service answering single redemptions): proofs and statuses in pinned host memory, device transcripts
+    # (2b) the crate's own call shape: one proof per call (src/lib.rs:781-786, benches/benchmark.rs:166-212), and small batches.
+    #      Proofs and statuses in pinned host memory; both transcript modes
     lat = {}
-    hs1 = torch.zeros(4096, dtype=torch.uint8, pin_memory=True); hp1 = torch.empty((4096, PB), dtype=torch.uint8, pin_memory=True); hp1.copy_(dev[:4096]); sync()
-    for k in (1, 64, 4096):
-        ts = []
-        for _ in range(7):
-            t0 = time.perf_counter(); eng.verify_spend_ptr(sk, k, capi.MEM_HOST, hp1.data_ptr(), hs1.data_ptr()); ts.append(time.perf_counter() - t0)
-        assert torch.equal(hs1[:k], expect[:k].cpu())
-        lat["%d" % k] = round(1e3 * sorted(ts)[len(ts) // 2], 3)
-    ex["call_latency_ms"] = {"proofs_per_call": lat, "what": "median wall time of act_verify_spend_batch over 1 / 64 / 4 096 proofs in pinned host memory (device transcripts): "
-                             "one proof is two wavefronts of the range kernel, i.e. the chain's serial depth"}
+    nl = min(n, 16384)
+    hs1 = torch.zeros(nl, dtype=torch.uint8, pin_memory=True); hp1 = torch.empty((nl, PB), dtype=torch.uint8, pin_memory=True); hp1.copy_(dev[:nl]); sync()
+    for mode, key in ((capi.TRANSCRIPT_DEVICE, "device_transcripts"), (capi.TRANSCRIPT_HOST, "host_transcripts")):
+        eng.set_transcript_mode(mode)
+        row = {}
+        for k in (1, 64, 1024, 4096, 16384):
+            if k > nl:
+                continue
+            ts = []
+            for _ in range(7):
+                t0 = time.perf_counter(); eng.verify_spend_ptr(sk, k, capi.MEM_HOST, hp1.data_ptr(), hs1.data_ptr()); ts.append(time.perf_counter() - t0)
+            assert torch.equal(hs1[:k], expect[:k].cpu())
+            med = sorted(ts)[len(ts) // 2]
+            row["%d" % k] = {"ms": round(1e3 * med, 3), "verifies_per_s": round(k / med)}
+        lat[key] = row
+    eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
+    ex["call_latency_ms"] = {"proofs_per_call": lat, "what": "median wall time of one act_verify_spend_batch call over k proofs in pinned host memory"}
     del hp1
-    # (3) the path the Rust binding takes: act_node_verify_spend_batch over devices = [this GPU], proofs and statuses in ordinary
-    #     host memory.  The node's context shares this device's fixed-base tables with the bench's engine (engine.hip table cache).
-    ex["node_host_path"] = node_host_path(args, capi, torch, np, sk, dev, expect, h, local, L, PB)
     # (4) refund = verify + sign (src/lib.rs:787-868), per-lane rng resident in HBM
     g = torch.Generator(device="cuda"); g.manual_seed(7)
     rng = torch.randint(0, 256, (m, 128), dtype=torch.uint8, device="cuda", generator=g)
@@ -588,43 +692,120 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
         assert int(st64.sum()) == 0
         ex["verify_L64"] = {"value": n64 / dt, "unit": "verifies/s", "what": "BASELINE configs[1]: 2^16 distinct spend-proof verifies, 64-bit range, one launch chunk, device transcripts"}
         e64.close()
+    ex["host_pool"] = capi.host_pool_stats()
     return ex
 
 
-def node_host_path(args, capi, torch, np, sk, dev, expect, h, local, L, PB):
+def node_host_path(args, capi, torch, np, sk, dev, expect, h, devices, L, PB):
+    """ONE batch of 2^batch_log2 proofs in ordinary host memory through act_node_verify_spend_batch over `devices` -- one process,
+    one context + one host thread per device, all contexts hashing on the process's one worker pool: what rust/src/mi355x.rs calls.
+    One device: pageable and pinned memory, both transcript modes.  Several devices (rank 0's proofs; the other ranks idle):
+    pageable memory, host transcripts (the library default), plus device transcripts for comparison."""
     n = dev.shape[0]
-    # two host copies of the batch (pinned + pageable): scale the batch down on a box without the memory for it
-    need_gb = 2 * n * PB / 1e9 + 8
+    ndev = len(devices)
+    # host copies of the batch (pinned + pageable at one device): scale the batch down on a box without the memory for it
+    copies = 2 if ndev == 1 else 1
+    need_gb = copies * n * PB / 1e9 + 8
     m = n
-    while m > 4096 and 2 * m * PB / 1e9 + 8 > mem_available_gb():
+    while m > 4096 and copies * m * PB / 1e9 + 8 > mem_available_gb():
         m //= 2
     sync = torch.cuda.synchronize
-    res = {"proofs": m, "host_mem_available_gb": round(mem_available_gb(), 1)}
+    res = {"proofs": m, "devices": list(devices), "host_mem_available_gb": round(mem_available_gb(), 1), "host_threads_usable": usable_cores()}
     if m < n:
-        res["note"] = "batch scaled down from 2^%d: %.0f GB of host memory needed for a pinned and a pageable copy" % (args.batch_log2, need_gb)
-    node = capi.Node(h, L, devices=(local,), max_batch=args.max_batch, transcript=capi.TRANSCRIPT_HOST)
+        res["note"] = "batch scaled down from 2^%d: %.0f GB of host memory needed" % (args.batch_log2, need_gb)
+    node = capi.Node(h, L, devices=devices, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_HOST)
     try:
+        res["streams_overlap"] = node.streams_overlap()
         exp_host = expect[:m].cpu().numpy()
-        pinned = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); pinned.copy_(dev[:m]); sync()
-        st_pin = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
-        for mode, key in ((capi.TRANSCRIPT_HOST, "pinned_host_transcripts"), (capi.TRANSCRIPT_DEVICE, "pinned_device_transcripts")):
-            node.set_transcript_mode(mode)
-            dt = timed(lambda: node.verify_spend_ptr(sk, m, pinned.data_ptr(), st_pin.data_ptr()), sync)
-            assert np.array_equal(st_pin.numpy(), exp_host)
-            res[key] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9}
-        pageable = np.empty((m, PB), np.uint8); pageable[:] = pinned.numpy()
-        del pinned
+        pageable = np.empty((m, PB), np.uint8)
+        step = 1 << 16
+        for off in range(0, m, step):           # through a bounded bounce buffer: no second full-size copy
+            pageable[off:off + step] = dev[off:off + step].cpu().numpy()
         st_pg = np.zeros(m, np.uint8)
         for mode, key in ((capi.TRANSCRIPT_HOST, "pageable_host_transcripts"), (capi.TRANSCRIPT_DEVICE, "pageable_device_transcripts")):
             node.set_transcript_mode(mode)
             dt = timed(lambda: node.verify_spend_ptr(sk, m, pageable.ctypes.data, st_pg.ctypes.data), sync)
             assert np.array_equal(st_pg, exp_host)
             res[key] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9}
-        res["what"] = ("act_node_verify_spend_batch(devices=[%d]) over host pointers: pageable = an ordinary allocation (a Rust Vec), pinned = page-locked; "
-                       "host transcripts = the library default (src/transcript.rs on host threads), %d usable host threads" % (local, usable_cores()))
+        if ndev == 1:
+            pinned = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); pinned.numpy()[:] = pageable
+            st_pin = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
+            for mode, key in ((capi.TRANSCRIPT_HOST, "pinned_host_transcripts"), (capi.TRANSCRIPT_DEVICE, "pinned_device_transcripts")):
+                node.set_transcript_mode(mode)
+                dt = timed(lambda: node.verify_spend_ptr(sk, m, pinned.data_ptr(), st_pin.data_ptr()), sync)
+                assert np.array_equal(st_pin.numpy(), exp_host)
+                res[key] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9}
+            del pinned
+        res["value"] = res["pageable_host_transcripts"]["value"]; res["unit"] = "verifies/s"
+        res["what"] = ("act_node_verify_spend_batch(devices=%s), ONE process, over host pointers: pageable = an ordinary allocation (a Rust Vec), pinned = page-locked; "
+                       "host transcripts = the library default (src/transcript.rs on the process's shared worker pool, %d usable host threads); `value` = pageable, host transcripts"
+                       % (list(devices), usable_cores()))
+        res["host_pool"] = capi.host_pool_stats()
     finally:
         node.close()
     return res
+
+
+def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_batch):
+    """BASELINE configs[2] (2^20 prove_spend): the proof generation in front of the timed region IS that workload, so its kernels
+    are timed with the same HIP events.  Work per proof = field operations executed by the prover kernels' own lane bodies
+    (csrc/prove_lanes.h) on the host, counted by tests/hostcheck; table bytes per proof = fixed-base products x windows x 128 B."""
+    bits = prof.get("k_prove_bits")
+    if not bits:
+        return {"error": "no k_prove_bits launches were timed"}
+    ops = count_prover_ops(hc_path, h, L, eng.fixed_base_bits())
+    launch_s = bits["busy_ms"] / 1e3 / bits["launches"]
+    proofs_per_launch = bits["lanes"] / bits["launches"] / L
+    mad_bits = MAD_PER_MUL * ops["k_prove_bits"]["fe_mul"] + MAD_PER_SQ * ops["k_prove_bits"]["fe_sq"]
+    mad_all = sum(MAD_PER_MUL * v["fe_mul"] + MAD_PER_SQ * v["fe_sq"] for v in ops.values())
+    rate = mad_bits * proofs_per_launch / launch_s
+    table_bytes = ops["k_prove_bits"]["table_reads"] * 128
+    rnd = {}
+    try:
+        from act_amd import capi
+        gbps, ms = capi.ubench_random_read(eng.device)
+        rnd = {"random_128B_read_GBps_measured": gbps, "probe_ms": ms}
+    except Exception as e:
+        rnd = {"random_read_probe_error": repr(e)}
+    tb_rate = table_bytes * proofs_per_launch / launch_s / 1e9
+    out = {"kernel": "k_prove_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
+           "valu": {"achieved": rate, "peak": peak_mad, "frac": rate / peak_mad, "unit": "lane multiply-accumulates (v_mad_u64_u32) per second",
+                    "algorithmic_mad_per_proof_in_this_kernel": mad_bits, "mad_per_proof_whole_path": mad_all},
+           "table_reads": {"bytes_per_proof": table_bytes, "achieved_GBps": tb_rate, "what": "scalar-addressed 128-byte entries of the 24-/16-bit fixed-base tables (47 GB): every read a different line"},
+           "per_kernel_field_ops_per_proof": ops,
+           "kernel_ms_per_65536_proofs": {k: round(v["busy_ms"] / v["launches"], 3) for k, v in prof.items() if k.startswith("k_prove")},
+           "prove_spend_proofs_per_s_wall": round(n_proofs / t_prove) if t_prove else None}
+    out.update(rnd)
+    if rnd.get("random_128B_read_GBps_measured"):
+        out["table_reads"]["frac_of_measured_random_read_rate"] = tb_rate / rnd["random_128B_read_GBps_measured"]
+        f_valu, f_mem = rate / peak_mad, tb_rate / rnd["random_128B_read_GBps_measured"]
+        out["bound"] = "random-read-hbm" if f_mem > f_valu else "valu-int-mad"
+        out["frac"] = max(f_valu, f_mem)
+    return out
+
+
+def count_prover_ops(hc_path, h, L, fb_bits, sample=2):
+    """fe_mul / fe_sq / 128-byte table entries read per proof by each prover kernel: csrc/prove_lanes.h executed on the host with
+    counting field operations (tests/hostcheck hc_prove_spend), restated for the product's window widths like count_field_ops."""
+    hc = ctypes.CDLL(hc_path)
+    if not hasattr(hc, "hc_prove_spend"):
+        raise RuntimeError("tests/hostcheck has no hc_prove_spend")
+    import random
+    r = random.Random(5)
+    n = sample
+    tok = ctypes.create_string_buffer(160 * n); sp = ctypes.create_string_buffer(32 * n); rng = bytes(r.getrandbits(8) for _ in range(64 * (4 * L + 12) * n))
+    c = (ctypes.c_uint64 * 31)()
+    proofs = ctypes.create_string_buffer(proof_bytes(L) * n); prer = ctypes.create_string_buffer(96 * n); st = ctypes.create_string_buffer(n)
+    ok = hc.hc_prove_spend(h, L, n, None, None, rng, proofs, prer, st, c)       # token = None: a synthetic token made from the rng bytes
+    assert ok == 1
+    windows = [-(-253 // b) for b in fb_bits]
+    per = {}
+    for k, name in enumerate(("k_prove_head", "k_prove_bits", "k_prove_enc", "k_prove_tail")):
+        mul, sq = c[6 * k], c[6 * k + 1]
+        fb = [c[6 * k + 2 + b] for b in range(4)]
+        per[name] = {"fe_mul": (mul - sum(fb[b] * (c[24] - windows[b]) * 7 for b in range(4))) / n, "fe_sq": sq / n,
+                     "table_reads": sum(fb[b] * windows[b] for b in range(4)) / n}
+    return per
 
 
 if __name__ == "__main__":

@@ -85,6 +85,9 @@ extern "C" {
 #define ACT_STATUS_AMOUNT_TOO_BIG 8
 #define ACT_STATUS_SCALAR_OUT_OF_RANGE 9
 #define ACT_STATUS_UNDECODABLE 255
+/* act_redeem_batch / act_node_redeem_batch only, and only together with a non-zero function result (see there) */
+#define ACT_STATUS_NULLIFIER_UNDETERMINED 252   /* verified; the nullifier step could not answer: NOT recorded, NOT signed -- resubmit */
+#define ACT_STATUS_RECORDED_UNSIGNED 251        /* verified, nullifier recorded, the signature step failed: the refund is owed -- sign, never redeem again */
 
 typedef struct act_ctx act_ctx;
 
@@ -109,7 +112,25 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
 int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act_ctx **out);
 void act_ctx_destroy(act_ctx *ctx);
 int act_ctx_set_transcript_mode(act_ctx *ctx, int mode);    /* default ACT_TRANSCRIPT_HOST */
-int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);   /* host BLAKE3 workers; 0 = the CPUs the process may use (affinity, cgroup quota) */
+/* Host BLAKE3 workers of the host-transcript mode.  All contexts of a process share ONE pool of act_host_usable_cpus() workers,
+ * started on the first hashing call (never, if only device transcripts are used).  A call takes its fair share of it -- pool size /
+ * (contexts hashing at that moment) -- so the 8 contexts of a node handle get an eighth each when they all hash and the whole pool
+ * when they hash alone; nthreads > 0 caps the share of this context, 0 = no cap.  ACT_NUMA=1 pins worker k to the k-th CPU of the
+ * process's affinity mask. */
+int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);
+int act_host_usable_cpus(void);                             /* CPUs the process may use (affinity mask, cgroup quota) = pool size */
+/* The pool's hashing entry point (what the host-transcript mode calls; pure host code, usable and tested without a GPU):
+ * xof[16*i ..] = first 64 XOF bytes of BLAKE3(msgs + i*stride, len), i < n; max_threads as nthreads above. */
+void act_host_hash_many(const uint8_t *msgs, size_t stride, uint32_t len, size_t n, int max_threads, uint32_t *xof);
+/* diagnostics: hashing calls served, worker threads ever created by this process (constant after the first call), pool size */
+void act_host_pool_stats(uint64_t *jobs, uint64_t *threads_created, int *pool_size);
+/* A context pipelines two chunks on two HIP streams.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware
+ * queues per device and priority (default 4): in a process with many streams both may land on one queue and the chunks then run
+ * one after the other (measured: 415 k instead of 466 k verifies/s from host memory).  act_ctx_create measures this (two idle
+ * wavefronts, 0.3 ms) and, if they share a queue, moves the second stream to another priority class, which has its own queues.
+ * 1 = the streams run side by side, 0 = they still share a queue (set GPU_MAX_HW_QUEUES=8 in the embedding process before HIP
+ * initialises: INTEGRATION.md), -1 = not measured (ACT_NO_STREAM_PROBE set).  The library never edits the process environment. */
+int act_ctx_streams_overlap(const act_ctx *ctx);
 /* chunks in flight per call: 2 (default; chunk i+1's kernels overlap chunk i's low-occupancy head / tail kernels and, in
  * host-transcript mode, its host hashing) or 1 (strictly one after the other: profiling runs whose per-kernel durations
  * must not overlap) */
@@ -127,6 +148,8 @@ int act_build_has_ct_secret_tables(void);
 /* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
  * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 when max_batch >= 32768 and the device has the memory (see above) */
 int act_ctx_fixed_base_bits(const act_ctx *ctx, int base);
+/* Text of the last failure on this handle.  Every *_last_error function copies the text under the handle's lock into a buffer of
+ * the CALLING THREAD (another thread's failing call may be rewriting it), valid until that thread asks again. */
 const char *act_last_error(const act_ctx *ctx);
 size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
 size_t act_prove_rng_bytes(const act_ctx *ctx);             /* 64*(4L+12) */
@@ -282,7 +305,8 @@ int act_nullifier_check_and_insert_batch(act_nullifier_set *set, size_t n, int m
  * Failure of one device: the other devices have checked and inserted their keys all the same, so the call fills in their
  * answers (final), marks the lanes owned by the failed device ACT_NULLIFIER_UNDETERMINED in out_spent, and returns the error;
  * only the undetermined lanes may be resubmitted -- a blind retry of the whole batch would report the honest spends that
- * were already inserted as double spends. */
+ * were already inserted as double spends.  The single-GPU form answers the same way: a batch the set has no room for is refused as
+ * a whole (nothing recorded, every unmasked lane ACT_NULLIFIER_UNDETERMINED). */
 #define ACT_NULLIFIER_UNDETERMINED 2
 typedef struct act_node_nullifier_set act_node_nullifier_set;
 int act_node_nullifier_set_create(const int *devices, int n_devices, size_t capacity_per_device, const uint8_t salt[16],
@@ -303,7 +327,16 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set *set, size_
  * before calling refund and unwraps: same result for valid proofs).  rng / rng_mode as in act_refund_batch: ACT_RNG_SEQUENTIAL hands
  * consecutive 128-byte slices to the lanes that are SIGNED.  The set must live on the context's device.  The node form runs the
  * verification and the signatures on all GPUs and the look-up through the node-level set.  The three steps take their handles'
- * locks one after the other: concurrent callers interleave between steps, never inside one. */
+ * locks one after the other: concurrent callers interleave between steps, never inside one.
+ * Failures: a non-zero result never hides a decision already taken -- status[] is complete when the call returns.
+ *   verification failed (a HIP error)   nothing recorded, nothing signed; status[] not written.
+ *   the nullifier step failed           lanes it answered are finished as usual (0 + refund, or ACT_STATUS_DOUBLE_SPEND); lanes it could
+ *                                       not answer -- the set was too small for the batch, or (node form) their owner GPU failed -- get
+ *                                       ACT_STATUS_NULLIFIER_UNDETERMINED: not recorded, not signed, safe to resubmit.
+ *   the signature step failed           nullifiers ARE recorded; the lanes that were to be signed (node form: those of the failing GPU's
+ *                                       shard) get ACT_STATUS_RECORDED_UNSIGNED and a zero record.  Their refund is owed: call
+ *                                       act_verify_spend_batch(out_kprime) and act_refund_sign_batch on exactly those lanes.  Redeeming them
+ *                                       again would report DoubleSpendError and the client would lose its credits. */
 int act_redeem_batch(act_ctx *ctx, act_nullifier_set *set, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof,
                      const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
 int act_node_redeem_batch(act_node *node, act_node_nullifier_set *set, size_t n, const uint8_t sk[64], const uint8_t *proof,
@@ -337,6 +370,10 @@ int act_prof_get_busy(act_ctx *ctx, int i, double *ms_busy);
 /* ALU roofline probe: rate of the 64-bit multiply-accumulate (v_mad_u64_u32) the field arithmetic is made of, with every
  * SIMD of `device` saturated by register-resident dependency chains.  lane_mads_per_s is summed over lanes; ms = probe time. */
 int act_ubench_mad_u64_u32(int device, double *lane_mads_per_s, double *ms);
+/* Memory-side roofline probe of the scalar-addressed fixed-base tables: every lane reads pseudo-random 128-byte lines (seven 16-byte
+ * loads each, as an affine-Niels table entry is read) of a `gib` GiB buffer (0 = 16) allocated for the probe.  gbytes_per_s counts 128
+ * bytes per read. */
+int act_ubench_random_read(int device, size_t gib, double *gbytes_per_s, double *ms);
 
 #ifdef __cplusplus
 }

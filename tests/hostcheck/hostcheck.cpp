@@ -274,3 +274,79 @@ extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint3
   if (counts) memcpy(counts, c, sizeof(c));
   return 1;
 }
+
+// ---- the prover kernels' own lane bodies (csrc/prove_lanes.h), run lane by lane on the host -----------------------------
+// CreditToken::prove_spend for `n` tokens exactly as k_prove_head / bits / enc / tail / (BLAKE3) / resp execute it: proofs,
+// PreRefunds and statuses out, plus per-kernel operation counts in the layout of hc_spend_verify (counts[6*k ..] for k = head, bits,
+// enc, tail; counts[24] = this build's window count).  tok == nullptr: synthetic tokens (a = the generator's encoding, e | k | r | c
+// and the charges taken from the rng bytes) -- enough for counting, which does not depend on the values.
+#include "../../anonymous-credit-tokens_amd/csrc/prove_lanes.h"
+namespace {
+struct HostFb {
+  const DevParams& P;
+  void stage(int) {}
+  ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc(acc, P.tab[base], s); }
+};
+}  // namespace
+extern "C" int hc_prove_spend(const uint8_t* h, int L, uint32_t n, const uint8_t* tok, const uint8_t* s_amount, const uint8_t* rng, uint8_t* out_proofs,
+                              uint8_t* out_prerefund, uint8_t* out_status, uint64_t* counts) {
+  if (L < 1 || L > 128 || !build_tables(h)) return 0;
+  ProveArgs a{};
+  for (int b = 0; b < 4; b++) a.P.tab[b] = FbTab{g_tabs.tab[b].data(), (uint32_t)FB_WBITS, (uint32_t)b};
+  a.P.L = L;
+  static const char* const labels[4] = {"request", "respond", "spend", "refund"};
+  static const char version[] = "curve25519-ristretto anonymous-credits v1.0";
+  for (int l = 0; l < 4; l++) {
+    std::vector<uint8_t> p; put_lp(p, (const uint8_t*)version, sizeof(version) - 1);
+    put_lp(p, h, 32); put_lp(p, h + 32, 32); put_lp(p, h + 64, 32); put_lp(p, (const uint8_t*)labels[l], strlen(labels[l]));
+    a.P.prefix_len[l] = (uint32_t)p.size(); p.resize(PREFIX_WORDS * 4, 0); memcpy(a.P.prefix[l], p.data(), PREFIX_WORDS * 4);
+  }
+  // the two-entry table of the bit term: identity, h1 / 2 (engine.hip launch_half_point_table)
+  std::vector<uint32_t> half_h1((size_t)2 * NIELS_WORDS, 0u);
+  {
+    niels_store(half_h1.data(), ge_niels_identity());
+    sc one = sc_zero(); one.v[0] = 1;
+    ge hp = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], sc_half(one));
+    fe zi = fe_invert(hp.Z); ge af; af.X = fe_mul(hp.X, zi); af.Y = fe_mul(hp.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
+    niels_store(half_h1.data() + NIELS_WORDS, niels_from_affine(af));
+  }
+  a.P.half_h1 = half_h1.data();
+  std::vector<uint8_t> syn_tok, syn_s;
+  const size_t rb = 64u * (4u * (size_t)L + 12u);
+  if (!tok) {
+    syn_tok.assign((size_t)n * 160, 0); syn_s.assign((size_t)n * 32, 0);
+    for (uint32_t p = 0; p < n; p++) {
+      memcpy(&syn_tok[(size_t)p * 160], kGen, 32);
+      for (int f = 1; f < 5; f++) { memcpy(&syn_tok[(size_t)p * 160 + 32 * f], rng + p * rb + 64 * f, 31); }
+      memcpy(&syn_s[(size_t)p * 32], rng + p * rb + 640, 15);
+    }
+    tok = syn_tok.data(); s_amount = syn_s.data();
+  }
+  const SpendTranscript st{L}; const ProofLayout pl{L};
+  std::vector<uint8_t> tr((size_t)n * st.stride(), 0), status(n, 0);
+  std::vector<uint32_t> d3((size_t)n * 3 * GE_WORDS), half((size_t)n * (L < 2 ? 2 : L) * BUCKET_WORDS), state((size_t)n * 24, 0), flags(n, 0), xof((size_t)n * 16);
+  a.n = n; a.tok = tok; a.s = s_amount; a.rng = rng; a.tr = tr.data(); a.tr_stride = (uint32_t)st.stride(); a.d3 = d3.data(); a.half = half.data();
+  a.state = state.data(); a.flags = flags.data(); a.xof = xof.data(); a.proof = out_proofs; a.prerefund = out_prerefund; a.status = status.data();
+  uint64_t c[31] = {0};
+  c[24] = FB_WINDOWS;
+  auto snap = [&](int k) {
+    c[6 * k] += fe_counts.mul; c[6 * k + 1] += fe_counts.sq;
+    for (int b = 0; b < 4; b++) c[6 * k + 2 + b] += fe_counts.fixed_base[b];
+    fe_counts = fe_counts_t{0, 0, {0, 0, 0, 0}};
+  };
+  fe_counts = fe_counts_t{0, 0, {0, 0, 0, 0}};
+  HostFb fb{a.P};
+  for (uint32_t p = 0; p < n; p++) prove_head_lane(a, p, fb);
+  snap(0);
+  for (uint32_t g = 0; g < n * (uint32_t)L; g++) prove_bits_lane(a, g, fb);
+  snap(1);
+  for (uint64_t q0 = 0; q0 < (uint64_t)n * L * 3; q0 += PROVE_ENC_BATCH) prove_enc_lane(a, q0);
+  snap(2);
+  for (uint32_t p = 0; p < n; p++) prove_tail_lane(a, p, fb);
+  snap(3);
+  for (uint32_t p = 0; p < n; p++) b3_hash_xof64(&xof[(size_t)p * 16], reinterpret_cast<const uint32_t*>(tr.data() + (size_t)p * st.stride()), (uint32_t)st.bytes());
+  for (uint32_t g = 0; g < n * (uint32_t)L; g++) prove_resp_lane(a, g);
+  memcpy(out_status, status.data(), n);
+  if (counts) memcpy(counts, c, sizeof(c));
+  return 1;
+}

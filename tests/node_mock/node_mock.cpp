@@ -18,7 +18,9 @@
 #include "../../include/act_mi355x.h"
 
 struct act_ctx { int device; int L; size_t lanes = 0; std::string err; };
-struct act_nullifier_set { std::set<std::vector<uint8_t>> keys; std::string err; };
+struct act_nullifier_set { std::set<std::vector<uint8_t>> keys; std::string err; int device = 0; };
+// failure injection (error-path tests): the device whose nullifier set / whose signature step fails, -1 = none
+static int g_fail_null_device = -1, g_fail_sign_device = -1;
 static const size_t kPB = 64;        // mock "spend proof" record: 64 bytes
 static std::mutex g_mu;
 
@@ -31,6 +33,7 @@ int act_ctx_set_host_threads(act_ctx*, int) { return ACT_OK; }
 size_t act_spend_proof_bytes(const act_ctx*) { return kPB; }
 size_t act_prove_rng_bytes(const act_ctx*) { return 256; }
 size_t act_mock_lanes(const act_ctx* c) { return c->lanes; }
+void act_mock_fail(int null_device, int sign_device) { g_fail_null_device = null_device; g_fail_sign_device = sign_device; }
 
 static void emit(uint8_t* out, size_t rec, const uint8_t* in, const uint8_t* rng) { memset(out, 0, rec); memcpy(out, in, 8); if (rng) memcpy(out + 8, rng, rec - 8 < 120 ? rec - 8 : 120); }
 
@@ -82,17 +85,19 @@ int act_refund_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* p
   return sign_like(c, n, proof, kPB, nullptr, 7, rng, mode, out, 128, status);
 }
 int act_refund_sign_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status) {
+  if (c->device == g_fail_sign_device) { c->err = "mock: signature step failed"; return ACT_ERR_HIP; }
   return sign_like(c, n, kprime, 32, status_in, 7, rng, mode, out, 128, status);      // K' carries the record's 8-byte tag
 }
 int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int, const uint8_t* prer, const uint8_t* proof, const uint8_t* refund, const uint8_t*, uint8_t* out, uint8_t* status) {
   c->lanes += n; for (size_t i = 0; i < n; i++) { emit(out + 160 * i, 160, prer + 96 * i, refund + 128 * i); out[159 + 160 * i] = proof[kPB * i]; status[i] = 0; } return ACT_OK;
 }
 
-int act_nullifier_set_create(int, size_t, const uint8_t*, act_nullifier_set** out) { *out = new act_nullifier_set(); return ACT_OK; }
+int act_nullifier_set_create(int device, size_t, const uint8_t*, act_nullifier_set** out) { *out = new act_nullifier_set(); (*out)->device = device; return ACT_OK; }
 void act_nullifier_set_destroy(act_nullifier_set* s) { delete s; }
 size_t act_nullifier_set_len(const act_nullifier_set* s) { return s->keys.size(); }
 const char* act_nullifier_set_last_error(const act_nullifier_set* s) { return s->err.c_str(); }
 int act_nullifier_check_and_insert_batch(act_nullifier_set* s, size_t n, int, const uint8_t* k, size_t stride, const uint8_t* mask, uint8_t* spent) {
+  if (s->device == g_fail_null_device) { s->err = "mock: device lost"; return ACT_ERR_HIP; }
   for (size_t i = 0; i < n; i++) {                // like the real set: keys are scalars (reduced mod l) -- so an alias k + l is
     if (mask && mask[i]) { spent[i] = 0; continue; }   // reported spent only if the ROUTING sent it to the set that holds k
     static const uint64_t Lw[4] = {0x5812631a5cf5d3edull, 0x14def9dea2f79cd6ull, 0, 0x1000000000000000ull};

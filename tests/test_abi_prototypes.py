@@ -32,10 +32,10 @@ def kind(param: str) -> str:
             return "ptr:" + re.match(r"(const )?(\w+) \*", p).group(2)
         return "void_p"                      # uint8_t* / uint32_t* / opaque handles
     t = p.rsplit(" ", 1)[0].replace("const ", "")
-    return {"int": "int", "size_t": "size_t", "uint64_t": "u64", "double": "double"}[t]
+    return {"int": "int", "size_t": "size_t", "uint64_t": "u64", "uint32_t": "u32", "double": "double"}[t]
 
 
-CT = {"int": C.c_int, "size_t": C.c_size_t, "u64": C.c_uint64, "double": C.c_double, "void_p": C.c_void_p, "char_p": C.c_char_p}
+CT = {"int": C.c_int, "size_t": C.c_size_t, "u64": C.c_uint64, "u32": C.c_uint32, "double": C.c_double, "void_p": C.c_void_p, "char_p": C.c_char_p}
 
 
 def test_every_prototype_matches_the_binding():

@@ -114,3 +114,69 @@ def test_redeem_over_a_node(engine_factory, oracle, bench_params):
         assert len(ns) == len(db)
     finally:
         ns.close(); node.close()
+
+
+def test_redeem_failures_keep_every_decision(engine_factory, oracle, bench_params, monkeypatch):
+    """a redeem call that fails after verification must still say, lane by lane, what happened.
+    (a) the set has no room for the batch: refused as a whole -- verified lanes 252 (not recorded, not signed), rejected lanes keep
+        their verdict, the set is unchanged, and the same batch goes through on a set that is large enough;
+    (b) the signature step fails after the nullifiers were recorded: lanes that were to be signed report 251 with a zero record,
+        their nullifiers ARE in the set, and verify + refund_sign on exactly those lanes yields the refunds of the loop."""
+    import torch
+    from act_amd import capi
+    L = 8
+    eng = engine_factory(bench_params, L, max_batch=5, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("rd-sk", 64))
+    octx = oracle.ctx(bench_params, L)
+    first, _ = _batches(eng, sk, L)
+    rng = shake("rdf-rng", 128 * 32)
+    want = _sequential_loop(octx, sk, first, rng, set())
+    verdict = [7 if i == 2 else 6 if i == 5 else 255 if i == 7 else 0 for i in range(len(first))]
+    # (a) capacity: a set made for 4 nullifiers holds 1024 slots / 2 = 512: fill it to the brim first
+    small = capi.NullifierSet(4)
+    filler = b"".join((10**9 + i).to_bytes(32, "little") for i in range(505))
+    assert small.check_and_insert(filler) == bytes(505)
+    for mem in ("host", "device"):
+        if mem == "host":
+            with pytest.raises(capi.ActError, match="capacity"):
+                eng.redeem(small, sk, b"".join(first), rng, capi.RNG_SEQUENTIAL)
+        else:
+            d = lambda b: torch.from_numpy(np.frombuffer(b, np.uint8).copy()).cuda()
+            n = len(first)
+            d_p, d_r = d(b"".join(first)), d(rng)
+            d_o = torch.full((n * 128,), 7, dtype=torch.uint8, device="cuda"); d_s = torch.full((n,), 99, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            with pytest.raises(capi.ActError, match="capacity"):
+                eng.redeem_dev(small, sk, n, d_p.data_ptr(), d_r.data_ptr(), capi.RNG_SEQUENTIAL, d_o.data_ptr(), d_s.data_ptr())
+            assert list(d_s.cpu().numpy()) == [v if v else 252 for v in verdict]
+            assert not d_o.cpu().numpy().any()
+        assert len(small) == 505
+    # the host-memory form wrote its statuses too (capi raises before returning them: call the ABI directly)
+    n = len(first)
+    st = np.zeros(n, np.uint8); out = np.full(128 * n, 7, np.uint8)
+    pr = np.frombuffer(b"".join(first), np.uint8); rg = np.frombuffer(rng, np.uint8); skb = np.frombuffer(sk, np.uint8)
+    rc = eng.lib.act_redeem_batch(eng.ctx, small.h, n, capi.MEM_HOST, skb.ctypes.data, pr.ctypes.data, rg.ctypes.data, capi.RNG_SEQUENTIAL, out.ctypes.data, st.ctypes.data)
+    assert rc != 0 and list(st) == [v if v else 252 for v in verdict] and not out.any()
+    small.close()
+    big = capi.NullifierSet(1000)
+    assert eng.redeem(big, sk, b"".join(first), rng, capi.RNG_SEQUENTIAL) == want[:2]
+    big.close()
+    # (b) signature step fails (test hook): recorded, unsigned
+    ns = capi.NullifierSet(1000)
+    monkeypatch.setenv("ACT_TEST_FAIL_REDEEM_SIGN", "1")
+    st = np.zeros(n, np.uint8); out = np.full(128 * n, 7, np.uint8)
+    rc = eng.lib.act_redeem_batch(eng.ctx, ns.h, n, capi.MEM_HOST, skb.ctypes.data, pr.ctypes.data, rg.ctypes.data, capi.RNG_SEQUENTIAL, out.ctypes.data, st.ctypes.data)
+    monkeypatch.delenv("ACT_TEST_FAIL_REDEEM_SIGN")
+    assert rc != 0 and b"signature step" in eng.lib.act_last_error(eng.ctx)
+    assert list(st) == [251 if w == 0 else w for w in want[0]] and not out.any()
+    assert len(ns) == sum(1 for w in want[0] if w == 0)                 # the nullifiers ARE recorded ...
+    owed = [i for i in range(n) if st[i] == 251]
+    sub = b"".join(first[i] for i in owed)
+    st_v, kp = eng.verify_spend(sk, sub, want_kprime=True)              # ... so the refunds are signed, not redeemed again
+    assert st_v == bytes(len(owed))
+    rf = np.zeros(128 * len(owed), np.uint8); st2 = np.zeros(len(owed), np.uint8)
+    kpa = np.frombuffer(kp, np.uint8); sin = np.zeros(len(owed), np.uint8)
+    assert eng.lib.act_refund_sign_batch(eng.ctx, len(owed), capi.MEM_HOST, skb.ctypes.data, kpa.ctypes.data, sin.ctypes.data, rg.ctypes.data, capi.RNG_SEQUENTIAL,
+                                         rf.ctypes.data, st2.ctypes.data) == 0
+    assert rf.tobytes() == b"".join(want[1][128 * i:128 * i + 128] for i in owed)
+    ns.close()

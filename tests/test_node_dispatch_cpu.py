@@ -169,3 +169,65 @@ def test_node_nullifier_routing_is_by_scalar(lib):
     assert lib.act_node_nullifier_check_and_insert_batch(ns, C.c_size_t(300), keys, C.c_size_t(32), mask, spent) == 0
     assert spent.raw == bytes(0 if i % 3 == 0 else 1 for i in range(300))
     lib.act_node_nullifier_set_destroy(ns)
+
+
+def test_node_redeem_keeps_every_decision_when_a_step_fails(lib):
+    """a failure of the nullifier step or of the signature step must not lose what was already decided.  A nullifier
+    device that fails leaves ITS lanes 252 (not recorded, not signed) while all others are finished; a GPU that fails while
+    signing leaves the to-be-signed lanes of ITS shard 251 (recorded, refund owed); the call reports the error either way."""
+    lib.act_node_last_error.restype = C.c_char_p
+    n, ndev = 400, 4
+    recs = records(n, PB, 77)
+    rrng = records(n, 128, 78)
+    verdict = [7 if recs[PB * i] & 1 else 0 for i in range(n)]
+    cut = [(n * k // ndev, n * (k + 1) // ndev) for k in range(ndev)]
+
+    # (a) one device of the nullifier set is lost
+    nd = make_node(lib, ndev)
+    ns = C.c_void_p(); devs = (C.c_int * ndev)(*range(ndev))
+    assert lib.act_node_nullifier_set_create(devs, ndev, C.c_size_t(4 * n), b"0123456789abcdef", C.byref(ns)) == 0
+    lib.act_mock_fail(2, -1)
+    out = C.create_string_buffer(128 * n); st = C.create_string_buffer(n)
+    rc = lib.act_node_redeem_batch(nd, ns, C.c_size_t(n), bytes(64), recs, rrng, 1, out, st)
+    lib.act_mock_fail(-1, -1)
+    assert rc != 0 and b"nullifier set" in lib.act_node_last_error(nd)
+    undetermined = [i for i in range(n) if st.raw[i] == 252]
+    assert 0 < len(undetermined) < sum(1 for v in verdict if v == 0)          # only the failed device's keys
+    cur = 0
+    for i in range(n):
+        if verdict[i]:
+            assert st.raw[i] == 7
+        elif st.raw[i] == 0:                                                    # finished: signed from the sequential stream
+            assert out.raw[128 * i:128 * i + 8] == recs[PB * i:PB * i + 8] and out.raw[128 * i + 8:128 * i + 16] == rrng[128 * cur:128 * cur + 8]
+            cur += 1
+        else:
+            assert st.raw[i] == 252 and out.raw[128 * i:128 * (i + 1)] == bytes(128)
+    recorded = lib.act_node_nullifier_set_len(ns)
+    assert recorded == sum(1 for i in range(n) if st.raw[i] == 0)
+    # resubmitting exactly the undetermined lanes finishes them; nothing is reported as a double spend
+    sub = b"".join(recs[PB * i:PB * (i + 1)] for i in undetermined)
+    out2 = C.create_string_buffer(128 * len(undetermined)); st2 = C.create_string_buffer(len(undetermined))
+    assert lib.act_node_redeem_batch(nd, ns, C.c_size_t(len(undetermined)), bytes(64), sub, rrng, 1, out2, st2) == 0
+    assert st2.raw == bytes(len(undetermined))
+    assert lib.act_node_nullifier_set_len(ns) == recorded + len(undetermined)
+    lib.act_node_nullifier_set_destroy(ns)
+
+    # (b) one GPU fails while signing: its shard's accepted lanes are recorded but unsigned, the other shards are complete
+    ns = C.c_void_p()
+    assert lib.act_node_nullifier_set_create(devs, ndev, C.c_size_t(4 * n), b"0123456789abcdef", C.byref(ns)) == 0
+    lib.act_mock_fail(-1, 1)
+    out = C.create_string_buffer(128 * n); st = C.create_string_buffer(n)
+    rc = lib.act_node_redeem_batch(nd, ns, C.c_size_t(n), bytes(64), recs, rrng, 0, out, st)
+    lib.act_mock_fail(-1, -1)
+    assert rc != 0 and b"device 1" in lib.act_node_last_error(nd)
+    for k, (a, b) in enumerate(cut):
+        for i in range(a, b):
+            if verdict[i]:
+                assert st.raw[i] == 7
+            elif k == 1:
+                assert st.raw[i] == 251 and out.raw[128 * i:128 * (i + 1)] == bytes(128)
+            else:
+                assert st.raw[i] == 0 and out.raw[128 * i:128 * i + 8] == recs[PB * i:PB * i + 8] and out.raw[128 * i + 8:128 * i + 16] == rrng[128 * i:128 * i + 8]
+    assert lib.act_node_nullifier_set_len(ns) == sum(1 for v in verdict if v == 0)      # every accepted nullifier IS recorded
+    lib.act_node_nullifier_set_destroy(ns)
+    lib.act_node_destroy(nd)
