@@ -17,7 +17,7 @@ _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
@@ -77,6 +77,7 @@ def load() -> C.CDLL:
     lib.act_ctx_set_transcript_mode.argtypes = [vp, i32]
     lib.act_ctx_set_host_threads.argtypes = [vp, i32]
     lib.act_ctx_set_pipeline_depth.argtypes = [vp, i32]
+    lib.act_ctx_set_small_batch_max.argtypes = [vp, sz]
     lib.act_host_usable_cpus.argtypes = []
     lib.act_host_hash_many.argtypes = [u8p, sz, C.c_uint32, sz, i32, u8p]
     lib.act_host_hash_many.restype = None
@@ -277,6 +278,10 @@ class Engine:
 
     def set_host_threads(self, n: int):
         self._ck(self.lib.act_ctx_set_host_threads(self.ctx, n))
+
+    def set_small_batch_max(self, n: int):
+        """Calls of at most n proofs take the small-batch (latency) schedule; 0 = never."""
+        self._ck(self.lib.act_ctx_set_small_batch_max(self.ctx, n))
 
     def streams_overlap(self) -> int:
         """1 = the two pipeline streams run side by side, 0 = they share a hardware queue, -1 = not measured."""

@@ -29,10 +29,10 @@ const char kProtocolVersion[] = "curve25519-ristretto anonymous-credits v1.0";  
 const uint8_t kGeneratorEnc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
                                    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
 
-enum ProfId { PK_SPEND_PREP, PK_SPEND_BITS, PK_SPEND_ENC, PK_SPEND_TAIL, PK_HASH_SPEND, PK_SPEND_FINISH, PK_SIGN_A, PK_HASH_SMALL, PK_SIGN_B,
+enum ProfId { PK_SPEND_PREP, PK_SPEND_PREP_A, PK_SPEND_PREP_B, PK_SPEND_PREP_C, PK_SPEND_PREP_JOIN, PK_SPEND_COORDS, PK_SPEND_BITS, PK_SPEND_ENC, PK_SPEND_TAIL, PK_HASH_SPEND, PK_SPEND_FINISH, PK_SIGN_A, PK_HASH_SMALL, PK_SIGN_B,
               PK_ISSUE_A, PK_ISSUE_CHECK, PK_REQUEST_A, PK_REQUEST_B, PK_PROVE_HEAD, PK_PROVE_BITS, PK_PROVE_ENC, PK_PROVE_TAIL, PK_PROVE_RESP,
               PK_CLIENT, PK_COPY_H2D, PK_COPY_D2H, PK_COUNT };
-const char* const kProfNames[PK_COUNT] = {"k_spend_prep", "k_spend_bits", "k_spend_enc", "k_spend_tail", "k_hash_xof(spend)", "k_spend_finish",
+const char* const kProfNames[PK_COUNT] = {"k_spend_prep", "k_spend_prep_a", "k_spend_prep_b", "k_spend_prep_c", "k_spend_prep_join", "k_spend_coords", "k_spend_bits", "k_spend_enc", "k_spend_tail", "k_hash_xof(spend)", "k_spend_finish",
                                           "k_sign_a", "k_hash_xof(small)", "k_sign_b", "k_issue_a", "k_issue_check", "k_request_a",
                                           "k_request_b", "k_prove_head", "k_prove_bits", "k_prove_enc", "k_prove_tail", "k_prove_resp", "k_client_verify",
                                           "copy_h2d(bulk)", "copy_d2h(transcripts)"};
@@ -87,6 +87,11 @@ struct act_ctx {
   double prof_ms[PK_COUNT]{}; uint64_t prof_launches[PK_COUNT]{}; uint64_t prof_lanes[PK_COUNT]{};
   hipEvent_t prof_base = nullptr;                                  // time origin of the launch intervals below
   std::vector<std::pair<float, float>> prof_iv[PK_COUNT];          // [start, end) of every launch, ms since prof_base
+  // small-batch schedule (spend_small_locked): two more streams, the events that tie the four streams together, per-proof scratch
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t sm_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  uint32_t* d_small = nullptr; size_t d_small_cap = 0, d_small_dirty = 0;      // bytes
+  size_t small_max = 16384;            // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
   double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
@@ -104,17 +109,20 @@ namespace {
     }                                                                                               \
   } while (0)
 
+// timing events go on the stream the launch goes on (`stream`; the slot keeps the pending pair)
 template <class F>
-int prof_launch(act_ctx* c, Slot& sl, int id, uint64_t lanes, F&& f) {
+int prof_launch_on(act_ctx* c, Slot& sl, hipStream_t stream, int id, uint64_t lanes, F&& f) {
   if (!c->prof_on) { f(); return ACT_OK; }
   PendingProf p{id, nullptr, nullptr, lanes};
   HIPCK(c, hipEventCreate(&p.e0)); HIPCK(c, hipEventCreate(&p.e1));
-  HIPCK(c, hipEventRecord(p.e0, sl.stream));
+  HIPCK(c, hipEventRecord(p.e0, stream));
   f();
-  HIPCK(c, hipEventRecord(p.e1, sl.stream));
+  HIPCK(c, hipEventRecord(p.e1, stream));
   sl.pending.push_back(p);
   return ACT_OK;
 }
+template <class F>
+int prof_launch(act_ctx* c, Slot& sl, int id, uint64_t lanes, F&& f) { return prof_launch_on(c, sl, sl.stream, id, lanes, static_cast<F&&>(f)); }
 int prof_collect(act_ctx* c, Slot& sl) {
   for (auto& p : sl.pending) {
     HIPCK(c, hipEventSynchronize(p.e1));
@@ -420,6 +428,9 @@ int finish_call(act_ctx* c, size_t n) {
   for (Slot& sl : c->slots) {
     for (int i = 0; i < Slot::N_STAGE; i++)
       if (sl.d_stage_dirty[i]) { HIPCK(c, hipMemsetAsync(sl.d_stage[i], 0, sl.d_stage_dirty[i], sl.stream)); sl.d_stage_dirty[i] = 0; }
+    if (&sl == &c->slots[0] && c->d_small_dirty) {          // the small-batch schedule's partial sums ((e_bar - x gamma) A' among them) and buckets
+      HIPCK(c, hipMemsetAsync(c->d_small, 0, c->d_small_dirty, sl.stream)); c->d_small_dirty = 0;
+    }
     if (lanes) {
       HIPCK(c, hipMemsetAsync(sl.d_state, 0, lanes * 24 * 4, sl.stream));
       HIPCK(c, hipMemsetAsync(sl.d_d01, 0, lanes * 3 * GE_WORDS * 4, sl.stream));
@@ -506,7 +517,7 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
   SpendArgs& a = ch.a;
   a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = ch.d_proofs; a.n = ch.m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride();
   a.coords = sl.d_coords; a.d01 = sl.d_d01; a.buckets = sl.d_buckets; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
-  a.kprime_enc = ch.d_kprime; a.naf = sl.d_naf; a.dig = sl.d_dig;
+  a.kprime_enc = ch.d_kprime; a.naf = sl.d_naf; a.dig = sl.d_dig; a.pbk = sl.d_buckets;
   int rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_PREP, ch.m, [&] { launch_spend_prep(a, sl.stream); }))) return rc;
   // Staggering.  Left alone, the range kernels of the two chunks in flight run side by side, finish together, and then
@@ -659,6 +670,9 @@ void act_ctx_destroy(act_ctx* c) {
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->prof_base) (void)hipEventDestroy(c->prof_base);
+  for (hipStream_t& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
+  for (hipEvent_t& e : c->sm_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (c->d_small) { (void)hipMemset(c->d_small, 0, c->d_small_cap); (void)hipFree(c->d_small); }
   for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
@@ -679,6 +693,7 @@ int act_build_has_ct_secret_tables(void) {
   return 0;
 #endif
 }
+int act_ctx_set_small_batch_max(act_ctx* c, size_t n) { if (!c) return ACT_ERR_ARG; std::lock_guard<std::mutex> lk(c->mu); c->small_max = n; return ACT_OK; }
 int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
 int act_ctx_set_host_threads(act_ctx* c, int n) { if (!c || n < 0) return ACT_ERR_ARG; c->host_threads = n; return ACT_OK; }
 // copied under the context's lock into a buffer of the calling thread (another thread's failing call may rewrite c->err at any
@@ -839,11 +854,86 @@ int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], c
 struct WireSrc { const uint8_t* cbor; const uint64_t* offsets; size_t msg_len; };
 static int wire_unframe_chunk(act_ctx* c, Slot& sl, const WireSrc& w, int mem, size_t off, uint32_t m, const uint8_t** d_records);     // cbor_impl.inc
 
+// ---- the small-batch schedule: one chunk, four streams (spend_lanes.h) ------------------------------------------------------
+// The per-proof kernels run NEXT TO the range kernel instead of in front of and behind it:
+//     slot 0's stream   H2D -> prep role C -> k_spend_bits -> k_spend_enc ............. hash -> finish (-> sign) -> D2H
+//     aux 0             ........ prep role A
+//     aux 1             ........ prep role B -> (A, C done) A1 / A2
+//     slot 1's stream   ........ Com_j decode -> k_spend_tail
+// No two-slot pipeline, no taper: one launch per kernel.  Scratch of the roles lives in d_small, wiped like every other
+// key-dependent buffer (finish_call).
+static int small_prepare(act_ctx* c, size_t n) {
+  if (!c->aux[0]) {
+    int least = 0, greatest = 0;
+    HIPCK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // a priority class of their own: the runtime keeps separate hardware queues per class, so these cannot alias the slots' streams
+    for (hipStream_t& a : c->aux) HIPCK(c, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest));
+    for (hipEvent_t& e : c->sm_ev) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const size_t per_proof = ((size_t)PREP_BUCKET_SETS * BUCKET_WORDS + (size_t)PART_POINTS * GE_WORDS) * 4;
+  if (n * per_proof > c->d_small_cap) {
+    const size_t cap = std::min(c->max_batch, std::max<size_t>(c->small_max, n)) * per_proof;
+    if (c->d_small) { HIPCK(c, hipMemset(c->d_small, 0, c->d_small_cap)); HIPCK(c, hipFree(c->d_small)); c->d_small = nullptr; c->d_small_cap = 0; }
+    HIPCK(c, hipMalloc(&c->d_small, cap)); c->d_small_cap = cap;
+  }
+  c->d_small_dirty = std::max(c->d_small_dirty, n * per_proof);
+  return ACT_OK;
+}
+static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proof, bool sign, const uint8_t* rng, int rng_mode, uint8_t* out_refund,
+                              uint8_t* status, uint8_t* out_kprime) {
+  const SpendTranscript st{c->L};
+  const size_t pb = ProofLayout{c->L}.bytes();
+  int rc = small_prepare(c, n); if (rc) return rc;
+  Slot& sl = c->slots[0];
+  hipStream_t s0 = sl.stream, s_tail = c->slots[1].stream, s_a = c->aux[0], s_b = c->aux[1];
+  hipEvent_t ev_in = c->sm_ev[0], ev_a = c->sm_ev[1], ev_c = c->sm_ev[2], ev_join = c->sm_ev[3], ev_tail = c->sm_ev[4];
+  SpendChunk ch; ch.m = (uint32_t)n; ch.off = 0;
+  if ((rc = dev_in(c, sl, 0, mem, proof, n * pb, &ch.d_proofs))) return rc;
+  if (out_kprime && (rc = dev_out_begin(c, sl, 2, mem, out_kprime, n * 32, &ch.d_kprime))) return rc;
+  if (sign && (rc = dev_out_begin(c, sl, 4, mem, out_refund, n * 128, &ch.d_out))) return rc;
+  SpendArgs& a = ch.a;
+  a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = ch.d_proofs; a.n = ch.m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride();
+  a.coords = sl.d_coords; a.d01 = sl.d_d01; a.buckets = sl.d_buckets; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
+  a.kprime_enc = ch.d_kprime; a.naf = sl.d_naf; a.dig = sl.d_dig;
+  a.pbk = c->d_small; a.part = c->d_small + n * PREP_BUCKET_SETS * BUCKET_WORDS;
+  HIPCK(c, hipMemsetAsync(sl.d_flags, 0, n * 4, s0));               // every kernel ORs its flags in
+  HIPCK(c, hipEventRecord(ev_in, s0));
+  for (hipStream_t s : {s_tail, s_a, s_b}) HIPCK(c, hipStreamWaitEvent(s, ev_in, 0));
+  if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_A, n, [&] { launch_spend_prep_role(a, 0, s_a); }))) return rc;
+  HIPCK(c, hipEventRecord(ev_a, s_a));
+  if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_B, n, [&] { launch_spend_prep_role(a, 1, s_b); }))) return rc;
+  if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_COORDS, n * c->L, [&] { launch_spend_coords(a, s_tail); }))) return rc;
+  if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, n, [&] { launch_spend_tail(a, s_tail); }))) return rc;
+  HIPCK(c, hipEventRecord(ev_tail, s_tail));
+  if ((rc = prof_launch_on(c, sl, s0, PK_SPEND_PREP_C, n, [&] { launch_spend_prep_role(a, 2, s0); }))) return rc;
+  HIPCK(c, hipEventRecord(ev_c, s0));
+  HIPCK(c, hipStreamWaitEvent(s_b, ev_a, 0)); HIPCK(c, hipStreamWaitEvent(s_b, ev_c, 0));
+  if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_JOIN, n, [&] { launch_spend_prep_role(a, 3, s_b); }))) return rc;
+  HIPCK(c, hipEventRecord(ev_join, s_b));
+  if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)n * c->L, [&] { launch_spend_bits(a, s0); }))) return rc;
+  if ((rc = prof_launch(c, sl, PK_SPEND_ENC, (uint64_t)n * c->L * 2, [&] { launch_spend_enc(a, s0); }))) return rc;
+  HIPCK(c, hipStreamWaitEvent(s0, ev_join, 0)); HIPCK(c, hipStreamWaitEvent(s0, ev_tail, 0));
+  if ((rc = hash_step(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), ch.m))) return rc;
+  sl.last_spend_lanes = ch.m; c->last_spend_slot = 0;
+  if ((rc = prof_launch(c, sl, PK_SPEND_FINISH, n, [&] { launch_spend_finish(a, s0); }))) return rc;
+  if (out_kprime && (rc = dev_out_end(c, sl, mem, out_kprime, ch.d_kprime, n * 32))) return rc;
+  if (sign) {
+    const uint8_t* d_rng; size_t cursor = 0;
+    if ((rc = prepare_rng_slots(c, sl, ch.m, 0, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
+    if ((rc = sign_phase(c, sl, ch.m, LABEL_REFUND, d_rng, nullptr, ch.d_out))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_refund, ch.d_out, n * 128))) return rc;
+  }
+  if ((rc = copy_status_out(c, sl, mem, status, ch.m))) return rc;
+  // the other three streams have been joined into s0 by events; sync_all waits for both slots' streams and collects the timings
+  return sync_all(c);
+}
+
 // verify (sign == false) or refund (sign == true), two-slot software pipeline: stage 1 of chunk i+1 is enqueued before
 // the host touches chunk i again.  The caller holds the context (Call).
 static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
                               int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime, const WireSrc* wire = nullptr) {
   int rc = set_key(c, sk); if (rc) return rc;
+  if (!wire && n && n <= c->small_max && n <= c->max_batch) return spend_small_locked(c, n, mem, proof, sign, rng, rng_mode, out_refund, status, out_kprime);
   const size_t pb = ProofLayout{c->L}.bytes();
   static const size_t host_chunk_env = [] { const char* e = getenv("ACT_HOST_CHUNK"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning knob
   // host-transcript mode: a chunk's transcripts go to the host, are hashed there and come back before its status kernel, all
@@ -1073,7 +1163,8 @@ int act_ubench_random_read(int device, size_t gib, double* gbytes_per_s, double*
   if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
-  const size_t bytes = (gib ? gib : 16) << 30;
+  size_t g2 = 1; while (g2 * 2 <= (gib ? gib : 16)) g2 *= 2;                     // a power of two: the kernel masks its line numbers
+  const size_t bytes = g2 << 30;
   const uint64_t lines = bytes / 128;
   const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = 2048;
   uint32_t *buf = nullptr, *out = nullptr; hipEvent_t e0, e1; hipStream_t st;

@@ -154,7 +154,7 @@ void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream
 
 // Random-read roofline probe: what the scalar-addressed look-ups into the wide fixed-base tables (msm.h fixed_base_acc: one 128-byte
 // affine-Niels entry per window, 112 bytes of it read as seven 16-byte loads, every entry on a different line of a 23.6 GB table)
-// can get from HBM at best.  Every lane reads `iters` pseudo-random lines of `lines` (xorshift per lane, so no two lanes share a
+// can get from HBM at best.  Every lane reads `iters` pseudo-random lines of `lines` (a power of two) (xorshift per lane, so no two lanes share a
 // line more than by chance), four independent reads in flight per lane as fixed_base_acc's software pipeline has two.
 __global__ void __launch_bounds__(256) k_ubench_random_read(const uint4* buf, uint64_t lines, uint32_t iters, uint32_t* out) {
   uint64_t x = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_ubench_random_read(const uint4* buf, ui
   for (uint32_t it = 0; it < iters; it += 4) {
     const uint4* q[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; q[k] = buf + (x % lines) * 8; }
+    for (int k = 0; k < 4; k++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; q[k] = buf + (x & (lines - 1)) * 8; }      // lines is a power of two
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll

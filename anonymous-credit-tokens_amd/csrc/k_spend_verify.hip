@@ -12,6 +12,13 @@ __global__ void __launch_bounds__(64, 2) k_spend_prep(SpendArgs a) {
   if (p < a.n) spend_prep_lane(a, p);
 }
 
+// the small-batch schedule's kernels (spend_lanes.h): one role of k_spend_prep each, and the Com_j decode in front of k_spend_tail
+__global__ void __launch_bounds__(64, 2) k_spend_prep_a(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_a_lane(a, p); }
+__global__ void __launch_bounds__(64, 2) k_spend_prep_b(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_b_lane(a, p); }
+__global__ void __launch_bounds__(64, 2) k_spend_prep_c(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_c_lane(a, p); }
+__global__ void __launch_bounds__(64, 2) k_spend_prep_join(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_join_lane(a, p); }
+__global__ void __launch_bounds__(64, 2) k_spend_coords(SpendArgs a) { spend_coords_lane(a, blockIdx.x * 64 + threadIdx.x); }
+
 #ifndef ACT_BITS_BLOCK
 #define ACT_BITS_BLOCK 256
 #endif
@@ -37,6 +44,21 @@ __global__ void __launch_bounds__(256) k_spend_finish(SpendArgs a) {
 }
 
 void launch_spend_prep(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_prep, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
+void launch_spend_prep_role(const SpendArgs& a, int role, hipStream_t s) {
+  if (!a.n) return;
+  const dim3 grid((a.n + 63) / 64), block(64);
+  switch (role) {
+    case 0: hipLaunchKernelGGL(k_spend_prep_a, grid, block, 0, s, a); break;
+    case 1: hipLaunchKernelGGL(k_spend_prep_b, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_spend_prep_c, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_spend_prep_join, grid, block, 0, s, a); break;
+  }
+}
+void launch_spend_coords(const SpendArgs& a, hipStream_t s) {
+  if (!a.n) return;
+  const size_t lanes = (size_t)a.n * a.P.L;
+  hipLaunchKernelGGL(k_spend_coords, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
+}
 void launch_spend_bits(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t lanes = (size_t)a.n * a.P.L;

@@ -74,6 +74,7 @@ struct SpendTranscript {
   ACT_HDC size_t stride() const { return (bytes() + 15u) & ~(size_t)15u; }
 };
 
+constexpr int PART_POINTS = 4;           // small-batch schedule: partial sums of A1 / A2 per proof (spend_lanes.h)
 constexpr int PREP_BUCKET_SETS = 3;      // bucket sets per proof that k_spend_prep's three roles use side by side: d_buckets holds max(L, 3) per proof
 
 struct SpendArgs {
@@ -94,6 +95,10 @@ struct SpendArgs {
   uint8_t* kprime_enc;       // n * 32 or null
   uint32_t* naf;             // n * NAF_WORDS       : width-3-NAF digit string of gamma / 2 (k_spend_prep -> k_spend_bits, msm.h)
   uint32_t* dig;             // n * L * 8           : biased radix-16 digit words of gamma_j0 / 2, per (proof, bit) lane
+  uint32_t* pbk;             // n * PREP_BUCKET_SETS * BUCKET_WORDS: bucket sets of the per-proof kernels (prep role B: sets 1, 2; tail: set 0).
+                             // Large batches: = buckets (prep, bits, tail run one after the other).  Small-batch schedule: an area of
+                             // its own, because those kernels then run NEXT TO k_spend_bits (spend_lanes.h)
+  uint32_t* part;            // small-batch schedule only: n * 4 * GE_WORDS partial sums of A1 / A2 (spend_lanes.h PART_POINTS)
 };
 
 struct SignArgs {
@@ -202,6 +207,8 @@ constexpr int UBENCH_MADS_PER_ITER = 80;    // 8 chains x 10 dependent multiply-
 void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream_t s);
 void launch_debug_scalarmult(const uint8_t* pts, const uint8_t* scs, uint32_t n, uint32_t* pbk, uint8_t* out, uint8_t* status, hipStream_t s);
 void launch_spend_prep(const SpendArgs& a, hipStream_t s);
+void launch_spend_prep_role(const SpendArgs& a, int role /* 0 A, 1 B, 2 C, 3 join */, hipStream_t s);
+void launch_spend_coords(const SpendArgs& a, hipStream_t s);
 void launch_spend_bits(const SpendArgs& a, hipStream_t s);
 void launch_spend_enc(const SpendArgs& a, hipStream_t s);
 void launch_spend_tail(const SpendArgs& a, hipStream_t s);

@@ -73,7 +73,7 @@ ACT_PIECE void spend_prep_role_b(const SpendArgs& a, uint32_t p, uint32_t& flags
   tr_put_aligned(el + 40 * st.el_b_bar(), wb);
   ge acc[2] = {ge_identity(), ge_identity()};
   sc sb[2] = {load_sc(rec + 32 * pl.r2_bar()), load_sc(rec + 32 * pl.r3_bar())};
-  chain_b<2>(acc, B, sb, a.buckets + ((size_t)p * PREP_BUCKET_SETS + 1) * BUCKET_WORDS);
+  chain_b<2>(acc, B, sb, a.pbk + ((size_t)p * PREP_BUCKET_SETS + 1) * BUCKET_WORDS);
   a1b = acc[0]; a2b = acc[1];
 }
 ACT_PIECE ge spend_prep_role_c(const SpendArgs& a, uint32_t p) {
@@ -110,6 +110,52 @@ ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
   spend_prep_put(a, p, st.el_a1(), ge_add(a1a, a1b));
   spend_prep_put(a, p, st.el_a2(), ge_add(a2f, a2b));
   a.flags[p] = flags;     // bits kernel ORs its decode failures in afterwards (same stream)
+}
+
+// ---- the small-batch schedule (engine.hip spend_small): the same pieces as kernels of their own ---------------------------------
+// The crate's call shape is ONE proof per call (/root/reference/src/lib.rs:781-786, benches/benchmark.rs:166-212).  A lane of
+// k_spend_prep is ~8 200 dependent field operations, one of k_spend_tail ~5 300, and below ~2^15 proofs a launch of either leaves
+// most of the chip idle: the serial depth of prep -> bits -> enc -> tail IS the call's latency (5.7 ms for one proof in round 3).
+// Nothing but the transcript hash needs all of them, so small calls run them side by side on four streams:
+//     prep role C -> k_spend_bits -> k_spend_enc   |   prep role A   |   prep role B, then A1 / A2   |   Com_j decode -> k_spend_tail
+// Same lane bodies, same bytes; the roles leave their partial sums in `part` (four points per proof) and every kernel ORs its
+// flags in (the flag words are cleared up front).  Measured: 1 proof 5.7 -> ~2 ms, 4 096 proofs 281 k -> >400 k/s.
+// For throughput at 2^16 proofs per launch the one-lane-per-proof kernels stay as they are (section 8: the three-role form was slower).
+// `part` (kernels.h PART_POINTS = 4 points per proof): a1a = (e_bar - x gamma) A', a1b = r2_bar B_bar, a2b = r3_bar B_bar, a2f (fixed-base part of A2)
+ACT_HD void spend_prep_a_lane(const SpendArgs& a, uint32_t p) {
+  uint32_t flags = 0;
+  ge_store(a.part + ((size_t)p * PART_POINTS + 0) * GE_WORDS, spend_prep_role_a(a, p, flags));
+  if (flags) ACT_FLAG_OR(a.flags + p, flags);
+}
+ACT_HD void spend_prep_b_lane(const SpendArgs& a, uint32_t p) {
+  uint32_t flags = 0;
+  ge a1b, a2b;
+  spend_prep_role_b(a, p, flags, a1b, a2b);
+  ge_store(a.part + ((size_t)p * PART_POINTS + 1) * GE_WORDS, a1b);
+  ge_store(a.part + ((size_t)p * PART_POINTS + 2) * GE_WORDS, a2b);
+  if (flags) ACT_FLAG_OR(a.flags + p, flags);
+}
+ACT_HD void spend_prep_c_lane(const SpendArgs& a, uint32_t p) {
+  ge_store(a.part + ((size_t)p * PART_POINTS + 3) * GE_WORDS, spend_prep_role_c(a, p));
+}
+ACT_HD void spend_prep_join_lane(const SpendArgs& a, uint32_t p) {
+  const SpendTranscript st{a.P.L};
+  const uint32_t* q = a.part + (size_t)p * PART_POINTS * GE_WORDS;
+  spend_prep_put(a, p, st.el_a1(), ge_add(ge_load(q), ge_load(q + GE_WORDS)));
+  spend_prep_put(a, p, st.el_a2(), ge_add(ge_load(q + 3 * GE_WORDS), ge_load(q + 2 * GE_WORDS)));
+}
+// the decoded Com_j for k_spend_tail, which then does not have to wait for k_spend_bits (which decodes them again for itself and
+// stores the same bytes)
+ACT_HD void spend_coords_lane(const SpendArgs& a, uint32_t gid) {
+  const int L = a.P.L;
+  uint32_t p = gid / (uint32_t)L, j = gid % (uint32_t)L;
+  if (p >= a.n) return;
+  const ProofLayout pl{L};
+  uint32_t wc[8];
+  load8(wc, a.proofs + (size_t)p * pl.bytes() + 32 * pl.com(j));
+  ge C;
+  if (!ristretto_decode(C, wc)) ACT_FLAG_OR(a.flags + p, FLAG_UNDECODABLE);
+  niels_store(a.coords + ((size_t)p * L + j) * NIELS_WORDS, niels_from_affine(C));
 }
 
 // `lds_wave` (device): 2 * GE_LDS_WORDS_PER_WAVE words of LDS owned by the calling wavefront (msm.h chain_bu); unused on the host
@@ -209,7 +255,7 @@ ACT_HD void spend_tail_c(const SpendArgs& a, uint32_t p, const ge& kp, const ge&
   const SpendTranscript st{a.P.L};
   ge acc[1] = {f};
   sc sk_[1] = {sc_neg(load_sc(a.proofs + (size_t)p * pl.bytes() + 32 * pl.gamma()))};
-  chain_b<1>(acc, kp, sk_, a.buckets + (size_t)p * PREP_BUCKET_SETS * BUCKET_WORDS);      // the half-points were consumed by k_spend_enc
+  chain_b<1>(acc, kp, sk_, a.pbk + (size_t)p * PREP_BUCKET_SETS * BUCKET_WORDS);      // large batches: pbk = buckets, whose half-points k_spend_enc has consumed
   uint32_t enc[8];
   ristretto_encode(enc, acc[0]); tr_put_aligned(a.tr + (size_t)p * a.tr_stride + 184 + 40 * st.el_c(), enc);
 }

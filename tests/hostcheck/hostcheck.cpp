@@ -231,8 +231,8 @@ bool build_tables(const uint8_t h[96]) {
 void put_lp(std::vector<uint8_t>& v, const uint8_t* b, size_t n) { for (int i = 7; i >= 0; i--) v.push_back((uint8_t)((uint64_t)n >> (8 * i))); v.insert(v.end(), b, b + n); }
 }  // namespace
 
-extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint32_t n, const uint8_t* proofs, uint8_t* out_transcripts,
-                               uint8_t* out_status, uint8_t* out_kprime, uint64_t* counts) {
+static int spend_verify_impl(const uint8_t* h, int L, const uint8_t* sk, uint32_t n, const uint8_t* proofs, uint8_t* out_transcripts,
+                             uint8_t* out_status, uint8_t* out_kprime, uint64_t* counts, bool small_schedule) {
   if (L < 1 || L > 128 || !build_tables(h)) return 0;
   SpendArgs a{};
   for (int b = 0; b < 4; b++) a.P.tab[b] = FbTab{g_tabs.tab[b].data(), (uint32_t)FB_WBITS, (uint32_t)b};
@@ -250,7 +250,7 @@ extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint3
   std::vector<uint32_t> coords((size_t)n * L * NIELS_WORDS), d01((size_t)n * 2 * GE_WORDS), buckets((size_t)n * (L < PREP_BUCKET_SETS ? PREP_BUCKET_SETS : L) * BUCKET_WORDS),
       xa((size_t)n * GE_WORDS), flags(n, 0), xof((size_t)n * 16), naf((size_t)n * NAF_WORDS), dig((size_t)n * L * 8);
   a.proofs = proofs; a.n = n; a.tr = tr.data(); a.tr_stride = (uint32_t)st.stride(); a.coords = coords.data(); a.d01 = d01.data();
-  a.buckets = buckets.data(); a.xa = xa.data(); a.flags = flags.data(); a.xof = xof.data(); a.status = status.data(); a.kprime_enc = kp.data(); a.naf = naf.data(); a.dig = dig.data();
+  a.buckets = buckets.data(); a.xa = xa.data(); a.flags = flags.data(); a.xof = xof.data(); a.status = status.data(); a.kprime_enc = kp.data(); a.naf = naf.data(); a.dig = dig.data(); a.pbk = buckets.data();
   uint64_t c[25] = {0};
   c[24] = FB_WINDOWS;
   auto snap = [&](int k) {
@@ -259,20 +259,48 @@ extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint3
     fe_counts = fe_counts_t{0, 0, {0, 0, 0, 0}};
   };
   fe_counts = fe_counts_t{0, 0, {0, 0, 0, 0}};
-  for (uint32_t p = 0; p < n; p++) spend_prep_lane(a, p);
-  snap(0);
-  for (uint32_t g = 0; g < n * (uint32_t)L; g++) { if (L % 64 == 0) spend_bits_lane<true>(a, g, nullptr); else spend_bits_lane<false>(a, g, nullptr); }
-  snap(1);
-  for (uint64_t q0 = 0; q0 < (uint64_t)n * L * 2; q0 += ENC_BATCH) spend_enc_lane(a, q0);
-  snap(2);
-  for (uint32_t p = 0; p < n; p++) spend_tail_lane(a, p);
-  snap(3);
+  std::vector<uint32_t> small_scratch;
+  if (!small_schedule) {
+    for (uint32_t p = 0; p < n; p++) spend_prep_lane(a, p);
+    snap(0);
+    for (uint32_t g = 0; g < n * (uint32_t)L; g++) { if (L % 64 == 0) spend_bits_lane<true>(a, g, nullptr); else spend_bits_lane<false>(a, g, nullptr); }
+    snap(1);
+    for (uint64_t q0 = 0; q0 < (uint64_t)n * L * 2; q0 += ENC_BATCH) spend_enc_lane(a, q0);
+    snap(2);
+    for (uint32_t p = 0; p < n; p++) spend_tail_lane(a, p);
+    snap(3);
+  } else {
+    // the small-batch schedule's kernels (engine.hip spend_small_locked) in an order the four streams allow that is as far from
+    // the pipelined one as it gets: tail before bits, the roles of prep in reverse, their scratch in an area of its own
+    small_scratch.assign((size_t)n * (PREP_BUCKET_SETS * BUCKET_WORDS + PART_POINTS * GE_WORDS), 0u);
+    a.pbk = small_scratch.data(); a.part = small_scratch.data() + (size_t)n * PREP_BUCKET_SETS * BUCKET_WORDS;
+    for (uint32_t g = 0; g < n * (uint32_t)L; g++) spend_coords_lane(a, g);
+    for (uint32_t p = 0; p < n; p++) spend_tail_lane(a, p);
+    snap(3);
+    for (uint32_t p = 0; p < n; p++) spend_prep_c_lane(a, p);
+    for (uint32_t p = 0; p < n; p++) spend_prep_b_lane(a, p);
+    for (uint32_t p = 0; p < n; p++) spend_prep_a_lane(a, p);
+    for (uint32_t p = 0; p < n; p++) spend_prep_join_lane(a, p);
+    snap(0);
+    for (uint32_t g = 0; g < n * (uint32_t)L; g++) { if (L % 64 == 0) spend_bits_lane<true>(a, g, nullptr); else spend_bits_lane<false>(a, g, nullptr); }
+    snap(1);
+    for (uint64_t q0 = 0; q0 < (uint64_t)n * L * 2; q0 += ENC_BATCH) spend_enc_lane(a, q0);
+    snap(2);
+  }
   for (uint32_t p = 0; p < n; p++) b3_hash_xof64(&xof[(size_t)p * 16], reinterpret_cast<const uint32_t*>(tr.data() + (size_t)p * st.stride()), (uint32_t)st.bytes());
   for (uint32_t p = 0; p < n; p++) spend_finish_lane(a, p);
   for (uint32_t p = 0; p < n; p++) memcpy(out_transcripts + (size_t)p * st.bytes(), tr.data() + (size_t)p * st.stride(), st.bytes());
   memcpy(out_status, status.data(), n); memcpy(out_kprime, kp.data(), (size_t)n * 32);
   if (counts) memcpy(counts, c, sizeof(c));
   return 1;
+}
+extern "C" int hc_spend_verify(const uint8_t* h, int L, const uint8_t* sk, uint32_t n, const uint8_t* proofs, uint8_t* out_transcripts,
+                               uint8_t* out_status, uint8_t* out_kprime, uint64_t* counts) {
+  return spend_verify_impl(h, L, sk, n, proofs, out_transcripts, out_status, out_kprime, counts, false);
+}
+extern "C" int hc_spend_verify_small(const uint8_t* h, int L, const uint8_t* sk, uint32_t n, const uint8_t* proofs, uint8_t* out_transcripts,
+                                     uint8_t* out_status, uint8_t* out_kprime, uint64_t* counts) {
+  return spend_verify_impl(h, L, sk, n, proofs, out_transcripts, out_status, out_kprime, counts, true);
 }
 
 // ---- the prover kernels' own lane bodies (csrc/prove_lanes.h), run lane by lane on the host -----------------------------

@@ -159,7 +159,7 @@ def test_eight_contexts_on_one_pool_do_not_oversubscribe(engine_factory, bench_p
     import time
     import numpy as np
     from act_amd import capi
-    L, n = 128, 1 << 16
+    L, n = 128, 1 << 18          # 2^15 proofs = 8 chunks per context at 8 contexts: steady state, not pipeline fill and drain
     eng = engine_factory(bench_params, L, max_batch=4096, transcript=capi.TRANSCRIPT_DEVICE)
     sk = eng.private_key_random(shake("np-sk", 64))
     base = 64

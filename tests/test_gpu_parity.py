@@ -172,12 +172,18 @@ def test_crafted_scalars_reproduce_the_oracle_transcript(engine_factory, oracle,
         recs.append(bytes(t))
     nc = bytearray(recs[3]); nc[32 * (4 + L):32 * (5 + L)] = ((1 << 253) - 1).to_bytes(32, "little"); recs[3] = bytes(nc)   # gamma >= l
     batch = b"".join(recs)
-    st, kp = eng.verify_spend(sk, batch, True)
-    trs = eng.last_spend_transcripts(N)
-    for i in range(N):
-        so, kpo, tro = octx.verify_spend(sk, recs[i], True)
-        assert so == st[i] and so != 0, i
-        assert trs[i] == tro, i
+    want = [octx.verify_spend(sk, r, True) for r in recs]
+    try:
+        for small_max in (16384, 0):          # the small-batch schedule (N <= max_batch: one chunk on four streams), then the pipelined one
+            eng.set_small_batch_max(small_max)
+            st, kp = eng.verify_spend(sk, batch, True)
+            trs = eng.last_spend_transcripts(N)
+            for i in range(N):
+                so, kpo, tro = want[i]
+                assert so == st[i] and so != 0, (small_max, i)
+                assert trs[i] == tro, (small_max, i)
+    finally:
+        eng.set_small_batch_max(16384)
 
 
 def test_empty_and_single_lane_batches(engine_factory, bench_params):

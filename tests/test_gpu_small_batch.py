@@ -1,0 +1,106 @@
+"""The small-batch schedule (engine.hip spend_small_locked: calls of at most 16 384 proofs run the per-proof kernels next to the
+range kernel on four streams -- the crate's own call shape is ONE proof per call, /root/reference/src/lib.rs:781-786) against the
+pipelined schedule and the C oracle: statuses, enc(K'), refunds under both rng modes and the complete transcripts must be the same
+bytes whichever schedule runs them.  Every rejection kind, ragged widths, single-proof calls."""
+import pytest
+
+from conftest import ELL, shake, scb
+
+pytestmark = pytest.mark.gpu
+
+MODES = [0, 1]   # ACT_TRANSCRIPT_HOST, ACT_TRANSCRIPT_DEVICE
+
+
+def _tampered_batch(eng, octx, sk, L, N, tag):
+    pre = eng.pre_issuance_random(shake(tag + "-pre", 128 * N)); req = eng.request(pre, shake(tag + "-rq", 128 * N))
+    amounts = [(1 << min(L, 60)) // (i + 1) + i for i in range(N)]
+    st, resp = eng.issue(sk, req, b"".join(scb(a) for a in amounts), shake(tag + "-ir", 128 * N))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    assert st == bytes(N)
+    spend = [a // 3 for a in amounts]
+    spend[4] = amounts[4] + 1                               # overspend: produced, then rejected
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(v) for v in spend), shake(tag + "-pr", eng.prove_rng_bytes * N))
+    assert st == bytes(N)
+    pb = eng.proof_bytes
+    t = bytearray(proofs)
+    t[pb * 1 + 33] ^= 2                                     # s
+    t[pb * 3 + 64:pb * 3 + 96] = bytes(32)                  # A' = identity -> 6
+    t[pb * 8 + 32 * (4 + (L - 1)) + 9] ^= 0x40              # last Com: almost surely undecodable -> 255
+    t[pb * 10 + 32 * (12 + L) + 5] ^= 1                     # gamma0[0]
+    t[pb * 12 + 96 + 1] ^= 0x20                             # B_bar
+    t[pb * 13 + 32 * (4 + min(2, L - 1)):pb * 13 + 32 * (5 + min(2, L - 1))] = bytes(32)      # a Com = identity (the base the d-free additions cannot take)
+    t[pb * 15 + 32 * (12 + 2 * L):pb * 15 + 32 * (13 + 2 * L)] = b"\xff" * 32                 # z[0][0] not canonical
+    return bytes(t)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("L", [128, 64, 8, 100, 3])
+def test_both_schedules_give_the_oracle_bytes(engine_factory, oracle, bench_params, L, mode):
+    octx = oracle.ctx(bench_params, L)
+    N = 23
+    eng = engine_factory(bench_params, L, max_batch=32, transcript=mode)            # 23 <= 32: one chunk
+    sk = octx.private_key_random(shake("sb-pk-%d" % L, 64))
+    t = _tampered_batch(eng, octx, sk, L, N, "sb-%d" % L)
+    pb = eng.proof_bytes
+    rrng = shake("sb-rr-%d" % L, 128 * N)
+    want = [octx.verify_spend(sk, t[pb * i:pb * i + pb], True) for i in range(N)]
+    assert {0, 6, 7} <= {w[0] for w in want}
+    try:
+        for small_max in (16384, 0):                          # the small-batch schedule, then the pipelined one on the same engine
+            eng.set_small_batch_max(small_max)
+            st, kp = eng.verify_spend(sk, t, True)
+            trs = eng.last_spend_transcripts(N)
+            for i in range(N):
+                so, kpo, tro = want[i]
+                assert st[i] == so, (small_max, i)
+                assert kp[32 * i:32 * i + 32] == (kpo if so == 0 else bytes(32)), (small_max, i)
+                if so != 6:                                   # the reference returns before building a transcript when A' is the identity
+                    assert trs[i] == tro, (small_max, i)
+            for rng_mode in (0, 1):
+                st, rf = eng.refund(sk, t, rrng, rng_mode)
+                cur = 0
+                for i in range(N):
+                    slot = i if rng_mode == 0 else cur
+                    so, ro = octx.refund(sk, t[pb * i:pb * i + pb], rrng[128 * slot:128 * slot + 128])
+                    assert so == st[i] and ro == rf[128 * i:128 * i + 128], (small_max, rng_mode, i)
+                    cur += so == 0
+            # the crate's call shape: one proof per call
+            for i in (0, 1, 3, 8):
+                st1, kp1 = eng.verify_spend(sk, t[pb * i:pb * i + pb], True)
+                assert st1[0] == want[i][0] and kp1 == (want[i][1] if want[i][0] == 0 else bytes(32)), (small_max, i)
+                st1, rf1 = eng.refund(sk, t[pb * i:pb * i + pb], rrng[:128])
+                assert (st1[0], rf1) == octx.refund(sk, t[pb * i:pb * i + pb], rrng[:128]), (small_max, i)
+        assert eng.secret_residue() == 0                      # the roles' partial sums and buckets are wiped like everything else
+    finally:
+        eng.set_small_batch_max(16384)
+
+
+def test_small_schedule_from_device_memory_and_at_its_size_limit(engine_factory, bench_params):
+    """Device-memory pointers, n = the schedule's limit and one past it (the pipelined schedule takes over): statuses agree with each
+    other and with the tampering, whichever schedule ran."""
+    import numpy as np
+    import torch
+    from act_amd import capi
+    L, D = 8, 64
+    eng = engine_factory(bench_params, L, max_batch=4096, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("sbd-sk", 64))
+    pre = eng.pre_issuance_random(shake("sbd-pre", 128 * D)); req = eng.request(pre, shake("sbd-rq", 128 * D))
+    st, resp = eng.issue(sk, req, scb(200) * D, shake("sbd-ir", 128 * D))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i) for i in range(D)), shake("sbd-pr", eng.prove_rng_bytes * D))
+    assert st == bytes(D)
+    host = np.frombuffer(proofs, np.uint8).reshape(D, eng.proof_bytes)
+    try:
+        eng.set_small_batch_max(2048)
+        for n in (2048, 2049, 1, 63, 64, 65):
+            dev = torch.from_numpy(host.copy()).cuda().repeat((n + D - 1) // D, 1)[:n].contiguous()
+            idx = torch.arange(0, n, 7, device="cuda")
+            dev[idx, 32] ^= 1
+            status = torch.full((n,), 99, dtype=torch.uint8, device="cuda"); kp = torch.zeros((n, 32), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            eng.verify_spend_dev(sk, n, dev.data_ptr(), status.data_ptr(), kp.data_ptr())
+            exp = torch.zeros(n, dtype=torch.uint8, device="cuda"); exp[idx] = 7
+            assert torch.equal(status, exp), n
+            assert bool((kp[idx] == 0).all()) and bool(kp[exp == 0].any(dim=1).all())
+    finally:
+        eng.set_small_batch_max(16384)

@@ -13,13 +13,27 @@ hx = bytes.fromhex
 
 
 def host_verify(hc, h, L, sk, proofs):
+    """Runs the lane bodies in the order of the pipelined schedule AND in the small-batch schedule's (the roles of k_spend_prep as
+    kernels of their own, k_spend_tail in front of k_spend_bits, engine.hip spend_small_locked): the two must agree on every byte
+    and on the operation counts; returns the former."""
     pb = 32 * (14 + 4 * L)
     n = len(proofs) // pb
     tb = 184 + 40 * (6 + 3 * L)
-    tr = C.create_string_buffer(n * tb); st = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
-    counts = (C.c_uint64 * 25)()
-    assert hc.hc_spend_verify(h, L, sk, n, proofs, tr, st, kp, counts) == 1
-    return st.raw, kp.raw, [tr.raw[i * tb:(i + 1) * tb] for i in range(n)], op_counts(list(counts), n)
+    outs = []
+    for fn in (hc.hc_spend_verify, hc.hc_spend_verify_small):
+        tr = C.create_string_buffer(n * tb); st = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
+        counts = (C.c_uint64 * 25)()
+        assert fn(h, L, sk, n, proofs, tr, st, kp, counts) == 1
+        outs.append((st.raw, kp.raw, [tr.raw[i * tb:(i + 1) * tb] for i in range(n)], op_counts(list(counts), n)))
+    a, b = outs
+    assert a[0] == b[0] and a[1] == b[1]
+    for i in range(n):
+        if a[0][i] != 6:                   # A' = identity: the pipelined prep still writes A1 / A2 of a proof that is rejected anyway
+            assert a[2][i] == b[2][i], i
+    small_ops = {k: dict(v) for k, v in b[3].items()}
+    # the small schedule decodes every Com_j twice (once for the tail, once in the range kernel)
+    assert all(small_ops[k]["fe_mul"] == a[3][k]["fe_mul"] for k in ("k_spend_prep", "k_spend_bits", "k_spend_enc"))
+    return a
 
 
 def op_counts(c, n, product_windows=(16, 16, 16, 16)):
