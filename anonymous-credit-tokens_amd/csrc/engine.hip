@@ -87,9 +87,9 @@ struct act_ctx {
   double prof_ms[PK_COUNT]{}; uint64_t prof_launches[PK_COUNT]{}; uint64_t prof_lanes[PK_COUNT]{};
   hipEvent_t prof_base = nullptr;                                  // time origin of the launch intervals below
   std::vector<std::pair<float, float>> prof_iv[PK_COUNT];          // [start, end) of every launch, ms since prof_base
-  // small-batch schedule (spend_small_locked): two more streams, the events that tie the four streams together, per-proof scratch
-  hipStream_t aux[2] = {nullptr, nullptr};
-  hipEvent_t sm_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // small-batch schedule (spend_small_locked): four more streams, the events that tie its streams together, per-proof scratch
+  hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> sm_ev;       // SM_EVENTS per sub-chunk, created on first use, kept
   uint32_t* d_small = nullptr; size_t d_small_cap = 0, d_small_dirty = 0;      // bytes
   size_t small_max = 16384;            // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
   int last_spend_slot = 0;
@@ -671,7 +671,7 @@ void act_ctx_destroy(act_ctx* c) {
   }
   if (c->prof_base) (void)hipEventDestroy(c->prof_base);
   for (hipStream_t& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
-  for (hipEvent_t& e : c->sm_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  for (hipEvent_t e : c->sm_ev) (void)hipEventDestroy(e);
   if (c->d_small) { (void)hipMemset(c->d_small, 0, c->d_small_cap); (void)hipFree(c->d_small); }
   for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
@@ -854,22 +854,29 @@ int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], c
 struct WireSrc { const uint8_t* cbor; const uint64_t* offsets; size_t msg_len; };
 static int wire_unframe_chunk(act_ctx* c, Slot& sl, const WireSrc& w, int mem, size_t off, uint32_t m, const uint8_t** d_records);     // cbor_impl.inc
 
-// ---- the small-batch schedule: one chunk, four streams (spend_lanes.h) ------------------------------------------------------
-// The per-proof kernels run NEXT TO the range kernel instead of in front of and behind it:
-//     slot 0's stream   H2D -> prep role C -> k_spend_bits -> k_spend_enc ............. hash -> finish (-> sign) -> D2H
-//     aux 0             ........ prep role A
-//     aux 1             ........ prep role B -> (A, C done) A1 / A2
-//     slot 1's stream   ........ Com_j decode -> k_spend_tail
-// No two-slot pipeline, no taper: one launch per kernel.  Scratch of the roles lives in d_small, wiped like every other
-// key-dependent buffer (finish_call).
-static int small_prepare(act_ctx* c, size_t n) {
+// ---- the small-batch schedule (spend_lanes.h) ----------------------------------------------------------------------------------
+// A call of at most small_max proofs is cut into sub-chunks of ONE ROUND of the range kernel each (131 072 (proof, bit) lanes = two
+// wavefronts on every SIMD: 1 024 proofs at L = 128), and every kernel of a sub-chunk goes on the stream of its kind, so that the
+// range kernels of consecutive sub-chunks run back to back while everything else happens next to them:
+//     aux 3 (copies)        H2D_0  H2D_1  H2D_2 ...                                   (host-memory callers; then D2H of transcripts, H2D of challenges)
+//     aux 0                 prep role C_k -> prep role A_k                             (C first: the range kernel waits for its digits)
+//     aux 1                 prep role B_k -> (A_k, C_k done) A1 / A2
+//     slot 1's stream       Com_j decode_k -> k_spend_tail_k
+//     slot 0's stream       k_spend_bits_0  k_spend_bits_1  k_spend_bits_2 ...
+//     aux 2                 k_spend_enc_k -> (all of k done) hash_k -> finish_k
+// One proof is then the depth of its longest stream (~1.4 ms of kernels instead of 5); 4 096 proofs are four rounds with the copies
+// and the per-proof kernels hidden under them.  Scratch of the roles lives in d_small, wiped like every other key-dependent
+// buffer (finish_call).  Large calls keep the two-slot pipeline of 65 536-proof chunks (one lane per proof is the cheaper form
+// once a launch fills the chip: DESIGN.md section 8).
+enum { SM_IN = 0, SM_A, SM_C, SM_JOIN, SM_TAIL, SM_BITS, SM_READY, SM_D2H, SM_EVENTS };
+static int small_prepare(act_ctx* c, size_t n, size_t subs) {
   if (!c->aux[0]) {
     int least = 0, greatest = 0;
     HIPCK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
     // a priority class of their own: the runtime keeps separate hardware queues per class, so these cannot alias the slots' streams
     for (hipStream_t& a : c->aux) HIPCK(c, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest));
-    for (hipEvent_t& e : c->sm_ev) HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
+  while (c->sm_ev.size() < subs * SM_EVENTS) { hipEvent_t e; HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->sm_ev.push_back(e); }
   const size_t per_proof = ((size_t)PREP_BUCKET_SETS * BUCKET_WORDS + (size_t)PART_POINTS * GE_WORDS) * 4;
   if (n * per_proof > c->d_small_cap) {
     const size_t cap = std::min(c->max_batch, std::max<size_t>(c->small_max, n)) * per_proof;
@@ -882,49 +889,103 @@ static int small_prepare(act_ctx* c, size_t n) {
 static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proof, bool sign, const uint8_t* rng, int rng_mode, uint8_t* out_refund,
                               uint8_t* status, uint8_t* out_kprime) {
   const SpendTranscript st{c->L};
-  const size_t pb = ProofLayout{c->L}.bytes();
-  int rc = small_prepare(c, n); if (rc) return rc;
+  const size_t pb = ProofLayout{c->L}.bytes(), L = (size_t)c->L;
+  static const size_t sub_env = [] { const char* e = getenv("ACT_SMALL_SUB"); return e ? (size_t)atol(e) : (size_t)0; }();      // tuning knob: proofs per sub-chunk
+  const size_t S = sub_env ? sub_env : std::max<size_t>(64, (131072 / L + 63) / 64 * 64);
+  const size_t K = (n + S - 1) / S;
+  int rc = small_prepare(c, n, K); if (rc) return rc;
   Slot& sl = c->slots[0];
-  hipStream_t s0 = sl.stream, s_tail = c->slots[1].stream, s_a = c->aux[0], s_b = c->aux[1];
-  hipEvent_t ev_in = c->sm_ev[0], ev_a = c->sm_ev[1], ev_c = c->sm_ev[2], ev_join = c->sm_ev[3], ev_tail = c->sm_ev[4];
-  SpendChunk ch; ch.m = (uint32_t)n; ch.off = 0;
-  if ((rc = dev_in(c, sl, 0, mem, proof, n * pb, &ch.d_proofs))) return rc;
-  if (out_kprime && (rc = dev_out_begin(c, sl, 2, mem, out_kprime, n * 32, &ch.d_kprime))) return rc;
-  if (sign && (rc = dev_out_begin(c, sl, 4, mem, out_refund, n * 128, &ch.d_out))) return rc;
-  SpendArgs& a = ch.a;
-  a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = ch.d_proofs; a.n = ch.m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride();
-  a.coords = sl.d_coords; a.d01 = sl.d_d01; a.buckets = sl.d_buckets; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
-  a.kprime_enc = ch.d_kprime; a.naf = sl.d_naf; a.dig = sl.d_dig;
-  a.pbk = c->d_small; a.part = c->d_small + n * PREP_BUCKET_SETS * BUCKET_WORDS;
-  HIPCK(c, hipMemsetAsync(sl.d_flags, 0, n * 4, s0));               // every kernel ORs its flags in
-  HIPCK(c, hipEventRecord(ev_in, s0));
-  for (hipStream_t s : {s_tail, s_a, s_b}) HIPCK(c, hipStreamWaitEvent(s, ev_in, 0));
-  if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_A, n, [&] { launch_spend_prep_role(a, 0, s_a); }))) return rc;
-  HIPCK(c, hipEventRecord(ev_a, s_a));
-  if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_B, n, [&] { launch_spend_prep_role(a, 1, s_b); }))) return rc;
-  if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_COORDS, n * c->L, [&] { launch_spend_coords(a, s_tail); }))) return rc;
-  if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, n, [&] { launch_spend_tail(a, s_tail); }))) return rc;
-  HIPCK(c, hipEventRecord(ev_tail, s_tail));
-  if ((rc = prof_launch_on(c, sl, s0, PK_SPEND_PREP_C, n, [&] { launch_spend_prep_role(a, 2, s0); }))) return rc;
-  HIPCK(c, hipEventRecord(ev_c, s0));
-  HIPCK(c, hipStreamWaitEvent(s_b, ev_a, 0)); HIPCK(c, hipStreamWaitEvent(s_b, ev_c, 0));
-  if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_JOIN, n, [&] { launch_spend_prep_role(a, 3, s_b); }))) return rc;
-  HIPCK(c, hipEventRecord(ev_join, s_b));
-  if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)n * c->L, [&] { launch_spend_bits(a, s0); }))) return rc;
-  if ((rc = prof_launch(c, sl, PK_SPEND_ENC, (uint64_t)n * c->L * 2, [&] { launch_spend_enc(a, s0); }))) return rc;
-  HIPCK(c, hipStreamWaitEvent(s0, ev_join, 0)); HIPCK(c, hipStreamWaitEvent(s0, ev_tail, 0));
-  if ((rc = hash_step(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), ch.m))) return rc;
-  sl.last_spend_lanes = ch.m; c->last_spend_slot = 0;
-  if ((rc = prof_launch(c, sl, PK_SPEND_FINISH, n, [&] { launch_spend_finish(a, s0); }))) return rc;
-  if (out_kprime && (rc = dev_out_end(c, sl, mem, out_kprime, ch.d_kprime, n * 32))) return rc;
+  hipStream_t s_bits = sl.stream, s_tail = c->slots[1].stream, s_a = c->aux[0], s_b = c->aux[1], s_e = c->aux[2], s_x = c->aux[3];
+  auto ev = [&](size_t k, int what) { return c->sm_ev[k * SM_EVENTS + what]; };
+  const bool host_tr = c->tr_mode == ACT_TRANSCRIPT_HOST;
+  // device views of the caller's arrays (staged on slot 0 for host memory; the copies themselves go piece by piece below)
+  const uint8_t* d_proofs = proof; uint8_t *d_kprime = out_kprime, *d_out = out_refund;
+  if (mem == ACT_MEM_HOST) { if ((rc = stage_reserve(c, sl, 0, n * pb))) return rc; d_proofs = sl.d_stage[0]; }
+  if (out_kprime && (rc = dev_out_begin(c, sl, 2, mem, out_kprime, n * 32, &d_kprime))) return rc;
+  if (sign && (rc = dev_out_begin(c, sl, 4, mem, out_refund, n * 128, &d_out))) return rc;
+  if (host_tr) {
+    if (n * st.stride() > sl.h_tr_cap) {
+      if (sl.h_tr) HIPCK(c, hipHostFree(sl.h_tr));
+      sl.h_tr = nullptr; sl.h_tr_cap = 0;
+      HIPCK(c, hipHostMalloc(&sl.h_tr, n * st.stride(), hipHostMallocDefault)); sl.h_tr_cap = n * st.stride();
+    }
+    if (n * 64 > sl.h_xof_cap) {
+      if (sl.h_xof) HIPCK(c, hipHostFree(sl.h_xof));
+      sl.h_xof = nullptr; sl.h_xof_cap = 0;
+      HIPCK(c, hipHostMalloc(&sl.h_xof, n * 64, hipHostMallocDefault)); sl.h_xof_cap = n * 64;
+    }
+  }
+  HIPCK(c, hipMemsetAsync(sl.d_flags, 0, n * 4, s_x));               // every kernel ORs its flags in
+  std::vector<SpendArgs> args(K);
+  for (size_t k = 0; k < K; k++) {
+    const size_t off = k * S, m = std::min(S, n - off);
+    if (mem == ACT_MEM_HOST) {
+      hipError_t ce = hipSuccess;
+      if ((rc = prof_launch_on(c, sl, s_x, PK_COPY_H2D, m * pb, [&] { ce = hipMemcpyAsync(sl.d_stage[0] + off * pb, proof + off * pb, m * pb, hipMemcpyHostToDevice, s_x); }))) return rc;
+      HIPCK(c, ce);
+    }
+    HIPCK(c, hipEventRecord(ev(k, SM_IN), s_x));
+    SpendArgs& a = args[k];
+    a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = d_proofs + off * pb; a.n = (uint32_t)m; a.tr = sl.d_tr + off * st.stride(); a.tr_stride = (uint32_t)st.stride();
+    a.coords = sl.d_coords + off * L * NIELS_WORDS; a.d01 = sl.d_d01 + off * 2 * GE_WORDS; a.buckets = sl.d_buckets + off * L * BUCKET_WORDS;
+    a.xa = sl.d_xa + off * GE_WORDS; a.flags = sl.d_flags + off; a.xof = sl.d_xof + off * 16; a.status = sl.d_status + off;
+    a.kprime_enc = d_kprime ? d_kprime + off * 32 : nullptr; a.naf = sl.d_naf + off * NAF_WORDS; a.dig = sl.d_dig + off * L * 8;
+    a.pbk = c->d_small + off * PREP_BUCKET_SETS * BUCKET_WORDS; a.part = c->d_small + n * PREP_BUCKET_SETS * BUCKET_WORDS + off * PART_POINTS * GE_WORDS;
+    for (hipStream_t s : {s_a, s_b, s_tail}) HIPCK(c, hipStreamWaitEvent(s, ev(k, SM_IN), 0));
+    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 2, s_a); }))) return rc;
+    HIPCK(c, hipEventRecord(ev(k, SM_C), s_a));
+    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_A, m, [&] { launch_spend_prep_role(a, 0, s_a); }))) return rc;
+    HIPCK(c, hipEventRecord(ev(k, SM_A), s_a));
+    if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_B, m, [&] { launch_spend_prep_role(a, 1, s_b); }))) return rc;
+    HIPCK(c, hipStreamWaitEvent(s_b, ev(k, SM_A), 0));                 // role C precedes role A on the same stream
+    if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_JOIN, m, [&] { launch_spend_prep_role(a, 3, s_b); }))) return rc;
+    HIPCK(c, hipEventRecord(ev(k, SM_JOIN), s_b));
+    if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_COORDS, m * L, [&] { launch_spend_coords(a, s_tail); }))) return rc;
+    if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, m, [&] { launch_spend_tail(a, s_tail); }))) return rc;
+    HIPCK(c, hipEventRecord(ev(k, SM_TAIL), s_tail));
+    HIPCK(c, hipStreamWaitEvent(s_bits, ev(k, SM_C), 0));               // implies SM_IN
+    if ((rc = prof_launch_on(c, sl, s_bits, PK_SPEND_BITS, (uint64_t)m * L, [&] { launch_spend_bits(a, s_bits); }))) return rc;
+    HIPCK(c, hipEventRecord(ev(k, SM_BITS), s_bits));
+    HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_BITS), 0));
+    if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_ENC, (uint64_t)m * L * 2, [&] { launch_spend_enc(a, s_e); }))) return rc;
+    HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_JOIN), 0)); HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_TAIL), 0));
+    if (!host_tr) {
+      HashArgs h{a.tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), (uint32_t)m, sl.d_xof + off * 16, nullptr};
+      if ((rc = prof_launch_on(c, sl, s_e, PK_HASH_SPEND, m, [&] { launch_hash(h, s_e); }))) return rc;
+      if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_FINISH, m, [&] { launch_spend_finish(a, s_e); }))) return rc;
+    } else {
+      HIPCK(c, hipEventRecord(ev(k, SM_READY), s_e));
+      HIPCK(c, hipStreamWaitEvent(s_x, ev(k, SM_READY), 0));
+      hipError_t ce = hipSuccess;
+      if ((rc = prof_launch_on(c, sl, s_x, PK_COPY_D2H, m * st.stride(), [&] { ce = hipMemcpyAsync(sl.h_tr + off * st.stride(), a.tr, m * st.stride(), hipMemcpyDeviceToHost, s_x); }))) return rc;
+      HIPCK(c, ce);
+      HIPCK(c, hipEventRecord(ev(k, SM_D2H), s_x));
+    }
+  }
+  if (host_tr)
+    for (size_t k = 0; k < K; k++) {      // hash sub-chunk k on the host while the GPU works on k + 1
+      const size_t off = k * S, m = std::min(S, n - off);
+      HIPCK(c, hipEventSynchronize(ev(k, SM_D2H)));
+      host_hash_many(c, sl.h_tr + off * st.stride(), st.stride(), (uint32_t)st.bytes(), m, sl.h_xof + off * 16);
+      HIPCK(c, hipMemcpyAsync(sl.d_xof + off * 16, sl.h_xof + off * 16, m * 64, hipMemcpyHostToDevice, s_x));
+      if ((rc = prof_launch_on(c, sl, s_x, PK_SPEND_FINISH, m, [&] { launch_spend_finish(args[k], s_x); }))) return rc;
+    }
+  // everything of this call joins slot 0's stream, which carries what is left: outputs, the signatures, the wipe (finish_call)
+  hipStream_t last = host_tr ? s_x : s_e;
+  HIPCK(c, hipEventRecord(ev(0, SM_IN), last));                        // (the events of sub-chunk 0 have all been consumed)
+  HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_IN), 0));
+  sl.last_spend_lanes = n; c->last_spend_slot = 0;
+  if (out_kprime && (rc = dev_out_end(c, sl, mem, out_kprime, d_kprime, n * 32))) return rc;
   if (sign) {
     const uint8_t* d_rng; size_t cursor = 0;
-    if ((rc = prepare_rng_slots(c, sl, ch.m, 0, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
-    if ((rc = sign_phase(c, sl, ch.m, LABEL_REFUND, d_rng, nullptr, ch.d_out))) return rc;
-    if ((rc = dev_out_end(c, sl, mem, out_refund, ch.d_out, n * 128))) return rc;
+    if ((rc = prepare_rng_slots(c, sl, (uint32_t)n, 0, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
+    if ((rc = sign_phase(c, sl, (uint32_t)n, LABEL_REFUND, d_rng, nullptr, d_out))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_refund, d_out, n * 128))) return rc;
   }
-  if ((rc = copy_status_out(c, sl, mem, status, ch.m))) return rc;
-  // the other three streams have been joined into s0 by events; sync_all waits for both slots' streams and collects the timings
+  if ((rc = copy_status_out(c, sl, mem, status, (uint32_t)n))) return rc;
+  // the range kernel's per-lane buckets hold nothing of the issuer's, but they sit where the pipelined schedule keeps per-proof
+  // buckets that do: clear what act_debug_secret_residue looks at
+  HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, std::min(n * L, c->max_batch * (size_t)PREP_BUCKET_SETS) * BUCKET_WORDS * 4, s_bits));
   return sync_all(c);
 }
 

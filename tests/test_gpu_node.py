@@ -154,8 +154,10 @@ def test_bench_two_ranks_on_one_device():
 
 def test_eight_contexts_on_one_pool_do_not_oversubscribe(engine_factory, bench_params):
     """a node handle over 8 contexts in host-transcript mode used to start 8 x all-CPUs threads per hash piece.
-    With the process-wide pool (csrc/host_pool.cpp) the same total batch through devices=(0,)*8 runs within a few percent of
-    devices=(0,)*2, the process creates its workers once, and statuses are identical."""
+    With the process-wide pool (csrc/host_pool.cpp) the process creates its workers once, statuses are identical, and what the
+    HOST side costs does not grow with the number of contexts: on the one GPU of a test box eight contexts contend for the device
+    (16 streams on its hardware queues) in either transcript mode, so the host side is isolated as the ratio host-transcripts /
+    device-transcripts at 8 contexts against the same ratio at 2."""
     import time
     import numpy as np
     from act_amd import capi
@@ -176,17 +178,21 @@ def test_eight_contexts_on_one_pool_do_not_oversubscribe(engine_factory, bench_p
         node = capi.Node(bench_params, L, devices=(0,) * ndev, max_batch=4096, transcript=capi.TRANSCRIPT_HOST)
         try:
             stn = np.zeros(n, np.uint8)
-            node.verify_spend_ptr(sk, n, batch.ctypes.data, stn.ctypes.data)           # warm-up: staging buffers, pinned transcripts, the pool
-            created = capi.host_pool_stats()["threads_created"]
-            best = 1e9
-            for _ in range(3):
-                t0 = time.perf_counter(); node.verify_spend_ptr(sk, n, batch.ctypes.data, stn.ctypes.data); best = min(best, time.perf_counter() - t0)
-            assert stn.tobytes() == want
-            assert capi.host_pool_stats()["threads_created"] == created <= capi.host_usable_cpus()
-            rates[ndev] = n / best
+            for mode in (capi.TRANSCRIPT_HOST, capi.TRANSCRIPT_DEVICE):
+                node.set_transcript_mode(mode)
+                node.verify_spend_ptr(sk, n, batch.ctypes.data, stn.ctypes.data)           # warm-up: staging buffers, pinned transcripts, the pool
+                created = capi.host_pool_stats()["threads_created"]
+                best = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter(); node.verify_spend_ptr(sk, n, batch.ctypes.data, stn.ctypes.data); best = min(best, time.perf_counter() - t0)
+                assert stn.tobytes() == want
+                assert capi.host_pool_stats()["threads_created"] == created <= capi.host_usable_cpus()
+                rates[ndev, mode] = n / best
         finally:
             node.close()
-    assert rates[8] > 0.93 * rates[2], rates
+    H, D = capi.TRANSCRIPT_HOST, capi.TRANSCRIPT_DEVICE
+    print("verifies/s (contexts, transcript mode):", rates)
+    assert rates[8, H] / rates[8, D] > 0.95 * rates[2, H] / rates[2, D], rates
 
 
 def test_bench_rccl_path_with_one_rank():

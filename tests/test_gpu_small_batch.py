@@ -54,7 +54,7 @@ def test_both_schedules_give_the_oracle_bytes(engine_factory, oracle, bench_para
                 so, kpo, tro = want[i]
                 assert st[i] == so, (small_max, i)
                 assert kp[32 * i:32 * i + 32] == (kpo if so == 0 else bytes(32)), (small_max, i)
-                if so != 6:                                   # the reference returns before building a transcript when A' is the identity
+                if so in (0, 7):                              # the reference builds no transcript for an identity A' or an undecodable point
                     assert trs[i] == tro, (small_max, i)
             for rng_mode in (0, 1):
                 st, rf = eng.refund(sk, t, rrng, rng_mode)
