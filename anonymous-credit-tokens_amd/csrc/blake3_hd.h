@@ -64,21 +64,30 @@ ACT_HD uint32_t b3_load_block(uint32_t m[16], const uint32_t* msg, uint32_t len,
   return blen;
 }
 
-// 64 bytes of root output (finalize_xof().fill(&mut [0u8; 64]), src/transcript.rs:150-152)
-ACT_HD void b3_hash_xof64(uint32_t out[16], const uint32_t* msg, uint32_t len) {
+// chaining value of chunk c of a message that has more chunks after it (a full 1 KiB chunk that cannot be the root)
+ACT_HD void b3_chunk_cv(uint32_t cv[8], const uint32_t* msg, uint32_t len, uint32_t c) {
+  uint32_t m[16], o[16];
+  for (int i = 0; i < 8; i++) cv[i] = b3_iv(i);
+  for (uint32_t b = 0; b < 16; b++) {
+    b3_load_block(m, msg, len, c * 1024u + b * 64u);
+    uint32_t fl = (b == 0 ? B3_CHUNK_START : 0u) | (b == 15 ? B3_CHUNK_END : 0u);
+    b3_compress(o, cv, m, c, 0u, 64u, fl);
+    for (int i = 0; i < 8; i++) cv[i] = o[i];
+  }
+}
+
+// 64 bytes of root output (finalize_xof().fill(&mut [0u8; 64]), src/transcript.rs:150-152).  `chunk_cv(c, cv)` supplies the chaining
+// value of every chunk but the last: computed on the spot (b3_hash_xof64) or by other lanes beforehand (k_hash_xof_par, k_misc.hip:
+// the chunks of a BLAKE3 input are independent until the tree is folded).
+template <class ChunkCv>
+ACT_HD void b3_hash_xof64_with(uint32_t out[16], const uint32_t* msg, uint32_t len, ChunkCv chunk_cv) {
   uint32_t nchunks = len ? (len + 1023u) >> 10 : 1u;
   uint32_t stack[8][8];      // one entry per level: enough for 2^8 chunks = messages up to 256 KiB (ours are <= 16 KiB)
   int sp = 0;
   uint32_t cv[8], m[16], o[16];
   // every chunk but the last is finished into a chaining value and merged into the stack
   for (uint32_t c = 0; c + 1 < nchunks; c++) {
-    for (int i = 0; i < 8; i++) cv[i] = b3_iv(i);
-    for (uint32_t b = 0; b < 16; b++) {
-      b3_load_block(m, msg, len, c * 1024u + b * 64u);
-      uint32_t fl = (b == 0 ? B3_CHUNK_START : 0u) | (b == 15 ? B3_CHUNK_END : 0u);
-      b3_compress(o, cv, m, c, 0u, 64u, fl);
-      for (int i = 0; i < 8; i++) cv[i] = o[i];
-    }
+    chunk_cv(c, cv);
     uint32_t t = c + 1;
     while ((t & 1u) == 0u) {       // completed subtree pairs up with the one on the stack
       sp--;
@@ -112,6 +121,9 @@ ACT_HD void b3_hash_xof64(uint32_t out[16], const uint32_t* msg, uint32_t len) {
     ctr = 0; blen = 64u; fl = B3_PARENT;
   }
   b3_compress(out, cv, m, 0u, 0u, blen, fl | B3_ROOT);   // root: counter = output block index 0
+}
+ACT_HD void b3_hash_xof64(uint32_t out[16], const uint32_t* msg, uint32_t len) {
+  b3_hash_xof64_with(out, msg, len, [&](uint32_t c, uint32_t* cv) { b3_chunk_cv(cv, msg, len, c); });
 }
 
 }  // namespace act

@@ -91,7 +91,7 @@ struct act_ctx {
   hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<hipEvent_t> sm_ev;       // SM_EVENTS per sub-chunk, created on first use, kept
   uint32_t* d_small = nullptr; size_t d_small_cap = 0, d_small_dirty = 0;      // bytes
-  size_t small_max = 16384;            // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
+  size_t small_max = 8192;             // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
   double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
@@ -434,7 +434,10 @@ int finish_call(act_ctx* c, size_t n) {
     if (lanes) {
       HIPCK(c, hipMemsetAsync(sl.d_state, 0, lanes * 24 * 4, sl.stream));
       HIPCK(c, hipMemsetAsync(sl.d_d01, 0, lanes * 3 * GE_WORDS * 4, sl.stream));
-      HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, lanes * PREP_BUCKET_SETS * BUCKET_WORDS * 4, sl.stream));
+      // the per-proof kernels' bucket sets -- and, where the range kernel's per-lane buckets (n * L lane areas, nothing of the issuer's
+      // in them) reach into the region those sets live in (calls shorter than max_batch), that part too
+      const size_t sets = std::min(lanes * (size_t)std::max(c->L, PREP_BUCKET_SETS), c->max_batch * (size_t)PREP_BUCKET_SETS);
+      HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, sets * BUCKET_WORDS * 4, sl.stream));
     }
   }
   return sync_all(c);
@@ -874,7 +877,8 @@ static int small_prepare(act_ctx* c, size_t n, size_t subs) {
     int least = 0, greatest = 0;
     HIPCK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
     // a priority class of their own: the runtime keeps separate hardware queues per class, so these cannot alias the slots' streams
-    for (hipStream_t& a : c->aux) HIPCK(c, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, greatest));
+    static const bool normal_prio = getenv("ACT_SMALL_NORMAL_PRIO") != nullptr;      // tuning knob: the same class as the slots' streams
+    for (hipStream_t& a : c->aux) HIPCK(c, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, normal_prio ? 0 : greatest));
   }
   while (c->sm_ev.size() < subs * SM_EVENTS) { hipEvent_t e; HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->sm_ev.push_back(e); }
   const size_t per_proof = ((size_t)PREP_BUCKET_SETS * BUCKET_WORDS + (size_t)PART_POINTS * GE_WORDS) * 4;
@@ -891,7 +895,7 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   const SpendTranscript st{c->L};
   const size_t pb = ProofLayout{c->L}.bytes(), L = (size_t)c->L;
   static const size_t sub_env = [] { const char* e = getenv("ACT_SMALL_SUB"); return e ? (size_t)atol(e) : (size_t)0; }();      // tuning knob: proofs per sub-chunk
-  const size_t S = sub_env ? sub_env : std::max<size_t>(64, (131072 / L + 63) / 64 * 64);
+  const size_t S = sub_env ? sub_env : std::max<size_t>(64, ((size_t)1 << 20) / L);        // measured (profiles/r04_small_sweep.txt): sub-chunks of one round lose to one launch
   const size_t K = (n + S - 1) / S;
   int rc = small_prepare(c, n, K); if (rc) return rc;
   Slot& sl = c->slots[0];
@@ -932,8 +936,9 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     a.kprime_enc = d_kprime ? d_kprime + off * 32 : nullptr; a.naf = sl.d_naf + off * NAF_WORDS; a.dig = sl.d_dig + off * L * 8;
     a.pbk = c->d_small + off * PREP_BUCKET_SETS * BUCKET_WORDS; a.part = c->d_small + n * PREP_BUCKET_SETS * BUCKET_WORDS + off * PART_POINTS * GE_WORDS;
     for (hipStream_t s : {s_a, s_b, s_tail}) HIPCK(c, hipStreamWaitEvent(s, ev(k, SM_IN), 0));
-    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 2, s_a); }))) return rc;
+    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 4, s_a); }))) return rc;      // C1: digits and h2 terms of the range kernel
     HIPCK(c, hipEventRecord(ev(k, SM_C), s_a));
+    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 5, s_a); }))) return rc;      // C2: the fixed-base part of A2
     if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_A, m, [&] { launch_spend_prep_role(a, 0, s_a); }))) return rc;
     HIPCK(c, hipEventRecord(ev(k, SM_A), s_a));
     if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_B, m, [&] { launch_spend_prep_role(a, 1, s_b); }))) return rc;
@@ -947,11 +952,11 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     if ((rc = prof_launch_on(c, sl, s_bits, PK_SPEND_BITS, (uint64_t)m * L, [&] { launch_spend_bits(a, s_bits); }))) return rc;
     HIPCK(c, hipEventRecord(ev(k, SM_BITS), s_bits));
     HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_BITS), 0));
-    if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_ENC, (uint64_t)m * L * 2, [&] { launch_spend_enc(a, s_e); }))) return rc;
+    if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_ENC, (uint64_t)m * L * 2, [&] { launch_spend_enc_small(a, s_e); }))) return rc;
     HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_JOIN), 0)); HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_TAIL), 0));
     if (!host_tr) {
       HashArgs h{a.tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), (uint32_t)m, sl.d_xof + off * 16, nullptr};
-      if ((rc = prof_launch_on(c, sl, s_e, PK_HASH_SPEND, m, [&] { launch_hash(h, s_e); }))) return rc;
+      if ((rc = prof_launch_on(c, sl, s_e, PK_HASH_SPEND, m, [&] { launch_hash_par(h, s_e); }))) return rc;
       if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_FINISH, m, [&] { launch_spend_finish(a, s_e); }))) return rc;
     } else {
       HIPCK(c, hipEventRecord(ev(k, SM_READY), s_e));
@@ -983,9 +988,6 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     if ((rc = dev_out_end(c, sl, mem, out_refund, d_out, n * 128))) return rc;
   }
   if ((rc = copy_status_out(c, sl, mem, status, (uint32_t)n))) return rc;
-  // the range kernel's per-lane buckets hold nothing of the issuer's, but they sit where the pipelined schedule keeps per-proof
-  // buckets that do: clear what act_debug_secret_residue looks at
-  HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, std::min(n * L, c->max_batch * (size_t)PREP_BUCKET_SETS) * BUCKET_WORDS * 4, s_bits));
   return sync_all(c);
 }
 

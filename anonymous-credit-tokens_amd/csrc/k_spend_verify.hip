@@ -16,6 +16,11 @@ __global__ void __launch_bounds__(64, 2) k_spend_prep(SpendArgs a) {
 __global__ void __launch_bounds__(64, 2) k_spend_prep_a(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_a_lane(a, p); }
 __global__ void __launch_bounds__(64, 2) k_spend_prep_b(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_b_lane(a, p); }
 __global__ void __launch_bounds__(64, 2) k_spend_prep_c(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_c_lane(a, p); }
+__global__ void __launch_bounds__(64, 2) k_spend_prep_c1(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_c1_lane(a, p); }
+__global__ void __launch_bounds__(64, 2) k_spend_prep_c2(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_c2_lane(a, p); }
+__global__ void __launch_bounds__(256, 2) k_spend_enc_small(SpendArgs a) {
+  spend_enc_lane_e<ENC_BATCH_SMALL>(a, ((uint64_t)blockIdx.x * 256 + threadIdx.x) * ENC_BATCH_SMALL);
+}
 __global__ void __launch_bounds__(64, 2) k_spend_prep_join(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_join_lane(a, p); }
 __global__ void __launch_bounds__(64, 2) k_spend_coords(SpendArgs a) { spend_coords_lane(a, blockIdx.x * 64 + threadIdx.x); }
 
@@ -51,6 +56,8 @@ void launch_spend_prep_role(const SpendArgs& a, int role, hipStream_t s) {
     case 0: hipLaunchKernelGGL(k_spend_prep_a, grid, block, 0, s, a); break;
     case 1: hipLaunchKernelGGL(k_spend_prep_b, grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL(k_spend_prep_c, grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(k_spend_prep_c1, grid, block, 0, s, a); break;
+    case 5: hipLaunchKernelGGL(k_spend_prep_c2, grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL(k_spend_prep_join, grid, block, 0, s, a); break;
   }
 }
@@ -70,6 +77,11 @@ void launch_spend_enc(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t threads = ((size_t)a.n * a.P.L * 2 + ENC_BATCH - 1) / ENC_BATCH;
   hipLaunchKernelGGL(k_spend_enc, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+}
+void launch_spend_enc_small(const SpendArgs& a, hipStream_t s) {
+  if (!a.n) return;
+  size_t threads = ((size_t)a.n * a.P.L * 2 + ENC_BATCH_SMALL - 1) / ENC_BATCH_SMALL;
+  hipLaunchKernelGGL(k_spend_enc_small, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
 }
 void launch_spend_tail(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
 void launch_spend_finish(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_finish, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }

@@ -200,6 +200,7 @@ void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipS
 void launch_keygen(const DevParams& P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk, hipStream_t s);
 void launch_pre_issuance_random(const uint8_t* rng, uint32_t n, uint8_t* out, hipStream_t s);
 void launch_hash(const HashArgs& a, hipStream_t s);
+void launch_hash_par(const HashArgs& a, hipStream_t s);      // sixteen lanes per message: small calls
 void launch_iota(uint32_t* out, uint32_t n, uint32_t base, hipStream_t s);
 void launch_spin(uint32_t ticks_100mhz, hipStream_t s);
 void launch_ubench_random_read(const uint32_t* buf, uint64_t lines, uint32_t blocks, uint32_t iters, uint32_t* out, hipStream_t s);
@@ -207,7 +208,8 @@ constexpr int UBENCH_MADS_PER_ITER = 80;    // 8 chains x 10 dependent multiply-
 void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream_t s);
 void launch_debug_scalarmult(const uint8_t* pts, const uint8_t* scs, uint32_t n, uint32_t* pbk, uint8_t* out, uint8_t* status, hipStream_t s);
 void launch_spend_prep(const SpendArgs& a, hipStream_t s);
-void launch_spend_prep_role(const SpendArgs& a, int role /* 0 A, 1 B, 2 C, 3 join */, hipStream_t s);
+void launch_spend_prep_role(const SpendArgs& a, int role /* 0 A, 1 B, 2 C, 3 join, 4 C1 (what k_spend_bits waits for), 5 C2 */, hipStream_t s);
+void launch_spend_enc_small(const SpendArgs& a, hipStream_t s);
 void launch_spend_coords(const SpendArgs& a, hipStream_t s);
 void launch_spend_bits(const SpendArgs& a, hipStream_t s);
 void launch_spend_enc(const SpendArgs& a, hipStream_t s);

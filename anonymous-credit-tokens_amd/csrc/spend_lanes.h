@@ -76,23 +76,32 @@ ACT_PIECE void spend_prep_role_b(const SpendArgs& a, uint32_t p, uint32_t& flags
   chain_b<2>(acc, B, sb, a.pbk + ((size_t)p * PREP_BUCKET_SETS + 1) * BUCKET_WORDS);
   a1b = acc[0]; a2b = acc[1];
 }
-ACT_PIECE ge spend_prep_role_c(const SpendArgs& a, uint32_t p) {
+ACT_PIECE ge spend_prep_role_c_a2(const SpendArgs& a, uint32_t p) {
   const ProofLayout pl{a.P.L};
   const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
   tr_put_prefix(a.tr + (size_t)p * a.tr_stride, a.P, LABEL_SPEND);
   sc k = load_sc(rec + 32 * pl.k()), gamma = load_sc(rec + 32 * pl.gamma());
   sc c_bar = load_sc(rec + 32 * pl.c_bar()), r_bar = load_sc(rec + 32 * pl.r_bar());
-  sc w00 = load_sc(rec + 32 * pl.w00()), w01 = load_sc(rec + 32 * pl.w01());
   sc ngamma = sc_neg(gamma);
   ge f = fixed_base_acc(ge_identity(), a.P.tab[BASE_H1], c_bar);
   f = fixed_base_acc(f, a.P.tab[BASE_H3], r_bar);
   f = fixed_base_acc(f, a.P.tab[BASE_G], ngamma);
-  f = fixed_base_acc(f, a.P.tab[BASE_H2], sc_mul(ngamma, k));
+  return fixed_base_acc(f, a.P.tab[BASE_H2], sc_mul(ngamma, k));
+}
+ACT_PIECE void spend_prep_role_c_bits(const SpendArgs& a, uint32_t p) {
+  const ProofLayout pl{a.P.L};
+  const uint8_t* rec = a.proofs + (size_t)p * pl.bytes();
+  sc gamma = load_sc(rec + 32 * pl.gamma());
+  sc w00 = load_sc(rec + 32 * pl.w00()), w01 = load_sc(rec + 32 * pl.w01());
   ge d0 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w00));     // the bits kernel works on C'/2 (k_spend_enc)
   ge d1 = fixed_base_acc(ge_identity(), a.P.tab[BASE_H2], sc_half(w01));
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS, d0);
   ge_store(a.d01 + (size_t)p * 2 * GE_WORDS + GE_WORDS, d1);
   naf3_recode(a.naf + (size_t)p * NAF_WORDS, sc_half(gamma));                 // the proof-wide challenge's digit string for k_spend_bits (msm.h)
+}
+ACT_PIECE ge spend_prep_role_c(const SpendArgs& a, uint32_t p) {
+  ge f = spend_prep_role_c_a2(a, p);
+  spend_prep_role_c_bits(a, p);
   return f;
 }
 ACT_PIECE void spend_prep_put(const SpendArgs& a, uint32_t p, int element, const ge& pt) {
@@ -137,6 +146,12 @@ ACT_HD void spend_prep_b_lane(const SpendArgs& a, uint32_t p) {
 }
 ACT_HD void spend_prep_c_lane(const SpendArgs& a, uint32_t p) {
   ge_store(a.part + ((size_t)p * PART_POINTS + 3) * GE_WORDS, spend_prep_role_c(a, p));
+}
+// role C in two kernels: c1 = the part k_spend_bits waits for (gamma's digit string, w00 h2, w01 h2: two table products), c2 = the
+// rest (the transcript prefix and the four table products of A2)
+ACT_HD void spend_prep_c1_lane(const SpendArgs& a, uint32_t p) { spend_prep_role_c_bits(a, p); }
+ACT_HD void spend_prep_c2_lane(const SpendArgs& a, uint32_t p) {
+  ge_store(a.part + ((size_t)p * PART_POINTS + 3) * GE_WORDS, spend_prep_role_c_a2(a, p));
 }
 ACT_HD void spend_prep_join_lane(const SpendArgs& a, uint32_t p) {
   const SpendTranscript st{a.P.L};
@@ -209,13 +224,17 @@ ACT_HD void spend_bits_lane(const SpendArgs& a, uint32_t gid, uint32_t* lds_wave
 }
 
 // point q = 2 * (p * L + j) + b lives in slot b of lane (p, j)'s bucket area; this lane encodes q0 .. q0 + ENC_BATCH - 1
-ACT_HD void spend_enc_lane(const SpendArgs& a, uint64_t q0) {
+// (E points per lane: ENC_BATCH in the pipelined schedule; the small-batch schedule takes ENC_BATCH_SMALL -- four times the lanes, each
+// a quarter as deep, on a chip it does not fill anyway)
+constexpr int ENC_BATCH_SMALL = 8;
+template <int E>
+ACT_HD void spend_enc_lane_e(const SpendArgs& a, uint64_t q0) {
   const uint32_t L = (uint32_t)a.P.L;
   const uint64_t total = (uint64_t)a.n * L * 2u;
   if (q0 >= total) return;
-  const int count = (int)(total - q0 < (uint64_t)ENC_BATCH ? total - q0 : (uint64_t)ENC_BATCH);
+  const int count = (int)(total - q0 < (uint64_t)E ? total - q0 : (uint64_t)E);
   const SpendTranscript st{a.P.L};
-  dc_encode_batch<ENC_BATCH>(
+  dc_encode_batch<E>(
       count,
       [&](int i) { uint64_t q = q0 + (uint64_t)i; return a.buckets + (size_t)(q >> 1) * BUCKET_WORDS + (q & 1u) * GE_WORDS; },
       [&](int i, const uint32_t* enc) {
@@ -224,6 +243,7 @@ ACT_HD void spend_enc_lane(const SpendArgs& a, uint64_t q0) {
         tr_put_aligned(a.tr + (size_t)p * a.tr_stride + 184 + 40 * st.el_cprime(j, (int)(q & 1u)), enc);
       });
 }
+ACT_HD void spend_enc_lane(const SpendArgs& a, uint64_t q0) { spend_enc_lane_e<ENC_BATCH>(a, q0); }
 
 // ---- k_spend_tail ---------------------------------------------------------------------------------------------------------
 //   K' = sum_j 2^j Com_j by Horner over the decoded points (src/lib.rs:819-824: the reference does 128 separate mults)

@@ -106,6 +106,16 @@ void hc_blake3_xof64(const uint8_t* msg, uint32_t len, uint8_t* out) {
   uint32_t o[16]; b3_hash_xof64(o, w.data(), len); memcpy(out, o, 64);
 }
 }
+// the chunk-parallel form of k_hash_xof_par: every chunk's chaining value first (any order), then the one-lane fold reading them
+extern "C" void hc_blake3_xof64_par(const uint8_t* msg, uint32_t len, uint8_t* out) {
+  std::vector<uint32_t> w((len + 3) / 4 + 1, 0u); if (len) memcpy(w.data(), msg, len);
+  const uint32_t nchunks = len ? (len + 1023u) >> 10 : 1u;
+  std::vector<uint32_t> cvs((size_t)nchunks * 8, 0u);
+  for (uint32_t c = nchunks; c-- > 0;) if (c + 1 < nchunks) b3_chunk_cv(&cvs[(size_t)c * 8], w.data(), len, c);
+  uint32_t o[16];
+  b3_hash_xof64_with(o, w.data(), len, [&](uint32_t c, uint32_t* cv) { memcpy(cv, &cvs[(size_t)c * 8], 32); });
+  memcpy(out, o, 64);
+}
 extern "C" int hc_chain2u(const uint8_t* pt, const uint8_t* s0, const uint8_t* s1, uint8_t* o0, uint8_t* o1) {
   uint32_t w[8], r[8]; ld(w, pt); ge p; if (!ristretto_decode(p, w)) return 0;
   ge al = ge_identity(), au = ge_identity();

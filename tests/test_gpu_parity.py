@@ -174,7 +174,7 @@ def test_crafted_scalars_reproduce_the_oracle_transcript(engine_factory, oracle,
     batch = b"".join(recs)
     want = [octx.verify_spend(sk, r, True) for r in recs]
     try:
-        for small_max in (16384, 0):          # the small-batch schedule (N <= max_batch: one chunk on four streams), then the pipelined one
+        for small_max in (8192, 0):          # the small-batch schedule (N <= max_batch: one chunk on four streams), then the pipelined one
             eng.set_small_batch_max(small_max)
             st, kp = eng.verify_spend(sk, batch, True)
             trs = eng.last_spend_transcripts(N)
@@ -183,7 +183,7 @@ def test_crafted_scalars_reproduce_the_oracle_transcript(engine_factory, oracle,
                 assert so == st[i] and so != 0, (small_max, i)
                 assert trs[i] == tro, (small_max, i)
     finally:
-        eng.set_small_batch_max(16384)
+        eng.set_small_batch_max(8192)
 
 
 def test_empty_and_single_lane_batches(engine_factory, bench_params):

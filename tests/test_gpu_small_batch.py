@@ -46,7 +46,7 @@ def test_both_schedules_give_the_oracle_bytes(engine_factory, oracle, bench_para
     want = [octx.verify_spend(sk, t[pb * i:pb * i + pb], True) for i in range(N)]
     assert {0, 6, 7} <= {w[0] for w in want}
     try:
-        for small_max in (16384, 0):                          # the small-batch schedule, then the pipelined one on the same engine
+        for small_max in (8192, 0):                          # the small-batch schedule, then the pipelined one on the same engine
             eng.set_small_batch_max(small_max)
             st, kp = eng.verify_spend(sk, t, True)
             trs = eng.last_spend_transcripts(N)
@@ -72,7 +72,7 @@ def test_both_schedules_give_the_oracle_bytes(engine_factory, oracle, bench_para
                 assert (st1[0], rf1) == octx.refund(sk, t[pb * i:pb * i + pb], rrng[:128]), (small_max, i)
         assert eng.secret_residue() == 0                      # the roles' partial sums and buckets are wiped like everything else
     finally:
-        eng.set_small_batch_max(16384)
+        eng.set_small_batch_max(8192)
 
 
 def test_small_schedule_from_device_memory_and_at_its_size_limit(engine_factory, bench_params):
@@ -103,4 +103,60 @@ def test_small_schedule_from_device_memory_and_at_its_size_limit(engine_factory,
             assert torch.equal(status, exp), n
             assert bool((kp[idx] == 0).all()) and bool(kp[exp == 0].any(dim=1).all())
     finally:
-        eng.set_small_batch_max(16384)
+        eng.set_small_batch_max(8192)
+
+
+_CHILD = r"""
+import hashlib, json, sys
+sys.path.insert(0, %(root)r)
+from act_amd import capi
+sh = lambda l, n: hashlib.shake_256(l.encode()).digest(n)
+L, N = 8, 203
+h = bytes.fromhex(%(h)r)
+eng = capi.Engine(h, L, max_batch=256, transcript=int(sys.argv[1]))
+sk = bytes.fromhex(%(sk)r)
+batch = open(%(path)r, "rb").read()
+st, kp = eng.verify_spend(sk, batch, True)
+st2, rf = eng.refund(sk, batch, sh("sbs-rr", 128 * N), 1)
+print(json.dumps({"st": st.hex(), "kp": hashlib.sha256(kp).hexdigest(), "st2": st2.hex(), "rf": hashlib.sha256(rf).hexdigest(), "residue": eng.secret_residue()}))
+"""
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_sub_chunked_small_schedule(engine_factory, bench_params, tmp_path, mode):
+    """The schedule's sub-chunking (several sub-chunks on the six streams, ACT_SMALL_SUB: a tuning knob read once per process, so a
+    child process) against this process's pipelined schedule: 203 proofs in sub-chunks of 64, the last one ragged."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    L, N = 8, 203
+    eng = engine_factory(bench_params, L, max_batch=256, transcript=mode)
+    sk = eng.private_key_random(shake("sbs-sk", 64))
+    pre = eng.pre_issuance_random(shake("sbs-pre", 128 * N)); req = eng.request(pre, shake("sbs-rq", 128 * N))
+    st, resp = eng.issue(sk, req, scb(200) * N, shake("sbs-ir", 128 * N))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i % 150) for i in range(N)), shake("sbs-pr", eng.prove_rng_bytes * N))
+    assert st == bytes(N)
+    t = bytearray(proofs); pb = eng.proof_bytes
+    for i in range(0, N, 9):
+        t[pb * i + 33] ^= 1
+    t[pb * 70 + 64:pb * 70 + 96] = bytes(32)
+    t = bytes(t)
+    try:
+        eng.set_small_batch_max(0)
+        st, kp = eng.verify_spend(sk, t, True)
+        st2, rf = eng.refund(sk, t, shake("sbs-rr", 128 * N), 1)
+    finally:
+        eng.set_small_batch_max(8192)
+    assert {0, 6, 7} <= set(st)
+    path = tmp_path / "batch.bin"
+    path.write_bytes(t)
+    src = _CHILD % {"root": ROOT, "h": bench_params.hex(), "sk": sk.hex(), "path": str(path)}
+    r = subprocess.run([sys.executable, "-c", src, str(mode)], capture_output=True, text=True, timeout=600, env=dict(os.environ, ACT_SMALL_SUB="64"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["st"] == st.hex() and d["kp"] == hashlib.sha256(kp).hexdigest()
+    assert d["st2"] == st2.hex() and d["rf"] == hashlib.sha256(rf).hexdigest() and d["residue"] == 0

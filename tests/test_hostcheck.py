@@ -115,6 +115,9 @@ def test_blake3_against_upstream_vectors(hostcheck):
         out = C.create_string_buffer(64)
         hostcheck.hc_blake3_xof64(data, v["len"], out)
         assert out.raw.hex() == v["xof"][:128], v["len"]
+        # the chunk-parallel form (k_hash_xof_par: chaining values of the chunks first, then the fold)
+        hostcheck.hc_blake3_xof64_par(data, v["len"], out)
+        assert out.raw.hex() == v["xof"][:128], ("par", v["len"])
 
 
 def test_group_and_msm_shapes(hostcheck):

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-kernel timeline (HIP events on the engine's streams, ACT_TIMELINE_FILE) of ONE small-batch call: where the latency of
+act_verify_spend_batch over n proofs goes.  Usage: python tools/small_batch_timeline.py n [host|dev]"""
+import hashlib
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+tl = tempfile.mktemp(suffix=".csv")
+os.environ["ACT_TIMELINE_FILE"] = tl
+import numpy as np
+import torch
+from act_amd import capi
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+mode = capi.TRANSCRIPT_HOST if (len(sys.argv) > 2 and sys.argv[2] == "host") else capi.TRANSCRIPT_DEVICE
+sh = lambda l, k: hashlib.shake_256(l.encode()).digest(k)
+L, D = 128, 64
+h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
+eng = capi.Engine(h, L, max_batch=65536, transcript=mode)
+sk = eng.private_key_random(sh("sw-sk", 64))
+pre = eng.pre_issuance_random(sh("sw-pre", 128 * D)); req = eng.request(pre, sh("sw-rq", 128 * D))
+st, resp = eng.issue(sk, req, b"".join((1000 + i).to_bytes(32, "little") for i in range(D)), sh("sw-ir", 128 * D))
+st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+st, proofs, _ = eng.prove_spend(tok, b"".join((i % 900).to_bytes(32, "little") for i in range(D)), sh("sw-pr", eng.prove_rng_bytes * D))
+PB = eng.proof_bytes
+hp = torch.empty((max(n, D), PB), dtype=torch.uint8, pin_memory=True)
+hp.numpy()[:] = np.tile(np.frombuffer(proofs, np.uint8).reshape(D, PB), ((max(n, D) + D - 1) // D, 1))[:max(n, D)]
+hs = torch.zeros(max(n, D), dtype=torch.uint8, pin_memory=True)
+import time
+for _ in range(3):
+    eng.verify_spend_ptr(sk, n, capi.MEM_HOST, hp.data_ptr(), hs.data_ptr())
+eng.prof_reset(); eng.prof_enable(True)
+open(tl, "w").close()
+t0 = time.perf_counter(); eng.verify_spend_ptr(sk, n, capi.MEM_HOST, hp.data_ptr(), hs.data_ptr()); wall = time.perf_counter() - t0
+eng.prof_enable(False)
+rows = [l.strip().split(",") for l in open(tl) if l.strip()]
+rows = [(r[0], float(r[2]), float(r[3]), int(r[4])) for r in rows]
+base = min(r[1] for r in rows)
+print("n = %d, %s transcripts: wall %.3f ms (with event overhead)" % (n, "host" if mode == capi.TRANSCRIPT_HOST else "device", 1e3 * wall))
+for name, a, b, lanes in sorted(rows, key=lambda r: r[1]):
+    print("  %-24s %8.3f -> %8.3f  (%7.3f ms)  lanes %d" % (name, a - base, b - base, b - a, lanes))
