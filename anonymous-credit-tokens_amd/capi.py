@@ -128,7 +128,7 @@ def load() -> C.CDLL:
     lib.act_prof_get.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.act_prof_get_busy.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.act_ubench_mad_u64_u32.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    lib.act_ubench_random_read.argtypes = [i32, sz, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.act_ubench_random_read.argtypes = [i32, sz, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.act_issue_check_batch.argtypes = [vp, sz, i32, u8p, u8p]
     lib.act_issue_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_refund_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
@@ -218,10 +218,10 @@ def ubench_mad(device: int = 0):
     return r.value, ms.value
 
 
-def ubench_random_read(device: int = 0, gib: int = 0):
+def ubench_random_read(device: int = 0, gib: int = 0, waves_per_simd: int = 0, in_flight: int = 0):
     """(GB/s of 128-byte random reads, probe ms): the memory-side roofline of the scalar-addressed fixed-base tables."""
     r, ms = C.c_double(0), C.c_double(0)
-    rc = load().act_ubench_random_read(device, gib, C.byref(r), C.byref(ms))
+    rc = load().act_ubench_random_read(device, gib, waves_per_simd, in_flight, C.byref(r), C.byref(ms))
     if rc:
         raise ActError(f"act_ubench_random_read failed: {_ERRS.get(rc, rc)}")
     return r.value, ms.value

@@ -1218,8 +1218,9 @@ int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
 }
 
 // 128-byte random-read micro-benchmark (k_misc.hip k_ubench_random_read): the memory-side roofline of the scalar-addressed
-// fixed-base tables.  `gib` GiB of device memory are allocated for the probe and freed again (0 = 16).
-int act_ubench_random_read(int device, size_t gib, double* gbytes_per_s, double* ms) {
+// fixed-base tables.  `gib` GiB of device memory are allocated for the probe and freed again (0 = 16); waves_per_simd (0 = 2) and
+// in_flight (1, 2 or 4; 0 = 2) set how many lines a CU has outstanding.
+int act_ubench_random_read(int device, size_t gib, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
   if (!gbytes_per_s) return ACT_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
@@ -1229,16 +1230,19 @@ int act_ubench_random_read(int device, size_t gib, double* gbytes_per_s, double*
   size_t g2 = 1; while (g2 * 2 <= (gib ? gib : 16)) g2 *= 2;                     // a power of two: the kernel masks its line numbers
   const size_t bytes = g2 << 30;
   const uint64_t lines = bytes / 128;
-  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = 2048;
+  if (waves_per_simd <= 0) waves_per_simd = 2;
+  if (waves_per_simd > 8) waves_per_simd = 8;
+  if (in_flight <= 0) in_flight = 2;
+  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)waves_per_simd, iters = 4096u * 8u / (uint32_t)waves_per_simd;
   uint32_t *buf = nullptr, *out = nullptr; hipEvent_t e0, e1; hipStream_t st;
   if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
   if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return ACT_ERR_HIP; }
   int rc = ACT_OK; float t = 0;
   if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(buf); (void)hipFree(out); return ACT_ERR_HIP; }
   (void)hipMemsetAsync(buf, 0x5a, bytes, st);                                  // touch every page
-  launch_ubench_random_read(buf, lines, blocks, 64, out, st);                  // warm-up
+  launch_ubench_random_read(buf, lines, blocks, 64, in_flight, out, st);       // warm-up
   (void)hipEventRecord(e0, st);
-  launch_ubench_random_read(buf, lines, blocks, iters, out, st);
+  launch_ubench_random_read(buf, lines, blocks, iters, in_flight, out, st);
   (void)hipEventRecord(e1, st);
   if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = ACT_ERR_HIP;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(buf); (void)hipFree(out);

@@ -154,24 +154,31 @@ void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream
 
 // Random-read roofline probe: what the scalar-addressed look-ups into the wide fixed-base tables (msm.h fixed_base_acc: one 128-byte
 // affine-Niels entry per window, 112 bytes of it read as seven 16-byte loads, every entry on a different line of a 23.6 GB table)
-// can get from HBM at best.  Every lane reads `iters` pseudo-random lines of `lines` (a power of two) (xorshift per lane, so no two lanes share a
-// line more than by chance), four independent reads in flight per lane as fixed_base_acc's software pipeline has two.
+// can get from HBM at best.  Every lane reads `iters` pseudo-random lines of `lines` (a power of two; xorshift per lane, so no two
+// lanes share a line more than by chance), IN_FLIGHT independent entries at a time (fixed_base_acc's software pipeline has two).
+// The grid is `waves_per_simd` blocks of 256 threads per CU, so the lines in flight per CU can be held where the kernels hold
+// theirs (k_prove_bits / k_spend_bits run two wavefronts per SIMD): with many more in flight the seven loads of an entry miss in
+// the vector cache separately and every line is fetched several times.
+template <int IN_FLIGHT>
 __global__ void __launch_bounds__(256) k_ubench_random_read(const uint4* buf, uint64_t lines, uint32_t iters, uint32_t* out) {
   uint64_t x = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
   uint4 acc = make_uint4(0, 0, 0, 0);
-  for (uint32_t it = 0; it < iters; it += 4) {
-    const uint4* q[4];
+  for (uint32_t it = 0; it < iters; it += IN_FLIGHT) {
+    const uint4* q[IN_FLIGHT];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; q[k] = buf + (x & (lines - 1)) * 8; }      // lines is a power of two
+    for (int k = 0; k < IN_FLIGHT; k++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; q[k] = buf + (x & (lines - 1)) * 8; }
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < IN_FLIGHT; k++)
 #pragma unroll
       for (int i = 0; i < 7; i++) { const uint4 v = q[k][i]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
   }
   out[blockIdx.x * 256 + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
-void launch_ubench_random_read(const uint32_t* buf, uint64_t lines, uint32_t blocks, uint32_t iters, uint32_t* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_ubench_random_read, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint4*>(buf), lines, iters, out);
+void launch_ubench_random_read(const uint32_t* buf, uint64_t lines, uint32_t blocks, uint32_t iters, int in_flight, uint32_t* out, hipStream_t s) {
+  const uint4* b = reinterpret_cast<const uint4*>(buf);
+  if (in_flight <= 1) hipLaunchKernelGGL(k_ubench_random_read<1>, dim3(blocks), dim3(256), 0, s, b, lines, iters, out);
+  else if (in_flight == 2) hipLaunchKernelGGL(k_ubench_random_read<2>, dim3(blocks), dim3(256), 0, s, b, lines, iters, out);
+  else hipLaunchKernelGGL(k_ubench_random_read<4>, dim3(blocks), dim3(256), 0, s, b, lines, iters, out);
 }
 
 // One wavefront that does nothing for `ticks` of the 100 MHz constant-rate counter (s_memrealtime).  act_ctx_create runs one on each

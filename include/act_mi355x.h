@@ -376,9 +376,10 @@ int act_prof_get_busy(act_ctx *ctx, int i, double *ms_busy);
  * SIMD of `device` saturated by register-resident dependency chains.  lane_mads_per_s is summed over lanes; ms = probe time. */
 int act_ubench_mad_u64_u32(int device, double *lane_mads_per_s, double *ms);
 /* Memory-side roofline probe of the scalar-addressed fixed-base tables: every lane reads pseudo-random 128-byte lines (seven 16-byte
- * loads each, as an affine-Niels table entry is read) of a `gib` GiB buffer (0 = 16) allocated for the probe.  gbytes_per_s counts 128
- * bytes per read. */
-int act_ubench_random_read(int device, size_t gib, double *gbytes_per_s, double *ms);
+ * loads each, as an affine-Niels table entry is read) of a `gib` GiB buffer (0 = 16) allocated for the probe, `in_flight` (1, 2 or 4;
+ * 0 = 2) entries at a time, with `waves_per_simd` (0 = 2, the occupancy of the kernels that do these look-ups) wavefronts per SIMD.
+ * gbytes_per_s counts 128 bytes per read. */
+int act_ubench_random_read(int device, size_t gib, int waves_per_simd, int in_flight, double *gbytes_per_s, double *ms);
 
 #ifdef __cplusplus
 }

@@ -410,6 +410,104 @@ E = ristretto_encode
 G = BASEPOINT
 
 
+# --------------------------------------------------------------------------------------------
+# Orders and polarities.  The arithmetic of this model is pinned by third-party code (libsodium, LLVM BLAKE3:
+# tests/golden/sodium_*.json); what that cannot see is a misreading of /root/reference/src/lib.rs that every restatement
+# shares -- the order of the rng draws, the order of the transcript elements, which argument of a conditional_select is taken,
+# the key order of the records.  So those are TABLES here, the functions below are driven by them (they draw, hash, select and
+# serialise through the helpers that read the tables), and tests/test_source_pins.py extracts the same tables from the reference's
+# source text and compares: a swap in either place fails.
+# --------------------------------------------------------------------------------------------
+# function -> names of its `Scalar::random(&mut rng)` bindings in source order; "x[]" = L draws in a loop / collect
+DRAW_ORDER = {
+    "request": ("k_prime", "r_prime"),                                                    # src/lib.rs:468-469
+    "issue": ("e", "alpha"),                                                              # :643, :649
+    "refund": ("e", "alpha"),                                                             # :846, :852
+    "prove_spend": ("r1", "r2", "c_prime", "r_prime", "e_prime", "r2_prime", "r3_prime",  # :978-984
+                    "k_star", "s_i[]", "k0_prime", "s_i_prime[]", "gamma_i[]", "w0", "z[]",   # :998-1023
+                    "k_prime", "s_prime"),                                                # :1057-1058
+}
+# (function, label) -> what its Transcript::with closure adds, in order; "x[]" = every element of an array, "x[][]" = of an
+# array of pairs.  Names are the source's with `self.` / `request.` / `response.` / `spend_proof.` / `refund.` taken off.
+TRANSCRIPT_ORDER = {
+    ("request", "request"): ("big_k", "k1"),                                              # :473-475
+    ("issue", "request"): ("big_k", "k1"),                                                # :633-635
+    ("issue", "respond"): ("c", "e", "a", "x_a", "x_g", "y_a", "y_g"),                    # :654-657
+    ("to_credit_token", "respond"): ("c", "e", "a", "x_a", "x_g", "y_a", "y_g"),          # :544-547
+    ("prove_spend", "spend"): ("k", "a_prime", "b_bar", "a1", "a2", "com[]", "big_c_prime[][]", "c_"),        # :1061-1070
+    ("refund", "spend"): ("k", "a_prime", "b_bar", "a1", "a2", "com[]", "big_c_prime[][]", "big_c"),          # :831-840
+    ("refund", "refund"): ("e", "a", "x_a", "x_g", "y_a", "y_g"),                         # :856-859
+    ("to_credit_token", "refund"): ("e", "a", "x_a", "x_g", "y_a", "y_g"),                # :1236-1239
+}
+# prove_spend's conditional_select(a, b, i[j].ct_eq(&Scalar::ZERO)) calls (:1025-1118): target -> (a, b).  subtle's
+# conditional_select returns b when the choice is true, i.e. when the bit is 0, and a when the bit is 1.
+#   sim[b]  = the simulated commitment of branch b: (h2 w0 +) h3 z[j] - big_c[j][b] gamma_i[j]
+#   real    = the real commitment: (h2 k0' +) h3 s_i'[j]
+#   resp0/1 = gamma00[j] s_i[j] + s_i'[j]  /  (gamma - gamma00[j]) s_i[j] + s_i'[j];  resp_k0/1 = the same with k* and k0'
+SELECTS = {
+    "big_c_prime[.][0]": ("sim[0]", "real"),                                              # :1025-1029, :1041-1045
+    "big_c_prime[.][1]": ("real", "sim[1]"),                                              # :1031-1035, :1046-1050
+    "gamma00[.]": ("gamma_i", "gamma-gamma_i"),                                           # :1078-1082, :1105-1109
+    "w00": ("w0", "resp_k0"),                                                             # :1083-1087
+    "w01": ("resp_k1", "w0"),                                                             # :1088-1092
+    "z00[.][0]": ("z", "resp0"),                                                          # :1094-1098, :1110-1114
+    "z00[.][1]": ("resp1", "z"),                                                          # :1099-1103, :1115-1119
+}
+# record = the struct's fields as consecutive 32-byte strings in the key order of its CBOR map (src/cbor.rs to_cbor)
+RECORD_ORDER = {
+    "IssuanceRequest": ("big_k", "gamma", "k_bar", "r_bar"),                              # src/cbor.rs:105-110
+    "IssuanceResponse": ("a", "e", "gamma", "z", "c"),                                    # :163-169
+    "SpendProof": ("k", "s", "a_prime", "b_bar", "com", "gamma", "e_bar", "r2_bar", "r3_bar", "c_bar", "r_bar", "w00", "w01",
+                   "gamma0", "z", "k_bar", "s_bar"),                                      # :250-268
+    "Refund": ("a", "e", "gamma", "z"),                                                   # :422-427
+    "PrivateKey": ("x", "w"),                                                             # :477-480
+    "PreIssuance": ("r", "k"),                                                            # :546-549
+    "CreditToken": ("a", "e", "k", "r", "c"),                                             # :596-602
+    "PreRefund": ("r", "k", "m"),                                                         # :656-660
+}
+
+
+def _draw(rng: "ByteRng", fn: str, nbits: int = 0) -> dict:
+    """The function's Scalar::random draws, in DRAW_ORDER, as name -> scalar (or list of L scalars)."""
+    out = {}
+    for name in DRAW_ORDER[fn]:
+        if name.endswith("[]"):
+            out[name[:-2]] = [rng.scalar() for _ in range(nbits)]
+        else:
+            out[name] = rng.scalar()
+    return out
+
+
+def _enc32(v) -> bytes:
+    """Scalar -> as_bytes, point -> compress, array (of arrays) -> its elements in order."""
+    if isinstance(v, int):
+        return sc_bytes(v)
+    if isinstance(v, tuple) and len(v) == 4 and all(isinstance(c, int) for c in v):
+        return E(v)
+    return b"".join(_enc32(x) for x in v)
+
+
+def _challenge(params: "Params", fn: str, label: str, env: dict) -> int:
+    """Transcript::with(params, label, |t| ...) of function `fn`: the elements TRANSCRIPT_ORDER names, taken from `env`."""
+    items = []
+    for name in TRANSCRIPT_ORDER[(fn, label)]:
+        blob = _enc32(env[name.rstrip("[]")])
+        items += [blob[i:i + 32] for i in range(0, len(blob), 32)]
+    return transcript_challenge(params, label.encode(), items)
+
+
+def _select(target: str, bit: int, env: dict):
+    """conditional_select(a, b, bit.ct_eq(0)) for the (a, b) SELECTS records: b when the bit is 0, a when it is 1.
+    env values may be thunks (only the chosen one is evaluated: this is a model, not constant-time code)."""
+    a, b = SELECTS[target]
+    v = env[b] if bit == 0 else env[a]
+    return v() if callable(v) else v
+
+
+def _record(obj, type_name: str) -> bytes:
+    return b"".join(_enc32(getattr(obj, name)) for name in RECORD_ORDER[type_name])
+
+
 @dataclass
 class PrivateKey:
     x: int
@@ -421,7 +519,7 @@ class PrivateKey:
         return PrivateKey(x, pt_mul(G, x))    # :191
 
     def record(self) -> bytes:                # CBOR order x, w (src/cbor.rs:477-480)
-        return sc_bytes(self.x) + E(self.w)
+        return _record(self, "PrivateKey")
 
 
 @dataclass
@@ -436,7 +534,7 @@ class PreIssuance:
         return PreIssuance(r, k)
 
     def record(self) -> bytes:                # r, k (src/cbor.rs:546-549)
-        return sc_bytes(self.r) + sc_bytes(self.k)
+        return _record(self, "PreIssuance")
 
 
 @dataclass
@@ -447,7 +545,7 @@ class IssuanceRequest:
     r_bar: int
 
     def record(self) -> bytes:                # K, gamma, k_bar, r_bar (src/cbor.rs:105-110)
-        return E(self.big_k) + sc_bytes(self.gamma) + sc_bytes(self.k_bar) + sc_bytes(self.r_bar)
+        return _record(self, "IssuanceRequest")
 
 
 @dataclass
@@ -459,7 +557,7 @@ class IssuanceResponse:
     c: int
 
     def record(self) -> bytes:                # A, e, gamma, z, c (src/cbor.rs:163-169)
-        return E(self.a) + b"".join(sc_bytes(v) for v in (self.e, self.gamma, self.z, self.c))
+        return _record(self, "IssuanceResponse")
 
 
 @dataclass
@@ -471,7 +569,7 @@ class CreditToken:
     c: int
 
     def record(self) -> bytes:                # a, e, k, r, c (src/cbor.rs:596-602)
-        return E(self.a) + b"".join(sc_bytes(v) for v in (self.e, self.k, self.r, self.c))
+        return _record(self, "CreditToken")
 
 
 @dataclass
@@ -497,13 +595,7 @@ class SpendProof:
     def record(self) -> bytes:
         """k,s,A',B_bar,Com[L],gamma,e_bar,r2_bar,r3_bar,c_bar,r_bar,w00,w01,gamma0[L],z[L][2],
         k_bar,s_bar (src/cbor.rs:250-268): 32*(14+4L) bytes."""
-        out = sc_bytes(self.k) + sc_bytes(self.s) + E(self.a_prime) + E(self.b_bar)
-        out += b"".join(E(c) for c in self.com)
-        for v in (self.gamma, self.e_bar, self.r2_bar, self.r3_bar, self.c_bar, self.r_bar, self.w00, self.w01):
-            out += sc_bytes(v)
-        out += b"".join(sc_bytes(g) for g in self.gamma0)
-        out += b"".join(sc_bytes(z0) + sc_bytes(z1) for z0, z1 in self.z)
-        return out + sc_bytes(self.k_bar) + sc_bytes(self.s_bar)
+        return _record(self, "SpendProof")
 
 
 @dataclass
@@ -513,7 +605,7 @@ class PreRefund:
     m: int
 
     def record(self) -> bytes:                # r, k, m (src/cbor.rs:656-660)
-        return sc_bytes(self.r) + sc_bytes(self.k) + sc_bytes(self.m)
+        return _record(self, "PreRefund")
 
 
 @dataclass
@@ -524,16 +616,16 @@ class Refund:
     z: int
 
     def record(self) -> bytes:                # A*, e, gamma, z (src/cbor.rs:422-427)
-        return E(self.a) + sc_bytes(self.e) + sc_bytes(self.gamma) + sc_bytes(self.z)
+        return _record(self, "Refund")
 
 
 def request(pre: PreIssuance, params: Params, rng: ByteRng) -> IssuanceRequest:
     """PreIssuance::request, src/lib.rs:463-487."""
     big_k = pt_add(pt_mul(params.h2, pre.k), pt_mul(params.h3, pre.r))           # :465
-    k_prime = rng.scalar()                                                        # :468
-    r_prime = rng.scalar()                                                        # :469
+    d = _draw(rng, "request")                                                     # :468-469
+    k_prime, r_prime = d["k_prime"], d["r_prime"]
     k1 = pt_add(pt_mul(params.h2, k_prime), pt_mul(params.h3, r_prime))           # :470
-    gamma = transcript_challenge(params, b"request", [E(big_k), E(k1)])           # :473-475
+    gamma = _challenge(params, "request", "request", {"big_k": big_k, "k1": k1})  # :473-475
     k_bar = (k_prime + pre.k * gamma) % ELL                                       # :478
     r_bar = (r_prime + pre.r * gamma) % ELL                                       # :479
     return IssuanceRequest(big_k, gamma, k_bar, r_bar)
@@ -543,18 +635,18 @@ def issue(sk: PrivateKey, params: Params, req: IssuanceRequest, c: int, rng: Byt
     """PrivateKey::issue, src/lib.rs:621-663.  RNG is drawn only after the PoK verifies."""
     k1 = pt_sub(pt_add(pt_mul(params.h2, req.k_bar), pt_mul(params.h3, req.r_bar)),
                 pt_mul(req.big_k, req.gamma))                                     # :629-630
-    gamma = transcript_challenge(params, b"request", [E(req.big_k), E(k1)])       # :633-635
+    gamma = _challenge(params, "issue", "request", {"big_k": req.big_k, "k1": k1})   # :633-635
     if gamma != req.gamma:                                                        # :638
         raise ActError(ERR_INVALID_ISSUANCE_REQUEST_PROOF)
-    e = rng.scalar()                                                              # :643
+    # e before alpha (:643, :649): both are drawn before either is used, so one _draw is the source's order
+    d = _draw(rng, "issue")
+    e, alpha = d["e"], d["alpha"]
     x_a = pt_add(pt_add(G, pt_mul(params.h1, c)), req.big_k)                      # :644
     a = pt_mul(x_a, sc_inv((e + sk.x) % ELL))                                     # :645
     x_g = pt_add(pt_mul(G, e), sk.w)                                              # :646
-    alpha = rng.scalar()                                                          # :649
     y_a = pt_mul(a, alpha)                                                        # :650
     y_g = pt_mul(G, alpha)                                                        # :651
-    gamma = transcript_challenge(params, b"respond",
-                                 [sc_bytes(c), sc_bytes(e), E(a), E(x_a), E(x_g), E(y_a), E(y_g)])  # :654-657
+    gamma = _challenge(params, "issue", "respond", {"c": c % ELL, "e": e, "a": a, "x_a": x_a, "x_g": x_g, "y_a": y_a, "y_g": y_g})  # :654-657
     z = (gamma * (sk.x + e) + alpha) % ELL                                        # :660
     return IssuanceResponse(a, e, gamma, z, c % ELL)
 
@@ -567,8 +659,8 @@ def issuance_to_credit_token(pre: PreIssuance, params: Params, w: Point, req: Is
     ng = (-resp.gamma) % ELL
     y_a = pt_add(pt_mul(resp.a, resp.z), pt_mul(x_a, ng))                         # :540
     y_g = pt_add(pt_mul(G, resp.z), pt_mul(x_g, ng))                              # :541
-    gamma = transcript_challenge(params, b"respond",
-                                 [sc_bytes(resp.c), sc_bytes(resp.e), E(resp.a), E(x_a), E(x_g), E(y_a), E(y_g)])
+    gamma = _challenge(params, "to_credit_token", "respond",
+                       {"c": resp.c, "e": resp.e, "a": resp.a, "x_a": x_a, "x_g": x_g, "y_a": y_a, "y_g": y_g})   # :544-547
     if gamma != resp.gamma:                                                       # :550
         raise ActError(ERR_INVALID_ISSUANCE_RESPONSE_PROOF)
     return CreditToken(resp.a, resp.e, pre.k, pre.r, resp.c)
@@ -582,10 +674,14 @@ def bits_of(s: int, nbits: int) -> List[int]:
 
 def prove_spend(tok: CreditToken, params: Params, s: int, rng: ByteRng, nbits: int = L_DEFAULT
                 ) -> Tuple[SpendProof, PreRefund]:
-    """CreditToken::prove_spend, src/lib.rs:972-1152 (RNG draw order: SURVEY.md App. B)."""
+    """CreditToken::prove_spend, src/lib.rs:972-1152.  Every draw happens before any later draw's value is needed and nothing
+    else consumes the generator, so drawing all of DRAW_ORDER["prove_spend"] up front is the source's order."""
     h1, h2, h3 = params.h1, params.h2, params.h3
-    r1 = rng.scalar(); r2 = rng.scalar(); c_prime = rng.scalar(); r_prime = rng.scalar()   # :978-981
-    e_prime = rng.scalar(); r2_prime = rng.scalar(); r3_prime = rng.scalar()                # :982-984
+    d = _draw(rng, "prove_spend", nbits)
+    r1, r2, c_prime, r_prime = d["r1"], d["r2"], d["c_prime"], d["r_prime"]                 # :978-981
+    e_prime, r2_prime, r3_prime = d["e_prime"], d["r2_prime"], d["r3_prime"]                # :982-984
+    k_star, s_i, k0_prime, s_i_prime = d["k_star"], d["s_i"], d["k0_prime"], d["s_i_prime"]  # :998-1014
+    gamma_i, w0, z, k_prime, s_prime = d["gamma_i"], d["w0"], d["z"], d["k_prime"], d["s_prime"]   # :1016-1023, :1057-1058
     b = pt_add(pt_add(pt_add(G, pt_mul(h1, tok.c)), pt_mul(h2, tok.k)), pt_mul(h3, tok.r))  # :986-989
     a_prime = pt_mul(tok.a, r1 * r2 % ELL)                                                  # :990
     b_bar = pt_mul(b, r1)                                                                   # :991
@@ -593,41 +689,26 @@ def prove_spend(tok: CreditToken, params: Params, s: int, rng: ByteRng, nbits: i
     a1 = pt_add(pt_mul(a_prime, e_prime), pt_mul(b_bar, r2_prime))                          # :993
     a2 = pt_add(pt_add(pt_mul(b_bar, r3_prime), pt_mul(h1, c_prime)), pt_mul(h3, r_prime))  # :994
     i = bits_of((tok.c - s) % ELL, nbits)                                                   # :996
-    k_star = rng.scalar()                                                                   # :998
-    s_i = [rng.scalar() for _ in range(nbits)]                                              # :999
     com = [None] * nbits
     com[0] = pt_add(pt_add(pt_mul(h1, i[0]), pt_mul(h2, k_star)), pt_mul(h3, s_i[0]))       # :1001
     for j in range(1, nbits):
         com[j] = pt_add(pt_mul(h1, i[j]), pt_mul(h3, s_i[j]))                               # :1003
-    k0_prime = rng.scalar()                                                                 # :1010
-    s_i_prime = [rng.scalar() for _ in range(nbits)]                                        # :1012-1014
-    gamma_i = [rng.scalar() for _ in range(nbits)]                                          # :1016-1018
-    w0 = rng.scalar()                                                                       # :1019
-    z = [rng.scalar() for _ in range(nbits)]                                                # :1021-1023
     big_c_prime = [[None, None] for _ in range(nbits)]
-    c00 = com[0]
-    c01 = pt_sub(com[0], h1)                                                                # :1008
-    sim0 = lambda base: pt_sub(pt_add(pt_mul(h2, w0), pt_mul(h3, z[0])), pt_mul(base, gamma_i[0]))
-    real0 = pt_add(pt_mul(h2, k0_prime), pt_mul(h3, s_i_prime[0]))
-    # conditional_select(a, b, choice) returns b when choice is true (subtle semantics)
-    big_c_prime[0][0] = real0 if i[0] == 0 else sim0(c00)                                   # :1025-1029
-    big_c_prime[0][1] = sim0(c01) if i[0] == 0 else real0                                   # :1031-1035
-    for j in range(1, nbits):
-        cj0 = com[j]
-        cj1 = pt_sub(com[j], h1)                                                            # :1039
-        real = pt_mul(h3, s_i_prime[j])
-        sim = lambda base, j=j: pt_sub(pt_mul(h3, z[j]), pt_mul(base, gamma_i[j]))
-        big_c_prime[j][0] = real if i[j] == 0 else sim(cj0)                                 # :1041-1045
-        big_c_prime[j][1] = sim(cj1) if i[j] == 0 else real                                 # :1046-1050
+    for j in range(nbits):
+        big_c = (com[j], pt_sub(com[j], h1))                                                # :1007-1008, :1038-1039
+        if j == 0:                                                                          # the h2 terms of bit 0 (:1025-1035)
+            real = lambda: pt_add(pt_mul(h2, k0_prime), pt_mul(h3, s_i_prime[0]))
+            sim = lambda base: pt_sub(pt_add(pt_mul(h2, w0), pt_mul(h3, z[0])), pt_mul(base, gamma_i[0]))
+        else:                                                                               # :1041-1050
+            real = lambda j=j: pt_mul(h3, s_i_prime[j])
+            sim = lambda base, j=j: pt_sub(pt_mul(h3, z[j]), pt_mul(base, gamma_i[j]))
+        env = {"real": real, "sim[0]": lambda: sim(big_c[0]), "sim[1]": lambda: sim(big_c[1])}
+        big_c_prime[j][0] = _select("big_c_prime[.][0]", i[j], env)
+        big_c_prime[j][1] = _select("big_c_prime[.][1]", i[j], env)
     r_star = sum(si << idx for idx, si in enumerate(s_i)) % ELL                             # :1052-1056
-    k_prime = rng.scalar()                                                                  # :1057
-    s_prime = rng.scalar()                                                                  # :1058
     c_ = pt_add(pt_add(pt_mul(h1, (-c_prime) % ELL), pt_mul(h2, k_prime)), pt_mul(h3, s_prime))  # :1059
-    items = [sc_bytes(tok.k), E(a_prime), E(b_bar), E(a1), E(a2)] + [E(c) for c in com]
-    for cp in big_c_prime:
-        items += [E(cp[0]), E(cp[1])]
-    items.append(E(c_))
-    gamma = transcript_challenge(params, b"spend", items)                                   # :1061-1070
+    gamma = _challenge(params, "prove_spend", "spend", {"k": tok.k, "a_prime": a_prime, "b_bar": b_bar, "a1": a1, "a2": a2, "com": com,
+                                                        "big_c_prime": big_c_prime, "c_": c_})   # :1061-1070
     ng = (-gamma) % ELL
     e_bar = (ng * tok.e + e_prime) % ELL                                                    # :1072
     r2_bar = (gamma * r2 + r2_prime) % ELL                                                  # :1073
@@ -637,12 +718,12 @@ def prove_spend(tok: CreditToken, params: Params, s: int, rng: ByteRng, nbits: i
     gamma00 = [0] * nbits
     zz = [(0, 0)] * nbits
     for j in range(nbits):
-        gamma00[j] = (gamma - gamma_i[j]) % ELL if i[j] == 0 else gamma_i[j]                # :1078-1082, :1105-1109
-        z0 = (gamma00[j] * s_i[j] + s_i_prime[j]) % ELL if i[j] == 0 else z[j]              # :1094-1098, :1110-1114
-        z1 = z[j] if i[j] == 0 else ((gamma - gamma00[j]) * s_i[j] + s_i_prime[j]) % ELL    # :1099-1103, :1115-1119
-        zz[j] = (z0, z1)
-    w00 = (gamma00[0] * k_star + k0_prime) % ELL if i[0] == 0 else w0                       # :1083-1087
-    w01 = w0 if i[0] == 0 else ((gamma - gamma00[0]) * k_star + k0_prime) % ELL             # :1088-1092
+        gamma00[j] = _select("gamma00[.]", i[j], {"gamma_i": gamma_i[j], "gamma-gamma_i": (gamma - gamma_i[j]) % ELL})   # :1078-1082, :1105-1109
+        env = {"z": z[j], "resp0": (gamma00[j] * s_i[j] + s_i_prime[j]) % ELL, "resp1": ((gamma - gamma00[j]) * s_i[j] + s_i_prime[j]) % ELL}
+        zz[j] = (_select("z00[.][0]", i[j], env), _select("z00[.][1]", i[j], env))          # :1094-1103, :1110-1119
+    env = {"w0": w0, "resp_k0": (gamma00[0] * k_star + k0_prime) % ELL, "resp_k1": ((gamma - gamma00[0]) * k_star + k0_prime) % ELL}
+    w00 = _select("w00", i[0], env)                                                         # :1083-1087
+    w01 = _select("w01", i[0], env)                                                         # :1088-1092
     k_bar = (gamma * k_star + k_prime) % ELL                                                # :1121
     s_bar = (gamma * r_star + s_prime) % ELL                                                # :1122
     proof = SpendProof(tok.k, s % ELL, a_prime, b_bar, com, gamma, e_bar, r2_bar, r3_bar, c_bar, r_bar,
@@ -678,10 +759,10 @@ def spend_verify_challenge(sk_x: int, params: Params, pr: SpendProof) -> Tuple[i
     com_ = pt_add(pt_mul(h1, pr.s), k_prime)                                                # :825
     big_c = pt_sub(pt_add(pt_add(pt_mul(h1, (-pr.c_bar) % ELL), pt_mul(h2, pr.k_bar)), pt_mul(h3, pr.s_bar)),
                    pt_mul(com_, pr.gamma))                                                  # :826-829
-    items = [sc_bytes(pr.k), E(pr.a_prime), E(pr.b_bar), E(a1), E(a2)] + [E(c) for c in pr.com]
-    items += [E(p) for p in cps]
-    items.append(E(big_c))
-    return transcript_challenge(params, b"spend", items), k_prime                           # :831-840
+    big_c_prime = [[cps[2 * j], cps[2 * j + 1]] for j in range(nbits)]
+    gamma = _challenge(params, "refund", "spend", {"k": pr.k, "a_prime": pr.a_prime, "b_bar": pr.b_bar, "a1": a1, "a2": a2, "com": pr.com,
+                                                   "big_c_prime": big_c_prime, "big_c": big_c})   # :831-840
+    return gamma, k_prime
 
 
 def refund(sk: PrivateKey, params: Params, pr: SpendProof, rng: ByteRng) -> Refund:
@@ -691,14 +772,14 @@ def refund(sk: PrivateKey, params: Params, pr: SpendProof, rng: ByteRng) -> Refu
     gamma, k_prime = spend_verify_challenge(sk.x, params, pr)
     if gamma != pr.gamma:                                                                   # :842
         raise ActError(ERR_INVALID_CLIENT_SPEND_PROOF)
-    e = rng.scalar()                                                                        # :846
+    d = _draw(rng, "refund")                                                                # e (:846), alpha (:852)
+    e, alpha = d["e"], d["alpha"]
     x_a = pt_add(G, k_prime)                                                                # :848
     a = pt_mul(x_a, sc_inv((e + sk.x) % ELL))                                               # :849
     x_g = pt_add(pt_mul(G, e), sk.w)                                                        # :851
-    alpha = rng.scalar()                                                                    # :852
     y_a = pt_mul(a, alpha)                                                                  # :853
     y_g = pt_mul(G, alpha)                                                                  # :854
-    rg = transcript_challenge(params, b"refund", [sc_bytes(e), E(a), E(x_a), E(x_g), E(y_a), E(y_g)])  # :856-859
+    rg = _challenge(params, "refund", "refund", {"e": e, "a": a, "x_a": x_a, "x_g": x_g, "y_a": y_a, "y_g": y_g})   # :856-859
     z = (rg * (sk.x + e) + alpha) % ELL                                                     # :861
     return Refund(a, e, rg, z)
 
@@ -713,7 +794,7 @@ def refund_to_credit_token(pre: PreRefund, params: Params, pr: SpendProof, rf: R
     ng = (-rf.gamma) % ELL
     y_a = pt_add(pt_mul(rf.a, rf.z), pt_mul(x_a, ng))                                       # :1233
     y_g = pt_add(pt_mul(G, rf.z), pt_mul(x_g, ng))                                          # :1234
-    gamma = transcript_challenge(params, b"refund", [sc_bytes(rf.e), E(rf.a), E(x_a), E(x_g), E(y_a), E(y_g)])
+    gamma = _challenge(params, "to_credit_token", "refund", {"e": rf.e, "a": rf.a, "x_a": x_a, "x_g": x_g, "y_a": y_a, "y_g": y_g})   # :1236-1239
     if gamma != rf.gamma:                                                                   # :1241
         raise ActError(ERR_INVALID_REFUND_PROOF)
     return CreditToken(rf.a, rf.e, pre.k, pre.r, pre.m)
