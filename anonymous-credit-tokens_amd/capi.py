@@ -19,7 +19,7 @@ EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
     "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
-    "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_verify_spend_batch",
+    "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_prove_spend_seeded_batch", "act_node_prove_spend_seeded_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
     "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32", "act_ubench_random_read",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch", "act_verify_spend_cbor_batch",
@@ -97,6 +97,8 @@ def load() -> C.CDLL:
     lib.act_issue_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_issuance_to_credit_token_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
     lib.act_prove_spend_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
+    lib.act_prove_spend_seeded_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, C.c_uint64, u8p, u8p, u8p]
+    lib.act_node_prove_spend_seeded_batch.argtypes = [vp, sz, u8p, u8p, u8p, C.c_uint64, u8p, u8p, u8p]
     lib.act_verify_spend_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p]
     lib.act_refund_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_refund_to_credit_token_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, u8p]
@@ -319,6 +321,13 @@ class Engine:
         self._ck(self.lib.act_prove_spend_batch(self.ctx, n, MEM_HOST, p0, p1, p2, out.ctypes.data, pr.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes(), pr.tobytes()
 
+    def prove_spend_seeded(self, tok: bytes, s: bytes, seed: bytes, first_lane: int = 0):
+        """prove_spend with lane i's rng = BLAKE3-XOF(seed | u64_le(first_lane + i)), expanded on the device."""
+        n = len(tok) // 160; out = np.zeros(self.proof_bytes * n, np.uint8); pr = np.zeros(96 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(tok, 160 * n); p1, k1 = _in(s, 32 * n); p2, k2 = _in(seed, 32)
+        self._ck(self.lib.act_prove_spend_seeded_batch(self.ctx, n, MEM_HOST, p0, p1, p2, first_lane, out.ctypes.data, pr.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes(), pr.tobytes()
+
     def verify_spend(self, sk: bytes, proofs: bytes, want_kprime: bool = False):
         n = len(proofs) // self.proof_bytes; st = np.zeros(n, np.uint8)
         kp = np.zeros(32 * n, np.uint8) if want_kprime else None
@@ -519,6 +528,12 @@ class Node:
         n = len(tok) // 160; out = np.zeros(self.proof_bytes * n, np.uint8); pr = np.zeros(96 * n, np.uint8); st = np.zeros(n, np.uint8)
         p0, k0 = _in(tok, 160 * n); p1, k1 = _in(s, 32 * n); p2, k2 = _in(rng, self.prove_rng_bytes * n)
         self._ck(self.lib.act_node_prove_spend_batch(self.nd, n, p0, p1, p2, out.ctypes.data, pr.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes(), pr.tobytes()
+
+    def prove_spend_seeded(self, tok: bytes, s: bytes, seed: bytes, first_lane: int = 0):
+        n = len(tok) // 160; out = np.zeros(self.proof_bytes * n, np.uint8); pr = np.zeros(96 * n, np.uint8); st = np.zeros(n, np.uint8)
+        p0, k0 = _in(tok, 160 * n); p1, k1 = _in(s, 32 * n); p2, k2 = _in(seed, 32)
+        self._ck(self.lib.act_node_prove_spend_seeded_batch(self.nd, n, p0, p1, p2, first_lane, out.ctypes.data, pr.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes(), pr.tobytes()
 
     def verify_spend(self, sk: bytes, proofs: bytes, want_kprime: bool = False):

@@ -1083,9 +1083,10 @@ int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const 
   return spend_batch(c, n, mem, sk, proof, true, rng, rng_mode, out_refund, status, nullptr);
 }
 
-int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng,
-                          uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
-  if (!c || (n && (!token || !s || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+// rng: the caller's bytes, or (seed != nullptr) expanded on the device from a 32-byte seed: lane i draws from the BLAKE3 XOF of
+// seed | u64_le(first_lane + i) (k_misc.hip k_xof_expand) -- 33 536 bytes per proof that then never cross PCIe
+static int prove_spend_impl(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng, const uint8_t* seed,
+                            uint64_t first_lane, uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
   Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   const size_t pb = ProofLayout{c->L}.bytes(), rb = act_prove_rng_bytes(c);
@@ -1103,7 +1104,15 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
     int rc;
     if ((rc = dev_in(c, sl, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, s + off * 32, (size_t)m * 32, &a.s))) return rc;
-    if ((rc = dev_in(c, sl, 3, mem, rng + off * rb, (size_t)m * rb, &a.rng))) return rc;
+    if (!seed) { if ((rc = dev_in(c, sl, 3, mem, rng + off * rb, (size_t)m * rb, &a.rng))) return rc; }
+    else {
+      // 48 bytes past the lanes' bytes hold the seed (read by the expansion kernel on this stream)
+      if ((rc = stage_reserve(c, sl, 3, (size_t)m * rb + 48))) return rc;
+      uint8_t* d_seed = sl.d_stage[3] + (size_t)m * rb;
+      HIPCK(c, hipMemcpyAsync(d_seed, seed, 32, hipMemcpyHostToDevice, sl.stream));
+      launch_xof_expand(reinterpret_cast<const uint32_t*>(d_seed), first_lane + off, m, (uint32_t)(rb / 64), sl.d_stage[3], sl.stream);
+      a.rng = sl.d_stage[3];
+    }
     if ((rc = dev_out_begin(c, sl, 2, mem, out_proof + off * pb, (size_t)m * pb, &a.proof))) return rc;
     if ((rc = dev_out_begin(c, sl, 4, mem, out_prerefund + off * 96, (size_t)m * 96, &a.prerefund))) return rc;
     if ((rc = prof_launch(c, sl, PK_PROVE_HEAD, m, [&] { launch_prove_head(a, sl.stream); }))) return rc;
@@ -1130,6 +1139,16 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, c
   }
   for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
   return call.finish();
+}
+int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng,
+                          uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
+  if (!c || (n && (!token || !s || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+  return prove_spend_impl(c, n, mem, token, s, rng, nullptr, 0, out_proof, out_prerefund, status);
+}
+int act_prove_spend_seeded_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t seed[32], uint64_t first_lane,
+                                 uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
+  if (!c || !seed || (n && (!token || !s || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+  return prove_spend_impl(c, n, mem, token, s, nullptr, seed, first_lane, out_proof, out_prerefund, status);
 }
 
 static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,

@@ -181,6 +181,30 @@ void launch_ubench_random_read(const uint32_t* buf, uint64_t lines, uint32_t blo
   else hipLaunchKernelGGL(k_ubench_random_read<4>, dim3(blocks), dim3(256), 0, s, b, lines, iters, out);
 }
 
+// Seeded prover rng (act_prove_spend_seeded_batch): lane i's generator is the BLAKE3 XOF of seed | u64_le(first_lane + i) -- what
+// `blake3::Hasher::new().update(seed).update(&lane.to_le_bytes()).finalize_xof()` yields, read sequentially by every
+// Scalar::random (64 bytes each, /root/reference/src/lib.rs:978-1058).  An XOF block is one compression of the same 40-byte root
+// block with the output-block counter t, so the 64 (4L + 12) bytes of a lane are 4L + 12 independent compressions: thread = (lane, t).
+__global__ void __launch_bounds__(256) k_xof_expand(const uint32_t* seed, uint64_t first_lane, uint32_t n, uint32_t blocks_per_lane, uint8_t* out) {
+  const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t lane = (uint32_t)(gid / blocks_per_lane), t = (uint32_t)(gid % blocks_per_lane);
+  if (lane >= n) return;
+  uint32_t m[16], cv[8], o[16];
+  for (int i = 0; i < 8; i++) { m[i] = seed[i]; cv[i] = b3_iv(i); }
+  const uint64_t id = first_lane + lane;
+  m[8] = (uint32_t)id; m[9] = (uint32_t)(id >> 32);
+  for (int i = 10; i < 16; i++) m[i] = 0;
+  b3_compress(o, cv, m, t, 0u, 40u, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+  uint4* q = reinterpret_cast<uint4*>(out + ((size_t)lane * blocks_per_lane + t) * 64);
+  q[0] = make_uint4(o[0], o[1], o[2], o[3]); q[1] = make_uint4(o[4], o[5], o[6], o[7]);
+  q[2] = make_uint4(o[8], o[9], o[10], o[11]); q[3] = make_uint4(o[12], o[13], o[14], o[15]);
+}
+void launch_xof_expand(const uint32_t* d_seed, uint64_t first_lane, uint32_t n, uint32_t blocks_per_lane, uint8_t* out, hipStream_t s) {
+  if (!n) return;
+  const uint64_t threads = (uint64_t)n * blocks_per_lane;
+  hipLaunchKernelGGL(k_xof_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_seed, first_lane, n, blocks_per_lane, out);
+}
+
 // One wavefront that does nothing for `ticks` of the 100 MHz constant-rate counter (s_memrealtime).  act_ctx_create runs one on each
 // of the context's two streams at the same time to learn whether the HIP runtime gave them different hardware queues (engine.hip
 // streams_overlap): two of these take one `ticks` when the streams run side by side and two when they share a queue.

@@ -203,6 +203,7 @@ void launch_hash(const HashArgs& a, hipStream_t s);
 void launch_hash_par(const HashArgs& a, hipStream_t s);      // sixteen lanes per message: small calls
 void launch_iota(uint32_t* out, uint32_t n, uint32_t base, hipStream_t s);
 void launch_spin(uint32_t ticks_100mhz, hipStream_t s);
+void launch_xof_expand(const uint32_t* d_seed /* 8 words, device */, uint64_t first_lane, uint32_t n, uint32_t blocks_per_lane, uint8_t* out, hipStream_t s);
 void launch_ubench_random_read(const uint32_t* buf, uint64_t lines, uint32_t blocks, uint32_t iters, int in_flight, uint32_t* out, hipStream_t s);
 constexpr int UBENCH_MADS_PER_ITER = 80;    // 8 chains x 10 dependent multiply-accumulates (k_misc.hip k_ubench_mad)
 void launch_ubench_mad(uint32_t* out, uint32_t blocks, uint32_t iters, hipStream_t s);

@@ -200,6 +200,17 @@ int act_node_prove_spend_batch(act_node* nd, size_t n, const uint8_t* token, con
   });
 }
 
+int act_node_prove_spend_seeded_batch(act_node* nd, size_t n, const uint8_t* token, const uint8_t* s_, const uint8_t seed[32], uint64_t first_lane,
+                                      uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
+  if (!nd || !seed || (n && (!token || !s_ || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
+  return run(nd, n, [&](size_t k, Shard s) {      // lane numbers are global: a shard starts at first_lane + its offset, whatever the number of GPUs
+    return act_prove_spend_seeded_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(token, s.off, 160), at(s_, s.off, 32), seed, first_lane + s.off, at(out_proof, s.off, pb),
+                                        at(out_prerefund, s.off, 96), status + s.off);
+  });
+}
+
 int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!nd || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);

@@ -175,6 +175,13 @@ int act_issuance_to_credit_token_batch(act_ctx *ctx, size_t n, int mem, const ui
 /* CreditToken::prove_spend: token n*160, s n*32, rng n*act_prove_rng_bytes -> proof n*act_spend_proof_bytes, prerefund n*96 */
 int act_prove_spend_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *token, const uint8_t *s, const uint8_t *rng,
                           uint8_t *out_proof, uint8_t *out_prerefund, uint8_t *status);
+/* The same with the generator SEEDED instead of spelled out: lane i draws from the BLAKE3 XOF of seed | u64_le(first_lane + i),
+ * read sequentially by every Scalar::random -- on the crate's side `prove_spend(params, s, XofRng(seed, lane))` with an RngCore over
+ * blake3::Hasher::new().update(seed).update(&lane.to_le_bytes()).finalize_xof().  The 64 (4L + 12) = 33 536 rng bytes per proof are
+ * expanded in HBM and never cross PCIe (streaming 2^16 lifecycles per call from host memory: 200 k -> see DESIGN.md section 6).  The
+ * seed is a secret of the prover like the rng bytes are; one seed must never serve the same lane number twice. */
+int act_prove_spend_seeded_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *token, const uint8_t *s, const uint8_t seed[32],
+                                 uint64_t first_lane, uint8_t *out_proof, uint8_t *out_prerefund, uint8_t *status);
 /* spend-proof verification only (src/lib.rs:787-844): proof -> status n; out_kprime (nullable) n*32 = enc(K') */
 int act_verify_spend_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof,
                            uint8_t *status, uint8_t *out_kprime);
@@ -232,6 +239,8 @@ int act_node_refund_sign_batch(act_node *node, size_t n, const uint8_t sk[64], c
                                const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
 int act_node_prove_spend_batch(act_node *node, size_t n, const uint8_t *token, const uint8_t *s, const uint8_t *rng,
                                uint8_t *out_proof, uint8_t *out_prerefund, uint8_t *status);
+int act_node_prove_spend_seeded_batch(act_node *node, size_t n, const uint8_t *token, const uint8_t *s, const uint8_t seed[32],
+                                      uint64_t first_lane, uint8_t *out_proof, uint8_t *out_prerefund, uint8_t *status);
 int act_node_verify_spend_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *proof, uint8_t *status,
                                 uint8_t *out_kprime);
 int act_node_refund_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *proof, const uint8_t *rng, int rng_mode,

@@ -66,6 +66,15 @@ int act_prove_spend_batch(act_ctx* c, size_t n, int, const uint8_t* tok, const u
   for (size_t i = 0; i < n; i++) { emit(proof + kPB * i, kPB, tok + 160 * i, rng + 256 * i); emit(prer + 96 * i, 96, s + 32 * i, rng + 256 * i + 128); status[i] = 0; }
   return ACT_OK;
 }
+// seeded prover: the record's tag, then seed[0..8) and the GLOBAL lane number the shard was handed
+int act_prove_spend_seeded_batch(act_ctx* c, size_t n, int, const uint8_t* tok, const uint8_t* s, const uint8_t* seed, uint64_t first_lane, uint8_t* proof, uint8_t* prer, uint8_t* status) {
+  c->lanes += n;
+  for (size_t i = 0; i < n; i++) {
+    uint8_t r[128] = {0}; memcpy(r, seed, 8); const uint64_t lane = first_lane + i; memcpy(r + 8, &lane, 8);
+    emit(proof + kPB * i, kPB, tok + 160 * i, r); emit(prer + 96 * i, 96, s + 32 * i, r); status[i] = 0;
+  }
+  return ACT_OK;
+}
 int act_verify_spend_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* proof, uint8_t* status, uint8_t* kp) {
   c->lanes += n;
   for (size_t i = 0; i < n; i++) { status[i] = (proof[kPB * i] & 1) ? 7 : 0; if (kp) { memset(kp + 32 * i, 0, 32); if (!status[i]) memcpy(kp + 32 * i, proof + kPB * i, 8); } }

@@ -289,3 +289,37 @@ def test_rejected_private_key_leaves_the_cached_key_untouched(engine_factory, be
     assert eng.verify_spend(sk, proof) == b"\x00"
     st, rf = eng.refund(sk, proof, shake("rr-cache", 128))
     assert st == b"\x00" and eng.refund_to_credit_token(prer, proof, rf, sk[32:])[0] == b"\x00"
+
+
+@pytest.mark.parametrize("L", [128, 8])
+def test_seeded_prover_equals_the_prover_on_the_expanded_bytes(engine_factory, oracle, bench_params, L):
+    """act_prove_spend_seeded_batch: lane i draws from the BLAKE3 XOF of seed | u64_le(first_lane + i), expanded on the device.  Must equal
+    the ordinary prover (and the oracle's) fed the same bytes expanded by the oracle's BLAKE3 (whose extended output is pinned by the
+    upstream vectors, tests/golden/blake3_llvm.json), across chunk boundaries and over a node handle whatever the number of shards."""
+    from act_amd import capi
+    import pymodel as m
+    octx = oracle.ctx(bench_params, L)
+    eng = engine_factory(bench_params, L, max_batch=5, transcript=MODES[0])
+    N = 12
+    sk = octx.private_key_random(shake("sd-pk", 64))
+    pre = eng.pre_issuance_random(shake("sd-pre-%d" % L, 128 * N)); req = eng.request(pre, shake("sd-rq", 128 * N))
+    st, resp = eng.issue(sk, req, b"".join(scb(50 + i) for i in range(N)), shake("sd-ir", 128 * N))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    assert st == bytes(N)
+    s_b = b"".join(scb(i) for i in range(N))
+    seed, first = shake("sd-seed", 32), (1 << 40) + 7
+    rb = eng.prove_rng_bytes
+    rng = b"".join(oracle.blake3(seed + (first + i).to_bytes(8, "little"), rb) for i in range(N))
+    assert rng[:200] == m.blake3(seed + first.to_bytes(8, "little"), 200)                     # the Python model's XOF agrees on the first blocks
+    got = eng.prove_spend_seeded(tok, s_b, seed, first)
+    assert got[0] == bytes(N)
+    assert got == eng.prove_spend(tok, s_b, rng)
+    assert got[1:] == octx.prove_spend_batch(tok, s_b, rng, 4)
+    assert eng.prove_spend_seeded(tok, s_b, seed, first + 1)[1] != got[1]                     # another lane number, another generator
+    for devices in ((0,), (0, 0, 0)):
+        node = capi.Node(bench_params, L, devices=devices, max_batch=5, transcript=MODES[1])
+        try:
+            assert node.prove_spend_seeded(tok, s_b, seed, first) == got
+        finally:
+            node.close()
+    assert eng.secret_residue() == 0

@@ -231,3 +231,18 @@ def test_node_redeem_keeps_every_decision_when_a_step_fails(lib):
     assert lib.act_node_nullifier_set_len(ns) == sum(1 for v in verdict if v == 0)      # every accepted nullifier IS recorded
     lib.act_node_nullifier_set_destroy(ns)
     lib.act_node_destroy(nd)
+
+
+@pytest.mark.parametrize("ndev", [1, 3, 8])
+def test_seeded_prover_lane_numbers_are_global(lib, ndev):
+    """act_node_prove_spend_seeded_batch: lane i's generator is named by first_lane + i whatever the number of shards, so a batch
+    proved on 8 GPUs equals the batch proved on one."""
+    n = 41
+    nd = make_node(lib, ndev)
+    tok = records(n, 160, 3); s = records(n, 32, 4); seed = bytes(range(100, 132))
+    proof = C.create_string_buffer(PB * n); prer = C.create_string_buffer(96 * n); st = C.create_string_buffer(n)
+    assert lib.act_node_prove_spend_seeded_batch(nd, C.c_size_t(n), tok, s, seed, C.c_uint64(1000), proof, prer, st) == 0
+    for i in range(n):
+        assert proof.raw[PB * i:PB * i + 8] == tok[160 * i:160 * i + 8]
+        assert proof.raw[PB * i + 8:PB * i + 16] == seed[:8] and int.from_bytes(proof.raw[PB * i + 16:PB * i + 24], "little") == 1000 + i
+    lib.act_node_destroy(nd)
