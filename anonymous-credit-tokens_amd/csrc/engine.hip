@@ -858,19 +858,22 @@ struct WireSrc { const uint8_t* cbor; const uint64_t* offsets; size_t msg_len; }
 static int wire_unframe_chunk(act_ctx* c, Slot& sl, const WireSrc& w, int mem, size_t off, uint32_t m, const uint8_t** d_records);     // cbor_impl.inc
 
 // ---- the small-batch schedule (spend_lanes.h) ----------------------------------------------------------------------------------
-// A call of at most small_max proofs is cut into sub-chunks of ONE ROUND of the range kernel each (131 072 (proof, bit) lanes = two
-// wavefronts on every SIMD: 1 024 proofs at L = 128), and every kernel of a sub-chunk goes on the stream of its kind, so that the
-// range kernels of consecutive sub-chunks run back to back while everything else happens next to them:
-//     aux 3 (copies)        H2D_0  H2D_1  H2D_2 ...                                   (host-memory callers; then D2H of transcripts, H2D of challenges)
-//     aux 0                 prep role C_k -> prep role A_k                             (C first: the range kernel waits for its digits)
-//     aux 1                 prep role B_k -> (A_k, C_k done) A1 / A2
-//     slot 1's stream       Com_j decode_k -> k_spend_tail_k
-//     slot 0's stream       k_spend_bits_0  k_spend_bits_1  k_spend_bits_2 ...
-//     aux 2                 k_spend_enc_k -> (all of k done) hash_k -> finish_k
-// One proof is then the depth of its longest stream (~1.4 ms of kernels instead of 5); 4 096 proofs are four rounds with the copies
-// and the per-proof kernels hidden under them.  Scratch of the roles lives in d_small, wiped like every other key-dependent
-// buffer (finish_call).  Large calls keep the two-slot pipeline of 65 536-proof chunks (one lane per proof is the cheaper form
-// once a launch fills the chip: DESIGN.md section 8).
+// Every kernel of a call goes on the stream of its kind, so that the per-proof kernels run NEXT TO the range kernel instead of in
+// front of and behind it:
+//     aux 3 (copies)        H2D                                                        (host-memory callers; then D2H of transcripts, H2D of challenges)
+//     aux 0                 prep role C1 -> role C2 -> role A                          (C1 first: the range kernel waits for its digits and h2 terms)
+//     aux 1                 prep role B -> (A, C done) A1 / A2
+//     slot 1's stream       Com_j decode -> k_spend_tail
+//     slot 0's stream       k_spend_bits
+//     aux 2                 k_spend_enc (8 points per lane) -> (all done) hash (16 lanes per transcript) -> finish
+// One proof is then the depth of its longest stream: 1.85 ms instead of 5.6 ms (profiles/r04_small_timeline2.txt).  The schedule can
+// cut a call into sub-chunks that follow each other through the six streams (ACT_SMALL_SUB proofs each; copies of sub-chunk k + 1
+// under the kernels of k), but measured (profiles/r04_small_sweep*.txt) one launch per kernel wins at every size: a range-kernel
+// launch of one round (1 024 proofs = two wavefronts on every SIMD) takes 3.1 ms instead of 2.2 ms when per-proof kernels -- 256
+// VGPRs each, i.e. half a SIMD -- hold some of its slots, because the displaced blocks need a second round; longer launches absorb
+// that.  So the default sub-chunk is 2^20 lanes (8 192 proofs at L = 128) = the schedule's size limit, and larger calls keep the
+// two-slot pipeline of 65 536-proof chunks (one lane per proof is the cheaper form once a launch fills the chip: DESIGN.md section 8).
+// Scratch of the roles lives in d_small, wiped like every other key-dependent buffer (finish_call).
 enum { SM_IN = 0, SM_A, SM_C, SM_JOIN, SM_TAIL, SM_BITS, SM_READY, SM_D2H, SM_EVENTS };
 static int small_prepare(act_ctx* c, size_t n, size_t subs) {
   if (!c->aux[0]) {

@@ -10,11 +10,13 @@
 //                                        wave-uniform scalar through two width-3-NAF accumulators in LDS
 //      chain_b<NACC> (per-proof kernels) every scalar through its own bucket set
 //      chain<NACC>, chain2u              the earlier radix-4 / plain-NAF forms, kept as cross-checks for the host build
-// 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as 16 mixed
-//    additions, one per scalar window, from position-specific affine-Niels tables
-//    T[pos][d] = d * 2^(w*pos) * B, w = FB_WBITS = 16 (16 windows x 65536 entries x 128 B = 128 MiB per base,
-//    512 MiB per context of the GPU's 288 GB; built once per context by k_build_table).  Measured on one MI355X
-//    against 12-bit windows (22 additions, 11 MiB per base): verify +2 %, prove_spend +12 %; 14 bits: +1.3 % / +7 %.
+// 2. fixed_base_acc: `&table * &scalar` (RistrettoBasepointTable, src/lib.rs:224-228) as one mixed addition per scalar
+//    window from position-specific affine-Niels tables T[pos][d] = d * 2^(w*pos) * B.  The window width w is a property of the
+//    table (FbTab): 16 bits by default (16 windows x 65 536 entries x 128 B = 128 MiB per base), 24 bits for h1 and h3 -- the
+//    range kernels' bases -- in contexts sized for throughput (11 windows, 23.6 GB per base; engine.hip act_ctx_create).  Tables
+//    are built on the GPU (k_build_table) once per (device, base, width) and shared by every context of the process on that GPU.
+//    Measured on one MI355X: 16 against 12 bits (22 additions, 11 MiB per base) verify +2 %, prove_spend +12 %; 24 against 16
+//    bits on distinct proofs +3.2 % verifies/s (profiles/r03_window_ab_distinct.json).
 #pragma once
 #include "ge25519.h"
 

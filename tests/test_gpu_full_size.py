@@ -124,11 +124,17 @@ def test_config3_2_20_prove_spend_at_L128(engine_factory, oracle, bench_params):
     note_rate("config3_prove_spend_L128_2^20", {"proofs_per_s": nchunks * chunk / t_prove, "ms": 1e3 * t_prove, "chunks": nchunks})
 
 
-def test_config5_2_20_lifecycles_streamed_from_pinned_host_memory(bench_params):
+@pytest.mark.parametrize("rng_source,nchunks", [("seeded", 32), ("bytes", 8)])
+def test_config5_lifecycles_streamed_from_pinned_host_memory(bench_params, oracle, rng_source, nchunks):
+    """BASELINE configs[4] at ONE GPU's share: 2^24 lifecycles over 8 GPUs = 2^21 per GPU, streamed in 2^16-lane calls through pinned
+    host memory (request -> issue -> to_credit_token -> prove_spend -> refund -> to_credit_token), every call a node-handle call.
+    "seeded": the prover's generators are seeded (act_node_prove_spend_seeded_batch: BLAKE3-XOF(seed | lane) expanded in HBM), so
+    the 33 536 rng bytes per proof never cross PCIe; "bytes" (2^19 lifecycles): every rng byte comes from host memory, the
+    round-3 form.  Balances of every lane; four lanes of the last call byte for byte against the oracle's whole lifecycle."""
     import numpy as np
     import torch
     from act_amd import capi
-    L, chunk, nchunks = 128, 1 << 16, 16
+    L, chunk = 128, 1 << 16
     node = capi.Node(bench_params, L, devices=(0, 0), max_batch=1 << 14, transcript=capi.TRANSCRIPT_DEVICE)
     pb, rb = node.proof_bytes, node.prove_rng_bytes
     eng0 = capi.Engine(bench_params, 8, max_batch=4)
@@ -136,8 +142,10 @@ def test_config5_2_20_lifecycles_streamed_from_pinned_host_memory(bench_params):
     pin = lambda *shape: torch.empty(shape, dtype=torch.uint8, pin_memory=True)
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     rnd = lambda *shape: torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
-    # rng streams: the 2.2 GB of prover bytes are drawn once and reused by every chunk (tokens differ per chunk)
-    r_pr = pin(chunk, rb); r_pr.copy_(rnd(chunk, rb))
+    seed = shake("c5-seed", 32)
+    if rng_source == "bytes":
+        # the 2.2 GB of prover bytes are drawn once and reused by every chunk (tokens differ per chunk)
+        r_pr = pin(chunk, rb); r_pr.copy_(rnd(chunk, rb))
     amounts = np.array([(i * 40503 + 11) % 100000 + 1 for i in range(chunk)], dtype=np.uint64)
     charges = amounts // np.uint64(3)
     le32 = lambda v: np.concatenate([v.astype("<u8").view(np.uint8).reshape(-1, 8), np.zeros((len(v), 24), np.uint8)], axis=1)
@@ -149,6 +157,7 @@ def test_config5_2_20_lifecycles_streamed_from_pinned_host_memory(bench_params):
     st = pin(chunk)
     import ctypes as C
     skb = (C.c_uint8 * 64).from_buffer_copy(sk); wb = (C.c_uint8 * 32).from_buffer_copy(sk[32:])
+    seedb = (C.c_uint8 * 32).from_buffer_copy(seed)
     cb = np.frombuffer(c_b, np.uint8); sb = np.frombuffer(s_b, np.uint8)
     # PreIssuance::random has no node-level twin (it is two scalar reductions): context 0 of the node does it
     ctx0 = lib.act_node_ctx(nd, 0)
@@ -165,7 +174,10 @@ def test_config5_2_20_lifecycles_streamed_from_pinned_host_memory(bench_params):
         assert int(st.sum()) == 0
         ck(lib.act_node_issuance_to_credit_token_batch(nd, chunk, ptr(bufs["pre"]), wb, ptr(bufs["req"]), ptr(bufs["resp"]), ptr(bufs["tok"]), ptr(st)))
         assert int(st.sum()) == 0
-        ck(lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st)))
+        if rng_source == "seeded":
+            ck(lib.act_node_prove_spend_seeded_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, seedb, C.c_uint64(c * chunk), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st)))
+        else:
+            ck(lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st)))
         assert int(st.sum()) == 0
         ck(lib.act_node_refund_batch(nd, chunk, skb, ptr(bufs["proof"]), ptr(r128["rr"]), capi.RNG_PER_LANE, ptr(bufs["rf"]), ptr(st)))
         assert int(st.sum()) == 0, "every honest spend must be refunded (chunk %d)" % c
@@ -177,9 +189,24 @@ def test_config5_2_20_lifecycles_streamed_from_pinned_host_memory(bench_params):
         assert np.array_equal(t2[:, 64:96], bufs["prer"].numpy()[:, 32:64])
         assert not np.array_equal(t2[:, 64:96], bufs["tok"].numpy()[:, 64:96])
     dt = time.perf_counter() - t0
+    # four lanes of the last call, every record of their lifecycle, against the oracle fed the same inputs
+    octx = oracle.ctx(bench_params, L)
+    last = (nchunks - 1) * chunk
+    for i in (0, 1, chunk // 2 + 3, chunk - 1):
+        row = lambda t, w: t.numpy()[i].tobytes()[:w]
+        pre = octx.pre_issuance_random(row(r128["pre"], 128)); assert pre == row(bufs["pre"], 64)
+        req = octx.request(pre, row(r128["rq"], 128)); assert req == row(bufs["req"], 128)
+        so, resp = octx.issue(sk, req, c_b[32 * i:32 * i + 32], row(r128["ir"], 128)); assert so == 0 and resp == row(bufs["resp"], 160)
+        so, tok = octx.issuance_to_credit_token(pre, sk[32:], req, resp); assert so == 0 and tok == row(bufs["tok"], 160)
+        prng = oracle.blake3(seed + (last + i).to_bytes(8, "little"), rb) if rng_source == "seeded" else row(r_pr, rb)
+        so, proof, prer = octx.prove_spend(tok, s_b[32 * i:32 * i + 32], prng); assert so == 0 and proof == row(bufs["proof"], pb) and prer == row(bufs["prer"], 96)
+        so, rf = octx.refund(sk, proof, row(r128["rr"], 128)); assert so == 0 and rf == row(bufs["rf"], 128)
+        so, tok2 = octx.refund_to_credit_token(prer, proof, rf, sk[32:]); assert so == 0 and tok2 == row(bufs["tok2"], 160)
     node.close()
-    note_rate("config5_lifecycles_L128_2^20_streamed_pinned_host", {"lifecycles_per_s": nchunks * chunk / dt, "ms": 1e3 * dt,
-              "note": "2^16-lane chunks through pinned host memory, two contexts on one GPU (node handle), device transcripts; includes drawing the rng bytes"})
+    note_rate("config5_lifecycles_L128_2^%d_streamed_pinned_host_%s_rng" % ((nchunks * chunk).bit_length() - 1, rng_source),
+              {"lifecycles_per_s": nchunks * chunk / dt, "ms": 1e3 * dt, "lifecycles": nchunks * chunk,
+               "note": "2^16-lane calls through pinned host memory, two contexts on one GPU (node handle), device transcripts; includes drawing the 128-byte rng slices; "
+                       + ("prover generators seeded (BLAKE3-XOF expanded in HBM)" if rng_source == "seeded" else "prover rng bytes (33 536 per proof) from host memory")})
 
 
 def _accepted_index(status):

@@ -302,6 +302,7 @@ def test_limb_bounds_hold(hostcheck):
     print('limb bounds (units of 2^-16):', [round(v / 65536, 4) for v in bd])
     for v, l in zip(bd, lim):
         assert 0 < v <= l * 2**16, (list(bd), lim)
+    assert bd[5] == 0, "a subtraction met a subtrahend limb above its offset (fe_limb_sub: |c - g| + f would be wrong on the GPU)"
 
 
 def test_generated_field_sources_are_current():

@@ -108,3 +108,4 @@ def test_lane_bodies_stay_inside_the_limb_budget(hostcheck, oracle, bench_params
     hostcheck.hc_bounds(bd)
     for v, l in zip(bd, [12.5, 12.5, 1.0, 1.0, 7.5]):
         assert 0 < v <= l * 2**16, list(bd)
+    assert bd[5] == 0, "a subtrahend limb above its offset"

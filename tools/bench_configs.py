@@ -112,13 +112,18 @@ def main():
         lib, ctx = eng.lib, eng.ctx
         import ctypes as C
         wbuf = (C.c_uint8 * 32).from_buffer_copy(w); skbuf = (C.c_uint8 * 64).from_buffer_copy(sk)
+        seedbuf = (C.c_uint8 * 32).from_buffer_copy(shake("lifecycle-seed", 32))
+        seeded = [False]
         def lifecycle_chunk():
             ck = eng._ck
             ck(lib.act_pre_issuance_random_batch(ctx, chunk, 1, r_pre.data_ptr(), b["pre"].data_ptr()))
             ck(lib.act_request_batch(ctx, chunk, 1, b["pre"].data_ptr(), r_rq.data_ptr(), b["req"].data_ptr()))
             ck(lib.act_issue_batch(ctx, chunk, 1, skbuf, b["req"].data_ptr(), d_c.data_ptr(), r_ir.data_ptr(), 0, b["resp"].data_ptr(), stt.data_ptr()))
             ck(lib.act_issuance_to_credit_token_batch(ctx, chunk, 1, b["pre"].data_ptr(), wbuf, b["req"].data_ptr(), b["resp"].data_ptr(), b["tok"].data_ptr(), stt.data_ptr()))
-            ck(lib.act_prove_spend_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), r_pr.data_ptr(), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr()))
+            if seeded[0]:
+                ck(lib.act_prove_spend_seeded_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), seedbuf, C.c_uint64(0), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr()))
+            else:
+                ck(lib.act_prove_spend_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), r_pr.data_ptr(), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr()))
             ck(lib.act_refund_batch(ctx, chunk, 1, skbuf, b["proof"].data_ptr(), r_rr.data_ptr(), 0, b["rf"].data_ptr(), stt.data_ptr()))
             ck(lib.act_refund_to_credit_token_batch(ctx, chunk, 1, b["prer"].data_ptr(), b["proof"].data_ptr(), b["rf"].data_ptr(), wbuf, b["tok2"].data_ptr(), stt.data_ptr()))
         torch.cuda.synchronize(); lifecycle_chunk(); torch.cuda.synchronize()
@@ -129,6 +134,14 @@ def main():
         torch.cuda.synchronize(); dt = time.perf_counter() - t
         print("lifecycle done", file=sys.stderr, flush=True)
         out["config5_lifecycles_L128_2^%d" % a.lifecycle_log2] = {"lifecycles_per_s": nl / dt, "ms": 1e3 * dt}
+        seeded[0] = True                  # the prover's generators expanded on the device from a seed (act_prove_spend_seeded_batch)
+        torch.cuda.synchronize(); lifecycle_chunk(); torch.cuda.synchronize()
+        assert int((stt == 0).sum()) == chunk
+        t = time.perf_counter()
+        for _ in range(nl // chunk):
+            lifecycle_chunk()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        out["config5_lifecycles_L128_2^%d_seeded_prover" % a.lifecycle_log2] = {"lifecycles_per_s": nl / dt, "ms": 1e3 * dt}
         # wire codec and nullifier set
         nc = 1 << 15
         recs = np.frombuffer(proofs, np.uint8).reshape(D, pb)
