@@ -163,25 +163,32 @@ def test_config5_lifecycles_streamed_from_pinned_host_memory(bench_params, oracl
     ctx0 = lib.act_node_ctx(nd, 0)
     ck = node._ck
     torch.cuda.synchronize()
+    spent = {}          # where a streamed lifecycle's time goes: seconds per call kind, summed over the chunks
+
+    def timed(key, fn):
+        t = time.perf_counter(); r = fn(); spent[key] = spent.get(key, 0.0) + time.perf_counter() - t
+        return r
     t0 = time.perf_counter()
     for c in range(nchunks):
-        for k in r128:
-            r128[k].copy_(rnd(chunk, 128))
-        torch.cuda.synchronize()
-        assert lib.act_pre_issuance_random_batch(ctx0, chunk, capi.MEM_HOST, ptr(r128["pre"]), ptr(bufs["pre"])) == 0
-        ck(lib.act_node_request_batch(nd, chunk, ptr(bufs["pre"]), ptr(r128["rq"]), ptr(bufs["req"])))
-        ck(lib.act_node_issue_batch(nd, chunk, skb, ptr(bufs["req"]), cb.ctypes.data, ptr(r128["ir"]), capi.RNG_PER_LANE, ptr(bufs["resp"]), ptr(st)))
+        def draw():
+            for k in r128:
+                r128[k].copy_(rnd(chunk, 128))
+            torch.cuda.synchronize()
+        timed("draw 4 x 128 rng bytes per lane (torch, D2H)", draw)
+        assert timed("pre_issuance_random", lambda: lib.act_pre_issuance_random_batch(ctx0, chunk, capi.MEM_HOST, ptr(r128["pre"]), ptr(bufs["pre"]))) == 0
+        ck(timed("request", lambda: lib.act_node_request_batch(nd, chunk, ptr(bufs["pre"]), ptr(r128["rq"]), ptr(bufs["req"]))))
+        ck(timed("issue", lambda: lib.act_node_issue_batch(nd, chunk, skb, ptr(bufs["req"]), cb.ctypes.data, ptr(r128["ir"]), capi.RNG_PER_LANE, ptr(bufs["resp"]), ptr(st))))
         assert int(st.sum()) == 0
-        ck(lib.act_node_issuance_to_credit_token_batch(nd, chunk, ptr(bufs["pre"]), wb, ptr(bufs["req"]), ptr(bufs["resp"]), ptr(bufs["tok"]), ptr(st)))
+        ck(timed("issuance_to_credit_token", lambda: lib.act_node_issuance_to_credit_token_batch(nd, chunk, ptr(bufs["pre"]), wb, ptr(bufs["req"]), ptr(bufs["resp"]), ptr(bufs["tok"]), ptr(st))))
         assert int(st.sum()) == 0
         if rng_source == "seeded":
-            ck(lib.act_node_prove_spend_seeded_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, seedb, C.c_uint64(c * chunk), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st)))
+            ck(timed("prove_spend", lambda: lib.act_node_prove_spend_seeded_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, seedb, C.c_uint64(c * chunk), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st))))
         else:
-            ck(lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st)))
+            ck(timed("prove_spend", lambda: lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st))))
         assert int(st.sum()) == 0
-        ck(lib.act_node_refund_batch(nd, chunk, skb, ptr(bufs["proof"]), ptr(r128["rr"]), capi.RNG_PER_LANE, ptr(bufs["rf"]), ptr(st)))
+        ck(timed("refund", lambda: lib.act_node_refund_batch(nd, chunk, skb, ptr(bufs["proof"]), ptr(r128["rr"]), capi.RNG_PER_LANE, ptr(bufs["rf"]), ptr(st))))
         assert int(st.sum()) == 0, "every honest spend must be refunded (chunk %d)" % c
-        ck(lib.act_node_refund_to_credit_token_batch(nd, chunk, ptr(bufs["prer"]), ptr(bufs["proof"]), ptr(bufs["rf"]), wb, ptr(bufs["tok2"]), ptr(st)))
+        ck(timed("refund_to_credit_token", lambda: lib.act_node_refund_to_credit_token_batch(nd, chunk, ptr(bufs["prer"]), ptr(bufs["proof"]), ptr(bufs["rf"]), wb, ptr(bufs["tok2"]), ptr(st))))
         assert int(st.sum()) == 0
         # final balances: the new token carries c - s; its nullifier k is the fresh k* of the spend, not the old one
         t2 = bufs["tok2"].numpy()
@@ -205,6 +212,8 @@ def test_config5_lifecycles_streamed_from_pinned_host_memory(bench_params, oracl
     node.close()
     note_rate("config5_lifecycles_L128_2^%d_streamed_pinned_host_%s_rng" % ((nchunks * chunk).bit_length() - 1, rng_source),
               {"lifecycles_per_s": nchunks * chunk / dt, "ms": 1e3 * dt, "lifecycles": nchunks * chunk,
+               "ms_per_2^16_lanes_by_call": {k: round(1e3 * v / nchunks, 2) for k, v in spent.items()},
+               "ms_per_2^16_lanes_python_checks": round(1e3 * (dt - sum(spent.values())) / nchunks, 2),
                "note": "2^16-lane calls through pinned host memory, two contexts on one GPU (node handle), device transcripts; includes drawing the 128-byte rng slices; "
                        + ("prover generators seeded (BLAKE3-XOF expanded in HBM)" if rng_source == "seeded" else "prover rng bytes (33 536 per proof) from host memory")})
 

@@ -114,26 +114,32 @@ def main():
         wbuf = (C.c_uint8 * 32).from_buffer_copy(w); skbuf = (C.c_uint8 * 64).from_buffer_copy(sk)
         seedbuf = (C.c_uint8 * 32).from_buffer_copy(shake("lifecycle-seed", 32))
         seeded = [False]
+        spent = {}
+        def tm(key, fn):              # every entry point returns with its outputs complete: its wall time is its cost
+            t = time.perf_counter(); r = fn(); spent[key] = spent.get(key, 0.0) + time.perf_counter() - t
+            return r
         def lifecycle_chunk():
             ck = eng._ck
-            ck(lib.act_pre_issuance_random_batch(ctx, chunk, 1, r_pre.data_ptr(), b["pre"].data_ptr()))
-            ck(lib.act_request_batch(ctx, chunk, 1, b["pre"].data_ptr(), r_rq.data_ptr(), b["req"].data_ptr()))
-            ck(lib.act_issue_batch(ctx, chunk, 1, skbuf, b["req"].data_ptr(), d_c.data_ptr(), r_ir.data_ptr(), 0, b["resp"].data_ptr(), stt.data_ptr()))
-            ck(lib.act_issuance_to_credit_token_batch(ctx, chunk, 1, b["pre"].data_ptr(), wbuf, b["req"].data_ptr(), b["resp"].data_ptr(), b["tok"].data_ptr(), stt.data_ptr()))
+            ck(tm("pre_issuance_random", lambda: lib.act_pre_issuance_random_batch(ctx, chunk, 1, r_pre.data_ptr(), b["pre"].data_ptr())))
+            ck(tm("request", lambda: lib.act_request_batch(ctx, chunk, 1, b["pre"].data_ptr(), r_rq.data_ptr(), b["req"].data_ptr())))
+            ck(tm("issue", lambda: lib.act_issue_batch(ctx, chunk, 1, skbuf, b["req"].data_ptr(), d_c.data_ptr(), r_ir.data_ptr(), 0, b["resp"].data_ptr(), stt.data_ptr())))
+            ck(tm("issuance_to_credit_token", lambda: lib.act_issuance_to_credit_token_batch(ctx, chunk, 1, b["pre"].data_ptr(), wbuf, b["req"].data_ptr(), b["resp"].data_ptr(), b["tok"].data_ptr(), stt.data_ptr())))
             if seeded[0]:
-                ck(lib.act_prove_spend_seeded_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), seedbuf, C.c_uint64(0), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr()))
+                ck(tm("prove_spend", lambda: lib.act_prove_spend_seeded_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), seedbuf, C.c_uint64(0), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr())))
             else:
-                ck(lib.act_prove_spend_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), r_pr.data_ptr(), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr()))
-            ck(lib.act_refund_batch(ctx, chunk, 1, skbuf, b["proof"].data_ptr(), r_rr.data_ptr(), 0, b["rf"].data_ptr(), stt.data_ptr()))
-            ck(lib.act_refund_to_credit_token_batch(ctx, chunk, 1, b["prer"].data_ptr(), b["proof"].data_ptr(), b["rf"].data_ptr(), wbuf, b["tok2"].data_ptr(), stt.data_ptr()))
+                ck(tm("prove_spend", lambda: lib.act_prove_spend_batch(ctx, chunk, 1, b["tok"].data_ptr(), d_s.data_ptr(), r_pr.data_ptr(), b["proof"].data_ptr(), b["prer"].data_ptr(), stt.data_ptr())))
+            ck(tm("refund", lambda: lib.act_refund_batch(ctx, chunk, 1, skbuf, b["proof"].data_ptr(), r_rr.data_ptr(), 0, b["rf"].data_ptr(), stt.data_ptr())))
+            ck(tm("refund_to_credit_token", lambda: lib.act_refund_to_credit_token_batch(ctx, chunk, 1, b["prer"].data_ptr(), b["proof"].data_ptr(), b["rf"].data_ptr(), wbuf, b["tok2"].data_ptr(), stt.data_ptr())))
         torch.cuda.synchronize(); lifecycle_chunk(); torch.cuda.synchronize()
         assert int((stt == 0).sum()) == chunk, "every lifecycle must close"
+        spent.clear()
         t = time.perf_counter()
         for _ in range(nl // chunk):
             lifecycle_chunk()
         torch.cuda.synchronize(); dt = time.perf_counter() - t
         print("lifecycle done", file=sys.stderr, flush=True)
-        out["config5_lifecycles_L128_2^%d" % a.lifecycle_log2] = {"lifecycles_per_s": nl / dt, "ms": 1e3 * dt}
+        out["config5_lifecycles_L128_2^%d" % a.lifecycle_log2] = {"lifecycles_per_s": nl / dt, "ms": 1e3 * dt,
+                                                                   "ms_per_2^16_lanes_by_call": {k: round(1e3 * v / (nl // chunk), 2) for k, v in spent.items()}}
         seeded[0] = True                  # the prover's generators expanded on the device from a seed (act_prove_spend_seeded_batch)
         torch.cuda.synchronize(); lifecycle_chunk(); torch.cuda.synchronize()
         assert int((stt == 0).sum()) == chunk

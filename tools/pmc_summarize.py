@@ -41,3 +41,31 @@ json.dump({"kernel": "k_spend_bits", "kernel_source_sha16": SHA, "range_bits": 1
            "note": "separate --pmc passes (tools/pmc_profile.sh, NB=%d); gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md), both figures given; includes the per-lane Pippenger bucket and scratch traffic, counted at the L2's memory side (Infinity-Cache hits are not excluded)" % NB},
           open("gpurun_out/%s_pmc_hbm_traffic.json" % tag, "w"), indent=1)
 print(json.dumps({k: v for k, v in valu.items() if k != "raw"}))
+
+# ---- the prover's range kernel from the same passes (pmc_run.py makes its proofs with the engine's prover: one k_prove_bits launch) ----
+pt = collections.defaultdict(float); pdur = {}; plaunches = collections.defaultdict(int)
+for d in sorted(glob.glob("gpurun_out/%s_pmc/p*" % tag)):
+    names = set()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_prove_bits" in r["Kernel_Name"]:
+                pt[r["Counter_Name"]] += float(r["Counter_Value"]); names.add(r["Counter_Name"])
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "k_prove_bits" in r["Kernel_Name"]:
+                for n in names: pdur[n] = pdur.get(n, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; plaunches[n] += 1
+if pt.get("SQ_WAVES"):
+    pw = pt["SQ_WAVES"]; nl = max(1, plaunches.get("SQ_INSTS_VALU", 1))
+    pf, pwr = pt["FETCH_SIZE"] * 1024, pt["WRITE_SIZE"] * 1024
+    prover = {"kernel": "k_prove_bits", "kernel_source_sha16": SHA, "range_bits": 128, "proofs_per_launch": NB, "launches": nl, "waves": pw,
+              "valu_instructions_per_wave": pt["SQ_INSTS_VALU"] / pw, "wave_lifetime_cycles": 4 * pt["SQ_WAVE_CYCLES"] / pw,
+              "cycles_per_valu_instruction_per_simd_2waves": 4 * pt["SQ_WAVE_CYCLES"] / (2 * pt["SQ_INSTS_VALU"]),
+              "wait_any_frac_of_wave_cycles": pt["SQ_WAIT_ANY"] / max(1.0, pt["SQ_WAVE_CYCLES"]),
+              "l2_hit_rate": pt["TCC_HIT_sum"] / max(1.0, pt["TCC_HIT_sum"] + pt["TCC_MISS_sum"]),
+              "launch_ms_under_pmc": {k: v / max(1, plaunches[k]) for k, v in pdur.items()},
+              "FETCH_SIZE_bytes_per_launch": pf / max(1, plaunches.get("FETCH_SIZE", 1)), "WRITE_SIZE_bytes_per_launch": pwr / max(1, plaunches.get("WRITE_SIZE", 1)),
+              "raw": dict(pt),
+              "note": "k_prove_bits (the input generation of tools/pmc_run.py: one launch of NB proofs per pass); FETCH_SIZE counts 128-byte requests at the L2's memory side: "
+                      "every table entry is one 128-byte line (no wide-coalescing under-count applies to single-line reads)"}
+    json.dump(prover, open("gpurun_out/%s_pmc_prover.json" % tag, "w"), indent=1)
+    print(json.dumps({k: v for k, v in prover.items() if k != "raw"}))

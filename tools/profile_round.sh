@@ -5,7 +5,7 @@
 #   gpurun_out/<tag>_kernel_stats_depth1.csv     rocprofv3's per-kernel summary of that run: with one chunk in flight its average
 #                                                k_spend_bits duration is an un-overlapped launch and must agree with roofline.avg_launch_ms
 #   gpurun_out/<tag>_pmc_valu.json, _pmc_hbm_traffic.json   separate --pmc passes (tools/pmc_profile.sh)
-tag=${1:-r03_c}
+tag=${1:-r04_a}
 root=${GRAFT_REPO_ROOT:-$PWD}
 cd $root
 python3 bench.py --steps 3 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
