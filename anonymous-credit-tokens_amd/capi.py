@@ -21,7 +21,7 @@ EXPORTS = [
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_prove_spend_seeded_batch", "act_node_prove_spend_seeded_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
-    "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32", "act_ubench_random_read",
+    "act_prof_reset", "act_prof_kernel_count", "act_prof_kernel_name", "act_prof_get", "act_prof_get_busy", "act_ubench_mad_u64_u32", "act_ubench_random_read", "act_ubench_table_read",
     "act_cbor_size", "act_cbor_record_bytes", "act_cbor_encode_batch", "act_cbor_decode_batch", "act_verify_spend_cbor_batch",
     "act_node_verify_spend_cbor_batch", "act_redeem_batch", "act_node_redeem_batch",
     "act_nullifier_set_create", "act_nullifier_set_destroy", "act_nullifier_set_len", "act_nullifier_set_last_error",
@@ -131,6 +131,7 @@ def load() -> C.CDLL:
     lib.act_prof_get_busy.argtypes = [vp, i32, C.POINTER(C.c_double)]
     lib.act_ubench_mad_u64_u32.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.act_ubench_random_read.argtypes = [i32, sz, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.act_ubench_table_read.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.act_issue_check_batch.argtypes = [vp, sz, i32, u8p, u8p]
     lib.act_issue_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_refund_sign_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
@@ -280,6 +281,12 @@ class Engine:
 
     def set_host_threads(self, n: int):
         self._ck(self.lib.act_ctx_set_host_threads(self.ctx, n))
+
+    def ubench_table_read(self, base: int, waves_per_simd: int = 0, in_flight: int = 0):
+        """(GB/s, ms) of random 128-byte reads over this context's own table of base 0..3 (g, h1, h2, h3)."""
+        r, ms = C.c_double(0), C.c_double(0)
+        self._ck(self.lib.act_ubench_table_read(self.ctx, base, waves_per_simd, in_flight, C.byref(r), C.byref(ms)))
+        return r.value, ms.value
 
     def set_small_batch_max(self, n: int):
         """Calls of at most n proofs take the small-batch (latency) schedule; 0 = never."""

@@ -1242,36 +1242,47 @@ int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
 // 128-byte random-read micro-benchmark (k_misc.hip k_ubench_random_read): the memory-side roofline of the scalar-addressed
 // fixed-base tables.  `gib` GiB of device memory are allocated for the probe and freed again (0 = 16); waves_per_simd (0 = 2) and
 // in_flight (1, 2 or 4; 0 = 2) set how many lines a CU has outstanding.
-int act_ubench_random_read(int device, size_t gib, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
+static int ubench_random_read_impl(int device, const uint32_t* table, size_t table_bytes, size_t gib, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
   if (!gbytes_per_s) return ACT_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
-  size_t g2 = 1; while (g2 * 2 <= (gib ? gib : 16)) g2 *= 2;                     // a power of two: the kernel masks its line numbers
-  const size_t bytes = g2 << 30;
+  size_t bytes;
+  if (table) { bytes = (size_t)1 << 20; while (bytes * 2 <= table_bytes) bytes *= 2; }      // the largest power-of-two prefix of the table
+  else { size_t g2 = 1; while (g2 * 2 <= (gib ? gib : 16)) g2 *= 2; bytes = g2 << 30; }     // a power of two: the kernel masks its line numbers
   const uint64_t lines = bytes / 128;
   if (waves_per_simd <= 0) waves_per_simd = 2;
   if (waves_per_simd > 8) waves_per_simd = 8;
   if (in_flight <= 0) in_flight = 2;
   const uint32_t blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)waves_per_simd, iters = 4096u * 8u / (uint32_t)waves_per_simd;
-  uint32_t *buf = nullptr, *out = nullptr; hipEvent_t e0, e1; hipStream_t st;
-  if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
-  if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return ACT_ERR_HIP; }
+  uint32_t *buf = const_cast<uint32_t*>(table), *out = nullptr; hipEvent_t e0, e1; hipStream_t st;
+  if (!table && hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
+  if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) { (void)hipGetLastError(); if (!table) (void)hipFree(buf); return ACT_ERR_HIP; }
   int rc = ACT_OK; float t = 0;
-  if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(buf); (void)hipFree(out); return ACT_ERR_HIP; }
-  (void)hipMemsetAsync(buf, 0x5a, bytes, st);                                  // touch every page
+  if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (!table) (void)hipFree(buf); (void)hipFree(out); return ACT_ERR_HIP; }
+  if (!table) (void)hipMemsetAsync(buf, 0x5a, bytes, st);                      // touch every page
   launch_ubench_random_read(buf, lines, blocks, 64, in_flight, out, st);       // warm-up
   (void)hipEventRecord(e0, st);
   launch_ubench_random_read(buf, lines, blocks, iters, in_flight, out, st);
   (void)hipEventRecord(e1, st);
   if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = ACT_ERR_HIP;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(buf); (void)hipFree(out);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); if (!table) (void)hipFree(buf); (void)hipFree(out);
   if (rc) { (void)hipGetLastError(); return rc; }
   *gbytes_per_s = (double)blocks * 256.0 * iters * 128.0 / (t * 1e-3) / 1e9;     // a 128-byte line per read (112 bytes of it used, as the tables' entries)
   if (ms) *ms = t;
   return ACT_OK;
+}
+int act_ubench_random_read(int device, size_t gib, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
+  return ubench_random_read_impl(device, nullptr, 0, gib, waves_per_simd, in_flight, gbytes_per_s, ms);
+}
+// the same probe on the context's OWN table of `base` (0..3 = g, h1, h2, h3): the product's entries in the product's memory, read
+// in the product's pattern with nothing else going on -- the ceiling of fixed_base_acc's look-ups as this context has them
+int act_ubench_table_read(act_ctx* c, int base, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
+  if (!c || base < 0 || base > 3) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return ubench_random_read_impl(c->device, c->d_tables[base], fb_table_words((uint32_t)c->fb_bits[base]) * 4, 0, waves_per_simd, in_flight, gbytes_per_s, ms);
 }
 
 int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* points, const uint8_t* scalars, uint8_t* out, uint8_t* status) {

@@ -61,7 +61,7 @@ ELL = 2**252 + 27742317777372353535851937790883648493
 CSRC = os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc")
 # sources that determine k_spend_bits: PMC summaries under profiles/ are only cited when they were taken from these bytes
 KERNEL_SOURCES = ["fe25519.h", "fe25519_gen.inc", "fe25519_consts.inc", "sc25519.h", "ge25519.h", "msm.h", "kernels.h", "spend_lanes.h",
-                  "k_spend_verify.hip"]
+                  "k_spend_verify.hip", "prove_lanes.h", "k_prove.hip"]
 MAD_PER_MUL, MAD_PER_SQ = 97, 61          # fe25519.h / tools/gen_fe_mul.py: 81 (45) limb products + 7 carries of the high half + 9 folds by 19, all v_mad_u64_u32
 LIMB_PRODUCTS_PER_MUL, LIMB_PRODUCTS_PER_SQ = 81, 45   # the part of those no 9-limb representation can avoid
 
@@ -762,13 +762,16 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
     table_bytes = ops["k_prove_bits"]["table_reads"] * 128
     rnd = {}
     try:
-        from act_amd import capi
-        # the chip's rate for this access pattern at several (wavefronts per SIMD, entries in flight per lane): the best is the ceiling
-        sweep = {"%dw x %d" % (w, f): round(capi.ubench_random_read(eng.device, 16, w, f)[0], 1) for w, f in ((2, 1), (2, 2), (2, 4), (4, 2), (8, 2), (8, 4))}
-        rnd = {"random_128B_read_GBps_measured": max(sweep.values()), "random_128B_read_GBps_by_waves_per_simd_x_entries_in_flight": sweep}
+        # the chip's rate for the tables' access pattern -- random 128-byte entries, seven 16-byte loads each -- measured on this
+        # context's own h3 table (the product's memory), at several (wavefronts per SIMD, entries in flight per lane); and on a
+        # fresh 16 GiB allocation for comparison
+        sweep = {"%dw x %d" % (w, f): round(eng.ubench_table_read(3, w, f)[0], 1) for w, f in ((2, 1), (2, 2), (2, 4), (4, 2), (8, 2), (8, 4))}
+        rnd = {"random_128B_read_GBps_measured": max(sweep.values()), "random_128B_read_GBps_on_the_h3_table_by_waves_per_simd_x_entries_in_flight": sweep,
+               "random_128B_read_GBps_on_a_fresh_16GiB_allocation": round(capi_mod().ubench_random_read(eng.device, 16, 8, 2)[0], 1)}
     except Exception as e:
         rnd = {"random_read_probe_error": repr(e)}
     tb_rate = table_bytes * proofs_per_launch / launch_s / 1e9
+    pm = newest_matching_pmc("pmc_prover", proofs_per_launch, kernel_source_sha16(), L)
     out = {"kernel": "k_prove_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
            "valu": {"achieved": rate, "peak": peak_mad, "frac": rate / peak_mad, "unit": "lane multiply-accumulates (v_mad_u64_u32) per second",
                     "algorithmic_mad_per_proof_in_this_kernel": mad_bits, "mad_per_proof_whole_path": mad_all},
@@ -777,12 +780,27 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
            "kernel_ms_per_65536_proofs": {k: round(v["busy_ms"] / v["launches"], 3) for k, v in prof.items() if k.startswith("k_prove")},
            "prove_spend_proofs_per_s_wall": round(n_proofs / t_prove) if t_prove else None}
     out.update(rnd)
+    f_valu = rate / peak_mad
+    out["bound"], out["frac"] = "valu-int-mad", f_valu
     if rnd.get("random_128B_read_GBps_measured"):
-        out["table_reads"]["frac_of_measured_random_read_rate"] = tb_rate / rnd["random_128B_read_GBps_measured"]
-        f_valu, f_mem = rate / peak_mad, tb_rate / rnd["random_128B_read_GBps_measured"]
-        out["bound"] = "random-read-hbm" if f_mem > f_valu else "valu-int-mad"
-        out["frac"] = max(f_valu, f_mem)
+        f_mem = tb_rate / rnd["random_128B_read_GBps_measured"]
+        out["table_reads"]["frac_of_measured_random_read_rate"] = f_mem
+        if f_mem > f_valu:
+            out["bound"], out["frac"] = "random-read-hbm", f_mem
+    if pm:
+        j = pm[1]
+        # issue-slot view (PMC): a SIMD with two wavefronts can issue one VALU instruction per 4 cycles
+        out["pmc"] = {"source": pm[0], "valu_instructions_per_wave": j["valu_instructions_per_wave"],
+                      "cycles_per_valu_instruction_per_simd_2waves": j["cycles_per_valu_instruction_per_simd_2waves"],
+                      "valu_issue_utilisation": 4.0 / j["cycles_per_valu_instruction_per_simd_2waves"],
+                      "mad_share_of_valu_instructions": mad_bits / L / j["valu_instructions_per_wave"],
+                      "l2_hit_rate": j["l2_hit_rate"], "FETCH_SIZE_bytes_per_launch": j["FETCH_SIZE_bytes_per_launch"]}
     return out
+
+
+def capi_mod():
+    from act_amd import capi
+    return capi
 
 
 def count_prover_ops(hc_path, h, L, fb_bits, sample=2):

@@ -389,6 +389,9 @@ int act_ubench_mad_u64_u32(int device, double *lane_mads_per_s, double *ms);
  * 0 = 2) entries at a time, with `waves_per_simd` (0 = 2, the occupancy of the kernels that do these look-ups) wavefronts per SIMD.
  * gbytes_per_s counts 128 bytes per read. */
 int act_ubench_random_read(int device, size_t gib, int waves_per_simd, int in_flight, double *gbytes_per_s, double *ms);
+/* The same probe over the context's own fixed-base table of base 0..3 (g, h1, h2, h3; the largest power-of-two prefix of it): the
+ * product's look-ups in the product's memory with nothing else running. */
+int act_ubench_table_read(act_ctx *ctx, int base, int waves_per_simd, int in_flight, double *gbytes_per_s, double *ms);
 
 #ifdef __cplusplus
 }

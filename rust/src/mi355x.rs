@@ -40,6 +40,8 @@ extern "C" {
                                                resp: *const u8, out_token: *mut u8, status: *mut u8) -> c_int;
     fn act_node_prove_spend_batch(node: *mut ActNode, n: usize, token: *const u8, s: *const u8, rng: *const u8,
                                   out_proof: *mut u8, out_prerefund: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_prove_spend_seeded_batch(node: *mut ActNode, n: usize, token: *const u8, s: *const u8, seed: *const u8, first_lane: u64,
+                                         out_proof: *mut u8, out_prerefund: *mut u8, status: *mut u8) -> c_int;
     fn act_node_verify_spend_batch(node: *mut ActNode, n: usize, sk: *const u8, proof: *const u8, status: *mut u8, out_kprime: *mut u8) -> c_int;
     fn act_node_refund_sign_batch(node: *mut ActNode, n: usize, sk: *const u8, kprime: *const u8, status_in: *const u8,
                                   rng: *const u8, rng_mode: c_int, out_refund: *mut u8, status: *mut u8) -> c_int;
@@ -61,7 +63,9 @@ extern "C" {
 /// guarantee lives in the library, not in a promise by the caller.
 pub struct Gpu(*mut ActNode);
 // SAFETY: the handle is only ever passed to act_node_* entry points, each of which locks it (csrc/node.cpp `node_lock`);
-// act_node_destroy runs from Drop, i.e. with exclusive access.
+// act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies it under
+// the handle's lock into a buffer of the CALLING thread (valid until this thread asks again), so `check` below never reads a
+// string another thread's failing call is rewriting.
 unsafe impl Send for Gpu {}
 unsafe impl Sync for Gpu {}
 impl Drop for Gpu {
@@ -94,6 +98,8 @@ impl Gpu {
         let devices: Vec<c_int> = std::env::var("ACT_MI355X_DEVICES")
             .map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect())
             .unwrap_or_else(|_| vec![0]);
+        // The library never touches the process environment.  A service with many HIP streams exports GPU_MAX_HW_QUEUES=8 before its
+        // first HIP call; the engine measures whether its two pipeline streams overlap either way.
         // ACT_MI355X_MAX_BATCH: records per internal launch.  Unset = the library default (65 536: 29 GB of workspace per GPU and,
         // where the device has the memory to spare, 47 GB of 24-bit fixed-base tables built in ~2 s, all GPUs concurrently);
         // a service that only ever sees small batches sets e.g. 4096 (1.8 GB, 16-bit tables, 0.02 s).
@@ -354,6 +360,47 @@ impl CreditToken {
         });
         (0..n).map(|i| {
             let p = &prer[96 * i..96 * i + 96]; // r | k | m (src/cbor.rs:656-660)
+            (SpendProof::from_record(&proofs[PROOF_BYTES * i..PROOF_BYTES * (i + 1)]), PreRefund { r: get_s(p, 0), k: get_s(p, 1), m: get_s(p, 2) })
+        }).collect()
+    }
+}
+
+/// The generator `prove_spend_seeded_batch` gives lane `lane`: the BLAKE3 XOF of `seed | lane.to_le_bytes()`, read sequentially.
+/// `tokens[i].prove_spend(params, charges[i], XofRng::new(&seed, first_lane + i as u64))` is the CPU twin of lane i.
+pub struct XofRng(blake3::OutputReader);
+impl XofRng {
+    pub fn new(seed: &[u8; 32], lane: u64) -> Self {
+        let mut h = blake3::Hasher::new();
+        h.update(seed);
+        h.update(&lane.to_le_bytes());
+        XofRng(h.finalize_xof())
+    }
+}
+impl rand_core::RngCore for XofRng {
+    fn next_u32(&mut self) -> u32 { let mut b = [0u8; 4]; self.0.fill(&mut b); u32::from_le_bytes(b) }
+    fn next_u64(&mut self) -> u64 { let mut b = [0u8; 8]; self.0.fill(&mut b); u64::from_le_bytes(b) }
+    fn fill_bytes(&mut self, dest: &mut [u8]) { self.0.fill(dest) }
+    fn try_fill_bytes(&mut self, dest: &mut [u8]) -> Result<(), rand_core::Error> { self.0.fill(dest); Ok(()) }
+}
+impl rand_core::CryptoRng for XofRng {}
+
+impl CreditToken {
+    /// `prove_spend_batch` with seeded generators: the 33 536 rng bytes per proof are expanded in HBM (k_xof_expand) instead of being
+    /// drawn on the host and copied over PCIe.  `seed` is a secret of the prover; a (seed, lane) pair must never be used twice.
+    pub fn prove_spend_seeded_batch(tokens: &[CreditToken], params: &Params, charges: &[Scalar], seed: &[u8; 32], first_lane: u64)
+        -> Vec<(SpendProof, PreRefund)> {
+        let n = tokens.len();
+        assert_eq!(charges.len(), n);
+        let (mut tok, mut s) = (Vec::with_capacity(160 * n), Vec::with_capacity(32 * n));
+        tokens.iter().for_each(|t| t.write_record(&mut tok));
+        charges.iter().for_each(|c| put_s(&mut s, c));
+        let (mut proofs, mut prer, mut status) = (vec![0u8; PROOF_BYTES * n], vec![0u8; 96 * n], vec![0u8; n]);
+        let gpu = params.gpu();
+        gpu.check(unsafe {
+            act_node_prove_spend_seeded_batch(gpu.0, n, tok.as_ptr(), s.as_ptr(), seed.as_ptr(), first_lane, proofs.as_mut_ptr(), prer.as_mut_ptr(), status.as_mut_ptr())
+        });
+        (0..n).map(|i| {
+            let p = &prer[96 * i..96 * i + 96];
             (SpendProof::from_record(&proofs[PROOF_BYTES * i..PROOF_BYTES * (i + 1)]), PreRefund { r: get_s(p, 0), k: get_s(p, 1), m: get_s(p, 2) })
         }).collect()
     }
