@@ -77,6 +77,7 @@ struct act_ctx {
   int fb_bits[4] = {0, 0, 0, 0};        // window width of each base's table
   uint32_t* d_half_h1 = nullptr;
   uint32_t* d_tables_ct = nullptr;     // the four scanned tables (msm.h fixed_base_acc_ct)
+  uint8_t* d_tables_mf = nullptr;      // the four matrix-core table images (msm.h fixed_base_acc_mf)
   void* wire_layout = nullptr;         // the running wire-bytes call's CborDev (cbor_impl.inc)
   uint8_t* d_wire_flags = nullptr; size_t d_wire_flags_cap = 0;     // per message of a wire-bytes call: 0x80 = not the canonical encoding (cbor_impl.inc)
   // key cache
@@ -636,6 +637,11 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
     launch_build_table_ct(d_ext + b * GE_WORDS, c->d_tables_ct + (size_t)b * CT_TABLE_WORDS, s0);
     c->P.tab_ct[b] = c->d_tables_ct + (size_t)b * CT_TABLE_WORDS;
   }
+  HIPCK(c, hipMalloc(&c->d_tables_mf, 4 * MF_TABLE_BYTES));
+  for (int b = 0; b < 4; b++) {
+    launch_build_table_mf(d_ext + b * GE_WORDS, c->d_tables_mf + (size_t)b * MF_TABLE_BYTES, s0);
+    c->P.tab_mf[b] = c->d_tables_mf + (size_t)b * MF_TABLE_BYTES;
+  }
   HIPCK(c, hipMalloc(&c->d_half_h1, (size_t)2 * NIELS_WORDS * 4));
   launch_half_point_table(c->P.tab[BASE_H1], c->d_half_h1, s0);
   c->P.half_h1 = c->d_half_h1;
@@ -679,6 +685,7 @@ void act_ctx_destroy(act_ctx* c) {
   for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
+  if (c->d_tables_mf) (void)hipFree(c->d_tables_mf);
   if (c->d_wire_flags) (void)hipFree(c->d_wire_flags);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
   delete c;

@@ -49,6 +49,36 @@ void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_
   hipLaunchKernelGGL(k_build_table_ct, dim3((CT_WINDOWS * CT_ENTRIES + 63) / 64), dim3(64), 0, s, base_ext, table);
 }
 
+// The matrix-core table image of a base (msm.h fixed_base_acc_mf): entry e = 1..32 of window w is e * 64^w * B as affine Niels, its
+// 108 bytes scattered into the window's MFMA A-operand image: byte b of the entry at [tile b / 32][lane half (e-1) / 16][row b % 32]
+// [K-slot (e-1) % 16].  lane = (w, e).  Runs once per context.
+__global__ void __launch_bounds__(64) k_build_table_mf(const uint32_t* base_ext, uint8_t* image) {
+  const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+  if (gid >= 43u * 32u) return;
+  const uint32_t wd = gid / 32u, e = gid % 32u + 1u;
+  ge b = ge_load(base_ext);
+  for (uint32_t i = 0; i < 6u * wd; i++) b = ge_double(b);
+  ge acc = ge_identity();
+  const ge_cached bc = ge_to_cached(b);
+  for (int bit = 5; bit >= 0; bit--) {
+    acc = ge_double(acc);
+    if ((e >> bit) & 1u) acc = ge_add_cached(acc, bc);
+  }
+  fe zi = fe_invert(acc.Z);
+  ge af; af.X = fe_mul(acc.X, zi); af.Y = fe_mul(acc.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
+  uint32_t words[NIELS_WORDS];
+  niels_store(words, niels_from_affine(af));
+  const uint32_t k = e - 1u, h = k / 16u, j = k % 16u;
+  uint8_t* win = image + (size_t)wd * 4096u;
+  for (uint32_t byte = 0; byte < 128u; byte++) {
+    const uint32_t t = byte / 32u, r = byte % 32u;
+    win[((t * 2u + h) * 32u + r) * 16u + j] = byte < 108u ? (uint8_t)(words[byte / 4u] >> (8u * (byte % 4u))) : (uint8_t)0;
+  }
+}
+void launch_build_table_mf(const uint32_t* base_ext, uint8_t* image, hipStream_t s) {
+  hipLaunchKernelGGL(k_build_table_mf, dim3((43 * 32 + 63) / 64), dim3(64), 0, s, base_ext, image);
+}
+
 // out[0] = identity, out[1] = B / 2 as affine Niels, B the base of `table`: the prover works at half scale (k_prove.hip)
 __global__ void k_half_point_table(FbTab table, uint32_t* out) {
   if (blockIdx.x || threadIdx.x) return;
@@ -88,9 +118,9 @@ void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipS
 __global__ void __launch_bounds__(64) k_keygen(DevParams P, const uint8_t* rng64, uint32_t n, uint8_t* out_sk) {
   IssuerFb fb{P};                                                 // the issuer's key never addresses memory, in either build
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  sc x = i < n ? load_wide(rng64 + (size_t)i * 64) : sc_zero();
+  ge w = fb.mul(ge_identity(), BASE_G, x);                        // every lane of the wavefront (IssuerFb: matrix-core look-up)
   if (i >= n) return;
-  sc x = load_wide(rng64 + (size_t)i * 64);
-  ge w = fb.mul(ge_identity(), BASE_G, x);
   uint32_t e[8]; ristretto_encode(e, w);
   store_sc(out_sk + (size_t)i * 64, x); store8(out_sk + (size_t)i * 64 + 32, e);
 }

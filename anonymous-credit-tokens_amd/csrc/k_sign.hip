@@ -9,19 +9,25 @@ namespace act {
 // ---- sign, phase A: e, alpha <- rng;  A = (e+x)^-1 X_A;  X_g = e g + w;  Y_A = alpha A;  Y_g = alpha g --------
 // A and Y_A share X_A's doubling chain: Y_A = (alpha (e+x)^-1) X_A.
 __global__ void __launch_bounds__(64, 2) k_sign_a(SignArgs a) {
-  IssuerFb fb{a.P};                                               // nonces and key: scanned tables, register-only chain, in either build
+  IssuerFb fb{a.P};                                               // nonces and key: no digit of them ever selects an address, in either build
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
-  if (p >= a.n) return;
-  if (a.status[p] != 0) return;                                   // rng is drawn only after verification (:638-643, :842-846)
-  const uint8_t* rng = a.rng + (size_t)a.rng_slot[p] * 128;
-  sc e = load_wide(rng), alpha = load_wide(rng + 64);             // :643/:649, :846/:852
-  sc inv = sc_invert(sc_add(e, a.K.x));                           // :645 / :849
-  ge xa = ge_load(a.xa + (size_t)p * GE_WORDS);
+  const bool live = p < a.n && a.status[p < a.n ? p : 0] == 0;    // rng is drawn only after verification (:638-643, :842-846)
+  sc e = sc_zero(), alpha = sc_zero();
+  ge xa = ge_identity();
   ge acc[2] = {ge_identity(), ge_identity()};
-  sc s[2] = {inv, sc_mul(alpha, inv)};
-  chain_ct<2>(acc, xa, s);                                                                                // acc[0] = A, acc[1] = Y_A (:650 / :853)
+  if (live) {
+    const uint8_t* rng = a.rng + (size_t)a.rng_slot[p] * 128;
+    e = load_wide(rng); alpha = load_wide(rng + 64);              // :643/:649, :846/:852
+    sc inv = sc_invert(sc_add(e, a.K.x));                         // :645 / :849
+    xa = ge_load(a.xa + (size_t)p * GE_WORDS);
+    sc s[2] = {inv, sc_mul(alpha, inv)};
+    chain_ct<2>(acc, xa, s);                                                                              // acc[0] = A, acc[1] = Y_A (:650 / :853)
+  }
+  // the two products on g run in every lane of the wavefront, signing or not (IssuerFb: the matrix-core look-up takes its table
+  // operand from all 64 lanes; a lane that does not sign multiplies by zero)
   ge xg = ge_add(fb.mul(ge_identity(), BASE_G, e), a.K.w);        // :646 / :851
   ge yg = fb.mul(ge_identity(), BASE_G, alpha);                   // :651 / :854
+  if (!live) return;
 
   // transcript: prefix | [c] | e | A | X_A | X_g | Y_A | Y_g   (:654-657 / :856-859)
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
@@ -122,11 +128,11 @@ __global__ void __launch_bounds__(64, 2) k_request_a(RequestArgs a) {
   }
   // K = k h2 + r h3 (:465), K1 = k' h2 + r' h3 (:470): the products grouped by base (one staged table at a time in the ct build)
   ge big_k = ge_identity(), k1 = ge_identity();
-  fb.stage(BASE_H2);
-  if (live) { big_k = fb.mul(big_k, BASE_H2, k); k1 = fb.mul(k1, BASE_H2, kp); }
+  fb.stage(BASE_H2);                                              // (every lane multiplies, live or not: prove_lanes.h prove_head_lane)
+  big_k = fb.mul(big_k, BASE_H2, k); k1 = fb.mul(k1, BASE_H2, kp);
   fb.stage(BASE_H3);
-  if (!live) return;
   big_k = fb.mul(big_k, BASE_H3, r); k1 = fb.mul(k1, BASE_H3, rp);
+  if (!live) return;
   uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
   tr_put_prefix(tr, a.P, LABEL_REQUEST);
   uint8_t* el = tr + a.P.prefix_len[LABEL_REQUEST];

@@ -31,6 +31,7 @@ struct DevParams {
   FbTab tab[4];                           // position-specific fixed-base tables of g, h1, h2, h3 with their window widths (msm.h)
   const uint32_t* half_h1;                // two affine-Niels entries: identity, h1 / 2 (the prover's bit term at half scale)
   const uint32_t* tab_ct[4];              // small tables the secret-scalar products scan in full (msm.h fixed_base_acc_ct)
+  const uint8_t* tab_mf[4];               // matrix-core table images: 43 windows x 32 entries as MFMA A operands (msm.h fixed_base_acc_mf)
   uint32_t prefix[4][PREFIX_WORDS];       // Transcript::new(params, label) bytes, zero padded
   uint32_t prefix_len[4];
   int L;                                  // range-proof width (src/lib.rs:116)
@@ -194,6 +195,8 @@ struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n;
 // launchers (defined in the .hip files)
 void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, uint32_t wbits, hipStream_t s);
 void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_t s);
+void launch_build_table_mf(const uint32_t* base_ext, uint8_t* image /* MF_WINDOWS * MF_WINDOW_BYTES */, hipStream_t s);
+constexpr size_t MF_TABLE_BYTES = (size_t)43 * 4096;
 void launch_half_point_table(FbTab table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
 void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s);
 void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s);
@@ -250,16 +253,29 @@ void launch_client_b(const ClientArgs& a, hipStream_t s);
 // (0.27x -> 0.15x of the default build: 128 KiB copied per 64 lanes for four products) and prove_spend 3 % faster; the cost of the ct
 // build's fixed-base products is their 64 additions per product (the default build's 24- / 16-bit windows need 11 / 16), not the scan.
 #if defined(__HIPCC__)
-struct IssuerFb {
+#if defined(ACT_CT_GLOBAL_SCAN)
+struct IssuerFb {          // round 3's form, kept for same-box A/B: 8-entry windows scanned where the table lies in global memory
   const DevParams& P;
   __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_ct(acc, P.tab_ct[base], s); }
 };
+#else
+struct IssuerFb {          // 32-entry windows picked on the matrix cores (msm.h fixed_base_acc_mf): EVERY lane of a wavefront calls mul()
+  const DevParams& P;
+  __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_mf(acc, P.tab_mf[base], s); }
+};
+#endif
 #if defined(ACT_CT_SECRET_TABLES)
 struct SecretFb {
   const DevParams& P;
   __device__ __forceinline__ void stage(int) {}
+#if defined(ACT_CT_GLOBAL_SCAN)
   __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_ct(acc, P.tab_ct[base], s); }
+#else
+  __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_mf(acc, P.tab_mf[base], s); }
+#endif
 };
+#if defined(ACT_CT_LDS_SCAN)
+// round 3's form, kept for same-box A/B (make ct CTFLAGS=-DACT_CT_LDS_SCAN): the block stages the 64 KiB scanned table in LDS
 struct SecretFbLds {
   uint32_t* lds; const DevParams& P;
   __device__ __forceinline__ void stage(int base) {
@@ -271,8 +287,18 @@ struct SecretFbLds {
   }
   __device__ __forceinline__ ge mul(const ge& acc, int, const sc& s) const { return fixed_base_acc_ct(acc, lds, s); }
 };
-#define ACT_SECRET_FB(name, P) SecretFb name{P}
 #define ACT_SECRET_FB_LDS(name, P) __shared__ uint32_t name##_lds_[CT_TABLE_WORDS]; SecretFbLds name{name##_lds_, P}
+#else
+// the range kernel of the ct build: 32-entry windows picked on the matrix cores (msm.h fixed_base_acc_mf).  Every lane of a
+// wavefront must call mul() together (non-live lanes with zero scalars): the table operand's rows come from all 64 lanes.
+struct SecretFbMf {
+  const DevParams& P;
+  __device__ __forceinline__ void stage(int) {}
+  __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_mf(acc, P.tab_mf[base], s); }
+};
+#define ACT_SECRET_FB_LDS(name, P) SecretFbMf name{P}
+#endif
+#define ACT_SECRET_FB(name, P) SecretFb name{P}
 #else
 struct SecretFb {
   const DevParams& P;

@@ -78,22 +78,27 @@ ACT_HD void prove_head_lane(const ProveArgs& a, uint32_t p, Fb& fb) {
   // B_bar = r1 g + (r1 c) h1 + (r1 k) h2 + (r1 r) h3;  A1 = e' A' + r2' B_bar;  A2 = r3' B_bar + c' h1 + r' h3 -- the twelve products
   // (and the three h2 terms of bit 0, src/lib.rs:1001, 1025-1035, at half scale like everything k_prove_bits computes) grouped
   // by base: the ct build stages one base's table in LDS at a time
+  // Every fb.mul below runs in EVERY lane, live or not (a lane past the batch multiplies zeros / lane 0's rng: its results are
+  // dropped): the ct build's matrix-core look-up (msm.h fixed_base_acc_mf) takes its table operand from all 64 lanes of a wavefront.
   ge bbar = ge_identity(), a1 = acc[1], a2 = ge_identity();
   fb.stage(BASE_G);
-  if (live) { bbar = fb.mul(bbar, BASE_G, r1); a1 = fb.mul(a1, BASE_G, sc_mul(r2_prime, r1)); a2 = fb.mul(a2, BASE_G, sc_mul(r3_prime, r1)); }
+  bbar = fb.mul(bbar, BASE_G, r1); a1 = fb.mul(a1, BASE_G, sc_mul(r2_prime, r1)); a2 = fb.mul(a2, BASE_G, sc_mul(r3_prime, r1));
   fb.stage(BASE_H1);
-  if (live) { bbar = fb.mul(bbar, BASE_H1, r1c); a1 = fb.mul(a1, BASE_H1, sc_mul(r2_prime, r1c)); a2 = fb.mul(a2, BASE_H1, sc_muladd(r3_prime, r1c, c_prime)); }
+  bbar = fb.mul(bbar, BASE_H1, r1c); a1 = fb.mul(a1, BASE_H1, sc_mul(r2_prime, r1c)); a2 = fb.mul(a2, BASE_H1, sc_muladd(r3_prime, r1c, c_prime));
   fb.stage(BASE_H2);
-  if (live) {
-    bbar = fb.mul(bbar, BASE_H2, r1k); a1 = fb.mul(a1, BASE_H2, sc_mul(r2_prime, r1k)); a2 = fb.mul(a2, BASE_H2, sc_mul(r3_prime, r1k));
-    uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
-    ge_store(d3, fb.mul(ge_identity(), BASE_H2, sc_half(k_star)));
-    ge_store(d3 + GE_WORDS, fb.mul(ge_identity(), BASE_H2, sc_half(rv.k0_prime())));
-    ge_store(d3 + 2 * GE_WORDS, fb.mul(ge_identity(), BASE_H2, sc_half(sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star)))));
+  bbar = fb.mul(bbar, BASE_H2, r1k); a1 = fb.mul(a1, BASE_H2, sc_mul(r2_prime, r1k)); a2 = fb.mul(a2, BASE_H2, sc_mul(r3_prime, r1k));
+  {
+    const ge d0 = fb.mul(ge_identity(), BASE_H2, sc_half(k_star));
+    const ge d1 = fb.mul(ge_identity(), BASE_H2, sc_half(rv.k0_prime()));
+    const ge d2 = fb.mul(ge_identity(), BASE_H2, sc_half(sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star))));
+    if (live) {
+      uint32_t* d3 = a.d3 + (size_t)p * 3 * GE_WORDS;
+      ge_store(d3, d0); ge_store(d3 + GE_WORDS, d1); ge_store(d3 + 2 * GE_WORDS, d2);
+    }
   }
   fb.stage(BASE_H3);
-  if (!live) return;
   bbar = fb.mul(bbar, BASE_H3, r1r); a1 = fb.mul(a1, BASE_H3, sc_mul(r2_prime, r1r)); a2 = fb.mul(a2, BASE_H3, sc_muladd(r3_prime, r1r, r_prime));
+  if (!live) return;
 
   uint8_t* rec = a.proof + (size_t)p * pl.bytes();
   uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
@@ -126,16 +131,16 @@ ACT_HD void prove_bits_lane(const ProveArgs& a, uint32_t gid, Fb& fb) {
   }
   // Half scale throughout (k_prove_enc encodes the doubles): Com_j / 2 = i_j (h1 / 2) + (s_j / 2) h3 (+ (k* / 2) h2)
   // real branch: s'_j h3 (+ k0' h2);  simulated: (z_j - gamma_j s_j) h3 -/+ gamma_j h1 (+ (w0 - gamma_0 k*) h2)
+  // (the four products run in EVERY lane, live or not -- a lane past the batch multiplies by zero: the ct build's matrix-core
+  // look-up needs all 64 lanes of a wavefront in it, and a lane that sits out costs the same as one that computes)
   ge com = ge_identity(), real = ge_identity(), sim = ge_identity();
   fb.stage(BASE_H3);
-  if (live) {
-    com = fb.mul(com, BASE_H3, sc_half(s_j));
-    real = fb.mul(real, BASE_H3, sc_half(s_jp));
-    sim = fb.mul(sim, BASE_H3, sc_half(sc_sub(z_j, sc_mul(g_j, s_j))));
-  }
+  com = fb.mul(com, BASE_H3, sc_half(s_j));
+  real = fb.mul(real, BASE_H3, sc_half(s_jp));
+  sim = fb.mul(sim, BASE_H3, sc_half(sc_sub(z_j, sc_mul(g_j, s_j))));
   fb.stage(BASE_H1);
-  if (!live) return;
   sim = fb.mul(sim, BASE_H1, sc_half(bit ? sc_neg(g_j) : g_j));
+  if (!live) return;
 #if defined(ACT_CT_SECRET_TABLES)
   {                                                                                // both entries read, the bit picks with masks
     const ge_niels e0 = niels_load(a.P.half_h1), e1 = niels_load(a.P.half_h1 + NIELS_WORDS);
@@ -186,13 +191,13 @@ ACT_HD void prove_tail_lane(const ProveArgs& a, uint32_t p, Fb& fb) {
   const SpendTranscript st{L};
   RngView rv{a.rng + (size_t)(live ? p : 0) * rng_bytes(L), L};
   ge cc = ge_identity();                                                      // C = -c' h1 + k' h2 + s' h3 (:1059)
-  fb.stage(BASE_H1);
-  if (live) cc = fb.mul(cc, BASE_H1, sc_neg(rv.c_prime()));
+  fb.stage(BASE_H1);                                                          // (every lane multiplies: see prove_head_lane)
+  cc = fb.mul(cc, BASE_H1, sc_neg(rv.c_prime()));
   fb.stage(BASE_H2);
-  if (live) cc = fb.mul(cc, BASE_H2, rv.k_prime());
+  cc = fb.mul(cc, BASE_H2, rv.k_prime());
   fb.stage(BASE_H3);
-  if (!live) return;
   cc = fb.mul(cc, BASE_H3, rv.s_prime());
+  if (!live) return;
   sc rstar = sc_zero();                                                       // r* = sum s_j 2^j (:1052-1056), Horner
   for (int j = L - 1; j >= 0; j--) rstar = sc_add(sc_add(rstar, rstar), rv.s_i(j));
   uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
