@@ -49,18 +49,18 @@ void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_
   hipLaunchKernelGGL(k_build_table_ct, dim3((CT_WINDOWS * CT_ENTRIES + 63) / 64), dim3(64), 0, s, base_ext, table);
 }
 
-// The matrix-core table image of a base (msm.h fixed_base_acc_mf): entry e = 1..32 of window w is e * 64^w * B as affine Niels, its
-// 108 bytes scattered into the window's MFMA A-operand image: byte b of the entry at [tile b / 32][lane half (e-1) / 16][row b % 32]
-// [K-slot (e-1) % 16].  lane = (w, e).  Runs once per context.
+// The matrix-core table image of a base (msm.h fixed_base_acc_mf): entry e = 1..MF_ENTRIES of window w is e * 2^(MF_WBITS w) * B as
+// affine Niels, its 108 bytes scattered into the window's MFMA A-operand image: byte b of the entry at [K-step (e-1) / 32][tile b / 32]
+// [lane half ((e-1) % 32) / 16][row b % 32][K-slot (e-1) % 16].  lane = (w, e).  Runs once per context.
 __global__ void __launch_bounds__(64) k_build_table_mf(const uint32_t* base_ext, uint8_t* image) {
   const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
-  if (gid >= 43u * 32u) return;
-  const uint32_t wd = gid / 32u, e = gid % 32u + 1u;
+  if (gid >= (uint32_t)(MF_WINDOWS * MF_ENTRIES)) return;
+  const uint32_t wd = gid / (uint32_t)MF_ENTRIES, e = gid % (uint32_t)MF_ENTRIES + 1u;
   ge b = ge_load(base_ext);
-  for (uint32_t i = 0; i < 6u * wd; i++) b = ge_double(b);
+  for (uint32_t i = 0; i < (uint32_t)MF_WBITS * wd; i++) b = ge_double(b);
   ge acc = ge_identity();
   const ge_cached bc = ge_to_cached(b);
-  for (int bit = 5; bit >= 0; bit--) {
+  for (int bit = MF_WBITS - 1; bit >= 0; bit--) {
     acc = ge_double(acc);
     if ((e >> bit) & 1u) acc = ge_add_cached(acc, bc);
   }
@@ -68,15 +68,15 @@ __global__ void __launch_bounds__(64) k_build_table_mf(const uint32_t* base_ext,
   ge af; af.X = fe_mul(acc.X, zi); af.Y = fe_mul(acc.Y, zi); af.Z = fe_one(); af.T = fe_mul(af.X, af.Y);
   uint32_t words[NIELS_WORDS];
   niels_store(words, niels_from_affine(af));
-  const uint32_t k = e - 1u, h = k / 16u, j = k % 16u;
-  uint8_t* win = image + (size_t)wd * 4096u;
+  const uint32_t k = e - 1u, ks = k / 32u, h = (k % 32u) / 16u, j = k % 16u;
+  uint8_t* win = image + (size_t)wd * (uint32_t)MF_WINDOW_BYTES;
   for (uint32_t byte = 0; byte < 128u; byte++) {
     const uint32_t t = byte / 32u, r = byte % 32u;
-    win[((t * 2u + h) * 32u + r) * 16u + j] = byte < 108u ? (uint8_t)(words[byte / 4u] >> (8u * (byte % 4u))) : (uint8_t)0;
+    win[(((ks * 4u + t) * 2u + h) * 32u + r) * 16u + j] = byte < 108u ? (uint8_t)(words[byte / 4u] >> (8u * (byte % 4u))) : (uint8_t)0;
   }
 }
 void launch_build_table_mf(const uint32_t* base_ext, uint8_t* image, hipStream_t s) {
-  hipLaunchKernelGGL(k_build_table_mf, dim3((43 * 32 + 63) / 64), dim3(64), 0, s, base_ext, image);
+  hipLaunchKernelGGL(k_build_table_mf, dim3((MF_WINDOWS * MF_ENTRIES + 63) / 64), dim3(64), 0, s, base_ext, image);
 }
 
 // out[0] = identity, out[1] = B / 2 as affine Niels, B the base of `table`: the prover works at half scale (k_prove.hip)

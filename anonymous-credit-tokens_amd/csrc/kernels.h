@@ -31,7 +31,7 @@ struct DevParams {
   FbTab tab[4];                           // position-specific fixed-base tables of g, h1, h2, h3 with their window widths (msm.h)
   const uint32_t* half_h1;                // two affine-Niels entries: identity, h1 / 2 (the prover's bit term at half scale)
   const uint32_t* tab_ct[4];              // small tables the secret-scalar products scan in full (msm.h fixed_base_acc_ct)
-  const uint8_t* tab_mf[4];               // matrix-core table images: 43 windows x 32 entries as MFMA A operands (msm.h fixed_base_acc_mf)
+  const uint8_t* tab_mf[4];               // matrix-core table images: 37 windows x 64 entries as MFMA A operands (msm.h fixed_base_acc_mf)
   uint32_t prefix[4][PREFIX_WORDS];       // Transcript::new(params, label) bytes, zero padded
   uint32_t prefix_len[4];
   int L;                                  // range-proof width (src/lib.rs:116)
@@ -195,8 +195,8 @@ struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n;
 // launchers (defined in the .hip files)
 void launch_build_table(const uint32_t* base_ext /*GE_WORDS, device*/, uint32_t* table, uint32_t wbits, hipStream_t s);
 void launch_build_table_ct(const uint32_t* base_ext, uint32_t* table, hipStream_t s);
-void launch_build_table_mf(const uint32_t* base_ext, uint8_t* image /* MF_WINDOWS * MF_WINDOW_BYTES */, hipStream_t s);
-constexpr size_t MF_TABLE_BYTES = (size_t)43 * 4096;
+void launch_build_table_mf(const uint32_t* base_ext, uint8_t* image /* MF_TABLE_BYTES */, hipStream_t s);
+constexpr size_t MF_TABLE_BYTES = (size_t)64 * 16384;       // room for any of the three window shapes (msm.h: 43 x 4, 37 x 8, 32 x 16 KiB)
 void launch_half_point_table(FbTab table, uint32_t* out /*2 * NIELS_WORDS*/, hipStream_t s);
 void launch_decode_points(const uint8_t* enc, uint32_t n, uint32_t* out_ext, uint32_t* ok, hipStream_t s);
 void launch_from_uniform(const uint8_t* in64, uint32_t n, uint8_t* out_enc, hipStream_t s);
@@ -259,7 +259,7 @@ struct IssuerFb {          // round 3's form, kept for same-box A/B: 8-entry win
   __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_ct(acc, P.tab_ct[base], s); }
 };
 #else
-struct IssuerFb {          // 32-entry windows picked on the matrix cores (msm.h fixed_base_acc_mf): EVERY lane of a wavefront calls mul()
+struct IssuerFb {          // 64-entry windows picked on the matrix cores (msm.h fixed_base_acc_mf): EVERY lane of a wavefront calls mul()
   const DevParams& P;
   __device__ __forceinline__ ge mul(const ge& acc, int base, const sc& s) const { return fixed_base_acc_mf(acc, P.tab_mf[base], s); }
 };
@@ -289,7 +289,7 @@ struct SecretFbLds {
 };
 #define ACT_SECRET_FB_LDS(name, P) __shared__ uint32_t name##_lds_[CT_TABLE_WORDS]; SecretFbLds name{name##_lds_, P}
 #else
-// the range kernel of the ct build: 32-entry windows picked on the matrix cores (msm.h fixed_base_acc_mf).  Every lane of a
+// the range kernel of the ct build: 64-entry windows picked on the matrix cores (msm.h fixed_base_acc_mf).  Every lane of a
 // wavefront must call mul() together (non-live lanes with zero scalars): the table operand's rows come from all 64 lanes.
 struct SecretFbMf {
   const DevParams& P;

@@ -540,23 +540,34 @@ ACT_HD ge fixed_base_acc_ct(ge acc, const uint32_t* table, const sc& s) {
   }
   return acc;
 }
-// ---- the same product with the table look-up on the MATRIX CORES (device only; the ct build's range kernel) ----------------------
+// ---- the same product with the table look-up on the MATRIX CORES (device only) ---------------------------------------------------
 // "Every lane picks entry |digit_l| of a window" is a matrix product with a shared operand, selected = Table^T x onehot(digits), and
 // the digit never becomes an address: D[byte][lane] = sum_e T[e][byte] * (e == |digit_lane|), one v_mfma_i32_32x32x32_i8 per 32 bytes
-// x 32 lanes x 32 entries.  Byte values arrive exactly (one nonzero term per sum; a byte >= 128 comes out as value - 256, whose low
-// byte is the value).  So a window can hold 32 entries (signed radix 64: 43 windows instead of the scan's 64) for the price the scan
-// pays for 8: measured on MI355X (tools/ubench_mfma_select.hip, profiles/r04_ubench_mfma_select.txt) 0.76 us of SIMD time per
-// look-up against 0.70 / 1.27 / 2.37 us for a masked scan of 8 / 16 / 32 entries.  Any consistent numbering of k serves (A and B
-// use the same one); the C/D map is col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), so after a half exchange
-// (v_permlane32_swap) every lane holds its own entry.  Table image (k_build_table_mf): per window 4 tiles of 32 bytes x 2 lane
-// halves x 32 rows x 16 entries = 4 KiB, the 108 bytes of entry e = 1..32 at K-slot e - 1; 176 KiB per base, read with
-// wave-uniform coalesced 16-byte loads (L2 / vector-cache resident).
+// x 32 lanes x 32 entries (more entries: chain MFMAs through the accumulator).  Byte values arrive exactly (one nonzero term per
+// sum; a byte >= 128 comes out as value - 256, whose low byte is the value).  So a window can hold 64 entries (signed radix 128: 37
+// windows instead of the scan's 64) for LESS than the scan pays for 8: measured on
+// MI355X (tools/ubench_mfma_select.hip, profiles/r04_ubench_mfma_select.txt) 0.56 / 0.66 / 0.94 us of SIMD time per look-up among
+// 32 / 64 / 128 entries against 0.70 / 1.27 / 2.37 us for a masked scan of 8 / 16 / 32 entries from LDS; a mixed addition is ~2 us.
+// Any consistent numbering of k serves (A and B use the same one); the C/D map is col = lane & 31, row = (reg & 3) + 8 (reg >> 2) +
+// 4 (lane >> 5), so after a half exchange (v_permlane32_swap) every lane holds its own entry.  Table image (k_build_table_mf): per
+// window [K-step] 4 tiles of 32 bytes x 2 lane halves x 32 rows x 16 entries = 4 KiB per K-step, the 108 bytes of entry e >= 1 at
+// K-slot e - 1; 296 KiB per base at 64 entries, read with wave-uniform coalesced 16-byte loads (L2 resident).
 // EVERY lane of the wavefront must call this together (the table operand's rows come from all 64 lanes): non-live lanes pass s = 0.
+// MF_KSTEPS chained MFMAs per tile = 32 * MF_KSTEPS entries per window = windows of 5 + log2(MF_KSTEPS) + 1 bits.  Measured in the
+// kernels (two wavefronts per SIMD, where a chained accumulate's latency is NOT hidden as it is in the micro-benchmark's eight), ct
+// prove_spend on one MI355X: 32 entries (43 windows) 1.118 M/s, 64 entries (37 windows) 1.162 M/s on the same box
+// (profiles/r04_j_ct_mf_entries_ab.txt); 128 entries (32 windows) 1.02 M/s against 1.13 M/s on another (r04_i_ / r04_h_other_configs_1gpu_ct.json).
+#ifndef ACT_MF_KSTEPS
+#define ACT_MF_KSTEPS 2
+#endif
+constexpr int MF_KSTEPS = ACT_MF_KSTEPS, MF_ENTRIES = 32 * MF_KSTEPS;
+constexpr int MF_WBITS = MF_KSTEPS == 1 ? 6 : MF_KSTEPS == 2 ? 7 : 8, MF_WINDOWS = (253 + MF_WBITS - 1) / MF_WBITS;
+constexpr int MF_WINDOW_BYTES = MF_KSTEPS * 4 * 2 * 32 * 16;
+static_assert(MF_KSTEPS == 1 || MF_KSTEPS == 2 || MF_KSTEPS == 4, "32, 64 or 128 entries per window");
 #if defined(__HIP_DEVICE_COMPILE__)
-constexpr int MF_WINDOWS = 43, MF_ENTRIES = 32, MF_WINDOW_BYTES = 4 * 2 * 32 * 16;
 typedef int mf_v4i __attribute__((ext_vector_type(4)));
 typedef int mf_v16i __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ mf_v4i mf_onehot16(int idx, int h) {      // byte j of the 16 is 1 iff idx == 16 h + j
+__device__ __forceinline__ mf_v4i mf_onehot16(int idx, int h) {      // byte j of the 16 is 1 iff idx == 16 h + j (none outside [0, 32))
   const int rel = idx - 16 * h;
   const int val = (int)(1u << (8 * (rel & 3))), w = rel >> 2;
   mf_v4i b;
@@ -570,14 +581,20 @@ __device__ __forceinline__ uint32_t mf_pack4(const mf_v16i& v, int q) {   // the
 // w[0 .. 26] = the Niels words of entry idx + 1 of the window whose image starts at tabA (all zero for idx < 0)
 __device__ __forceinline__ void mf_select(uint32_t w[27], const uint8_t* tabA, int idx) {
   const int lane = (int)(threadIdx.x & 63u), h = lane >> 5, r = lane & 31;
-  const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
-  const mf_v4i b_lo = mf_onehot16((int)sw[0], h), b_hi = mf_onehot16((int)sw[1], h);      // digits of lanes 0..31 resp. 32..63
+  const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);      // digits of lanes 0..31 resp. 32..63
+  mf_v4i b_lo[MF_KSTEPS], b_hi[MF_KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < MF_KSTEPS; ks++) { b_lo[ks] = mf_onehot16((int)sw[0] - 32 * ks, h); b_hi[ks] = mf_onehot16((int)sw[1] - 32 * ks, h); }
   const mf_v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int t = 0; t < 4; t++) {
-    const mf_v4i a = *reinterpret_cast<const mf_v4i*>(tabA + ((t * 2 + h) * 32 + r) * 16);
-    const mf_v16i x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_lo, zero, 0, 0, 0);      // columns = lanes 0..31's entries
-    const mf_v16i y = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_hi, zero, 0, 0, 0);      // columns = lanes 32..63's entries
+    mf_v16i x = zero, y = zero;
+#pragma unroll
+    for (int ks = 0; ks < MF_KSTEPS; ks++) {
+      const mf_v4i a = *reinterpret_cast<const mf_v4i*>(tabA + (((ks * 4 + t) * 2 + h) * 32 + r) * 16);
+      x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_lo[ks], x, 0, 0, 0);      // columns = lanes 0..31's entries
+      y = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_hi[ks], y, 0, 0, 0);      // columns = lanes 32..63's entries
+    }
     // lane l < 32 owns column l of x, lane l >= 32 column l - 32 of y, and each holds half the rows of both: pack the bytes of four
     // rows into a word first, then trade words -- bytes 8q .. 8q+3 of the tile come from lane half 0, 8q+4 .. 8q+7 from half 1
     const int nq = t < 3 ? 4 : 2;                                   // the last tile holds bytes 96 .. 107 only
@@ -591,21 +608,27 @@ __device__ __forceinline__ void mf_select(uint32_t w[27], const uint8_t* tabA, i
     }
   }
 }
+// word i of sum_w 2^(MF_WBITS - 1) * 2^(MF_WBITS * w): added to a scalar, MF_WBITS-bit group w of the sum, minus 2^(MF_WBITS - 1), is
+// signed digit w in [-2^(MF_WBITS-1), 2^(MF_WBITS-1) - 1] (the sum stays below 2^(MF_WBITS * MF_WINDOWS) <= 2^259: nine words)
+__device__ __forceinline__ constexpr uint32_t mf_bias_word(int i) {
+  uint32_t v = 0;
+  for (int w = 0; w < MF_WINDOWS; w++) { const int bit = MF_WBITS * w + MF_WBITS - 1; if (bit / 32 == i) v |= 1u << (bit % 32); }
+  return v;
+}
 // acc += s * B through B's matrix-core table image; s canonical (< l)
 __device__ __forceinline__ ge fixed_base_acc_mf(ge acc, const uint8_t* tab_mf, const sc& s) {
-  // t = s + sum_w 32 * 64^w: 6-bit group w of t, minus 32, is signed radix-64 digit w in [-32, 31] (t < 2^258: nine words)
-  const uint32_t bias[9] = {0x20820820u, 0x08208208u, 0x82082082u, 0x20820820u, 0x08208208u, 0x82082082u, 0x20820820u, 0x08208208u, 0x2u};
   uint32_t t[9];
   uint64_t c = 0;
+  constexpr uint32_t bias[9] = {mf_bias_word(0), mf_bias_word(1), mf_bias_word(2), mf_bias_word(3), mf_bias_word(4), mf_bias_word(5), mf_bias_word(6), mf_bias_word(7), mf_bias_word(8)};
   for (int i = 0; i < 8; i++) { c += (uint64_t)s.v[i] + bias[i]; t[i] = (uint32_t)c; c >>= 32; }
   t[8] = (uint32_t)c + bias[8];
 #pragma unroll 1
   for (int wd = 0; wd < MF_WINDOWS; wd++) {
-    const int d = (int)(t[0] & 63u) - 32;
-    for (int i = 0; i < 8; i++) t[i] = (t[i] >> 6) | (t[i + 1] << 26);       // static indices only: the digit words never live in scratch
-    t[8] >>= 6;
+    const int d = (int)(t[0] & ((1u << MF_WBITS) - 1u)) - (1 << (MF_WBITS - 1));
+    for (int i = 0; i < 8; i++) t[i] = (t[i] >> MF_WBITS) | (t[i + 1] << (32 - MF_WBITS));      // static indices only: the digit words never live in scratch
+    t[8] >>= MF_WBITS;
     const bool neg = d < 0;
-    const int mag = neg ? -d : d;                                  // 0 .. 32
+    const int mag = neg ? -d : d;                                  // 0 .. MF_ENTRIES
     uint32_t w[27];
     mf_select(w, tab_mf + (size_t)wd * MF_WINDOW_BYTES, mag - 1);
     const uint32_t one = mag == 0 ? 1u : 0u;                       // digit 0: the identity (ypx = ymx = 1, xy2d = 0)

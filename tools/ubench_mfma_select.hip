@@ -6,8 +6,8 @@
 // digit_l of a table for every lane l" is a matrix product with a SHARED operand -- selected = onehot(digits) x Table -- which is
 // exactly what MFMA wants: D[byte][lane] = sum_e T[e][byte] * onehot[e][lane], one v_mfma_i32_32x32x32_i8 per 32 bytes x 32 lanes
 // x 32 entries.  Byte values come through exactly (one nonzero term per sum; a byte >= 128 arrives as value - 256, whose low byte is
-// the value).  The result tile has the lane on the column, so after one v_permlane32_swap per register every lane holds its own
-// entry: 8 MFMAs + 64 swaps + 81 byte packs for a 108-byte affine-Niels entry out of 32, against 32 x (7 + 27) instructions for a
+// the value).  The result tile has the lane on the column, so after one v_permlane32_swap per packed word every lane holds its own
+// entry: 8 MFMAs + 96 byte packs + 32 swaps for a 128-byte entry out of 32, against 32 x (7 + 27) instructions for a
 // scan of the same width.  Any consistent numbering of k works (A and B use the same one), so only the C/D map has to be right:
 // col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
 //
@@ -21,7 +21,10 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-constexpr int ENTRIES = 32, TILES = 4, WORDS = 32;      // 4 tiles of 32 bytes = 128 bytes = 32 words per entry (27 used by a Niels entry)
+#ifndef KSTEPS
+#define KSTEPS 1
+#endif
+constexpr int ENTRIES = 32 * KSTEPS, TILES = 4, WORDS = 32;      // 4 tiles of 32 bytes = 128 bytes = 32 words per entry (27 used by a Niels entry)
 
 // one-hot column of this lane's MFMA-B fragment: byte j of the 16 is 1 iff idx == 16 h + j
 __device__ __forceinline__ v4i onehot16(int idx, int h) {
@@ -38,27 +41,29 @@ __device__ __forceinline__ void mfma_select(uint32_t out[WORDS], const uint8_t* 
   const int lane = threadIdx.x & 63, h = lane >> 5, r = lane & 31;
   const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
   const int idx_lo = (int)sw[0], idx_hi = (int)sw[1];   // the digit of lane (l & 31) resp. (l & 31) + 32, in every lane
-  const v4i b_lo = onehot16(idx_lo, h), b_hi = onehot16(idx_hi, h);
+  v4i b_lo[KSTEPS], b_hi[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ks++) { b_lo[ks] = onehot16(idx_lo - 32 * ks, h); b_hi[ks] = onehot16(idx_hi - 32 * ks, h); }
   const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int t = 0; t < TILES; t++) {
-    const v4i a = *reinterpret_cast<const v4i*>(tabA + ((t * 2 + h) * 32 + r) * 16);
-    v16i x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_lo, zero, 0, 0, 0);      // columns = lanes 0..31's entries
-    v16i y = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_hi, zero, 0, 0, 0);      // columns = lanes 32..63's entries
-    // lane l < 32 owns column l of x, lane l >= 32 column l - 32 of y; each holds half the rows of both: trade
+    v16i x = zero, y = zero;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const auto s = __builtin_amdgcn_permlane32_swap((unsigned)x[i], (unsigned)y[i], false, false);
-      x[i] = (int)s[0]; y[i] = (int)s[1];               // x[i]: rows of lane half 0, y[i]: rows of lane half 1, of MY entry
+    for (int ks = 0; ks < KSTEPS; ks++) {
+      const v4i a = *reinterpret_cast<const v4i*>(tabA + (((ks * TILES + t) * 2 + h) * 32 + r) * 16);
+      x = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_lo[ks], x, 0, 0, 0);      // columns = lanes 0..31's entries
+      y = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_hi[ks], y, 0, 0, 0);      // columns = lanes 32..63's entries
     }
-    // row = (i & 3) + 8 (i >> 2) + 4 half  ->  bytes 8q .. 8q+3 = x[4q .. 4q+3], bytes 8q+4 .. 8q+7 = y[4q .. 4q+3]
+    // lane l < 32 owns column l of x, lane l >= 32 column l - 32 of y, and each holds half the rows of both.  row = (i & 3) +
+    // 8 (i >> 2) + 4 half: pack the low bytes of four rows into a word first, then trade words (as msm.h mf_select does)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const uint32_t lo = __builtin_amdgcn_perm((uint32_t)x[4 * q + 1], (uint32_t)x[4 * q], 0x0c0c0400u) |
+      const uint32_t xw = __builtin_amdgcn_perm((uint32_t)x[4 * q + 1], (uint32_t)x[4 * q], 0x0c0c0400u) |
                           (__builtin_amdgcn_perm((uint32_t)x[4 * q + 3], (uint32_t)x[4 * q + 2], 0x0c0c0400u) << 16);
-      const uint32_t hi = __builtin_amdgcn_perm((uint32_t)y[4 * q + 1], (uint32_t)y[4 * q], 0x0c0c0400u) |
+      const uint32_t yw = __builtin_amdgcn_perm((uint32_t)y[4 * q + 1], (uint32_t)y[4 * q], 0x0c0c0400u) |
                           (__builtin_amdgcn_perm((uint32_t)y[4 * q + 3], (uint32_t)y[4 * q + 2], 0x0c0c0400u) << 16);
-      out[8 * t + 2 * q] = lo; out[8 * t + 2 * q + 1] = hi;
+      const auto s = __builtin_amdgcn_permlane32_swap(xw, yw, false, false);
+      out[8 * t + 2 * q] = s[0]; out[8 * t + 2 * q + 1] = s[1];      // bytes 8q .. 8q+3 from lane half 0, 8q+4 .. 8q+7 from half 1
     }
   }
 }
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(256) k_select(const uint8_t* tabA, const int* 
 
 // the scan the ct build uses today, at the same width, for the timing comparison: every lane reads all entries, keeps one with masks
 __global__ void __launch_bounds__(256) k_scan(const uint32_t* tab /* [entry][32 words] */, const int* idx, uint32_t* out, int reps, int entries) {
-  __shared__ uint32_t lds[ENTRIES * WORDS];
+  __shared__ uint32_t lds[32 * WORDS];
   for (int i = threadIdx.x; i < entries * WORDS; i += 256) lds[i] = tab[i];
   __syncthreads();
   const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -107,11 +112,11 @@ __global__ void __launch_bounds__(256) k_scan(const uint32_t* tab /* [entry][32 
 
 int main() {
   const int blocks = 2048, lanes = blocks * 256;
-  std::vector<uint8_t> T(ENTRIES * 128), tabA(TILES * 2 * 32 * 16);
+  std::vector<uint8_t> T(ENTRIES * 128), tabA(KSTEPS * TILES * 2 * 32 * 16);
   srand(7);
   for (auto& b : T) b = (uint8_t)rand();
-  for (int t = 0; t < TILES; t++) for (int h = 0; h < 2; h++) for (int r = 0; r < 32; r++) for (int j = 0; j < 16; j++)
-    tabA[((t * 2 + h) * 32 + r) * 16 + j] = T[(16 * h + j) * 128 + 32 * t + r];
+  for (int ks = 0; ks < KSTEPS; ks++) for (int t = 0; t < TILES; t++) for (int h = 0; h < 2; h++) for (int r = 0; r < 32; r++) for (int j = 0; j < 16; j++)
+    tabA[(((ks * TILES + t) * 2 + h) * 32 + r) * 16 + j] = T[(32 * ks + 16 * h + j) * 128 + 32 * t + r];
   std::vector<int> idx(lanes);
   for (int i = 0; i < lanes; i++) idx[i] = (rand() % (ENTRIES + 1)) - 1;          // -1 = no entry (digit 0)
   uint8_t *d_tabA, *d_T; int* d_idx; uint32_t* d_out;
@@ -140,8 +145,8 @@ int main() {
       else hipLaunchKernelGGL(k_scan, dim3(blocks), dim3(256), 0, 0, reinterpret_cast<const uint32_t*>(d_T), d_idx, d_out, reps, which == 1 ? 8 : which == 2 ? 16 : 32);
       CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[which], e0, e1));
     }
-    if (pass) printf("per look-up per wavefront: mfma select (32 entries) %.1f ns; masked scan of 8 / 16 / 32 entries from LDS %.1f / %.1f / %.1f ns\n",
-                     1e6 * ms[0] / reps / (lanes / 64) * 1024, 1e6 * ms[1] / reps / (lanes / 64) * 1024, 1e6 * ms[2] / reps / (lanes / 64) * 1024, 1e6 * ms[3] / reps / (lanes / 64) * 1024);
+    if (pass) printf("per look-up per wavefront: mfma select (%d entries) %.1f ns; masked scan of 8 / 16 / 32 entries from LDS %.1f / %.1f / %.1f ns\n",
+                     ENTRIES, 1e6 * ms[0] / reps / (lanes / 64) * 1024, 1e6 * ms[1] / reps / (lanes / 64) * 1024, 1e6 * ms[2] / reps / (lanes / 64) * 1024, 1e6 * ms[3] / reps / (lanes / 64) * 1024);
   }
   return bad ? 1 : 0;
 }
