@@ -44,9 +44,9 @@ class ActError(RuntimeError):
 
 def build(jobs: int = 8) -> str:
     """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    # `all` = libact_mi355x.so; `ct` = libact_mi355x_ct.so, the same library with address-independent table / bucket
-    # selection for secret scalars (-DACT_CT_SECRET_TABLES)
-    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}", "-s", "all", "ct"], check=True)
+    # `all` = libact_mi355x.so, address-free for every secret (the reference's constant-time posture); `fast` =
+    # libact_mi355x_fast.so, the same library with scalar-addressed tables for the CLIENT's secrets (prover, request)
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), f"-j{jobs}", "-s", "all", "fast"], check=True)
     return LIB_PATH
 
 

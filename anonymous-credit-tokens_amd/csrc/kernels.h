@@ -238,20 +238,14 @@ void launch_client_b(const ClientArgs& a, hipStream_t s);
 
 // ---- fixed-base products of SECRET scalars (msm.h "secret scalars") ---------------------------------------------------------
 // Kernel code writes   ACT_SECRET_FB(fb, a.P);  fb.stage(BASE_G);  x = fb.mul(acc, BASE_G, e);
-//   IssuerFb           the issuer's secrets (signing nonces e, alpha; key generation): in EVERY build mul() scans all eight entries
-//                      of every window of the base's 64 KiB table (fixed_base_acc_ct).  The scan reads the table where it lies in
-//                      global memory; every lane of a wavefront reads the same addresses, so a window is 8 x 128 B per WAVEFRONT
-//                      through L2, not per lane.
-//   ACT_SECRET_FB      the client's secrets in the per-proof kernels (prover head / tail, request).  Default build: stage() is
-//                      nothing and mul() is fixed_base_acc on the context's wide tables (addressed look-ups); ct build: the scan
-//                      above.
-//   ACT_SECRET_FB_LDS  the same for k_prove_bits (256-thread blocks, three products per staged base): in the ct build the block
-//                      copies the table into 64 KiB of LDS first -- stage(base) holds the block's barriers and a block-strided
-//                      copy, so EVERY thread of the block must call it, before any early exit -- and scans it with broadcast
-//                      ds_read_b128.
-// Measured on one MI355X (profiles/r03_b_other_configs_1gpu*.json): staging in LDS in the 64-thread kernels made `request` slower
-// (0.27x -> 0.15x of the default build: 128 KiB copied per 64 lanes for four products) and prove_spend 3 % faster; the cost of the ct
-// build's fixed-base products is their 64 additions per product (the default build's 24- / 16-bit windows need 11 / 16), not the scan.
+//   IssuerFb           the issuer's secrets (signing nonces e, alpha; key generation), in EVERY build;
+//   ACT_SECRET_FB      the client's secrets in the per-proof kernels (prover head / tail, request);
+//   ACT_SECRET_FB_LDS  the same for k_prove_bits (256-thread blocks).
+// In the default build all three are the matrix-core look-up (msm.h fixed_base_acc_mf: 64-entry windows, 37 additions per product;
+// stage() is nothing) and EVERY lane of a wavefront must call mul() together, live or not -- the table operand's rows come from all
+// 64 lanes -- which is why the lane bodies multiply in every lane and drop the results of the ones past the batch.  In `make fast`
+// the two client forms are fixed_base_acc on the context's wide tables (addressed look-ups).  Rounds 2-3: masked scans of 8-entry
+// windows from global memory / staged in LDS (-DACT_CT_GLOBAL_SCAN / -DACT_CT_LDS_SCAN keep them for A/B: 64 additions per product).
 #if defined(__HIPCC__)
 #if defined(ACT_CT_GLOBAL_SCAN)
 struct IssuerFb {          // round 3's form, kept for same-box A/B: 8-entry windows scanned where the table lies in global memory

@@ -497,22 +497,19 @@ ACT_HD void chain_b(ge* acc, const ge& N, const sc* s, uint32_t* bk) {
 
 // ---- secret scalars --------------------------------------------------------------------------------------------
 // The reference is constant-time in its table accesses (`subtle`, /root/reference/src/lib.rs:98, 1025-1118; dalek's table scans).
-// Here, in EVERY build, the ISSUER's secrets -- the key x (the verifier's (e_bar - x gamma) A', the signer's (e + x)^-1) and the
-// signing nonces e, alpha -- never select a memory address: their chains are chain_ct and their fixed-base products scan
-// (IssuerFb in kernels.h).  Measured cost against addressed look-ups: verify 1.00x, refund 0.99x, issue 0.88x.
-// The CLIENT's secrets (prover: SecretFb in kernels.h and chain_s here; request) use fixed_base_acc / chain_b in the default build --
-// table entries and buckets addressed by scalar digits, so the memory-access pattern depends on them (the instruction stream does
-// not) -- and the address-free forms when built with -DACT_CT_SECRET_TABLES (make ct -> libact_mi355x_ct.so): prove_spend 0.26x,
-// request 0.26x of the default build, because a scanned table cannot be wider than a few entries per window:
-//   fixed-base products   signed radix-16 windows over a small table of the base (64 windows x 8 entries x 128 B = 64 KiB)
-//                         that the BLOCK first stages in LDS (ct_stage); every lane then reads all eight entries of a window --
-//                         the same LDS addresses in every lane: broadcast reads, no bank conflicts -- and keeps one with masks.
-//                         Round 2 scanned the table in global memory: 8 x 128 B per window per lane through L2, 64 KiB per
-//                         product per lane, which made the all-fixed-base functions run at a quarter of the default build.
+// Here no secret scalar ever selects a memory address in the default build (-DACT_CT_SECRET_TABLES, which the Makefile's `all` sets):
+//   the ISSUER's secrets (the key x in the verifier's (e_bar - x gamma) A' and the signer's (e + x)^-1, the signing nonces e, alpha)
+//                         in EVERY build: variable-base chains are chain_ct, fixed-base products go through IssuerFb (kernels.h);
+//   the CLIENT's secrets  (prover: SecretFb / ACT_SECRET_FB_LDS in kernels.h and chain_s here; request) in the default build the
+//                         same; in `make fast` (libact_mi355x_fast.so) fixed_base_acc / chain_b -- table entries and buckets
+//                         addressed by scalar digits: the memory-access pattern depends on them, the instruction stream does not.
+//   fixed-base products   fixed_base_acc_mf below: the entry of a 64-entry window picked on the MATRIX CORES (37 additions per
+//                         product; measured prove_spend 0.48 x, request 0.55 x of the fast build).  Rounds 2-3 scanned 8-entry
+//                         windows with masks (fixed_base_acc_ct: 64 additions per product, 0.26 x); that form is kept for the host
+//                         test build and for same-box A/B (-DACT_CT_GLOBAL_SCAN / -DACT_CT_LDS_SCAN).
 //   variable-base chains  chain_ct: radix-4 digits on the shared doubling chain, EVERY digit addition executed (a zero digit adds
-//                         the identity, picked with masks), everything in registers: no buckets, so nothing to address.  Round 2
-//                         read and rewrote all nine Pippenger buckets of a scalar at every step (369 KB of traffic per
-//                         signature); this form costs 1.36x the default chain's multiplications and no memory traffic.
+//                         the identity, picked with masks), everything in registers: no buckets, so nothing to address; 1.36 x the
+//                         bucket chain's multiplications and no memory traffic.
 constexpr int CT_WINDOWS = 64, CT_ENTRIES = 8;
 constexpr size_t CT_TABLE_WORDS = (size_t)CT_WINDOWS * CT_ENTRIES * NIELS_WORDS;       // T[pos][e-1] = e * 16^pos * B, e = 1..8: 64 KiB
 // acc += s * B; `table` = B's CT table (in LDS on the device: SecretFb::stage)

@@ -753,7 +753,10 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
     bits = prof.get("k_prove_bits")
     if not bits:
         return {"error": "no k_prove_bits launches were timed"}
-    ops = count_prover_ops(hc_path, h, L, eng.fixed_base_bits())
+    # the default build picks its table entries on the matrix cores: 7-bit windows = 37 mixed additions per fixed-base product,
+    # whatever the base (csrc/msm.h fixed_base_acc_mf); the `fast` build addresses the context's 16- / 24-bit tables
+    ct = bool(capi_mod().load().act_build_has_ct_secret_tables())
+    ops = count_prover_ops(hc_path, h, L, [7, 7, 7, 7] if ct else eng.fixed_base_bits())
     launch_s = bits["busy_ms"] / 1e3 / bits["launches"]
     proofs_per_launch = bits["lanes"] / bits["launches"] / L
     mad_bits = MAD_PER_MUL * ops["k_prove_bits"]["fe_mul"] + MAD_PER_SQ * ops["k_prove_bits"]["fe_sq"]
@@ -762,6 +765,8 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
     table_bytes = ops["k_prove_bits"]["table_reads"] * 128
     rnd = {}
     try:
+        if ct:
+            raise RuntimeError("address-free build: table entries are picked by MFMA from L2-resident images (296 KiB per base), no random HBM reads")
         # the chip's rate for the tables' access pattern -- random 128-byte entries, seven 16-byte loads each -- measured on this
         # context's own h3 table (the product's memory), at several (wavefronts per SIMD, entries in flight per lane); and on a
         # fresh 16 GiB allocation for comparison
@@ -769,20 +774,23 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
         rnd = {"random_128B_read_GBps_measured": max(sweep.values()), "random_128B_read_GBps_on_the_h3_table_by_waves_per_simd_x_entries_in_flight": sweep,
                "random_128B_read_GBps_on_a_fresh_16GiB_allocation": round(capi_mod().ubench_random_read(eng.device, 16, 8, 2)[0], 1)}
     except Exception as e:
-        rnd = {"random_read_probe_error": repr(e)}
+        rnd = {"random_read_probe": str(e)}
     tb_rate = table_bytes * proofs_per_launch / launch_s / 1e9
     pm = newest_matching_pmc("pmc_prover", proofs_per_launch, kernel_source_sha16(), L)
     out = {"kernel": "k_prove_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
+           "build": ("default: address-free for the client's secrets too (matrix-core table look-ups, 37 additions per fixed-base product); "
+                     "libact_mi355x_fast.so: 2.1 x this rate with scalar-addressed tables (profiles/r04_*_other_configs_1gpu*.json)") if ct else
+                    "fast: scalar-addressed 16- / 24-bit tables for the client's secrets",
            "valu": {"achieved": rate, "peak": peak_mad, "frac": rate / peak_mad, "unit": "lane multiply-accumulates (v_mad_u64_u32) per second",
                     "algorithmic_mad_per_proof_in_this_kernel": mad_bits, "mad_per_proof_whole_path": mad_all},
-           "table_reads": {"bytes_per_proof": table_bytes, "achieved_GBps": tb_rate, "what": "scalar-addressed 128-byte entries of the 24-/16-bit fixed-base tables (47 GB): every read a different line"},
+           "table_reads": None if ct else {"bytes_per_proof": table_bytes, "achieved_GBps": tb_rate, "what": "scalar-addressed 128-byte entries of the 24-/16-bit fixed-base tables (47 GB): every read a different line"},
            "per_kernel_field_ops_per_proof": ops,
            "kernel_ms_per_65536_proofs": {k: round(v["busy_ms"] / v["launches"], 3) for k, v in prof.items() if k.startswith("k_prove")},
            "prove_spend_proofs_per_s_wall": round(n_proofs / t_prove) if t_prove else None}
     out.update(rnd)
     f_valu = rate / peak_mad
     out["bound"], out["frac"] = "valu-int-mad", f_valu
-    if rnd.get("random_128B_read_GBps_measured"):
+    if rnd.get("random_128B_read_GBps_measured") and not ct:
         f_mem = tb_rate / rnd["random_128B_read_GBps_measured"]
         out["table_reads"]["frac_of_measured_random_read_rate"] = f_mem
         if f_mem > f_valu:

@@ -141,14 +141,17 @@ int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
  * calls pipeline 65 536-proof chunks as before (one lane per proof is the faster form once a launch fills the chip). */
 int act_ctx_set_small_batch_max(act_ctx *ctx, size_t n);
 /* Secrets and memory addresses.  The reference is constant-time in its table accesses (`subtle`, src/lib.rs:98, 1025-1118;
- * dalek's table scans).  In EVERY build of this library the ISSUER's secrets -- the private key x and the signing nonces, i.e.
- * everything act_issue_* / act_refund_* / act_verify_spend_* / act_private_key_random compute with -- never select a memory
- * address: variable-base products run a register-only chain that executes every digit addition, fixed-base products scan all
- * entries of small tables and pick with masks.  The CLIENT's secrets (act_prove_spend_batch, act_request_batch: tokens, blinding
- * factors, the prover's rng) use scalar-addressed tables in the default build and the same address-free forms in
- * libact_mi355x_ct.so (make ct, -DACT_CT_SECRET_TABLES), which returns 1 here; same bytes either way.  Cost of the ct build on one
- * MI355X: prove_spend 0.26x, request 0.26x of the default build; every issuer-side call within 1 %.  A deployment that runs the
- * client side on a GPU it shares with parties it does not trust loads the ct build; an issuer can load either. */
+ * dalek's table scans).  libact_mi355x.so (the default build, for which this returns 1) matches that for EVERY secret: the issuer's
+ * private key and signing nonces, and the client's tokens, blinding factors and prover rng, never select a memory address --
+ * variable-base products run a register-only chain that executes every digit addition, and fixed-base products pick their table
+ * entries on the matrix cores: selected = Table x onehot(digits), one v_mfma_i32_32x32x32_i8 per 32 bytes x 32 lanes x 32 entries,
+ * so a window holds 64 entries (37 per product) with no entry ever addressed by a digit (csrc/msm.h fixed_base_acc_mf).
+ * libact_mi355x_fast.so (make fast; returns 0) differs only for the CLIENT's secrets (act_prove_spend_*, act_request_batch): they go
+ * through scalar-addressed 16- / 24-bit tables and Pippenger buckets -- the instruction stream still does not depend on them, the
+ * memory-access pattern does.  Same bytes either way.  Measured on one MI355X (profiles/r04_*_other_configs_1gpu*.json): default
+ * vs fast build prove_spend 0.48 x (1.16 M/s vs 2.40 M/s; round 3's masked scan: 0.26 x), request 0.55 x, a whole lifecycle
+ * 0.85 x; every issuer-side call -- verify, refund, issue, redeem -- is the same code in both.  A client that owns its GPU may load
+ * the fast build; an issuer gains nothing from it. */
 int act_build_has_ct_secret_tables(void);
 /* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
  * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 when max_batch >= 32768 and the device has the memory (see above) */
