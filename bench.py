@@ -545,7 +545,9 @@ def main():
                 "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": 8000.0, "unit": "GB/s", "frac": hbm_achieved / 8000.0,
                         "algorithmic_bytes_per_verify": algo_bytes,
                         "note": "the view the contract template asks for; not binding: 16.8 KB in per verify against ~40 M 64-bit multiply-accumulates"}}
-        t = newest_matching_pmc("pmc_hbm_traffic", proofs_per_launch, sha, L)
+        # (PMC summaries are collected on full launches of --max-batch proofs; the timed region's average launch is smaller when the
+        # engine opens and closes a call with quarter- and half-size chunks)
+        t = newest_matching_pmc("pmc_hbm_traffic", args.max_batch, sha, L)
         if t:
             j = t[1]
             roof["traffic"] = j.get("hbm_bytes_per_launch_calibrated", j["hbm_bytes_per_launch_fetch_x2"]); roof["traffic_source"] = t[0]
@@ -553,10 +555,11 @@ def main():
                                     "access pattern (profiles/r03_calib_fetch_144.txt) as MI355X_MICROARCH.md prescribes for anything but wide streaming reads; "
                                     "dominated by the per-lane Pippenger buckets cycling through L2 / Infinity Cache")
             roof["traffic_other_corrections"] = {"uncorrected": j["hbm_bytes_per_launch_uncorrected"], "fetch_x2_as_for_streaming_reads": j["hbm_bytes_per_launch_fetch_x2"]}
-            roof["traffic_over_algorithmic_bytes"] = roof["traffic"] / (algo_bytes * proofs_per_launch)
+            roof["traffic_proofs_per_launch"] = args.max_batch
+            roof["traffic_over_algorithmic_bytes"] = roof["traffic"] / (algo_bytes * args.max_batch)
         else:
             roof["traffic_source"] = "none: no profiles/*_pmc_hbm_traffic.json was collected from these kernel sources (sha %s) at L = %d" % (sha, L)
-        v = newest_matching_pmc("pmc_valu", proofs_per_launch, sha, L)
+        v = newest_matching_pmc("pmc_valu", args.max_batch, sha, L)
         if v:
             j = v[1]
             roof["pmc_valu"] = {"source": v[0], "valu_instructions_per_wave": j["valu_instructions_per_wave"],
@@ -776,7 +779,7 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
     except Exception as e:
         rnd = {"random_read_probe": str(e)}
     tb_rate = table_bytes * proofs_per_launch / launch_s / 1e9
-    pm = newest_matching_pmc("pmc_prover", proofs_per_launch, kernel_source_sha16(), L)
+    pm = newest_matching_pmc("pmc_prover", max_batch, kernel_source_sha16(), L)
     out = {"kernel": "k_prove_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
            "build": ("default: address-free for the client's secrets too (matrix-core table look-ups, 37 additions per fixed-base product); "
                      "libact_mi355x_fast.so: 2.1 x this rate with scalar-addressed tables (profiles/r04_*_other_configs_1gpu*.json)") if ct else

@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 cd $root
 python3 bench.py --steps 3 --warmup 1 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_prof -- python3 $root/bench.py --steps 2 --warmup 1 --pipeline-depth 1 --no-extras --no-cpu-baseline > $root/gpurun_out/${tag}_bench_depth1.json 2> $root/gpurun_out/${tag}_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_prof -- python3 $root/bench.py --steps 2 --warmup 1 --pipeline-depth 1 --no-extras --no-cpu-baseline --no-node-multi > $root/gpurun_out/${tag}_bench_depth1.json 2> $root/gpurun_out/${tag}_prof.err
 cd $root
 f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats_depth1.csv
@@ -24,6 +24,6 @@ python3 - <<P
 import json
 for n in ("bench", "bench_depth1"):
     d = json.load(open("gpurun_out/${tag}_%s.json" % n))
-    print(n, round(d["value"]), "avg_launch_ms", round(d["roofline"]["avg_launch_ms"], 2), "alu", d["roofline"].get("alu", {}).get("frac"))
+    print(n, round(d["value"]), "avg_launch_ms", round(d["roofline"]["avg_launch_ms"], 2), "frac", round(d["roofline"]["frac"], 4))
 print(open("gpurun_out/${tag}_pmc.log").read()[-600:])
 P
