@@ -195,3 +195,16 @@ def test_redeem_batch_and_nullifier_db(env):              # examples/act.rs:62-7
     assert db.spend_batch([p.nullifier() for p in proofs[:4]]) == [False] * 4
     fresh = issue_token(api, params, rng, sk, 5)
     assert db.spend(fresh.nullifier()) is True and db.spend(fresh.nullifier()) is False and len(db) == 5
+
+
+def test_roofline_probes_run(engine_factory, bench_params):
+    """The library's three roofline probes (bench.py: the MAD issue rate; the random 128-byte read rate on a fresh allocation and on a
+    context's own table) return sane numbers."""
+    from act_amd import capi
+    rate, ms = capi.ubench_mad(0)
+    assert 1e13 < rate < 6e13 and ms > 0
+    gbps, ms = capi.ubench_random_read(0, 1, 2, 2)
+    assert 50 < gbps < 20000 and ms > 0
+    eng = engine_factory(bench_params, 8, max_batch=4)
+    gbps, ms = eng.ubench_table_read(3, 2, 2)
+    assert 50 < gbps < 20000 and ms > 0

@@ -14,7 +14,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 r = random.Random(seed)
 for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
     o = Oracle(); h = o.params_new("soak-org", "svc", "env", "v%d" % seed); octx = o.ctx(h, L)
-    eng = capi.Engine(h, L, max_batch=600, transcript=capi.TRANSCRIPT_DEVICE)
+    # ACT_SOAK_MAX_BATCH >= n: one chunk = the small-batch schedule (engine.hip spend_small_locked); the default, 600, pipelines chunks
+    eng = capi.Engine(h, L, max_batch=int(os.environ.get("ACT_SOAK_MAX_BATCH", "600")), transcript=capi.TRANSCRIPT_DEVICE)
     sk = eng.private_key_random(sh("sk%d" % seed, 64))
     pre = eng.pre_issuance_random(sh("pre%d" % seed, 128 * n)); req = eng.request(pre, sh("rq%d" % seed, 128 * n))
     amounts = [r.randrange(1, 1 << min(L, 100)) for _ in range(n)]
