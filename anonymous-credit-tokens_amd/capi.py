@@ -17,7 +17,7 @@ _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_parallel_for", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_prove_spend_seeded_batch", "act_node_prove_spend_seeded_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
@@ -81,6 +81,8 @@ def load() -> C.CDLL:
     lib.act_host_usable_cpus.argtypes = []
     lib.act_host_hash_many.argtypes = [u8p, sz, C.c_uint32, sz, i32, u8p]
     lib.act_host_hash_many.restype = None
+    lib.act_host_parallel_for.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t), C.c_void_p]
+    lib.act_host_parallel_for.restype = None
     lib.act_host_pool_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     lib.act_host_pool_stats.restype = None
     lib.act_ctx_streams_overlap.argtypes = [vp]

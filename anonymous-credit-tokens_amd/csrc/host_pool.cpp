@@ -52,21 +52,28 @@ int usable_cpus_now() {
 
 constexpr size_t GRAIN = 64;       // messages per work item: four SIMD groups of sixteen
 
+// a job = fn(ctx, i0, i1) over [0, n) in items of `grain`; whoever holds a ticket takes items until none are left
 struct Job {
-  const uint8_t* msgs; size_t stride; uint32_t len; size_t n; uint32_t* xof;
+  void (*fn)(void*, size_t, size_t); void* ctx; size_t n, grain;
   std::atomic<size_t> next{0}, done{0};
   void work() {
     for (;;) {
-      const size_t i0 = next.fetch_add(GRAIN, std::memory_order_relaxed);
+      const size_t i0 = next.fetch_add(grain, std::memory_order_relaxed);
       if (i0 >= n) return;
-      const size_t i1 = std::min(n, i0 + GRAIN);
-      size_t i = i0;
-      for (; i + 16 <= i1; i += 16) act_host_b3_xof64_x16(msgs + i * stride, stride, len, xof + i * 16);
-      for (; i < i1; i++) act::b3_hash_xof64(xof + i * 16, reinterpret_cast<const uint32_t*>(msgs + i * stride), len);
+      const size_t i1 = std::min(n, i0 + grain);
+      fn(ctx, i0, i1);
       done.fetch_add(i1 - i0, std::memory_order_release);
     }
   }
 };
+
+struct HashArgs { const uint8_t* msgs; size_t stride; uint32_t len; uint32_t* xof; };
+void hash_items(void* p, size_t i0, size_t i1) {
+  const HashArgs& a = *static_cast<const HashArgs*>(p);
+  size_t i = i0;
+  for (; i + 16 <= i1; i += 16) act_host_b3_xof64_x16(a.msgs + i * a.stride, a.stride, a.len, a.xof + i * 16);
+  for (; i < i1; i++) act::b3_hash_xof64(a.xof + i * 16, reinterpret_cast<const uint32_t*>(a.msgs + i * a.stride), a.len);
+}
 
 class Pool {
  public:
@@ -74,7 +81,7 @@ class Pool {
   int size() const { return size_; }
   // hashes the job on up to `par` threads, the caller among them; returns when every message is hashed
   void run(const std::shared_ptr<Job>& job, int par) {
-    const size_t items = (job->n + GRAIN - 1) / GRAIN;
+    const size_t items = (job->n + job->grain - 1) / job->grain;
     const int helpers = (int)std::min<size_t>((size_t)std::max(par, 1) - 1, items > 0 ? items - 1 : 0);
     if (helpers > 0) {
       start_workers();
@@ -140,8 +147,23 @@ void act_host_hash_many(const uint8_t* msgs, size_t stride, uint32_t len, size_t
   const int active = g_hashing.fetch_add(1, std::memory_order_acq_rel) + 1;
   int par = std::max(1, pool.size() / active);
   if (max_threads > 0) par = std::min(par, max_threads);
+  HashArgs args{msgs, stride, len, xof};
   auto job = std::make_shared<Job>();
-  job->msgs = msgs; job->stride = stride; job->len = len; job->n = n; job->xof = xof;
+  job->fn = hash_items; job->ctx = &args; job->n = n; job->grain = GRAIN;
+  pool.run(job, par);
+  g_hashing.fetch_sub(1, std::memory_order_acq_rel);
+}
+
+// fn(ctx, i0, i1) over [0, n) in items of `grain` indices on the same workers (node.cpp routes nullifiers to their owners with it).
+// Items run in any order and concurrently; the call returns when all have.  max_threads as above.
+void act_host_parallel_for(size_t n, size_t grain, int max_threads, void (*fn)(void*, size_t, size_t), void* ctx) {
+  if (!n || !fn) return;
+  Pool& pool = Pool::get();
+  const int active = g_hashing.fetch_add(1, std::memory_order_acq_rel) + 1;
+  int par = std::max(1, pool.size() / active);
+  if (max_threads > 0) par = std::min(par, max_threads);
+  auto job = std::make_shared<Job>();
+  job->fn = fn; job->ctx = ctx; job->n = n; job->grain = grain ? grain : 1;
   pool.run(job, par);
   g_hashing.fetch_sub(1, std::memory_order_acq_rel);
 }

@@ -283,6 +283,12 @@ struct act_node_nullifier_set {
   uint64_t route_key[2] = {0, 0};
   std::string err;
   std::mutex mu;
+  // routing scratch, kept between calls (under mu) and only ever grown: a fresh 32 MB of key buckets per million-key call would
+  // be page-faulted in by one thread every time
+  struct Bucket { std::vector<uint32_t> lanes; std::vector<uint8_t> keys, spent; size_t count = 0; };
+  std::vector<Bucket> buckets;
+  std::vector<uint16_t> owner;
+  std::vector<size_t> place;
 };
 
 namespace {
@@ -321,7 +327,7 @@ uint64_t route_hash(const uint64_t k[4], const uint64_t key[2]) {
 
 extern "C" {
 int act_node_nullifier_set_create(const int* devices, int n_devices, size_t capacity_per_device, const uint8_t salt[16], act_node_nullifier_set** out) {
-  if (!devices || n_devices < 1 || !out || !capacity_per_device) return ACT_ERR_ARG;
+  if (!devices || n_devices < 1 || n_devices > 4096 || !out || !capacity_per_device) return ACT_ERR_ARG;
   act_node_nullifier_set* ns = new act_node_nullifier_set();
   *out = ns;
   if (salt) memcpy(ns->route_key, salt, 16);
@@ -363,21 +369,52 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t
   if (!ns || (n && (!nullifiers || !out_spent)) || stride < 32) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> lock(ns->mu);
   const size_t parts = ns->sets.size();
-  std::vector<std::vector<uint32_t>> lanes(parts);
-  std::vector<std::vector<uint8_t>> keys(parts), spent(parts);
-  for (size_t i = 0; i < n; i++) {
-    out_spent[i] = 0;
-    if (skip_mask && skip_mask[i]) continue;                   // e.g. the status of a rejected proof: neither checked nor inserted
-    uint64_t k[4]; reduce_mod_l(nullifiers + i * stride, k);
-    const size_t owner = (size_t)(route_hash(k, ns->route_key) % parts);
-    lanes[owner].push_back((uint32_t)i);
-    keys[owner].insert(keys[owner].end(), nullifiers + i * stride, nullifiers + i * stride + 32);
+  // Bucket the keys by owner, lane order kept inside every bucket, on the host workers (host_pool.cpp): the batch is cut into
+  // segments; pass 1 computes every lane's owner and the segment's count per owner, a prefix sum over (segment, owner) gives each
+  // segment its place in each bucket, pass 2 copies lanes and keys there.  (A million keys at the proof stride: one thread spends
+  // longer here than eight GPUs spend on their look-ups.)
+  struct Route { act_node_nullifier_set* ns; const uint8_t* nullifiers; size_t stride, n, seg, parts; const uint8_t* skip; uint8_t* out_spent; }
+      r{ns, nullifiers, stride, n, 0, parts, skip_mask, out_spent};
+  const size_t segs = std::max<size_t>(1, std::min<size_t>(256, n / 4096));
+  r.seg = (n + segs - 1) / segs;
+  if (ns->owner.size() < n) ns->owner.resize(n);
+  ns->place.assign(segs * parts, 0);                 // place[s * parts + p]: count, then first index, of segment s in bucket p
+  ns->buckets.resize(parts);
+  act_host_parallel_for(segs, 1, 0, [](void* p, size_t s0, size_t s1) {
+    Route& r = *static_cast<Route*>(p);
+    for (size_t s = s0; s < s1; s++)
+      for (size_t i = s * r.seg, e = std::min(r.n, i + r.seg); i < e; i++) {
+        r.out_spent[i] = 0;
+        if (r.skip && r.skip[i]) { r.ns->owner[i] = 0xFFFF; continue; }      // e.g. the status of a rejected proof: neither checked nor inserted
+        uint64_t k[4]; reduce_mod_l(r.nullifiers + i * r.stride, k);
+        const size_t o = (size_t)(route_hash(k, r.ns->route_key) % r.parts);
+        r.ns->owner[i] = (uint16_t)o; r.ns->place[s * r.parts + o]++;
+      }
+  }, &r);
+  for (size_t p = 0; p < parts; p++) {
+    size_t at = 0;
+    for (size_t s = 0; s < segs; s++) { const size_t c = ns->place[s * parts + p]; ns->place[s * parts + p] = at; at += c; }
+    auto& b = ns->buckets[p];
+    b.count = at;
+    if (b.lanes.size() < at) { b.lanes.resize(at); b.keys.resize(32 * at); b.spent.resize(at); }
   }
+  act_host_parallel_for(segs, 1, 0, [](void* p, size_t s0, size_t s1) {
+    Route& r = *static_cast<Route*>(p);
+    for (size_t s = s0; s < s1; s++)
+      for (size_t i = s * r.seg, e = std::min(r.n, i + r.seg); i < e; i++) {
+        const size_t o = r.ns->owner[i];
+        if (o == 0xFFFF) continue;
+        auto& b = r.ns->buckets[o];
+        const size_t at = r.ns->place[s * r.parts + o]++;
+        b.lanes[at] = (uint32_t)i;
+        memcpy(b.keys.data() + 32 * at, r.nullifiers + i * r.stride, 32);
+      }
+  }, &r);
   std::vector<int> rc(parts, ACT_OK);
   std::vector<std::thread> th;
   auto work = [&](size_t p) {
-    spent[p].assign(lanes[p].size(), 0);
-    if (!lanes[p].empty()) rc[p] = act_nullifier_check_and_insert_batch(ns->sets[p], lanes[p].size(), ACT_MEM_HOST, keys[p].data(), 32, nullptr, spent[p].data());
+    auto& b = ns->buckets[p];
+    if (b.count) rc[p] = act_nullifier_check_and_insert_batch(ns->sets[p], b.count, ACT_MEM_HOST, b.keys.data(), 32, nullptr, b.spent.data());
   };
   for (size_t p = 1; p < parts; p++) th.emplace_back(work, p);
   work(0);
@@ -391,9 +428,9 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t
     if (rc[p]) {
       if (!first_rc) first_rc = rc[p];
       ns->err += (ns->err.empty() ? "device " : "; device ") + std::to_string(ns->devices[p]) + ": " + act_nullifier_set_last_error(ns->sets[p]);
-      for (size_t j = 0; j < lanes[p].size(); j++) out_spent[lanes[p][j]] = ACT_NULLIFIER_UNDETERMINED;
+      for (size_t j = 0; j < ns->buckets[p].count; j++) out_spent[ns->buckets[p].lanes[j]] = ACT_NULLIFIER_UNDETERMINED;
     } else {
-      for (size_t j = 0; j < lanes[p].size(); j++) out_spent[lanes[p][j]] = spent[p][j];
+      for (size_t j = 0; j < ns->buckets[p].count; j++) out_spent[ns->buckets[p].lanes[j]] = ns->buckets[p].spent[j];
     }
   }
   return first_rc;

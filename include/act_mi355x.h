@@ -122,6 +122,10 @@ int act_host_usable_cpus(void);                             /* CPUs the process 
 /* The pool's hashing entry point (what the host-transcript mode calls; pure host code, usable and tested without a GPU):
  * xof[16*i ..] = first 64 XOF bytes of BLAKE3(msgs + i*stride, len), i < n; max_threads as nthreads above. */
 void act_host_hash_many(const uint8_t *msgs, size_t stride, uint32_t len, size_t n, int max_threads, uint32_t *xof);
+/* fn(ctx, i0, i1) over [0, n) in items of `grain` indices on the same workers, in any order, the caller among them; returns when
+ * all have run.  (What act_node_nullifier_check_and_insert_batch routes keys to their owning GPU with; max_threads as above.) */
+typedef void (*act_host_range_fn)(void *ctx, size_t i0, size_t i1);
+void act_host_parallel_for(size_t n, size_t grain, int max_threads, act_host_range_fn fn, void *ctx);
 /* diagnostics: hashing calls served, worker threads ever created by this process (constant after the first call), pool size */
 void act_host_pool_stats(uint64_t *jobs, uint64_t *threads_created, int *pool_size);
 /* A context pipelines two chunks on two HIP streams.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware

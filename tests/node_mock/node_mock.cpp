@@ -8,12 +8,14 @@
 //   outputs of an accepted lane = [8-byte global tag of the input record] | the first bytes of the rng slice it was given
 //   ACT_RNG_PER_LANE: lane i of a call uses rng + 128 i;  ACT_RNG_SEQUENTIAL: accepted lanes use consecutive slices
 //   every context counts its calls and lanes (act_mock_lanes) so that the test can see all of them were used
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/act_mi355x.h"
 
@@ -99,6 +101,18 @@ int act_refund_sign_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8
 }
 int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int, const uint8_t* prer, const uint8_t* proof, const uint8_t* refund, const uint8_t*, uint8_t* out, uint8_t* status) {
   c->lanes += n; for (size_t i = 0; i < n; i++) { emit(out + 160 * i, 160, prer + 96 * i, refund + 128 * i); out[159 + 160 * i] = proof[kPB * i]; status[i] = 0; } return ACT_OK;
+}
+
+// the host pool's parallel-for (csrc/host_pool.cpp), here on two threads that take the items from the far end: the dispatcher must
+// not depend on item order
+void act_host_parallel_for(size_t n, size_t grain, int, void (*fn)(void*, size_t, size_t), void* ctx) {
+  if (!n) return;
+  if (!grain) grain = 1;
+  const size_t items = (n + grain - 1) / grain;
+  auto run = [&](size_t parity) { for (size_t k = items; k-- > 0;) if ((k & 1) == parity) fn(ctx, k * grain, std::min(n, (k + 1) * grain)); };
+  std::thread t(run, (size_t)1);
+  run(0);
+  t.join();
 }
 
 int act_nullifier_set_create(int device, size_t, const uint8_t*, act_nullifier_set** out) { *out = new act_nullifier_set(); (*out)->device = device; return ACT_OK; }

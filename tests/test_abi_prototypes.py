@@ -32,6 +32,8 @@ def kind(param: str) -> str:
             return "ptr:" + re.match(r"(const )?(\w+) \*", p).group(2)
         return "void_p"                      # uint8_t* / uint32_t* / opaque handles
     t = p.rsplit(" ", 1)[0].replace("const ", "")
+    if t == "act_host_range_fn":
+        return "fnptr"
     return {"int": "int", "size_t": "size_t", "uint64_t": "u64", "uint32_t": "u32", "double": "double"}[t]
 
 
@@ -50,7 +52,9 @@ def test_every_prototype_matches_the_binding():
         assert len(fn.argtypes) == len(params), (name, params, fn.argtypes)
         for p, a in zip(params, fn.argtypes):
             k = kind(p)
-            if k in CT:
+            if k == "fnptr":
+                assert issubclass(a, C._CFuncPtr), (name, p, a)
+            elif k in CT:
                 assert a is CT[k], (name, p, a)
             elif k == "ptrptr":
                 assert a is C.POINTER(C.c_void_p), (name, p, a)

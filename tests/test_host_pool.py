@@ -71,3 +71,30 @@ def test_edge_sizes(capi):
     assert capi.host_hash_many(np.zeros(16, np.uint8), 16, 3, 0) == b""
     one = capi.host_hash_many(np.zeros(64, np.uint8), 64, 0, 1)
     assert one[:32].hex() == "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"      # BLAKE3("")
+
+
+def test_parallel_for_covers_every_index_once(capi):
+    """act_host_parallel_for (what the node-level nullifier set routes keys with): every index in exactly one item, items no
+    longer than the grain, callers on several threads at the same time, nothing lost."""
+    import ctypes as C
+    lib = capi.load()
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t)
+
+    def run(n, grain, par):
+        hits = np.zeros(n, np.int32); sizes = []; lock = threading.Lock()
+
+        def item(_, i0, i1):
+            hits[i0:i1] += 1                       # items never overlap, so no two threads write one element
+            with lock:
+                sizes.append(i1 - i0)
+        lib.act_host_parallel_for(n, grain, par, CB(item), None)
+        assert (hits == 1).all() and sum(sizes) == n and max(sizes) <= max(1, grain)
+
+    for n, grain, par in ((1, 1, 0), (1000, 7, 0), (4096, 64, 3), (5, 100, 0), (257, 1, 1)):
+        run(n, grain, par)
+    lib.act_host_parallel_for(0, 1, 0, CB(lambda *_: None), None)
+    th = [threading.Thread(target=run, args=(3000 + k, 11, 0)) for k in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()

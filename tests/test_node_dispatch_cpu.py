@@ -171,6 +171,33 @@ def test_node_nullifier_routing_is_by_scalar(lib):
     lib.act_node_nullifier_set_destroy(ns)
 
 
+def test_node_nullifier_routing_many_segments(lib):
+    """Enough keys that the routing runs as many segments on the host workers (the mock's parallel-for takes them from the far end
+    on two threads): repeats inside the batch, masked lanes and a key stride like a proof's keep the meaning of the sequential loop."""
+    n, stride = 40000, 40
+    r = random.Random(11)
+    pool = [r.randrange(2**256).to_bytes(32, "little") for _ in range(n // 2)]
+    lanes = [pool[r.randrange(len(pool))] for _ in range(n)]
+    mask = bytes(1 if r.randrange(10) == 0 else 0 for _ in range(n))
+    buf = b"".join(k + i.to_bytes(8, "little") for i, k in enumerate(lanes))
+    ns = C.c_void_p()
+    devs = (C.c_int * 3)(0, 1, 2)
+    assert lib.act_node_nullifier_set_create(devs, 3, C.c_size_t(4 * n), None, C.byref(ns)) == 0
+    spent = C.create_string_buffer(n)
+    assert lib.act_node_nullifier_check_and_insert_batch(ns, C.c_size_t(n), buf, C.c_size_t(stride), mask, spent) == 0
+    ELL = 2**252 + 27742317777372353535851937790883648493
+    seen, want = set(), bytearray(n)
+    for i, k in enumerate(lanes):
+        if mask[i]:
+            continue
+        v = int.from_bytes(k, "little") % ELL
+        want[i] = 1 if v in seen else 0
+        seen.add(v)
+    assert spent.raw == bytes(want)
+    assert lib.act_node_nullifier_set_len(ns) == len(seen)
+    lib.act_node_nullifier_set_destroy(ns)
+
+
 def test_node_redeem_keeps_every_decision_when_a_step_fails(lib):
     """a failure of the nullifier step or of the signature step must not lose what was already decided.  A nullifier
     device that fails leaves ITS lanes 252 (not recorded, not signed) while all others are finished; a GPU that fails while

@@ -149,14 +149,33 @@ def main():
         torch.cuda.synchronize(); dt = time.perf_counter() - t
         out["config5_lifecycles_L128_2^%d_seeded_prover" % a.lifecycle_log2] = {"lifecycles_per_s": nl / dt, "ms": 1e3 * dt}
         # wire codec and nullifier set
-        nc = 1 << 15
-        recs = np.frombuffer(proofs, np.uint8).reshape(D, pb)
-        host_recs = np.tile(recs, (nc // D, 1)).tobytes()
-        t = time.perf_counter(); enc = eng.cbor_encode("SpendProof", host_recs); dt_e = time.perf_counter() - t
-        t = time.perf_counter(); st_c, back = eng.cbor_decode("SpendProof", enc); dt_d = time.perf_counter() - t
-        assert st_c == bytes(nc) and back == host_recs
+        # timed through the C ABI on pinned host memory and on device memory: the Python wrappers (capi.Engine.cbor_encode /
+        # cbor_decode) build lists of byte strings, which costs more than the codec
+        nc = 1 << 17
+        T = capi.CBOR_TYPES["SpendProof"]; lib, ctx = eng.lib, eng.ctx
+        ml = lib.act_cbor_size(ctx, T)
+        recs = torch.from_numpy(np.frombuffer(proofs, np.uint8).reshape(D, pb).copy())
+        h_recs = torch.empty((nc, pb), dtype=torch.uint8, pin_memory=True); h_recs.copy_(recs.repeat(nc // D, 1))
+        h_wire = torch.empty(nc * ml, dtype=torch.uint8, pin_memory=True); h_back = torch.empty((nc, pb), dtype=torch.uint8, pin_memory=True)
+        h_st = torch.empty(nc, dtype=torch.uint8, pin_memory=True)
+        d_recs = h_recs.cuda(); d_wire = torch.zeros(nc * ml, dtype=torch.uint8, device="cuda"); d_back = torch.zeros((nc, pb), dtype=torch.uint8, device="cuda")
+        d_st = torch.zeros(nc, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        def timed2(f):
+            f(); torch.cuda.synchronize(); t = time.perf_counter(); f(); torch.cuda.synchronize(); return time.perf_counter() - t
+        ck = eng._ck
+        dt_e = timed2(lambda: ck(lib.act_cbor_encode_batch(ctx, T, nc, capi.MEM_HOST, h_recs.data_ptr(), h_wire.data_ptr())))
+        dt_d = timed2(lambda: ck(lib.act_cbor_decode_batch(ctx, T, nc, capi.MEM_HOST, h_wire.data_ptr(), None, h_back.data_ptr(), h_st.data_ptr())))
+        assert not h_st.any() and torch.equal(h_back, h_recs)
+        dt_ed = timed2(lambda: ck(lib.act_cbor_encode_batch(ctx, T, nc, capi.MEM_DEVICE, d_recs.data_ptr(), d_wire.data_ptr())))
+        dt_dd = timed2(lambda: ck(lib.act_cbor_decode_batch(ctx, T, nc, capi.MEM_DEVICE, d_wire.data_ptr(), None, d_back.data_ptr(), d_st.data_ptr())))
+        assert not d_st.any() and torch.equal(d_back, d_recs) and torch.equal(d_wire.cpu(), h_wire)
         print("cbor done", file=sys.stderr, flush=True)
-        out["cbor_spend_proof_2^15_host_memory"] = {"encode_msgs_per_s": nc / dt_e, "decode_msgs_per_s": nc / dt_d, "wire_bytes": len(enc[0])}
+        out["cbor_spend_proof_2^17"] = {"wire_bytes": ml, "record_bytes": pb,
+                                        "pinned_host_memory": {"encode_msgs_per_s": nc / dt_e, "decode_msgs_per_s": nc / dt_d,
+                                                               "encode_GBps_both_ways": nc * (ml + pb) / dt_e / 1e9, "decode_GBps_both_ways": nc * (ml + pb) / dt_d / 1e9},
+                                        "device_memory": {"encode_msgs_per_s": nc / dt_ed, "decode_msgs_per_s": nc / dt_dd,
+                                                          "encode_GBps_read_plus_written": nc * (ml + pb) / dt_ed / 1e9, "decode_GBps_read_plus_written": nc * (ml + pb) / dt_dd / 1e9}}
+        del h_recs, h_wire, h_back, d_recs, d_wire, d_back
         nn = 1 << 22
         keys = torch.randint(0, 256, (nn, 32), dtype=torch.uint8, device="cuda"); spent = torch.zeros(nn, dtype=torch.uint8, device="cuda")
         ns = capi.NullifierSet(capacity=4 * nn)
@@ -169,11 +188,14 @@ def main():
         out["nullifier_set_check_insert_2^22"] = {"nullifiers_per_s": nn / dt, "ms": 1e3 * dt}
         # the node-level set (act_node_nullifier_*: host memory in, host-side routing by owner, one HBM set per device) on this one GPU
         nh = 1 << 20
-        hk = keys2[:nh].cpu().numpy().tobytes(); hk0 = keys[:nh].cpu().numpy().tobytes()
+        hk = keys2[:nh].cpu().numpy().copy(); hk0 = keys[:nh].cpu().numpy().copy()       # numpy buffers handed over by pointer (C ABI)
         nns = capi.NodeNullifierSet(4 * nh, devices=(0,))
-        nns.check_and_insert(hk0)
-        t = time.perf_counter(); sp = nns.check_and_insert(hk); dt = time.perf_counter() - t
-        assert sum(sp) == nh // 2
+        sp = np.zeros(nh, np.uint8)
+        assert eng.lib.act_node_nullifier_check_and_insert_batch(nns.h, nh, hk0.ctypes.data, 32, None, sp.ctypes.data) == 0
+        t = time.perf_counter()
+        assert eng.lib.act_node_nullifier_check_and_insert_batch(nns.h, nh, hk.ctypes.data, 32, None, sp.ctypes.data) == 0
+        dt = time.perf_counter() - t
+        assert int(sp.sum()) == nh // 2
         out["node_nullifier_set_1gpu_host_memory_2^20"] = {"nullifiers_per_s": nh / dt, "ms": 1e3 * dt}
     print(json.dumps(out))
 
