@@ -55,8 +55,10 @@ struct Slot {
   std::vector<uint64_t> h_rel;            // message offsets of the chunk in flight, relative to its first byte (act_verify_spend_cbor_batch)
   uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
   uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
+  uint8_t* h_cst = nullptr; size_t h_cst_cap = 0;      // pinned: a codec chunk's statuses on their way to the host reader (cbor_impl.inc)
   hipEvent_t h_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per returned piece (HASH_PIECES)
   hipEvent_t bits_ev = nullptr;        // recorded after this slot's k_spend_bits (staggering, spend_stage1)
+  hipEvent_t cp_in_ev = nullptr, cp_out_ev = nullptr;   // after this slot's copy in / copy out of a codec chunk (cbor_impl.inc: the two slots take turns on each link direction)
   std::vector<PendingProf> pending;
   size_t last_spend_lanes = 0;
 };
@@ -674,8 +676,11 @@ void act_ctx_destroy(act_ctx* c) {
     for (int i = 0; i < Slot::N_STAGE; i++) if (sl.d_stage[i]) { (void)hipMemset(sl.d_stage[i], 0, sl.d_stage_cap[i]); (void)hipFree(sl.d_stage[i]); }   // staging may hold secrets
     if (sl.h_tr) (void)hipHostFree(sl.h_tr);
     if (sl.h_xof) (void)hipHostFree(sl.h_xof);
+    if (sl.h_cst) (void)hipHostFree(sl.h_cst);
     for (hipEvent_t& e : sl.h_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (sl.bits_ev) (void)hipEventDestroy(sl.bits_ev);
+    if (sl.cp_in_ev) (void)hipEventDestroy(sl.cp_in_ev);
+    if (sl.cp_out_ev) (void)hipEventDestroy(sl.cp_out_ev);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
   }
   if (c->prof_base) (void)hipEventDestroy(c->prof_base);

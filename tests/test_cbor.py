@@ -82,8 +82,12 @@ def _variants(t, rec, L):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [None, "3"])
 @pytest.mark.parametrize("L", [128, 8])
-def test_codec_against_model(engine_factory, bench_params, L):
+def test_codec_against_model(engine_factory, bench_params, L, chunk, monkeypatch):
+    """chunk = "3": the codec's chunk pipeline (alternating slots, copies out beside copies in) over batches this small"""
+    if chunk:
+        monkeypatch.setenv("ACT_CBOR_CHUNK_MSGS", chunk)
     eng = engine_factory(bench_params, L, max_batch=8)
     sk = eng.private_key_random(shake("cbor-sk", 64))
     pre = eng.pre_issuance_random(shake("cbor-pre", 128 * 3)); req = eng.request(pre, shake("cbor-rq", 128 * 3))
@@ -108,3 +112,40 @@ def test_codec_against_model(engine_factory, bench_params, L):
             assert st[i] == es, (t, i, st[i], es, msgs[i][:24].hex())
             assert out[rb * i:rb * i + rb] == er, (t, i)
         assert {0, 1, 2}.issubset(set(st)) and (3 in st or t in ("PreIssuance", "PreRefund"))      # every error class exercised
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [None, "5"])
+def test_codec_device_memory_round_trip(engine_factory, bench_params, chunk, monkeypatch):
+    """Device-memory callers (one stream, no staging), whole and cut into chunks: encode == the model's bytes, decode gives the
+    records back, and messages broken in the middle of a chunk are the only ones the host reader is asked about."""
+    import numpy as np
+    import torch
+    from act_amd import capi
+    if chunk:
+        monkeypatch.setenv("ACT_CBOR_CHUNK_MSGS", chunk)
+    L, D = 8, 23
+    eng = engine_factory(bench_params, L, max_batch=32)
+    sk = eng.private_key_random(shake("cbd-sk", 64))
+    pre = eng.pre_issuance_random(shake("cbd-pre", 128 * D)); req = eng.request(pre, shake("cbd-rq", 128 * D))
+    st, resp = eng.issue(sk, req, scb(77) * D, shake("cbd-ir", 128 * D))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proofs, _ = eng.prove_spend(tok, scb(7) * D, shake("cbd-pr", eng.prove_rng_bytes * D))
+    T = capi.CBOR_TYPES["SpendProof"]; pb = eng.proof_bytes; ml = eng.cbor_size("SpendProof")
+    d_recs = torch.from_numpy(np.frombuffer(proofs, np.uint8).copy()).cuda()
+    d_wire = torch.zeros(D * ml, dtype=torch.uint8, device="cuda"); d_back = torch.zeros(D * pb, dtype=torch.uint8, device="cuda")
+    d_st = torch.full((D,), 9, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    eng._ck(eng.lib.act_cbor_encode_batch(eng.ctx, T, D, capi.MEM_DEVICE, d_recs.data_ptr(), d_wire.data_ptr()))
+    wire = d_wire.cpu().numpy().tobytes()
+    assert [wire[i * ml:(i + 1) * ml] for i in range(D)] == [m.cbor_encode("SpendProof", proofs[i * pb:(i + 1) * pb], L) for i in range(D)]
+    d_wire[7 * ml] = 0x40                               # message 7: a byte string, not a map
+    d_wire[12 * ml + 1] = 0x18                          # message 12: its first key now reads as a two-byte head: no longer canonical
+    torch.cuda.synchronize()
+    eng._ck(eng.lib.act_cbor_decode_batch(eng.ctx, T, D, capi.MEM_DEVICE, d_wire.data_ptr(), None, d_back.data_ptr(), d_st.data_ptr()))
+    st_h = d_st.cpu().numpy(); back = d_back.cpu().numpy().tobytes()
+    broken = wire[:7 * ml] + b"\x40" + wire[7 * ml + 1:12 * ml + 1] + b"\x18" + wire[12 * ml + 2:]
+    for i in range(D):
+        es, er = m.cbor_decode("SpendProof", broken[i * ml:(i + 1) * ml], L)
+        assert st_h[i] == es, (i, st_h[i], es)
+        assert back[i * pb:(i + 1) * pb] == er, i
+    assert st_h[7] != 0 and st_h[12] != 0 and int((st_h == 0).sum()) == D - 2
