@@ -8,8 +8,10 @@
 #include <stdlib.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -905,8 +907,33 @@ static int small_prepare(act_ctx* c, size_t n, size_t subs) {
   c->d_small_dirty = std::max(c->d_small_dirty, n * per_proof);
   return ACT_OK;
 }
+// At most SMALL_IN_FLIGHT small-batch calls run on one device at a time, whatever number of contexts (threads of a server) issue
+// them: a small call keeps six streams busy, and once the streams of four or more contexts are active together the process has more
+// active hardware queues than the GPU schedules side by side -- the queues are then time-sliced and one-proof calls take 20 - 60 ms
+// instead of 2 (profiles/r04_concurrent_small_calls.txt, with GPU_MAX_HW_QUEUES=8; the default of 4 does not get there).  Two calls
+// in flight already use the chip better than one (900 against 585 one-proof calls per second); the rest wait their turn here.
+namespace {
+struct SmallGate {
+  std::mutex m; std::condition_variable cv; int in_flight = 0;
+  static SmallGate& of(int device) {
+    static std::mutex gm; static std::map<int, SmallGate*> gates;
+    std::lock_guard<std::mutex> lk(gm);
+    SmallGate*& g = gates[device];
+    if (!g) g = new SmallGate();
+    return *g;
+  }
+  static int limit() { static const int v = [] { const char* e = getenv("ACT_SMALL_IN_FLIGHT"); const int k = e ? atoi(e) : 2; return k < 1 ? 1 : k; }(); return v; }
+};
+struct SmallTicket {
+  SmallGate& g;
+  explicit SmallTicket(SmallGate& g_) : g(g_) { std::unique_lock<std::mutex> lk(g.m); g.cv.wait(lk, [&] { return g.in_flight < SmallGate::limit(); }); g.in_flight++; }
+  ~SmallTicket() { { std::lock_guard<std::mutex> lk(g.m); g.in_flight--; } g.cv.notify_one(); }
+};
+}  // namespace
+
 static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proof, bool sign, const uint8_t* rng, int rng_mode, uint8_t* out_refund,
                               uint8_t* status, uint8_t* out_kprime) {
+  SmallTicket ticket(SmallGate::of(c->device));      // held until this call's work has left the GPU (sync_all below)
   const SpendTranscript st{c->L};
   const size_t pb = ProofLayout{c->L}.bytes(), L = (size_t)c->L;
   static const size_t sub_env = [] { const char* e = getenv("ACT_SMALL_SUB"); return e ? (size_t)atol(e) : (size_t)0; }();      // tuning knob: proofs per sub-chunk

@@ -33,6 +33,7 @@ and at N = 1
   extra.hbm_device_transcripts     the round-1..3 headline: device BLAKE3, nothing crosses PCIe inside a step
   extra.tiled_4096                 the round-1/2 input (4 096 distinct proofs tiled x256): what tiling flatters
   extra.call_latency_ms            one call over 1 / 64 / 4 096 proofs (the crate's call shape is one proof per call)
+  extra.concurrent_callers         4 threads with a context each making such calls back to back: whole-GPU rate
   extra.refund                     verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
   extra.verify_L64                 BASELINE config 2: 2^16 verifies at L = 64
 
@@ -674,6 +675,37 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
         lat[key] = row
     eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
     ex["call_latency_ms"] = {"proofs_per_call": lat, "what": "median wall time of one act_verify_spend_batch call over k proofs in pinned host memory"}
+    # (2c) a server has several callers: 4 threads, a context each (the tables are shared), calls of k proofs back to back.  The library
+    #      lets two small calls run on a device at a time (engine.hip SmallGate: more, and the process has more active hardware queues
+    #      than the GPU runs side by side)
+    try:
+        import threading
+        kmax = min(nl, 4096); T = 4
+        engs = [capi.Engine(h, L, device=local, max_batch=8192, transcript=capi.TRANSCRIPT_DEVICE) for _ in range(T)]
+        hst = [torch.zeros(kmax, dtype=torch.uint8, pin_memory=True) for _ in range(T)]
+        conc = {}
+        for k in (1, kmax):
+            calls = 60 if k == 1 else 12
+            def work(t):
+                for _ in range(calls):
+                    engs[t].verify_spend_ptr(sk, k, capi.MEM_HOST, hp1.data_ptr(), hst[t].data_ptr())
+            for t in range(T):
+                engs[t].verify_spend_ptr(sk, k, capi.MEM_HOST, hp1.data_ptr(), hst[t].data_ptr())
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            dt = time.perf_counter() - t0
+            assert all(torch.equal(hst[t][:k], expect[:k].cpu()) for t in range(T))
+            conc["%d" % k] = {"verifies_per_s": round(T * calls * k / dt), "ms_per_call": round(1e3 * dt / calls, 3)}
+        ex["concurrent_callers"] = {"threads": T, "proofs_per_call": conc,
+                                    "what": "4 threads, one context each, calls back to back from pinned host memory, device transcripts: whole-GPU rate"}
+        for e in engs:
+            e.close()
+    except Exception as e:          # an accessory measurement must never cost the line
+        ex["concurrent_callers"] = {"error": repr(e)}
     del hp1
     # (4) refund = verify + sign (src/lib.rs:787-868), per-lane rng resident in HBM
     g = torch.Generator(device="cuda"); g.manual_seed(7)

@@ -160,3 +160,23 @@ def test_sub_chunked_small_schedule(engine_factory, bench_params, tmp_path, mode
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["st"] == st.hex() and d["kp"] == hashlib.sha256(kp).hexdigest()
     assert d["st2"] == st2.hex() and d["rf"] == hashlib.sha256(rf).hexdigest() and d["residue"] == 0
+
+
+def test_four_concurrent_callers_do_not_collapse():
+    """Four threads with a context each making one-proof calls at the same time, in a process that allows HIP eight hardware queues
+    per priority class (what INTEGRATION.md recommends): without the library's limit of two small calls in flight per device the
+    process has more active queues than the GPU runs side by side and a call takes 20 - 60 ms instead of ~2
+    (profiles/r04_concurrent_small_calls.txt).  With it, four callers wait their turn: a few times one caller's latency."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8", KS="1", TS="1,4")
+    env.pop("ACT_SMALL_IN_FLIGHT", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "concurrent_small_calls.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ms = [float(x) for x in re.findall(r"\(([0-9.]+) ms per call\)", r.stdout)]
+    assert len(ms) == 2, r.stdout
+    assert ms[0] < 4.0, ms                       # one caller: ~1.7 ms
+    assert ms[1] < 6 * ms[0], ms                 # four callers, two in flight: ~3 x; the collapse was 13 - 40 x
