@@ -469,6 +469,16 @@ def main():
                   "batch_per_gpu": n_s, "launch_chunks_per_gpu": -(-n_s // args.max_batch), "scaling": "strong",
                   "what": "BASELINE.json's metric as worded: ONE 2^%d batch over the whole node, contiguous shards of 2^%d / %d proofs per rank, no collective"
                           % (args.batch_log2, args.batch_log2, world)}
+        # the same one-batch-over-the-node region with the OTHER transcript mode: if the node's host cores cannot hash
+        # world x 0.5 M transcripts/s (15.8 KB each), the device-BLAKE3 curve shows what the GPUs do without them
+        other = capi.TRANSCRIPT_DEVICE if tr_mode == capi.TRANSCRIPT_HOST else capi.TRANSCRIPT_HOST
+        eng.set_transcript_mode(other)
+        status.zero_()
+        o_elapsed, _ = timed_region(n_s, max(1, args.steps // 2), 1)
+        eng.set_transcript_mode(tr_mode)
+        strong["other_transcript_mode"] = {"transcript": "device BLAKE3" if other == capi.TRANSCRIPT_DEVICE else "host BLAKE3",
+                                           "value": world * n_s * max(1, args.steps // 2) / o_elapsed, "unit": "verifies/s",
+                                           "ms_per_step": 1e3 * o_elapsed / max(1, args.steps // 2)}
     if scaling == "strong":
         elapsed, prof, n_rank = s_elapsed, s_prof, n_s
     else:
