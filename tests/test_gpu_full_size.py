@@ -124,97 +124,138 @@ def test_config3_2_20_prove_spend_at_L128(engine_factory, oracle, bench_params):
     note_rate("config3_prove_spend_L128_2^20", {"proofs_per_s": nchunks * chunk / t_prove, "ms": 1e3 * t_prove, "chunks": nchunks})
 
 
-@pytest.mark.parametrize("rng_source,nchunks", [("seeded", 32), ("bytes", 8)])
-def test_config5_lifecycles_streamed_from_pinned_host_memory(bench_params, oracle, rng_source, nchunks):
+@pytest.mark.parametrize("rng_source,nchunks,streams", [("seeded", 32, 1), ("seeded", 32, 2), ("bytes", 8, 1)])
+def test_config5_lifecycles_streamed_from_pinned_host_memory(bench_params, oracle, rng_source, nchunks, streams):
     """BASELINE configs[4] at ONE GPU's share: 2^24 lifecycles over 8 GPUs = 2^21 per GPU, streamed in 2^16-lane calls through pinned
     host memory (request -> issue -> to_credit_token -> prove_spend -> refund -> to_credit_token), every call a node-handle call.
     "seeded": the prover's generators are seeded (act_node_prove_spend_seeded_batch: BLAKE3-XOF(seed | lane) expanded in HBM), so
     the 33 536 rng bytes per proof never cross PCIe; "bytes" (2^19 lifecycles): every rng byte comes from host memory, the
-    round-3 form.  Balances of every lane; four lanes of the last call byte for byte against the oracle's whole lifecycle."""
+    round-3 form.  streams = 2: the configuration's "double-buffered" -- two host threads, a node handle and a set of buffers each,
+    every other 2^16-lane chunk each: one stream's copies cross PCIe while the other's kernels run.  Balances of every lane; four
+    lanes of each stream's last call byte for byte against the oracle's whole lifecycle."""
+    import threading
     import numpy as np
     import torch
+    import ctypes as C
     from act_amd import capi
     L, chunk = 128, 1 << 16
-    node = capi.Node(bench_params, L, devices=(0, 0), max_batch=1 << 14, transcript=capi.TRANSCRIPT_DEVICE)
-    pb, rb = node.proof_bytes, node.prove_rng_bytes
     eng0 = capi.Engine(bench_params, 8, max_batch=4)
     sk = eng0.private_key_random(shake("c5-sk", 64)); eng0.close()
     pin = lambda *shape: torch.empty(shape, dtype=torch.uint8, pin_memory=True)
-    g = torch.Generator(device="cuda"); g.manual_seed(5)
-    rnd = lambda *shape: torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
     seed = shake("c5-seed", 32)
-    if rng_source == "bytes":
-        # the 2.2 GB of prover bytes are drawn once and reused by every chunk (tokens differ per chunk)
-        r_pr = pin(chunk, rb); r_pr.copy_(rnd(chunk, rb))
     amounts = np.array([(i * 40503 + 11) % 100000 + 1 for i in range(chunk)], dtype=np.uint64)
     charges = amounts // np.uint64(3)
     le32 = lambda v: np.concatenate([v.astype("<u8").view(np.uint8).reshape(-1, 8), np.zeros((len(v), 24), np.uint8)], axis=1)
     c_b, s_b, m_b = le32(amounts).tobytes(), le32(charges).tobytes(), le32(amounts - charges)
-    lib, nd = node.lib, node.nd
-    ptr = lambda t: t.data_ptr()
-    bufs = {k: pin(chunk, v) for k, v in dict(pre=64, req=128, resp=160, tok=160, proof=pb, prer=96, rf=128, tok2=160).items()}
-    r128 = {k: pin(chunk, 128) for k in ("pre", "rq", "ir", "rr")}
-    st = pin(chunk)
-    import ctypes as C
+    cb = np.frombuffer(c_b, np.uint8); sb = np.frombuffer(s_b, np.uint8)
     skb = (C.c_uint8 * 64).from_buffer_copy(sk); wb = (C.c_uint8 * 32).from_buffer_copy(sk[32:])
     seedb = (C.c_uint8 * 32).from_buffer_copy(seed)
-    cb = np.frombuffer(c_b, np.uint8); sb = np.frombuffer(s_b, np.uint8)
-    # PreIssuance::random has no node-level twin (it is two scalar reductions): context 0 of the node does it
-    ctx0 = lib.act_node_ctx(nd, 0)
-    ck = node._ck
-    torch.cuda.synchronize()
-    spent = {}          # where a streamed lifecycle's time goes: seconds per call kind, summed over the chunks
+    ptr = lambda t: t.data_ptr()
+    spent = {}          # where a streamed lifecycle's time goes: seconds per call kind, summed over the chunks (and streams)
+    lock = threading.Lock()
+    errors = []
 
-    def timed(key, fn):
-        t = time.perf_counter(); r = fn(); spent[key] = spent.get(key, 0.0) + time.perf_counter() - t
-        return r
+    class Stream:
+        def __init__(self, tid):
+            self.tid = tid
+            # one stream: the node handle cuts every call over two contexts; two streams: a context each
+            self.node = capi.Node(bench_params, L, devices=(0, 0) if streams == 1 else (0,), max_batch=1 << 14, transcript=capi.TRANSCRIPT_DEVICE)
+            self.pb, self.rb = self.node.proof_bytes, self.node.prove_rng_bytes
+            self.g = torch.Generator(device="cuda"); self.g.manual_seed(5 + tid)
+            self.bufs = {k: pin(chunk, v) for k, v in dict(pre=64, req=128, resp=160, tok=160, proof=self.pb, prer=96, rf=128, tok2=160).items()}
+            self.r128 = {k: pin(chunk, 128) for k in ("pre", "rq", "ir", "rr")}
+            self.st = pin(chunk)
+            self.last = None
+            if rng_source == "bytes":
+                # the 2.2 GB of prover bytes are drawn once and reused by every chunk (tokens differ per chunk)
+                self.r_pr = pin(chunk, self.rb); self.r_pr.copy_(self.rnd(chunk, self.rb))
+
+        def rnd(self, *shape):
+            return torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=self.g)
+
+        def timed(self, key, fn):
+            t = time.perf_counter(); r = fn(); d = time.perf_counter() - t
+            with lock:
+                spent[key] = spent.get(key, 0.0) + d
+            return r
+
+        def run(self, chunks):
+            try:
+                self._run(chunks)
+            except BaseException as e:          # a failed assertion in a worker thread must fail the test
+                errors.append(e)
+
+        def _run(self, chunks):
+            node, bufs, r128, st, timed = self.node, self.bufs, self.r128, self.st, self.timed
+            lib, nd, ck = node.lib, node.nd, node._ck
+            # PreIssuance::random has no node-level twin (it is two scalar reductions): context 0 of the node does it
+            ctx0 = lib.act_node_ctx(nd, 0)
+            for c in chunks:
+                def draw():
+                    for k in r128:
+                        r128[k].copy_(self.rnd(chunk, 128))
+                    torch.cuda.current_stream().synchronize()
+                timed("draw 4 x 128 rng bytes per lane (torch, D2H)", draw)
+                assert timed("pre_issuance_random", lambda: lib.act_pre_issuance_random_batch(ctx0, chunk, capi.MEM_HOST, ptr(r128["pre"]), ptr(bufs["pre"]))) == 0
+                ck(timed("request", lambda: lib.act_node_request_batch(nd, chunk, ptr(bufs["pre"]), ptr(r128["rq"]), ptr(bufs["req"]))))
+                ck(timed("issue", lambda: lib.act_node_issue_batch(nd, chunk, skb, ptr(bufs["req"]), cb.ctypes.data, ptr(r128["ir"]), capi.RNG_PER_LANE, ptr(bufs["resp"]), ptr(st))))
+                assert int(st.sum()) == 0
+                ck(timed("issuance_to_credit_token", lambda: lib.act_node_issuance_to_credit_token_batch(nd, chunk, ptr(bufs["pre"]), wb, ptr(bufs["req"]), ptr(bufs["resp"]), ptr(bufs["tok"]), ptr(st))))
+                assert int(st.sum()) == 0
+                if rng_source == "seeded":
+                    ck(timed("prove_spend", lambda: lib.act_node_prove_spend_seeded_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, seedb, C.c_uint64(c * chunk), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st))))
+                else:
+                    ck(timed("prove_spend", lambda: lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(self.r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st))))
+                assert int(st.sum()) == 0
+                ck(timed("refund", lambda: lib.act_node_refund_batch(nd, chunk, skb, ptr(bufs["proof"]), ptr(r128["rr"]), capi.RNG_PER_LANE, ptr(bufs["rf"]), ptr(st))))
+                assert int(st.sum()) == 0, "every honest spend must be refunded (chunk %d)" % c
+                ck(timed("refund_to_credit_token", lambda: lib.act_node_refund_to_credit_token_batch(nd, chunk, ptr(bufs["prer"]), ptr(bufs["proof"]), ptr(bufs["rf"]), wb, ptr(bufs["tok2"]), ptr(st))))
+                assert int(st.sum()) == 0
+                # final balances: the new token carries c - s; its nullifier k is the fresh k* of the spend, not the old one
+                t2 = bufs["tok2"].numpy()
+                assert np.array_equal(t2[:, 128:160], m_b), "balance c - s wrong in chunk %d" % c
+                assert np.array_equal(t2[:, 64:96], bufs["prer"].numpy()[:, 32:64])
+                assert not np.array_equal(t2[:, 64:96], bufs["tok"].numpy()[:, 64:96])
+                self.last = c
+
+    ss = [Stream(t) for t in range(streams)]
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for c in range(nchunks):
-        def draw():
-            for k in r128:
-                r128[k].copy_(rnd(chunk, 128))
-            torch.cuda.synchronize()
-        timed("draw 4 x 128 rng bytes per lane (torch, D2H)", draw)
-        assert timed("pre_issuance_random", lambda: lib.act_pre_issuance_random_batch(ctx0, chunk, capi.MEM_HOST, ptr(r128["pre"]), ptr(bufs["pre"]))) == 0
-        ck(timed("request", lambda: lib.act_node_request_batch(nd, chunk, ptr(bufs["pre"]), ptr(r128["rq"]), ptr(bufs["req"]))))
-        ck(timed("issue", lambda: lib.act_node_issue_batch(nd, chunk, skb, ptr(bufs["req"]), cb.ctypes.data, ptr(r128["ir"]), capi.RNG_PER_LANE, ptr(bufs["resp"]), ptr(st))))
-        assert int(st.sum()) == 0
-        ck(timed("issuance_to_credit_token", lambda: lib.act_node_issuance_to_credit_token_batch(nd, chunk, ptr(bufs["pre"]), wb, ptr(bufs["req"]), ptr(bufs["resp"]), ptr(bufs["tok"]), ptr(st))))
-        assert int(st.sum()) == 0
-        if rng_source == "seeded":
-            ck(timed("prove_spend", lambda: lib.act_node_prove_spend_seeded_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, seedb, C.c_uint64(c * chunk), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st))))
-        else:
-            ck(timed("prove_spend", lambda: lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st))))
-        assert int(st.sum()) == 0
-        ck(timed("refund", lambda: lib.act_node_refund_batch(nd, chunk, skb, ptr(bufs["proof"]), ptr(r128["rr"]), capi.RNG_PER_LANE, ptr(bufs["rf"]), ptr(st))))
-        assert int(st.sum()) == 0, "every honest spend must be refunded (chunk %d)" % c
-        ck(timed("refund_to_credit_token", lambda: lib.act_node_refund_to_credit_token_batch(nd, chunk, ptr(bufs["prer"]), ptr(bufs["proof"]), ptr(bufs["rf"]), wb, ptr(bufs["tok2"]), ptr(st))))
-        assert int(st.sum()) == 0
-        # final balances: the new token carries c - s; its nullifier k is the fresh k* of the spend, not the old one
-        t2 = bufs["tok2"].numpy()
-        assert np.array_equal(t2[:, 128:160], m_b), "balance c - s wrong in chunk %d" % c
-        assert np.array_equal(t2[:, 64:96], bufs["prer"].numpy()[:, 32:64])
-        assert not np.array_equal(t2[:, 64:96], bufs["tok"].numpy()[:, 64:96])
+    if streams == 1:
+        ss[0].run(range(nchunks))
+    else:
+        th = [threading.Thread(target=ss[t].run, args=(range(t, nchunks, streams),)) for t in range(streams)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
     dt = time.perf_counter() - t0
-    # four lanes of the last call, every record of their lifecycle, against the oracle fed the same inputs
+    if errors:
+        raise errors[0]
+    # four lanes of every stream's last call, every record of their lifecycle, against the oracle fed the same inputs
     octx = oracle.ctx(bench_params, L)
-    last = (nchunks - 1) * chunk
-    for i in (0, 1, chunk // 2 + 3, chunk - 1):
-        row = lambda t, w: t.numpy()[i].tobytes()[:w]
-        pre = octx.pre_issuance_random(row(r128["pre"], 128)); assert pre == row(bufs["pre"], 64)
-        req = octx.request(pre, row(r128["rq"], 128)); assert req == row(bufs["req"], 128)
-        so, resp = octx.issue(sk, req, c_b[32 * i:32 * i + 32], row(r128["ir"], 128)); assert so == 0 and resp == row(bufs["resp"], 160)
-        so, tok = octx.issuance_to_credit_token(pre, sk[32:], req, resp); assert so == 0 and tok == row(bufs["tok"], 160)
-        prng = oracle.blake3(seed + (last + i).to_bytes(8, "little"), rb) if rng_source == "seeded" else row(r_pr, rb)
-        so, proof, prer = octx.prove_spend(tok, s_b[32 * i:32 * i + 32], prng); assert so == 0 and proof == row(bufs["proof"], pb) and prer == row(bufs["prer"], 96)
-        so, rf = octx.refund(sk, proof, row(r128["rr"], 128)); assert so == 0 and rf == row(bufs["rf"], 128)
-        so, tok2 = octx.refund_to_credit_token(prer, proof, rf, sk[32:]); assert so == 0 and tok2 == row(bufs["tok2"], 160)
-    node.close()
-    note_rate("config5_lifecycles_L128_2^%d_streamed_pinned_host_%s_rng" % ((nchunks * chunk).bit_length() - 1, rng_source),
-              {"lifecycles_per_s": nchunks * chunk / dt, "ms": 1e3 * dt, "lifecycles": nchunks * chunk,
+    for S in ss:
+        last = S.last * chunk
+        for i in (0, 1, chunk // 2 + 3, chunk - 1):
+            row = lambda t, w: t.numpy()[i].tobytes()[:w]
+            bufs, r128, pb, rb = S.bufs, S.r128, S.pb, S.rb
+            pre = octx.pre_issuance_random(row(r128["pre"], 128)); assert pre == row(bufs["pre"], 64)
+            req = octx.request(pre, row(r128["rq"], 128)); assert req == row(bufs["req"], 128)
+            so, resp = octx.issue(sk, req, c_b[32 * i:32 * i + 32], row(r128["ir"], 128)); assert so == 0 and resp == row(bufs["resp"], 160)
+            so, tok = octx.issuance_to_credit_token(pre, sk[32:], req, resp); assert so == 0 and tok == row(bufs["tok"], 160)
+            prng = oracle.blake3(seed + (last + i).to_bytes(8, "little"), rb) if rng_source == "seeded" else row(S.r_pr, rb)
+            so, proof, prer = octx.prove_spend(tok, s_b[32 * i:32 * i + 32], prng); assert so == 0 and proof == row(bufs["proof"], pb) and prer == row(bufs["prer"], 96)
+            so, rf = octx.refund(sk, proof, row(r128["rr"], 128)); assert so == 0 and rf == row(bufs["rf"], 128)
+            so, tok2 = octx.refund_to_credit_token(prer, proof, rf, sk[32:]); assert so == 0 and tok2 == row(bufs["tok2"], 160)
+        S.node.close()
+    note_rate("config5_lifecycles_L128_2^%d_streamed_pinned_host_%s_rng%s" % ((nchunks * chunk).bit_length() - 1, rng_source, "" if streams == 1 else "_%d_streams" % streams),
+              {"lifecycles_per_s": nchunks * chunk / dt, "ms": 1e3 * dt, "lifecycles": nchunks * chunk, "host_streams": streams,
                "ms_per_2^16_lanes_by_call": {k: round(1e3 * v / nchunks, 2) for k, v in spent.items()},
-               "ms_per_2^16_lanes_python_checks": round(1e3 * (dt - sum(spent.values())) / nchunks, 2),
-               "note": "2^16-lane calls through pinned host memory, two contexts on one GPU (node handle), device transcripts; includes drawing the 128-byte rng slices; "
+               "ms_per_2^16_lanes_python_checks": round(1e3 * (streams * dt - sum(spent.values())) / nchunks, 2),
+               "note": ("2^16-lane calls through pinned host memory, two contexts on one GPU (node handle), device transcripts; " if streams == 1 else
+                        "double-buffered: two host threads with a one-context node handle and buffers each, 2^16-lane calls through pinned host memory, device transcripts "
+                        "(per-call times are each thread's own wall time: they overlap); ")
+                       + "includes drawing the 128-byte rng slices; "
                        + ("prover generators seeded (BLAKE3-XOF expanded in HBM)" if rng_source == "seeded" else "prover rng bytes (33 536 per proof) from host memory")})
 
 
