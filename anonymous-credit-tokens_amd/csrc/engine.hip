@@ -1061,6 +1061,13 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
       head = {chunk_len / 4, chunk_len / 2}; tail = {chunk_len / 2, chunk_len / 4};
       left -= chunk_len / 4 * 2 + chunk_len / 2 * 2;
     }
+    // A call that fits one or a few chunks and reads its proofs from host memory (device transcripts: nothing else crosses PCIe):
+    // as one chunk its 16.8 KB per proof arrive before anything computes (19 ms of a 148 ms call over 65 536 proofs).  A proof
+    // takes ~0.3 us to arrive and ~1.95 us to verify, so a first chunk of an eighth of the call hides the arrival of the rest.
+    else if (c->tr_mode == ACT_TRANSCRIPT_DEVICE && mem == ACT_MEM_HOST && !taper_off && n >= 4096 && n < 4 * chunk_len) {
+      const size_t h = std::min(n, std::max<size_t>(2048, (n / 8 + 1023) / 1024 * 1024));
+      if (h < n) { head = {h}; left -= h; }
+    }
     size_t off = 0;
     for (size_t l : head) { sched.emplace_back(off, l); off += l; }
     while (left) { size_t l = std::min(chunk_len, left); sched.emplace_back(off, l); off += l; left -= l; }
@@ -1133,13 +1140,22 @@ static int prove_spend_impl(act_ctx* c, size_t n, int mem, const uint8_t* token,
   HIPCK(c, hipSetDevice(c->device));
   const size_t pb = ProofLayout{c->L}.bytes(), rb = act_prove_rng_bytes(c);
   const SpendTranscript st{c->L};
-  const size_t nchunks = (n + c->max_batch - 1) / c->max_batch;
+  // Chunk schedule: full-size chunks; a host-memory caller's LAST chunk is cut in two (11/16 + 5/16) -- its 16.8 KB per proof leave
+  // after everything is computed (19 ms of a 76 ms call over 65 536 proofs), and the first part's copy out fits under the second
+  // part's kernels (a proof takes ~0.3 us to leave, ~0.9 us to make)
+  std::vector<std::pair<size_t, size_t>> sched;          // (offset, lanes)
+  for (size_t off = 0; off < n; off += c->max_batch) sched.emplace_back(off, std::min(c->max_batch, n - off));
+  if (mem == ACT_MEM_HOST && !sched.empty() && sched.back().second >= 8192 && !getenv("ACT_NO_TAPER")) {
+    const size_t off = sched.back().first, l = sched.back().second, t = (l * 5 / 16 + 1023) / 1024 * 1024;
+    sched.back() = {off, l - t}; sched.emplace_back(off + l - t, t);
+  }
+  const size_t nchunks = sched.size();
   ProveArgs args[2]; uint32_t ms[2] = {0, 0}; size_t offs[2] = {0, 0};
   // two-slot pipeline like spend_batch: head/bits/tail + hash start of chunk i+1 are enqueued before chunk i is finished
   const size_t depth = (size_t)c->depth;
   auto stage1 = [&](size_t i) -> int {
     Slot& sl = c->slots[i % depth]; ProveArgs& a = args[i % depth];
-    size_t off = i * c->max_batch; uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    size_t off = sched[i].first; uint32_t m = (uint32_t)sched[i].second;
     ms[i % depth] = m; offs[i % depth] = off;
     a = ProveArgs{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.half = sl.d_buckets; a.state = sl.d_state;
     a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
@@ -1193,6 +1209,23 @@ int act_prove_spend_seeded_batch(act_ctx* c, size_t n, int mem, const uint8_t* t
   return prove_spend_impl(c, n, mem, token, s, nullptr, seed, first_lane, out_proof, out_prerefund, status);
 }
 
+// Two slots that each copy in, compute, copy out fall into step when left alone: both copy in at once (sharing the link), then both
+// compute, then both copy out, and nothing overlaps (profiles/r04_codec_trace.txt).  Chaining the copies of one direction across
+// the two streams keeps them in anti-phase: chunk k + 1 copies in while chunk k computes.
+// the chunk on `sl` is about to copy in (out = false) or out (out = true): after the other slot's copy of the same direction
+static int copy_chain_wait(act_ctx* c, Slot& sl, bool out) {
+  Slot& other = c->slots[&sl == &c->slots[0] ? 1 : 0];
+  hipEvent_t ev = out ? other.cp_out_ev : other.cp_in_ev;
+  if (ev) HIPCK(c, hipStreamWaitEvent(sl.stream, ev, 0));
+  return ACT_OK;
+}
+static int copy_chain_record(act_ctx* c, Slot& sl, bool out) {
+  hipEvent_t& ev = out ? sl.cp_out_ev : sl.cp_in_ev;
+  if (!ev) HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIPCK(c, hipEventRecord(ev, sl.stream));
+  return ACT_OK;
+}
+
 static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                         const uint8_t* resp, const uint8_t* proofs, uint8_t* out_token, uint8_t* status) {
   Call call(c, n);
@@ -1200,15 +1233,26 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
   int rc = set_pubkey(c, w); if (rc) return rc;
   const bool issuance = label == LABEL_RESPOND;
   const size_t pre_b = issuance ? 64 : 96, resp_b = issuance ? 160 : 128, pb = ProofLayout{c->L}.bytes();
-  Slot& sl = c->slots[0];
-  for (size_t off = 0; off < n; off += c->max_batch) {
-    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+  // Host-memory callers: the refund check reads every proof (16.8 KB per lane over PCIe against ~0.2 us of kernels), so the call is
+  // cut into quarters that alternate between the two slots -- a chunk's kernels and copy out run under the next chunk's copy in.
+  // Device-memory callers: one slot, full-size chunks.
+  size_t chunk = std::min(c->max_batch, std::max<size_t>(16384, (n / 4 + 1023) / 1024 * 1024));      // (below 16 384 lanes the kernels no longer fill the chip)
+  // (issuance: 352 B per lane, nothing to hide)
+  const bool two_slots = mem == ACT_MEM_HOST && !issuance && c->depth > 1 && n > chunk && !getenv("ACT_NO_TAPER");
+  if (!two_slots) chunk = c->max_batch;
+  size_t k = 0;
+  for (size_t off = 0; off < n; off += chunk, k++) {
+    Slot& sl = c->slots[two_slots ? (k & 1) : 0];
+    if (two_slots) HIPCK(c, hipStreamSynchronize(sl.stream));      // the chunk before last has left this slot's staging areas
+    uint32_t m = (uint32_t)std::min(chunk, n - off);
     ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = sl.d_coords; a.trs = sl.d_trs; a.flags = sl.d_flags; a.pbk = sl.d_buckets;
     a.xof = sl.d_xof; a.status = sl.d_status;
+    if (two_slots && (rc = copy_chain_wait(c, sl, false))) return rc;
     if ((rc = dev_in(c, sl, 0, mem, pre + off * pre_b, (size_t)m * pre_b, &a.pre))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, resp + off * resp_b, (size_t)m * resp_b, &a.resp))) return rc;
     if (issuance) { if ((rc = dev_in(c, sl, 3, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc; }
     else { if ((rc = dev_in(c, sl, 3, mem, proofs + off * pb, (size_t)m * pb, &a.proofs))) return rc; }
+    if (two_slots && (rc = copy_chain_record(c, sl, false))) return rc;
     if ((rc = dev_out_begin(c, sl, 2, mem, out_token + off * 160, (size_t)m * 160, &a.out_token))) return rc;
     if (!issuance) {
       HIPCK(c, hipMemsetAsync(sl.d_flags, 0, (size_t)m * 4, sl.stream));
@@ -1220,9 +1264,9 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
     if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_b(a, sl.stream); }))) return rc;
     if ((rc = dev_out_end(c, sl, mem, out_token + off * 160, a.out_token, (size_t)m * 160))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
-    if ((rc = sync_all(c))) return rc;
+    if (!two_slots && (rc = sync_all(c))) return rc;
   }
-  return call.finish();
+  return call.finish();      // waits for both streams
 }
 int act_issuance_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                                        const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
@@ -1357,7 +1401,7 @@ int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
     regions.emplace_back(sl.d_buckets, c->max_batch * PREP_BUCKET_SETS * BUCKET_WORDS * 4);
   }
   for (auto& r : regions) total += r.second;
-  if (total > ((size_t)1 << 28)) { c->err = "act_debug_secret_residue: context too large to read back (use a small max_batch)"; return ACT_ERR_ARG; }
+  if (total > ((size_t)1 << 30)) { c->err = "act_debug_secret_residue: context too large to read back (use a small max_batch)"; return ACT_ERR_ARG; }
   std::vector<uint8_t> buf;
   for (auto& r : regions) {
     buf.resize(r.second);
