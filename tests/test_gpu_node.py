@@ -192,7 +192,9 @@ def test_eight_contexts_on_one_pool_do_not_oversubscribe(engine_factory, bench_p
             node.close()
     H, D = capi.TRANSCRIPT_HOST, capi.TRANSCRIPT_DEVICE
     print("verifies/s (contexts, transcript mode):", rates)
-    assert rates[8, H] / rates[8, D] > 0.95 * rates[2, H] / rates[2, D], rates
+    # (box to box the two ratios move by a few per cent each: 0.976 / 0.988, 0.947 / 1.012 measured; the thread-creation assertions
+    # above are the functional guard)
+    assert rates[8, H] / rates[8, D] > 0.90 * rates[2, H] / rates[2, D], rates
 
 
 def test_bench_rccl_path_with_one_rank():
