@@ -26,7 +26,7 @@ st, resp = eng0.issue(sk, req, b"".join((1000 + i).to_bytes(32, "little") for i 
 st, tok = eng0.issuance_to_credit_token(pre, sk[32:], req, resp)
 st, proofs, _ = eng0.prove_spend(tok, b"".join((i % 900).to_bytes(32, "little") for i in range(D)), sh("sw-pr", eng0.prove_rng_bytes * D))
 PB = eng0.proof_bytes
-KMAX = 4096
+KMAX = int(os.environ.get("KMAX", "4096"))
 hp = torch.empty((KMAX, PB), dtype=torch.uint8, pin_memory=True)
 hp.numpy()[:] = np.tile(np.frombuffer(proofs, np.uint8).reshape(D, PB), (KMAX // D, 1))
 engines = [eng0] + [capi.Engine(h, L, max_batch=8192, transcript=mode) for _ in range(7)]
