@@ -17,7 +17,7 @@ _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_parallel_for", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_parallel_for", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_ctx_set_coalescing", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_prove_spend_seeded_batch", "act_node_prove_spend_seeded_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
@@ -28,7 +28,7 @@ EXPORTS = [
     "act_nullifier_check_and_insert_batch",
     "act_issue_check_batch", "act_issue_sign_batch", "act_refund_sign_batch",
     "act_node_create", "act_node_destroy", "act_node_device_count", "act_node_ctx", "act_node_last_error", "act_node_set_transcript_mode",
-    "act_node_set_host_threads", "act_node_request_batch", "act_node_issue_batch", "act_node_issuance_to_credit_token_batch",
+    "act_node_set_host_threads", "act_node_set_coalescing", "act_node_request_batch", "act_node_issue_batch", "act_node_issuance_to_credit_token_batch",
     "act_node_prove_spend_batch", "act_node_verify_spend_batch", "act_node_refund_batch", "act_node_refund_to_credit_token_batch",
     "act_node_issue_check_batch", "act_node_issue_sign_batch", "act_node_refund_sign_batch",
     "act_node_nullifier_set_create", "act_node_nullifier_set_destroy", "act_node_nullifier_set_len", "act_node_nullifier_set_last_error",
@@ -78,6 +78,7 @@ def load() -> C.CDLL:
     lib.act_ctx_set_host_threads.argtypes = [vp, i32]
     lib.act_ctx_set_pipeline_depth.argtypes = [vp, i32]
     lib.act_ctx_set_small_batch_max.argtypes = [vp, sz]
+    lib.act_ctx_set_coalescing.argtypes = [vp, sz]
     lib.act_host_usable_cpus.argtypes = []
     lib.act_host_hash_many.argtypes = [u8p, sz, C.c_uint32, sz, i32, u8p]
     lib.act_host_hash_many.restype = None
@@ -147,6 +148,7 @@ def load() -> C.CDLL:
     lib.act_node_last_error.restype = C.c_char_p
     lib.act_node_set_transcript_mode.argtypes = [vp, i32]
     lib.act_node_set_host_threads.argtypes = [vp, i32]
+    lib.act_node_set_coalescing.argtypes = [vp, sz]
     lib.act_node_request_batch.argtypes = [vp, sz, u8p, u8p, u8p]
     lib.act_node_issue_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_node_issuance_to_credit_token_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, u8p]
@@ -289,6 +291,10 @@ class Engine:
         r, ms = C.c_double(0), C.c_double(0)
         self._ck(self.lib.act_ubench_table_read(self.ctx, base, waves_per_simd, in_flight, C.byref(r), C.byref(ms)))
         return r.value, ms.value
+
+    def set_coalescing(self, max_proofs_per_call: int):
+        """calls of at most this many proofs from host memory merge with other threads' calls on this context (0 = off)"""
+        self._ck(self.lib.act_ctx_set_coalescing(self.ctx, max_proofs_per_call))
 
     def set_small_batch_max(self, n: int):
         """Calls of at most n proofs take the small-batch (latency) schedule; 0 = never."""
@@ -512,6 +518,9 @@ class Node:
 
     def set_host_threads(self, per_gpu: int):
         self._ck(self.lib.act_node_set_host_threads(self.nd, per_gpu))
+
+    def set_coalescing(self, max_proofs_per_call: int):
+        self._ck(self.lib.act_node_set_coalescing(self.nd, max_proofs_per_call))
 
     def streams_overlap(self) -> list:
         return [self.lib.act_ctx_streams_overlap(self.lib.act_node_ctx(self.nd, k)) for k in range(self.device_count())]

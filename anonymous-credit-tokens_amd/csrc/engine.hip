@@ -11,6 +11,7 @@
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -100,6 +101,13 @@ struct act_ctx {
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
   double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
+  // coalescing of concurrent callers' small verify / refund calls (act_ctx_set_coalescing; spend_coalesced below)
+  std::atomic<size_t> co_req_max{0};   // 0 = off; else: calls of at most this many proofs from host memory may be merged
+  std::mutex co_mu; std::condition_variable co_cv;
+  std::deque<struct CoReq*> co_q;      // requests not yet taken into a merged call
+  bool co_leader = false;              // some caller is running merged calls
+  uint8_t *h_co_proofs = nullptr, *h_co_rng = nullptr, *h_co_out = nullptr;   // pinned gather / scatter buffers of the leader (grow-only)
+  size_t h_co_cap = 0;                 // lanes
 };
 
 namespace {
@@ -689,6 +697,7 @@ void act_ctx_destroy(act_ctx* c) {
   for (hipStream_t& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
   for (hipEvent_t e : c->sm_ev) (void)hipEventDestroy(e);
   if (c->d_small) { (void)hipMemset(c->d_small, 0, c->d_small_cap); (void)hipFree(c->d_small); }
+  for (uint8_t* p : {c->h_co_proofs, c->h_co_rng, c->h_co_out}) if (p) (void)hipHostFree(p);
   for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
@@ -859,10 +868,25 @@ int act_issue_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], co
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   return sign_only_batch(c, n, mem, LABEL_RESPOND, sk, req, 128, camt, status_in, rng, rng_mode, out_resp, status);
 }
+// (requests of concurrent callers that merge into one call: spend_coalesced, further down)
+enum { CO_VERIFY = 0, CO_REFUND = 1, CO_SIGN = 2 };        // act_verify_spend_batch, act_refund_batch, act_refund_sign_batch
+struct CoReq {
+  int kind; const uint8_t* sk; const uint8_t* in; size_t n; const uint8_t* status_in; const uint8_t* rng; bool rng_if_accepted;
+  uint8_t* out_refund; uint8_t* status; uint8_t* out_kprime;
+  int rc = ACT_OK; bool done = false;
+};
+
+static int spend_coalesced(act_ctx* c, CoReq& r);
+
 int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in,
                           const uint8_t* rng, int rng_mode, uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  // (a one-lane ACT_RNG_SEQUENTIAL call draws its 128 bytes if and only if the lane is signed: per-lane in all but name)
+  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) {
+    CoReq r{CO_SIGN, sk, kprime, n, status_in, rng, rng_mode == ACT_RNG_SEQUENTIAL, out_refund, status, nullptr};
+    return spend_coalesced(c, r);
+  }
   return sign_only_batch(c, n, mem, LABEL_REFUND, sk, kprime, 32, nullptr, status_in, rng, rng_mode, out_refund, status);
 }
 
@@ -1121,14 +1145,108 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   return rc ? rc : call.finish();
 }
 
+// ---- several threads, one context, one proof per call ------------------------------------------------------------------------
+// The crate's entry points take ONE proof (src/lib.rs:781-786) and the Rust binding keeps one context inside `Params`, which the
+// threads of a server share.  A call over one proof is ~1.7 ms of latency whatever happens (the range kernel's dependent chain), so
+// callers that queue on the context's lock get ~600 verifies per second between them -- while the same 1.7 ms would verify a
+// thousand proofs.  With act_ctx_set_coalescing(ctx, k) the callers of one context merge instead of queueing: whoever arrives
+// while no merged call runs becomes the leader, takes every request that has queued (same key, same kind), runs them as ONE call
+// through the ordinary path from a pinned gather buffer, hands every caller its own statuses / K' / refunds and passes the
+// leadership on.  Nobody waits for company: a lone caller's request runs at once; requests pile up only while a call is running.
+// Per lane the result is what the caller's own call would have produced (lanes are independent; refunds: ACT_RNG_PER_LANE only,
+// lane i of a request draws from its own 128 bytes).  Off by default.
+static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
+  const int kind = batch[0]->kind;
+  const size_t in_b = kind == CO_SIGN ? 32 : ProofLayout{c->L}.bytes();          // a proof, or (sign only) the enc(K') the verification returned
+  const size_t in_max = ProofLayout{c->L}.bytes();
+  const bool sign = kind != CO_VERIFY;
+  bool want_kp = false;
+  for (CoReq* q : batch) want_kp = want_kp || q->out_kprime;
+  if (total > c->h_co_cap) {                              // only the leader is here: no other thread touches these buffers
+    if (hipSetDevice(c->device) != hipSuccess) return ACT_ERR_HIP;
+    const size_t cap = std::max<size_t>(total, 256);
+    for (uint8_t** p : {&c->h_co_proofs, &c->h_co_rng, &c->h_co_out}) if (*p) { (void)hipHostFree(*p); *p = nullptr; }
+    c->h_co_cap = 0;
+    if (hipHostMalloc(&c->h_co_proofs, cap * in_max, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&c->h_co_rng, cap * (128 + 1), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&c->h_co_out, cap * (128 + 32 + 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
+    c->h_co_cap = cap;
+  }
+  uint8_t *h_rf = c->h_co_out, *h_kp = c->h_co_out + c->h_co_cap * 128, *h_st = c->h_co_out + c->h_co_cap * 160, *h_sin = c->h_co_rng + c->h_co_cap * 128;
+  size_t off = 0;
+  for (CoReq* q : batch) {
+    memcpy(c->h_co_proofs + off * in_b, q->in, q->n * in_b);
+    if (kind == CO_SIGN) memcpy(h_sin + off, q->status_in, q->n);
+    if (sign) {
+      // a one-lane ACT_RNG_SEQUENTIAL request owns 128 bytes only if its lane is to be signed (the reference draws after the checks)
+      if (q->rng_if_accepted && q->status_in[0] != 0) memset(c->h_co_rng + off * 128, 0, 128);
+      else memcpy(c->h_co_rng + off * 128, q->rng, q->n * 128);
+    }
+    off += q->n;
+  }
+  int rc;
+  if (kind == CO_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_REFUND, batch[0]->sk, c->h_co_proofs, 32, nullptr, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_rf, h_st);
+  else rc = spend_batch(c, total, ACT_MEM_HOST, batch[0]->sk, c->h_co_proofs, sign, sign ? c->h_co_rng : nullptr, ACT_RNG_PER_LANE,
+                        sign ? h_rf : nullptr, h_st, want_kp ? h_kp : nullptr);
+  if (sign) memset(c->h_co_rng, 0, total * 128);        // signing nonces' seeds: not left in a long-lived buffer
+  off = 0;
+  for (CoReq* q : batch) {
+    q->rc = rc;
+    if (!rc) {
+      memcpy(q->status, h_st + off, q->n);
+      if (q->out_kprime) memcpy(q->out_kprime, h_kp + off * 32, q->n * 32);
+      if (sign) memcpy(q->out_refund, h_rf + off * 128, q->n * 128);
+    }
+    off += q->n;
+  }
+  return rc;
+}
+
+static int spend_coalesced(act_ctx* c, CoReq& r) {
+  const size_t cap = std::max<size_t>(c->co_req_max.load(), std::min<size_t>(c->max_batch, c->small_max ? c->small_max : c->max_batch));   // lanes per merged call
+  std::unique_lock<std::mutex> lk(c->co_mu);
+  c->co_q.push_back(&r);
+  for (;;) {
+    if (r.done) return r.rc;                              // a leader ran it
+    if (!c->co_leader) break;                             // nobody is leading: this caller does
+    c->co_cv.wait(lk);
+  }
+  c->co_leader = true;
+  while (!r.done) {
+    // the oldest request decides key and kind; every queued request of the same key and kind joins, in arrival order, while it fits
+    std::vector<CoReq*> batch; size_t total = 0;
+    CoReq* first = c->co_q.front();
+    for (auto it = c->co_q.begin(); it != c->co_q.end();) {
+      CoReq* q = *it;
+      if (q->kind == first->kind && memcmp(q->sk, first->sk, 64) == 0 && (batch.empty() || total + q->n <= cap)) { batch.push_back(q); total += q->n; it = c->co_q.erase(it); }
+      else ++it;
+    }
+    lk.unlock();
+    (void)co_run(c, batch, total);                        // every request of the batch carries the call's return code
+    lk.lock();
+    for (CoReq* q : batch) q->done = true;
+    c->co_cv.notify_all();
+  }
+  c->co_leader = false;                                   // this caller's own request is done: whoever still waits takes over
+  c->co_cv.notify_all();
+  return r.rc;
+}
+
+int act_ctx_set_coalescing(act_ctx* c, size_t max_proofs_per_call) {
+  if (!c) return ACT_ERR_ARG;
+  c->co_req_max.store(max_proofs_per_call);
+  return ACT_OK;
+}
+
 int act_verify_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!c || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
+  if (mem == ACT_MEM_HOST && n && n <= c->co_req_max.load()) { CoReq r{CO_VERIFY, sk, proof, n, nullptr, nullptr, false, nullptr, status, out_kprime}; return spend_coalesced(c, r); }
   return spend_batch(c, n, mem, sk, proof, false, nullptr, ACT_RNG_PER_LANE, nullptr, status, out_kprime);
 }
 int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
                      uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  if (mem == ACT_MEM_HOST && rng_mode == ACT_RNG_PER_LANE && n && n <= c->co_req_max.load()) { CoReq r{CO_REFUND, sk, proof, n, nullptr, rng, false, out_refund, status, nullptr}; return spend_coalesced(c, r); }
   return spend_batch(c, n, mem, sk, proof, true, rng, rng_mode, out_refund, status, nullptr);
 }
 

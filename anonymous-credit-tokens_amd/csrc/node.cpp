@@ -7,6 +7,7 @@
 // every shard signs from its own offset into the stream -- byte for byte what one loop over one generator produces.
 // Plain host C++ over the C ABI: nothing here touches a device.
 #include <algorithm>
+#include <atomic>
 #include <sys/random.h>
 #include <cstring>
 #include <mutex>
@@ -21,6 +22,10 @@ struct act_node {
   int L = 0;
   std::string err;
   std::mutex mu;      // every act_node_*_batch call holds it: a handle shared between host threads is used by one at a time
+  // ... except calls small enough to merge (act_node_set_coalescing): those go to ONE context, round robin, without the node's lock,
+  // and merge there with the calls of other threads (engine.hip spend_coalesced)
+  std::atomic<size_t> co_max{0};
+  std::atomic<unsigned> co_next{0};
 };
 
 namespace {
@@ -114,6 +119,15 @@ int act_node_set_host_threads(act_node* nd, int per_gpu) {
   for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_host_threads(c, per_gpu); if (rc) return rc; }
   return ACT_OK;
 }
+// verify / refund-sign calls of at most `max_proofs_per_call` proofs are not cut over the GPUs (a one-proof call has nothing to cut):
+// each goes to one context -- the next one, round robin -- and merges there with the small calls other threads make at the same time
+int act_node_set_coalescing(act_node* nd, size_t max_proofs_per_call) {
+  if (!nd) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_coalescing(c, max_proofs_per_call); if (rc) return rc; }
+  nd->co_max.store(max_proofs_per_call);
+  return ACT_OK;
+}
 
 int act_node_request_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
   if (!nd || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
@@ -175,6 +189,12 @@ int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], con
                                int rng_mode, uint8_t* out_refund, uint8_t* status) {
   if (!nd || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {
+    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    const int rc = act_refund_sign_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out_refund, status);
+    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    return rc;
+  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   return refund_sign_locked(nd, n, sk, kprime, status_in, rng, rng_mode, out_refund, status, nullptr);
 }
@@ -213,6 +233,12 @@ int act_node_prove_spend_seeded_batch(act_node* nd, size_t n, const uint8_t* tok
 
 int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!nd || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
+  if (n && n <= nd->co_max.load()) {
+    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    const int rc = act_verify_spend_batch(c, n, ACT_MEM_HOST, sk, proof, status, out_kprime);
+    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    return rc;
+  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   return run(nd, n, [&](size_t k, Shard s) {

@@ -146,6 +146,13 @@ int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
  * Threads with a context each may make such calls at the same time; two of them run on a device at once, the others wait their
  * turn inside the call (more active streams than that and the driver time-slices the process's queues: INTEGRATION.md). */
 int act_ctx_set_small_batch_max(act_ctx *ctx, size_t n);
+/* Several threads, ONE context, one proof per call -- what a server built on the crate's single-item API does with the context the
+ * Rust binding keeps inside `Params`.  Such callers queue on the context (a call is ~1.7 ms whatever its size: ~600 calls/s between
+ * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch / act_refund_batch (ACT_RNG_PER_LANE) calls of at most k proofs
+ * from host memory MERGE instead: the caller that finds no merged call running takes every request queued so far with the same
+ * key, runs them as one call and hands each caller its own statuses / K' / refunds; requests pile up only while a call runs, nobody
+ * waits for company.  Per lane the result is the one the caller's own call would have produced.  0 (default) = off. */
+int act_ctx_set_coalescing(act_ctx *ctx, size_t max_proofs_per_call);
 /* Secrets and memory addresses.  The reference is constant-time in its table accesses (`subtle`, src/lib.rs:98, 1025-1118;
  * dalek's table scans).  libact_mi355x.so (the default build, for which this returns 1) matches that for EVERY secret: the issuer's
  * private key and signing nonces, and the client's tokens, blinding factors and prover rng, never select a memory address --
@@ -234,6 +241,11 @@ act_ctx *act_node_ctx(act_node *node, int k);                  /* context k, e.g
 const char *act_node_last_error(const act_node *node);
 int act_node_set_transcript_mode(act_node *node, int mode);
 int act_node_set_host_threads(act_node *node, int per_gpu);    /* host BLAKE3 workers of every context */
+/* act_ctx_set_coalescing on every context, and: act_node_verify_spend_batch / act_node_refund_sign_batch calls of at most
+ * max_proofs_per_call proofs are no longer cut over the GPUs under the handle's lock -- each goes to one context (round robin) and
+ * merges there with the small calls other threads make on the same handle at the same time.  What the Rust binding's single-item
+ * `refund` turns into when a server's threads share one `Params`.  0 (default) = off. */
+int act_node_set_coalescing(act_node *node, size_t max_proofs_per_call);
 int act_node_request_batch(act_node *node, size_t n, const uint8_t *pre, const uint8_t *rng, uint8_t *out_req);
 int act_node_issue_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *req, const uint8_t *c, const uint8_t *rng,
                          int rng_mode, uint8_t *out_resp, uint8_t *status);

@@ -32,6 +32,7 @@ extern "C" {
     fn act_node_create(h: *const u8, l: c_int, devices: *const c_int, n_devices: c_int, max_batch: usize, out: *mut *mut ActNode) -> c_int;
     fn act_node_destroy(node: *mut ActNode);
     fn act_node_last_error(node: *const ActNode) -> *const c_char;
+    fn act_node_set_coalescing(node: *mut ActNode, max_proofs_per_call: usize) -> c_int;
     fn act_node_request_batch(node: *mut ActNode, n: usize, pre: *const u8, rng: *const u8, out_req: *mut u8) -> c_int;
     fn act_node_issue_check_batch(node: *mut ActNode, n: usize, req: *const u8, status: *mut u8) -> c_int;
     fn act_node_issue_sign_batch(node: *mut ActNode, n: usize, sk: *const u8, req: *const u8, c: *const u8, status_in: *const u8,
@@ -60,7 +61,8 @@ extern "C" {
 /// them itself -- every `act_node_*_batch` call takes the node handle's lock and every context entry point the context's
 /// (include/act_mi355x.h, "A node handle ... may be shared between host threads") -- so concurrent callers are served one after
 /// the other and never observe each other's staging buffers, cached key or error string.  That is why `Gpu` may be `Sync`; the
-/// guarantee lives in the library, not in a promise by the caller.
+/// guarantee lives in the library, not in a promise by the caller.  Small calls (the single-item API) do better than queue: they
+/// merge into one launch with the small calls of other threads (`act_node_set_coalescing`, set in `Gpu::new`).
 pub struct Gpu(*mut ActNode);
 // SAFETY: the handle is only ever passed to act_node_* entry points, each of which locks it (csrc/node.cpp `node_lock`);
 // act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies it under
@@ -110,6 +112,13 @@ impl Gpu {
             let msg = if node.is_null() { String::new() } else { unsafe { CStr::from_ptr(act_node_last_error(node)) }.to_string_lossy().into_owned() };
             panic!("act_node_create failed ({rc}): {msg}"); // infrastructure failure, not a protocol error
         }
+        // The single-item entry points (`refund`, src/lib.rs:781-786) are calls over ONE proof, ~2 ms each whatever happens; the threads
+        // of a server that share this `Params` would queue on the handle at ~220 refunds/s between them.  Calls of at most this many
+        // proofs merge with the other threads' instead (each caller still gets exactly its own answer): 64 threads, 4 600 refunds/s
+        // (profiles/r04_single_item_server.txt).  ACT_MI355X_COALESCE=0 turns it off.
+        let merge: usize = std::env::var("ACT_MI355X_COALESCE").ok().and_then(|s| s.parse().ok()).unwrap_or(64);
+        let rc = unsafe { act_node_set_coalescing(node, merge) };
+        assert_eq!(rc, 0, "act_node_set_coalescing");
         Gpu(node)
     }
     fn check(&self, rc: c_int) {

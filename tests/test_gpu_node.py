@@ -211,3 +211,56 @@ def test_bench_rccl_path_with_one_rank():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["distinct_proofs_per_gpu"] == 4096 and d["value"] > 0
+
+
+def test_single_item_refunds_from_many_threads_merge_on_a_node_handle(engine_factory, bench_params):
+    """The Rust binding's `PrivateKey::refund` (rust/src/mi355x.rs): act_node_verify_spend_batch over ONE proof, then -- with 128
+    bytes drawn only if it verified -- act_node_refund_sign_batch (ACT_RNG_SEQUENTIAL), on the one node handle every thread of a
+    server shares.  With act_node_set_coalescing such calls merge instead of queueing on the handle; every thread must get exactly
+    the refund (or the rejection) it gets alone."""
+    import threading
+    from act_amd import capi
+    L, D = 8, 40
+    eng = engine_factory(bench_params, L, max_batch=256, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("nm-sk", 64))
+    pre = eng.pre_issuance_random(shake("nm-pre", 128 * D)); req = eng.request(pre, shake("nm-rq", 128 * D))
+    st, resp = eng.issue(sk, req, b"".join(scb(70 + i) for i in range(D)), shake("nm-ir", 128 * D))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i % 30) for i in range(D)), shake("nm-pr", eng.prove_rng_bytes * D))
+    assert st == bytes(D)
+    pb = eng.proof_bytes
+    items = []
+    for i in range(D):
+        p = bytearray(proofs[pb * i:pb * (i + 1)])
+        if i % 5 == 0:
+            p[40] ^= 1                                   # rejected: no rng drawn, no refund
+        items.append(bytes(p))
+    node = capi.Node(bench_params, L, devices=(0, 0), max_batch=256, transcript=capi.TRANSCRIPT_DEVICE)
+
+    def refund_one(i):
+        stv, kp = node.verify_spend(sk, items[i], True)
+        rng = shake("nm-r%d" % i, 128) if stv[0] == 0 else b"\0"   # the binding draws after the verdict: nothing for a rejected proof (a non-null pointer to no bytes)
+        st2, rf = node.refund_sign(sk, kp, stv, rng, capi.RNG_SEQUENTIAL)
+        return stv, st2, rf
+    try:
+        alone = [refund_one(i) for i in range(D)]
+        node.set_coalescing(4)
+        merged = [None] * D
+
+        def work(t):
+            try:
+                for i in range(t, D, 8):
+                    merged[i] = refund_one(i)
+            except BaseException as e:
+                merged[t] = e
+        th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    finally:
+        node.close()
+    for i in range(D):
+        assert not isinstance(merged[i], BaseException), merged[i]
+        assert merged[i] == alone[i], i
+        assert alone[i][0][0] == (7 if i % 5 == 0 else 0) and (alone[i][2] == bytes(128)) == (i % 5 == 0)

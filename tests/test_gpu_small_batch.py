@@ -180,3 +180,74 @@ def test_four_concurrent_callers_do_not_collapse():
     assert len(ms) == 2, r.stdout
     assert ms[0] < 4.0, ms                       # one caller: ~1.7 ms
     assert ms[1] < 6 * ms[0], ms                 # four callers, two in flight: ~3 x; the collapse was 13 - 40 x
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_coalesced_callers_get_their_own_answers(engine_factory, bench_params, oracle, mode):
+    """act_ctx_set_coalescing: sixteen threads share ONE context and make calls of 1 - 3 proofs each (verify with K', refund with
+    per-lane rng, two different keys, some proofs tampered).  Whatever merges with whatever, every call must return exactly what the
+    same call returns alone: statuses, enc(K'), refunds byte for byte -- checked against a sequential pass with coalescing off."""
+    import random
+    import threading
+    L, D = 8, 48
+    eng = engine_factory(bench_params, L, max_batch=256, transcript=mode)
+    sks = [eng.private_key_random(shake("co-sk%d" % j, 64)) for j in range(2)]
+    proofs = []
+    for j, sk in enumerate(sks):
+        pre = eng.pre_issuance_random(shake("co-pre%d" % j, 128 * D)); req = eng.request(pre, shake("co-rq%d" % j, 128 * D))
+        st, resp = eng.issue(sk, req, b"".join(scb(60 + i) for i in range(D)), shake("co-ir%d" % j, 128 * D))
+        st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+        st, pr, _ = eng.prove_spend(tok, b"".join(scb(i % 40) for i in range(D)), shake("co-pr%d" % j, eng.prove_rng_bytes * D))
+        assert st == bytes(D)
+        proofs.append(pr)
+    pb = eng.proof_bytes
+    r = random.Random(9)
+    jobs = []                                   # (key index, proofs, refund?, rng)
+    for t in range(16):
+        mine = []
+        for c in range(12):
+            j = r.randrange(2); k = r.randrange(1, 4)
+            lanes = [r.randrange(D) for _ in range(k)]
+            blob = bytearray(b"".join(proofs[j][pb * i:pb * (i + 1)] for i in lanes))
+            if r.randrange(3) == 0:
+                blob[pb * r.randrange(k) + 40] ^= 1                 # a tampered scalar: InvalidClientSpendProof on that lane only
+            if r.randrange(11) == 0:
+                j ^= 1                                               # the other issuer's key: every lane of the call rejected
+            mine.append((j, bytes(blob), r.randrange(2) == 1, shake("co-r%d-%d" % (t, c), 128 * k)))
+        jobs.append(mine)
+
+    def run_all(out):
+        def work(t):
+            try:
+                res = []
+                for j, blob, sign, rng in jobs[t]:
+                    res.append(eng.refund(sks[j], blob, rng) if sign else eng.verify_spend(sks[j], blob, True))
+                out[t] = res
+            except BaseException as e:
+                out[t] = e
+        th = [threading.Thread(target=work, args=(t,)) for t in range(16)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+
+    try:
+        eng.set_coalescing(0)
+        alone = [None] * 16
+        for t in range(16):                      # one thread after the other, nothing to merge with
+            alone[t] = [eng.refund(sks[j], blob, rng) if sign else eng.verify_spend(sks[j], blob, True) for j, blob, sign, rng in jobs[t]]
+        eng.set_coalescing(8)
+        merged = [None] * 16
+        run_all(merged)
+    finally:
+        eng.set_coalescing(0)
+    for t in range(16):
+        assert not isinstance(merged[t], BaseException), merged[t]
+        assert merged[t] == alone[t], t
+    # and the answers are not vacuous: accepted lanes, rejected lanes and refunds all occur, and one call agrees with the oracle
+    flat = [st for t in range(16) for (st, _) in alone[t]]
+    assert any(0 in st for st in flat) and any(7 in st for st in flat)
+    j, blob, sign, rng = next(x for x in jobs[0] if x[2])
+    so, rf = oracle.ctx(bench_params, L).refund(sks[j], blob[:pb], rng[:128])
+    st, out = alone[0][jobs[0].index((j, blob, sign, rng))]
+    assert st[0] == so and out[:128] == rf

@@ -33,7 +33,12 @@ hp.numpy()[:] = np.tile(np.frombuffer(proofs, np.uint8).reshape(D, PB), ((max(n,
 hs = torch.zeros(max(n, D), dtype=torch.uint8, pin_memory=True)
 import time
 hbm = len(sys.argv) > 3 and sys.argv[3] == "hbm"
-if hbm:
+refund = "refund" in sys.argv            # verify + sign (act_refund_batch), device memory
+if refund:
+    d_p = hp.cuda(); d_s = torch.zeros(max(n, D), dtype=torch.uint8, device="cuda"); d_r = torch.randint(0, 256, (max(n, D), 128), dtype=torch.uint8, device="cuda")
+    d_o = torch.zeros((max(n, D), 128), dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    call = lambda: eng.refund_dev(sk, n, d_p.data_ptr(), d_r.data_ptr(), capi.RNG_PER_LANE, d_o.data_ptr(), d_s.data_ptr())
+elif hbm:
     d_p = hp.cuda(); d_s = torch.zeros(max(n, D), dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
     call = lambda: eng.verify_spend_dev(sk, n, d_p.data_ptr(), d_s.data_ptr())
 else:
