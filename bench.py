@@ -34,6 +34,7 @@ and at N = 1
   extra.tiled_4096                 the round-1/2 input (4 096 distinct proofs tiled x256): what tiling flatters
   extra.call_latency_ms            one call over 1 / 64 / 4 096 proofs (the crate's call shape is one proof per call)
   extra.concurrent_callers         4 threads with a context each making such calls back to back: whole-GPU rate
+  extra.single_item_refunds        16 threads sharing one node handle, each calling the single-item refund; coalescing off / on
   extra.refund                     verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
   extra.verify_L64                 BASELINE config 2: 2^16 verifies at L = 64
 
@@ -716,6 +717,42 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
             e.close()
     except Exception as e:          # an accessory measurement must never cost the line
         ex["concurrent_callers"] = {"error": repr(e)}
+    # (2d) the crate's API under a server's load: 16 threads share ONE node handle (what the Rust binding keeps inside `Params`) and
+    #      call the single-item refund -- verify over one proof, then refund-sign with 128 rng bytes -- in a loop; without and with
+    #      act_node_set_coalescing (rust/src/mi355x.rs turns it on)
+    try:
+        import ctypes as C
+        import threading
+        T = 16
+        node = capi.Node(h, L, devices=(local,), max_batch=8192, transcript=capi.TRANSCRIPT_DEVICE)
+        lib, nd = node.lib, node.nd
+        skb = (C.c_uint8 * 64).from_buffer_copy(sk)
+        valid = [i for i in range(64) if int(expect[i]) == 0]
+        items = hp1[:64].numpy().copy(); rbytes = np.frombuffer(shake("bench-single-item", 128 * 64), np.uint8).reshape(64, 128).copy()
+        single = {}
+        for co in (0, 64):
+            node.set_coalescing(co)
+            calls = 12 if not co else 48
+            def work(t):
+                s1, kp, s2, rf = np.zeros(1, np.uint8), np.zeros(32, np.uint8), np.zeros(1, np.uint8), np.zeros(128, np.uint8)
+                for c in range(calls):
+                    i = valid[(t + c) % len(valid)]
+                    assert lib.act_node_verify_spend_batch(nd, 1, skb, items[i].ctypes.data, s1.ctypes.data, kp.ctypes.data) == 0 and s1[0] == 0
+                    assert lib.act_node_refund_sign_batch(nd, 1, skb, kp.ctypes.data, s1.ctypes.data, rbytes[i].ctypes.data, capi.RNG_SEQUENTIAL, rf.ctypes.data, s2.ctypes.data) == 0 and s2[0] == 0
+            work(0)
+            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            dt = time.perf_counter() - t0
+            single["coalescing_off" if not co else "coalescing_64"] = {"refunds_per_s": round(T * calls / dt), "ms_per_refund": round(1e3 * dt / calls, 2)}
+        node.close()
+        ex["single_item_refunds"] = dict(single, threads=T, what="16 threads sharing one node handle, each: act_node_verify_spend_batch(1 proof) then "
+                                                                 "act_node_refund_sign_batch(1 lane, ACT_RNG_SEQUENTIAL); device transcripts")
+    except Exception as e:
+        ex["single_item_refunds"] = {"error": repr(e)}
     del hp1
     # (4) refund = verify + sign (src/lib.rs:787-868), per-lane rng resident in HBM
     g = torch.Generator(device="cuda"); g.manual_seed(7)
