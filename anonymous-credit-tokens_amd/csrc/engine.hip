@@ -817,8 +817,18 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
 // The two halves of issue / refund as separate calls, for callers that must see every verdict before any rng is assigned:
 // the node dispatcher (node.cpp) makes ACT_RNG_SEQUENTIAL exact across the GPUs of a node by checking on all shards,
 // counting the accepted lanes of the shards in front, and only then signing.
-int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uint8_t* status) {
-  if (!c || (n && (!req || !status))) return ACT_ERR_ARG;
+// (requests of concurrent callers that merge into one call: spend_coalesced, further down)
+enum { CO_VERIFY = 0, CO_REFUND, CO_SIGN, CO_ISSUE_CHECK, CO_ISSUE_SIGN };   // act_verify_spend / act_refund / act_refund_sign / act_issue_check / act_issue_sign _batch
+struct CoReq {
+  int kind; const uint8_t* sk;            // sk: null for the key-less check
+  const uint8_t* in; size_t n;            // proofs (verify, refund), enc(K') (refund sign), IssuanceRequests (issue check / sign)
+  const uint8_t* camt; const uint8_t* status_in; const uint8_t* rng; bool rng_if_accepted;
+  uint8_t* out; uint8_t* status; uint8_t* out_kprime;
+  int rc = ACT_OK; bool done = false;
+};
+static int spend_coalesced(act_ctx* c, CoReq& r);
+
+static int issue_check_impl(act_ctx* c, size_t n, int mem, const uint8_t* req, uint8_t* status) {
   Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc; size_t chunk = 0;
@@ -834,6 +844,11 @@ int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uin
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
   }
   return call.finish();
+}
+int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uint8_t* status) {
+  if (!c || (n && (!req || !status))) return ACT_ERR_ARG;
+  if (mem == ACT_MEM_HOST && n && n <= c->co_req_max.load()) { CoReq r{CO_ISSUE_CHECK, nullptr, req, n, nullptr, nullptr, nullptr, false, nullptr, status, nullptr}; return spend_coalesced(c, r); }
+  return issue_check_impl(c, n, mem, req, status);
 }
 // signs the lanes whose status_in is 0; `point` = IssuanceRequest records (label RESPOND, with amounts) or enc(K') (label REFUND)
 static int sign_only_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t sk[64], const uint8_t* point, size_t point_stride,
@@ -866,25 +881,19 @@ int act_issue_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], co
                          const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!c || !sk || (n && (!req || !camt || !status_in || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) {
+    CoReq r{CO_ISSUE_SIGN, sk, req, n, camt, status_in, rng, rng_mode == ACT_RNG_SEQUENTIAL, out_resp, status, nullptr};
+    return spend_coalesced(c, r);
+  }
   return sign_only_batch(c, n, mem, LABEL_RESPOND, sk, req, 128, camt, status_in, rng, rng_mode, out_resp, status);
 }
-// (requests of concurrent callers that merge into one call: spend_coalesced, further down)
-enum { CO_VERIFY = 0, CO_REFUND = 1, CO_SIGN = 2 };        // act_verify_spend_batch, act_refund_batch, act_refund_sign_batch
-struct CoReq {
-  int kind; const uint8_t* sk; const uint8_t* in; size_t n; const uint8_t* status_in; const uint8_t* rng; bool rng_if_accepted;
-  uint8_t* out_refund; uint8_t* status; uint8_t* out_kprime;
-  int rc = ACT_OK; bool done = false;
-};
-
-static int spend_coalesced(act_ctx* c, CoReq& r);
-
 int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in,
                           const uint8_t* rng, int rng_mode, uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   // (a one-lane ACT_RNG_SEQUENTIAL call draws its 128 bytes if and only if the lane is signed: per-lane in all but name)
   if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) {
-    CoReq r{CO_SIGN, sk, kprime, n, status_in, rng, rng_mode == ACT_RNG_SEQUENTIAL, out_refund, status, nullptr};
+    CoReq r{CO_SIGN, sk, kprime, n, nullptr, status_in, rng, rng_mode == ACT_RNG_SEQUENTIAL, out_refund, status, nullptr};
     return spend_coalesced(c, r);
   }
   return sign_only_batch(c, n, mem, LABEL_REFUND, sk, kprime, 32, nullptr, status_in, rng, rng_mode, out_refund, status);
@@ -1157,9 +1166,10 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
 // lane i of a request draws from its own 128 bytes).  Off by default.
 static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
   const int kind = batch[0]->kind;
-  const size_t in_b = kind == CO_SIGN ? 32 : ProofLayout{c->L}.bytes();          // a proof, or (sign only) the enc(K') the verification returned
-  const size_t in_max = ProofLayout{c->L}.bytes();
-  const bool sign = kind != CO_VERIFY;
+  const size_t pbytes = ProofLayout{c->L}.bytes();
+  const size_t in_b = kind == CO_SIGN ? 32 : (kind == CO_ISSUE_CHECK || kind == CO_ISSUE_SIGN) ? 128 : pbytes;
+  const size_t out_b = kind == CO_ISSUE_SIGN ? 160 : 128;
+  const bool sign = kind == CO_REFUND || kind == CO_SIGN || kind == CO_ISSUE_SIGN, has_sin = kind == CO_SIGN || kind == CO_ISSUE_SIGN;
   bool want_kp = false;
   for (CoReq* q : batch) want_kp = want_kp || q->out_kprime;
   if (total > c->h_co_cap) {                              // only the leader is here: no other thread touches these buffers
@@ -1167,15 +1177,18 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
     const size_t cap = std::max<size_t>(total, 256);
     for (uint8_t** p : {&c->h_co_proofs, &c->h_co_rng, &c->h_co_out}) if (*p) { (void)hipHostFree(*p); *p = nullptr; }
     c->h_co_cap = 0;
-    if (hipHostMalloc(&c->h_co_proofs, cap * in_max, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&c->h_co_rng, cap * (128 + 1), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(&c->h_co_out, cap * (128 + 32 + 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
+    if (hipHostMalloc(&c->h_co_proofs, cap * std::max<size_t>(pbytes, 128), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&c->h_co_rng, cap * (128 + 32 + 1), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(&c->h_co_out, cap * (160 + 32 + 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
     c->h_co_cap = cap;
   }
-  uint8_t *h_rf = c->h_co_out, *h_kp = c->h_co_out + c->h_co_cap * 128, *h_st = c->h_co_out + c->h_co_cap * 160, *h_sin = c->h_co_rng + c->h_co_cap * 128;
+  uint8_t *h_out = c->h_co_out, *h_kp = c->h_co_out + c->h_co_cap * 160, *h_st = c->h_co_out + c->h_co_cap * 192;
+  uint8_t *h_camt = c->h_co_rng + c->h_co_cap * 128, *h_sin = c->h_co_rng + c->h_co_cap * 160;
   size_t off = 0;
   for (CoReq* q : batch) {
     memcpy(c->h_co_proofs + off * in_b, q->in, q->n * in_b);
-    if (kind == CO_SIGN) memcpy(h_sin + off, q->status_in, q->n);
+    if (has_sin) memcpy(h_sin + off, q->status_in, q->n);
+    if (kind == CO_ISSUE_SIGN) memcpy(h_camt + off * 32, q->camt, q->n * 32);
     if (sign) {
       // a one-lane ACT_RNG_SEQUENTIAL request owns 128 bytes only if its lane is to be signed (the reference draws after the checks)
       if (q->rng_if_accepted && q->status_in[0] != 0) memset(c->h_co_rng + off * 128, 0, 128);
@@ -1184,9 +1197,11 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
     off += q->n;
   }
   int rc;
-  if (kind == CO_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_REFUND, batch[0]->sk, c->h_co_proofs, 32, nullptr, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_rf, h_st);
+  if (kind == CO_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_REFUND, batch[0]->sk, c->h_co_proofs, 32, nullptr, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
+  else if (kind == CO_ISSUE_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_RESPOND, batch[0]->sk, c->h_co_proofs, 128, h_camt, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
+  else if (kind == CO_ISSUE_CHECK) rc = issue_check_impl(c, total, ACT_MEM_HOST, c->h_co_proofs, h_st);
   else rc = spend_batch(c, total, ACT_MEM_HOST, batch[0]->sk, c->h_co_proofs, sign, sign ? c->h_co_rng : nullptr, ACT_RNG_PER_LANE,
-                        sign ? h_rf : nullptr, h_st, want_kp ? h_kp : nullptr);
+                        sign ? h_out : nullptr, h_st, want_kp ? h_kp : nullptr);
   if (sign) memset(c->h_co_rng, 0, total * 128);        // signing nonces' seeds: not left in a long-lived buffer
   off = 0;
   for (CoReq* q : batch) {
@@ -1194,7 +1209,7 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
     if (!rc) {
       memcpy(q->status, h_st + off, q->n);
       if (q->out_kprime) memcpy(q->out_kprime, h_kp + off * 32, q->n * 32);
-      if (sign) memcpy(q->out_refund, h_rf + off * 128, q->n * 128);
+      if (sign) memcpy(q->out, h_out + off * out_b, q->n * out_b);
     }
     off += q->n;
   }
@@ -1217,7 +1232,7 @@ static int spend_coalesced(act_ctx* c, CoReq& r) {
     CoReq* first = c->co_q.front();
     for (auto it = c->co_q.begin(); it != c->co_q.end();) {
       CoReq* q = *it;
-      if (q->kind == first->kind && memcmp(q->sk, first->sk, 64) == 0 && (batch.empty() || total + q->n <= cap)) { batch.push_back(q); total += q->n; it = c->co_q.erase(it); }
+      if (q->kind == first->kind && (!first->sk || memcmp(q->sk, first->sk, 64) == 0) && (batch.empty() || total + q->n <= cap)) { batch.push_back(q); total += q->n; it = c->co_q.erase(it); }
       else ++it;
     }
     lk.unlock();
@@ -1239,14 +1254,14 @@ int act_ctx_set_coalescing(act_ctx* c, size_t max_proofs_per_call) {
 
 int act_verify_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!c || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
-  if (mem == ACT_MEM_HOST && n && n <= c->co_req_max.load()) { CoReq r{CO_VERIFY, sk, proof, n, nullptr, nullptr, false, nullptr, status, out_kprime}; return spend_coalesced(c, r); }
+  if (mem == ACT_MEM_HOST && n && n <= c->co_req_max.load()) { CoReq r{CO_VERIFY, sk, proof, n, nullptr, nullptr, nullptr, false, nullptr, status, out_kprime}; return spend_coalesced(c, r); }
   return spend_batch(c, n, mem, sk, proof, false, nullptr, ACT_RNG_PER_LANE, nullptr, status, out_kprime);
 }
 int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
                      uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  if (mem == ACT_MEM_HOST && rng_mode == ACT_RNG_PER_LANE && n && n <= c->co_req_max.load()) { CoReq r{CO_REFUND, sk, proof, n, nullptr, rng, false, out_refund, status, nullptr}; return spend_coalesced(c, r); }
+  if (mem == ACT_MEM_HOST && rng_mode == ACT_RNG_PER_LANE && n && n <= c->co_req_max.load()) { CoReq r{CO_REFUND, sk, proof, n, nullptr, nullptr, rng, false, out_refund, status, nullptr}; return spend_coalesced(c, r); }
   return spend_batch(c, n, mem, sk, proof, true, rng, rng_mode, out_refund, status, nullptr);
 }
 

@@ -161,14 +161,26 @@ int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uin
 // by exactly 128 bytes per accepted lane, as the sequential loop would: INTEGRATION.md).
 int act_node_issue_check_batch(act_node* nd, size_t n, const uint8_t* req, uint8_t* status) {
   if (!nd || (n && (!req || !status))) return ACT_ERR_ARG;
+  if (n && n <= nd->co_max.load()) {          // small enough to merge with other threads' calls: one context, no node lock
+    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    const int rc = act_issue_check_batch(c, n, ACT_MEM_HOST, req, status);
+    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    return rc;
+  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   return run(nd, n, [&](size_t k, Shard s) { return act_issue_check_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(req, s.off, 128), status + s.off); });
 }
 int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* req, const uint8_t* c, const uint8_t* status_in,
                               const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!nd || !sk || (n && (!req || !c || !status_in || !rng || !out_resp || !status))) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> node_lock(nd->mu);
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {
+    act_ctx* cx = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    const int rc = act_issue_sign_batch(cx, n, ACT_MEM_HOST, sk, req, c, status_in, rng, rng_mode, out_resp, status);
+    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(cx); }
+    return rc;
+  }
+  std::lock_guard<std::mutex> node_lock(nd->mu);
   const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
   const std::vector<uint8_t> checked(status_in, status_in + n);
   return run(nd, n, [&](size_t k, Shard s) {

@@ -148,8 +148,8 @@ int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
 int act_ctx_set_small_batch_max(act_ctx *ctx, size_t n);
 /* Several threads, ONE context, one proof per call -- what a server built on the crate's single-item API does with the context the
  * Rust binding keeps inside `Params`.  Such callers queue on the context (a call is ~1.7 ms whatever its size: ~600 calls/s between
- * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch / act_refund_batch (ACT_RNG_PER_LANE) calls of at most k proofs
- * from host memory MERGE instead: the caller that finds no merged call running takes every request queued so far with the same
+ * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch, act_refund_batch, act_refund_sign_batch, act_issue_check_batch and
+ * act_issue_sign_batch calls of at most k lanes from host memory (rng: ACT_RNG_PER_LANE, or one lane in either mode) MERGE instead: the caller that finds no merged call running takes every request queued so far with the same
  * key, runs them as one call and hands each caller its own statuses / K' / refunds; requests pile up only while a call runs, nobody
  * waits for company.  Per lane the result is the one the caller's own call would have produced.  0 (default) = off. */
 int act_ctx_set_coalescing(act_ctx *ctx, size_t max_proofs_per_call);
@@ -241,7 +241,7 @@ act_ctx *act_node_ctx(act_node *node, int k);                  /* context k, e.g
 const char *act_node_last_error(const act_node *node);
 int act_node_set_transcript_mode(act_node *node, int mode);
 int act_node_set_host_threads(act_node *node, int per_gpu);    /* host BLAKE3 workers of every context */
-/* act_ctx_set_coalescing on every context, and: act_node_verify_spend_batch / act_node_refund_sign_batch calls of at most
+/* act_ctx_set_coalescing on every context, and: act_node_verify_spend_batch / _refund_sign_batch / _issue_check_batch / _issue_sign_batch calls of at most
  * max_proofs_per_call proofs are no longer cut over the GPUs under the handle's lock -- each goes to one context (round robin) and
  * merges there with the small calls other threads make on the same handle at the same time.  What the Rust binding's single-item
  * `refund` turns into when a server's threads share one `Params`.  0 (default) = off. */

@@ -264,3 +264,51 @@ def test_single_item_refunds_from_many_threads_merge_on_a_node_handle(engine_fac
         assert not isinstance(merged[i], BaseException), merged[i]
         assert merged[i] == alone[i], i
         assert alone[i][0][0] == (7 if i % 5 == 0 else 0) and (alone[i][2] == bytes(128)) == (i % 5 == 0)
+
+
+def test_single_item_issues_from_many_threads_merge_on_a_node_handle(engine_factory, bench_params, oracle):
+    """The Rust binding's `PrivateKey::issue`: act_node_issue_check_batch over ONE request, then act_node_issue_sign_batch
+    (ACT_RNG_SEQUENTIAL, 128 bytes drawn only if the request verified), from eight threads that share a node handle, merging."""
+    import threading
+    from act_amd import capi
+    L, D = 8, 32
+    eng = engine_factory(bench_params, L, max_batch=256, transcript=capi.TRANSCRIPT_DEVICE)
+    sk = eng.private_key_random(shake("ni-sk", 64))
+    pre = eng.pre_issuance_random(shake("ni-pre", 128 * D)); reqs = eng.request(pre, shake("ni-rq", 128 * D))
+    items = []
+    for i in range(D):
+        r = bytearray(reqs[128 * i:128 * (i + 1)])
+        if i % 6 == 0:
+            r[70] ^= 1                                   # k_bar tampered: InvalidIssuanceRequestProof, nothing drawn, nothing signed
+        items.append(bytes(r))
+    node = capi.Node(bench_params, L, devices=(0, 0), max_batch=256, transcript=capi.TRANSCRIPT_DEVICE)
+
+    def issue_one(i):
+        stc = node.issue_check(items[i])
+        rng = shake("ni-r%d" % i, 128) if stc[0] == 0 else b"\0"
+        st2, resp = node.issue_sign(sk, items[i], scb(10 + i), stc, rng, capi.RNG_SEQUENTIAL)
+        return stc, st2, resp
+    try:
+        alone = [issue_one(i) for i in range(D)]
+        node.set_coalescing(4)
+        merged = [None] * D
+
+        def work(t):
+            try:
+                for i in range(t, D, 8):
+                    merged[i] = issue_one(i)
+            except BaseException as e:
+                merged[t] = e
+        th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    finally:
+        node.close()
+    octx = oracle.ctx(bench_params, L)
+    for i in range(D):
+        assert not isinstance(merged[i], BaseException), merged[i]
+        assert merged[i] == alone[i], i
+        so, resp = octx.issue(sk, items[i], scb(10 + i), shake("ni-r%d" % i, 128))
+        assert alone[i][1][0] == so == (1 if i % 6 == 0 else 0) and alone[i][2] == resp
