@@ -1236,9 +1236,9 @@ static int spend_coalesced(act_ctx* c, CoReq& r) {
       else ++it;
     }
     lk.unlock();
-    (void)co_run(c, batch, total);                        // every request of the batch carries the call's return code
+    const int brc = co_run(c, batch, total);              // every request of the batch carries the call's return code
     lk.lock();
-    for (CoReq* q : batch) q->done = true;
+    for (CoReq* q : batch) { if (brc) q->rc = brc; q->done = true; }
     c->co_cv.notify_all();
   }
   c->co_leader = false;                                   // this caller's own request is done: whoever still waits takes over
