@@ -60,7 +60,63 @@ __global__ void __launch_bounds__(256) k_sign_b(SignArgs a) {
   store8(out, enc_a); store_sc(out + 32, e); store_sc(out + 64, gamma); store_sc(out + 96, z);
   if (a.label == LABEL_RESPOND) store_sc(out + 128, load_sc(a.c_amount + (size_t)p * 32));
 }
-void launch_sign_a(const SignArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_sign_a, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
+// The same phase for SHORT launches, eight lanes per signature.  One lane per signature is ~6 200 dependent field operations
+// (2.2 ms) however few signatures there are -- the issuer's single-item calls (one `issue`, one `refund`) are exactly that.  The
+// five points of the transcript do not depend on each other, so five lanes compute one each and encode it:
+//     lane 0   A   = (e+x)^-1 X_A          lane 1   Y_A = (alpha (e+x)^-1) X_A        (a doubling chain each instead of a shared one)
+//     lane 2   X_g = e g + w               lane 3   Y_g = alpha g                      lane 4   X_A (encode only)       lanes 5-7 idle
+// Same values, same bytes; the longest lane is one chain + one encode (~3 500 operations).  Used below SIGN_WIDE_MAX signatures,
+// where even eight lanes per signature leave the chip under-filled.
+// (256-lane blocks: a block's four wavefronts land on the four SIMDs of a CU; with 64-lane blocks 512 of them took twice as long as
+// 1 024 -- two blocks on one SIMD, other SIMDs idle: profiles/r04_sign_probe.txt)
+__global__ void __launch_bounds__(256) k_sign_a_wide(SignArgs a) {
+  IssuerFb fb{a.P};
+  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, p = gid >> 3, role = gid & 7;
+  const bool live = p < a.n && a.status[p < a.n ? p : 0] == 0;    // rng is drawn only after verification (:638-643, :842-846)
+  sc e = sc_zero(), alpha = sc_zero();
+  if (live) {
+    const uint8_t* rng = a.rng + (size_t)a.rng_slot[p] * 128;
+    e = load_wide(rng); alpha = load_wide(rng + 64);              // :643/:649, :846/:852
+  }
+  // the product on g runs in every lane of the wavefront (IssuerFb: the matrix-core look-up takes its table operand from all 64
+  // lanes); lanes that are not role 2 / 3 of a signing lane multiply by zero
+  const sc fs = (live && role == 2) ? e : (live && role == 3) ? alpha : sc_zero();
+  ge pt = fb.mul(ge_identity(), BASE_G, fs);                      // role 3: Y_g (:651 / :854)
+  if (!live || role > 4) return;
+  if (role == 2) pt = ge_add(pt, a.K.w);                          // X_g = e g + w (:646 / :851)
+  if (role == 0 || role == 1 || role == 4) {
+    const ge xa = ge_load(a.xa + (size_t)p * GE_WORDS);
+    if (role == 4) pt = xa;
+    else {
+      const sc inv = sc_invert(sc_add(e, a.K.x));                 // :645 / :849
+      sc s1[1] = {role == 0 ? inv : sc_mul(alpha, inv)};
+      ge acc[1] = {ge_identity()};
+      chain_ct<1>(acc, xa, s1);                                   // A, or Y_A = (alpha (e+x)^-1) X_A (:650 / :853)
+      pt = acc[0];
+    }
+  }
+  // transcript: prefix | [c] | e | A | X_A | X_g | Y_A | Y_g   (:654-657 / :856-859)
+  uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
+  uint8_t* el = tr + a.P.prefix_len[a.label] + (a.label == LABEL_RESPOND ? 40 : 0);
+  uint32_t enc[8];
+  ristretto_encode(enc, pt);
+  const int slot = role == 0 ? 1 : role == 4 ? 2 : role == 2 ? 3 : role == 1 ? 4 : 5;      // after e (slot 0)
+  tr_put_bytes(el + 40 * slot, enc);
+  if (role == 0) {
+    tr_put_prefix(tr, a.P, a.label);
+    if (a.label == LABEL_RESPOND) { sc c = load_sc(a.c_amount + (size_t)p * 32); tr_put_bytes(tr + a.P.prefix_len[a.label], c.v); }
+    tr_put_bytes(el, e.v);
+    uint32_t* stt = a.state + (size_t)p * 24;
+    for (int i = 0; i < 8; i++) { stt[i] = e.v[i]; stt[8 + i] = alpha.v[i]; stt[16 + i] = enc[i]; }
+  }
+}
+constexpr uint32_t SIGN_WIDE_MAX = 8192;
+void launch_sign_a(const SignArgs& a, hipStream_t s) {
+  if (!a.n) return;
+  static const bool no_wide = getenv("ACT_NO_WIDE_SIGN") != nullptr;     // A/B knob
+  if (a.n <= SIGN_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_sign_a_wide, dim3((a.n * 8 + 255) / 256), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_sign_a, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
+}
 void launch_sign_b(const SignArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_sign_b, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 
 // ---- issue, phase A: K1 = k_bar h2 + r_bar h3 - gamma K (:629-630); X_A = g + c h1 + K (:644) --------------

@@ -114,7 +114,7 @@ impl Gpu {
         }
         // The single-item entry points (`refund`, src/lib.rs:781-786) are calls over ONE proof, ~2 ms each whatever happens; the threads
         // of a server that share this `Params` would queue on the handle at ~220 refunds/s between them.  Calls of at most this many
-        // proofs merge with the other threads' instead (each caller still gets exactly its own answer): 64 threads, 4 600 refunds/s
+        // proofs merge with the other threads' instead (each caller still gets exactly its own answer): 64 threads, 5 150 refunds/s
         // (profiles/r04_single_item_server.txt).  ACT_MI355X_COALESCE=0 turns it off.
         let merge: usize = std::env::var("ACT_MI355X_COALESCE").ok().and_then(|s| s.parse().ok()).unwrap_or(64);
         let rc = unsafe { act_node_set_coalescing(node, merge) };
