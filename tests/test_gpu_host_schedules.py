@@ -12,12 +12,13 @@ from conftest import shake, scb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("mode", [0, 1])        # ACT_TRANSCRIPT_HOST, ACT_TRANSCRIPT_DEVICE
-def test_host_and_device_memory_calls_agree_at_sizes_that_split(engine_factory, bench_params, mode):
+@pytest.mark.parametrize("N", [20100, 5000])    # above the small-batch limit (8 192): the pipelined schedule; below: the small-batch one,
+@pytest.mark.parametrize("mode", [0, 1])        # whose copy-in and range kernel go in two halves.  mode: ACT_TRANSCRIPT_HOST, _DEVICE
+def test_host_and_device_memory_calls_agree_at_sizes_that_split(engine_factory, bench_params, mode, N):
     import numpy as np
     import torch
     from act_amd import capi
-    L, D, N = 8, 64, 20100                       # N > the small-batch limit (8 192): the pipelined schedule
+    L, D = 8, 64
     eng = engine_factory(bench_params, L, max_batch=32768, transcript=mode)
     sk = eng.private_key_random(shake("hs-sk", 64))
     pre = eng.pre_issuance_random(shake("hs-pre", 128 * D)); req = eng.request(pre, shake("hs-rq", 128 * D))
