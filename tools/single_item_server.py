@@ -29,7 +29,7 @@ PB = eng.proof_bytes
 items = [np.frombuffer(proofs[PB * i:PB * (i + 1)], np.uint8).copy() for i in range(D)]
 rngs = np.frombuffer(sh("si-r", 128 * D), np.uint8).reshape(D, 128).copy()
 mode = capi.TRANSCRIPT_HOST if (len(sys.argv) > 1 and sys.argv[1] == "host") else capi.TRANSCRIPT_DEVICE
-node = capi.Node(h, L, devices=(0,), max_batch=8192, transcript=mode)
+node = capi.Node(h, L, devices=tuple(int(x) for x in os.environ.get("DEVS", "0").split(",")), max_batch=8192, transcript=mode)
 lib, nd = node.lib, node.nd
 skb = (C.c_uint8 * 64).from_buffer_copy(sk)
 
