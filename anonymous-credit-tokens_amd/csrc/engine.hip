@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 #include "kernels.h"
+#include "coalesce.h"
 #include "../../include/act_mi355x.h"
 
 using namespace act;
@@ -66,6 +67,7 @@ struct Slot {
   size_t last_spend_lanes = 0;
 };
 
+struct CoReq;       // a small call waiting to be merged with others (defined with the entry points that merge)
 struct act_ctx {
   int device = 0, L = 128;
   size_t max_batch = 0;
@@ -103,9 +105,7 @@ struct act_ctx {
   double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
   // coalescing of concurrent callers' small verify / refund calls (act_ctx_set_coalescing; spend_coalesced below)
   std::atomic<size_t> co_req_max{0};   // 0 = off; else: calls of at most this many proofs from host memory may be merged
-  std::mutex co_mu; std::condition_variable co_cv;
-  std::deque<struct CoReq*> co_q;      // requests not yet taken into a merged call
-  bool co_leader = false;              // some caller is running merged calls
+  act::Combiner<struct CoReq>* co = nullptr;     // the queue of requests waiting to be merged (coalesce.h); created with the context
   uint8_t *h_co_proofs = nullptr, *h_co_rng = nullptr, *h_co_out = nullptr;   // pinned gather / scatter buffers of the leader (grow-only)
   size_t h_co_cap = 0;                 // lanes
 };
@@ -591,6 +591,7 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev) return ACT_ERR_ARG;
   act_ctx* c = new act_ctx();
+  c->co = new act::Combiner<CoReq>();
   *out = c;   // returned even on failure so that act_last_error() can be read; the caller destroys it
   // lanes per launch = max_batch * L must stay below 2^31 (kernels index lanes with 32-bit integers)
   if (max_batch > ((size_t)1 << 22)) { c->err = "max_batch above 2^22: lanes per launch (max_batch * L) must stay below 2^31"; return ACT_ERR_ARG; }
@@ -704,6 +705,7 @@ void act_ctx_destroy(act_ctx* c) {
   if (c->d_tables_mf) (void)hipFree(c->d_tables_mf);
   if (c->d_wire_flags) (void)hipFree(c->d_wire_flags);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
+  delete c->co;
   delete c;
 }
 int act_ctx_set_transcript_mode(act_ctx* c, int mode) {
@@ -1218,32 +1220,10 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
 
 static int spend_coalesced(act_ctx* c, CoReq& r) {
   const size_t cap = std::max<size_t>(c->co_req_max.load(), std::min<size_t>(c->max_batch, c->small_max ? c->small_max : c->max_batch));   // lanes per merged call
-  std::unique_lock<std::mutex> lk(c->co_mu);
-  c->co_q.push_back(&r);
-  for (;;) {
-    if (r.done) return r.rc;                              // a leader ran it
-    if (!c->co_leader) break;                             // nobody is leading: this caller does
-    c->co_cv.wait(lk);
-  }
-  c->co_leader = true;
-  while (!r.done) {
-    // the oldest request decides key and kind; every queued request of the same key and kind joins, in arrival order, while it fits
-    std::vector<CoReq*> batch; size_t total = 0;
-    CoReq* first = c->co_q.front();
-    for (auto it = c->co_q.begin(); it != c->co_q.end();) {
-      CoReq* q = *it;
-      if (q->kind == first->kind && (!first->sk || memcmp(q->sk, first->sk, 64) == 0) && (batch.empty() || total + q->n <= cap)) { batch.push_back(q); total += q->n; it = c->co_q.erase(it); }
-      else ++it;
-    }
-    lk.unlock();
-    const int brc = co_run(c, batch, total);              // every request of the batch carries the call's return code
-    lk.lock();
-    for (CoReq* q : batch) { if (brc) q->rc = brc; q->done = true; }
-    c->co_cv.notify_all();
-  }
-  c->co_leader = false;                                   // this caller's own request is done: whoever still waits takes over
-  c->co_cv.notify_all();
-  return r.rc;
+  // the oldest request decides key and kind; every queued request of the same key and kind joins (coalesce.h)
+  return c->co->submit(r, cap,
+                       [](const CoReq& a, const CoReq& b) { return a.kind == b.kind && (!a.sk || memcmp(a.sk, b.sk, 64) == 0); },
+                       [c](const std::vector<CoReq*>& batch, size_t total) { return co_run(c, batch, total); });
 }
 
 int act_ctx_set_coalescing(act_ctx* c, size_t max_proofs_per_call) {

@@ -9,6 +9,7 @@
 //   ACT_RNG_PER_LANE: lane i of a call uses rng + 128 i;  ACT_RNG_SEQUENTIAL: accepted lanes use consecutive slices
 //   every context counts its calls and lanes (act_mock_lanes) so that the test can see all of them were used
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -19,7 +20,7 @@
 #include <vector>
 #include "../../include/act_mi355x.h"
 
-struct act_ctx { int device; int L; size_t lanes = 0; std::string err; };
+struct act_ctx { int device; int L; std::atomic<size_t> lanes{0}; std::string err; };     // (lanes: calls that bypass the node's lock run on several threads)
 struct act_nullifier_set { std::set<std::vector<uint8_t>> keys; std::string err; int device = 0; };
 // failure injection (error-path tests): the device whose nullifier set / whose signature step fails, -1 = none
 static int g_fail_null_device = -1, g_fail_sign_device = -1;
@@ -103,6 +104,7 @@ int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int, const uint8_t* p
   c->lanes += n; for (size_t i = 0; i < n; i++) { emit(out + 160 * i, 160, prer + 96 * i, refund + 128 * i); out[159 + 160 * i] = proof[kPB * i]; status[i] = 0; } return ACT_OK;
 }
 
+#ifndef ACT_MOCK_NO_PARALLEL_FOR      // (the ThreadSanitizer driver links the real csrc/host_pool.cpp instead)
 // the host pool's parallel-for (csrc/host_pool.cpp), here on two threads that take the items from the far end: the dispatcher must
 // not depend on item order
 void act_host_parallel_for(size_t n, size_t grain, int, void (*fn)(void*, size_t, size_t), void* ctx) {
@@ -114,6 +116,7 @@ void act_host_parallel_for(size_t n, size_t grain, int, void (*fn)(void*, size_t
   run(0);
   t.join();
 }
+#endif
 
 int act_ctx_set_coalescing(act_ctx*, size_t) { return ACT_OK; }
 int act_nullifier_set_create(int device, size_t, const uint8_t*, act_nullifier_set** out) { *out = new act_nullifier_set(); (*out)->device = device; return ACT_OK; }
