@@ -231,7 +231,7 @@ int act_refund_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64],
  * the accepted lanes in front of every shard, then all shards sign from their offsets into the stream; refund carries
  * only enc(K') between the two phases.  ACT_RNG_PER_LANE needs no such barrier and is one pass.  A node handle (like a
  * context) may be shared between host threads: every *_batch call takes the handle's lock, so concurrent callers are
- * served one after the other.  act_node_create builds the contexts concurrently (one thread per entry); entries that name
+ * served one after the other (small calls can do better than queue: act_node_set_coalescing below).  act_node_create builds the contexts concurrently (one thread per entry); entries that name
  * the same device share that device's fixed-base tables. */
 typedef struct act_node act_node;
 int act_node_create(const uint8_t h[96], int L, const int *devices, int n_devices, size_t max_batch, act_node **out);
