@@ -49,7 +49,50 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
         for k, i in enumerate(range(0, n, max(1, n // 256))):
             so, ro = ref_o[k]
             assert so == st2[i] and ro == rf[128 * i:128 * i + 128], ("refund mismatch", L, mode, i)
+    # ACT_SOAK_THREADS=T: the same proofs once more as calls of 1 - 5 proofs from T threads that share the context, merging
+    # (act_ctx_set_coalescing): verify with K', refund with per-lane rng, the two-call refund of the Rust binding -- every call's
+    # answer against the batch answers above
+    T = int(os.environ.get("ACT_SOAK_THREADS", "0"))
+    if T:
+        import threading
+        eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
+        st_b, kp_b = eng.verify_spend(sk, t, True)
+        st2_b, rf_b = eng.refund(sk, t, rrng)
+        cuts, i = [], 0
+        while i < n:
+            k = min(n - i, r.randrange(1, 6)); cuts.append((i, k)); i += k
+        errs = []
+        eng.set_coalescing(8)
+        def work(tid):
+            try:
+                for j, (a, k) in enumerate(cuts):
+                    if j % T != tid:
+                        continue
+                    blob = t[pb * a:pb * (a + k)]
+                    what = (a + k) % 3
+                    if what == 0:
+                        s1, kp = eng.verify_spend(sk, blob, True)
+                        assert s1 == st_b[a:a + k] and kp == kp_b[32 * a:32 * (a + k)], ("verify", a, k)
+                    elif what == 1:
+                        s1, rf = eng.refund(sk, blob, rrng[128 * a:128 * (a + k)])
+                        assert s1 == st2_b[a:a + k] and rf == rf_b[128 * a:128 * (a + k)], ("refund", a, k)
+                    else:                                       # verify, then sign what verified (per-lane rng: the same bytes as the fused call)
+                        s1, kp = eng.verify_spend(sk, blob, True)
+                        out = eng.lib.act_refund_sign_batch
+                        import numpy as np
+                        o_rf = np.zeros(128 * k, np.uint8); o_st = np.zeros(k, np.uint8)
+                        p_sk, _k1 = capi._in(sk, 64); p_kp, _k2 = capi._in(kp, 32 * k); p_st, _k3 = capi._in(s1, k); p_r, _k4 = capi._in(rrng[128 * a:128 * (a + k)], 128 * k)
+                        assert out(eng.ctx, k, capi.MEM_HOST, p_sk, p_kp, p_st, p_r, capi.RNG_PER_LANE, o_rf.ctypes.data, o_st.ctypes.data) == 0
+                        assert o_st.tobytes() == st2_b[a:a + k] and o_rf.tobytes() == rf_b[128 * a:128 * (a + k)], ("two-call refund", a, k)
+            except BaseException as e:
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(x,)) for x in range(T)]
+        for x in th: x.start()
+        for x in th: x.join()
+        eng.set_coalescing(0)
+        if errs:
+            raise errs[0]
     hist = {}
     for s_ in st_o: hist[s_] = hist.get(s_, 0) + 1
-    print("L=%d: %d proofs, statuses %s: engine == oracle (both transcript modes, refunds sampled)" % (L, n, dict(sorted(hist.items()))))
+    print("L=%d: %d proofs, statuses %s: engine == oracle (both transcript modes, refunds sampled)%s" % (L, n, dict(sorted(hist.items())), "; %d merged small calls from %d threads == the batch answers" % (len(cuts), T) if T else ""))
     eng.close()
