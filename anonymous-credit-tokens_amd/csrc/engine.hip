@@ -1258,7 +1258,8 @@ static int prove_spend_impl(act_ctx* c, size_t n, int mem, const uint8_t* token,
   // part's kernels (a proof takes ~0.3 us to leave, ~0.9 us to make)
   std::vector<std::pair<size_t, size_t>> sched;          // (offset, lanes)
   for (size_t off = 0; off < n; off += c->max_batch) sched.emplace_back(off, std::min(c->max_batch, n - off));
-  if (mem == ACT_MEM_HOST && !sched.empty() && sched.back().second >= 8192 && !getenv("ACT_NO_TAPER")) {
+  static const bool taper_off = getenv("ACT_NO_TAPER") != nullptr;      // A/B knob, read once
+  if (mem == ACT_MEM_HOST && !sched.empty() && sched.back().second >= 8192 && !taper_off) {
     const size_t off = sched.back().first, l = sched.back().second, t = (l * 5 / 16 + 1023) / 1024 * 1024;
     sched.back() = {off, l - t}; sched.emplace_back(off + l - t, t);
   }
@@ -1351,7 +1352,8 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
   // Device-memory callers: one slot, full-size chunks.
   size_t chunk = std::min(c->max_batch, std::max<size_t>(16384, (n / 4 + 1023) / 1024 * 1024));      // (below 16 384 lanes the kernels no longer fill the chip)
   // (issuance: 352 B per lane, nothing to hide)
-  const bool two_slots = mem == ACT_MEM_HOST && !issuance && c->depth > 1 && n > chunk && !getenv("ACT_NO_TAPER");
+  static const bool taper_off = getenv("ACT_NO_TAPER") != nullptr;      // A/B knob, read once
+  const bool two_slots = mem == ACT_MEM_HOST && !issuance && c->depth > 1 && n > chunk && !taper_off;
   if (!two_slots) chunk = c->max_batch;
   size_t k = 0;
   for (size_t off = 0; off < n; off += chunk, k++) {
