@@ -7,7 +7,8 @@
 //! (src/cbor.rs:105-110, 163-169, 250-268, 422-427, 546-549, 596-602, 656-660), every `Scalar::random` is one 64-byte
 //! `fill_bytes`, and issue / refund draw only for accepted lanes (src/lib.rs:638-643, 842-846).
 //!
-//! The existing single-call signatures are kept (bottom of this file): with the feature on they are batches of one.
+//! The existing single-call signatures are kept (bottom of this file): with the feature on, those the GPU serves faster than one CPU core
+//! (`refund`, `prove_spend`, `PreRefund::to_credit_token`) are batches of one; `request`, `issue`, `PreIssuance::to_credit_token` stay on the CPU.
 use crate::{
     CreditToken, Error, IssuanceRequest, IssuanceResponse, Params, PreIssuance, PreRefund, PrivateKey, PublicKey, Refund,
     SpendProof, L,
@@ -439,26 +440,17 @@ impl PreRefund {
     }
 }
 
-// ---- the kept single-call signatures: batches of one ------------------------------------------------------------------
-// In src/lib.rs the six existing method bodies become `#[cfg(not(feature = "mi355x"))]`; these take their place otherwise.
-#[cfg(feature = "mi355x")]
-impl PreIssuance {
-    pub fn request(&self, params: &Params, rng: impl CryptoRngCore) -> IssuanceRequest {
-        // src/lib.rs:463
-        Self::request_batch(std::slice::from_ref(self), params, rng).pop().unwrap()
-    }
-    pub fn to_credit_token(&self, params: &Params, public: &PublicKey, request: &IssuanceRequest, response: &IssuanceResponse)
-        -> Result<CreditToken, Error> {
-        // src/lib.rs:528-534
-        Self::to_credit_token_batch(std::slice::from_ref(self), params, public, std::slice::from_ref(request), std::slice::from_ref(response)).pop().unwrap()
-    }
-}
+// ---- the kept single-call signatures ------------------------------------------------------------------------------------
+// One item per call is latency, not throughput, and a GPU's latency is a dependent chain on ONE lane.  Measured on an MI355X box
+// (profiles/r04_single_item_latency.txt) against the C port on one of its cores (bench.py cpu_baseline.config1):
+//     request 0.59 ms vs 0.05      issue 2.7 vs 0.25      PreIssuance::to_credit_token 2.6 (CPU: two fixed-base products + DLEQ, ~0.3)
+//     prove_spend 5.9 vs 15.5      refund 3.6 vs 17.3     PreRefund::to_credit_token 3.1 (CPU: 128 scalar multiplications for K')
+// So with the feature on, `refund`, `prove_spend` and `PreRefund::to_credit_token` become batches of one on the GPU (and merge with
+// other threads' calls: `act_node_set_coalescing` above) -- in src/lib.rs THOSE three bodies become `#[cfg(not(feature = "mi355x"))]`
+// -- while `request`, `issue` and `PreIssuance::to_credit_token` keep the crate's CPU bodies; their `*_batch` siblings above are
+// where the GPU takes over (24 M issues/s, 112 M requests/s).
 #[cfg(feature = "mi355x")]
 impl PrivateKey {
-    pub fn issue(&self, params: &Params, request: &IssuanceRequest, c: Scalar, rng: impl CryptoRngCore) -> Result<IssuanceResponse, Error> {
-        // src/lib.rs:621-627
-        self.issue_batch(params, std::slice::from_ref(request), &[c], rng).pop().unwrap()
-    }
     pub fn refund(&self, params: &Params, spend_proof: &SpendProof, rng: impl CryptoRngCore) -> Result<Refund, Error> {
         // src/lib.rs:781-786
         self.refund_batch(params, std::slice::from_ref(spend_proof), rng).pop().unwrap()

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Latency of every entry point over ONE item from host memory (the crate's call shape, benches/benchmark.rs:166-212), L = 128,
+device transcripts, median of 9 -- beside bench.py's cpu_baseline.config1 (the C port on one core) this says which single-item calls
+a deployment should leave on the CPU."""
+import hashlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from act_amd import capi
+
+sh = lambda l, k: hashlib.shake_256(l.encode()).digest(k)
+h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
+mode = capi.TRANSCRIPT_HOST if (len(sys.argv) > 1 and sys.argv[1] == "host") else capi.TRANSCRIPT_DEVICE
+eng = capi.Engine(h, 128, max_batch=4096, transcript=mode)
+sk = eng.private_key_random(sh("sl-sk", 64))
+pre = eng.pre_issuance_random(sh("sl-pre", 128)); req = eng.request(pre, sh("sl-rq", 128))
+c = (777).to_bytes(32, "little")
+st, resp = eng.issue(sk, req, c, sh("sl-ir", 128))
+st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+s = (123).to_bytes(32, "little")
+st, proof, prer = eng.prove_spend(tok, s, sh("sl-pr", eng.prove_rng_bytes))
+st, rf = eng.refund(sk, proof, sh("sl-rr", 128))
+assert st == bytes(1)
+calls = [("request", lambda: eng.request(pre, sh("sl-rq", 128))),
+         ("issue", lambda: eng.issue(sk, req, c, sh("sl-ir", 128))),
+         ("issuance_to_credit_token", lambda: eng.issuance_to_credit_token(pre, sk[32:], req, resp)),
+         ("prove_spend", lambda: eng.prove_spend(tok, s, sh("sl-pr", eng.prove_rng_bytes))),
+         ("verify_spend", lambda: eng.verify_spend(sk, proof)),
+         ("refund", lambda: eng.refund(sk, proof, sh("sl-rr", 128))),
+         ("refund_to_credit_token", lambda: eng.refund_to_credit_token(prer, proof, rf, sk[32:]))]
+print("one item per call, %s transcripts, ms (median of 9):" % ("host" if mode == capi.TRANSCRIPT_HOST else "device"))
+for name, f in calls:
+    f(); ts = []
+    for _ in range(9):
+        t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
+    print("  %-26s %.2f" % (name, 1e3 * sorted(ts)[4]))
