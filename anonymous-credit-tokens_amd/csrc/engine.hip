@@ -217,6 +217,8 @@ void host_hash_many(const act_ctx* c, const uint8_t* msgs, size_t stride, uint32
 int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_t stride, uint32_t len, uint32_t n) {
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) {
     HashArgs h{d_msgs, stride, len, n, sl.d_xof, nullptr};
+    // few long messages (a small prove_spend / verify call's "spend" transcripts): sixteen lanes per message (k_hash_xof_par)
+    if (len >= 2048 && n <= 4096) return prof_launch(c, sl, prof_id, n, [&] { launch_hash_par(h, sl.stream); });
     return prof_launch(c, sl, prof_id, n, [&] { launch_hash(h, sl.stream); });
   }
   size_t bytes = (size_t)n * stride;

@@ -444,7 +444,7 @@ impl PreRefund {
 // One item per call is latency, not throughput, and a GPU's latency is a dependent chain on ONE lane.  Measured on an MI355X box
 // (profiles/r04_single_item_latency.txt) against the C port on one of its cores (bench.py cpu_baseline.config1):
 //     request 0.59 ms vs 0.05      issue 2.7 vs 0.25      PreIssuance::to_credit_token 2.6 vs 0.21
-//     prove_spend 5.9 vs 15.5      refund 3.6 vs 17.3     PreRefund::to_credit_token 3.1 vs 5.0
+//     prove_spend 3.6 vs 15.5      refund 3.6 vs 17.3     PreRefund::to_credit_token 3.1 vs 5.0
 // So with the feature on, `refund`, `prove_spend` and `PreRefund::to_credit_token` become batches of one on the GPU (and merge with
 // other threads' calls: `act_node_set_coalescing` above) -- in src/lib.rs THOSE three bodies become `#[cfg(not(feature = "mi355x"))]`
 // -- while `request`, `issue` and `PreIssuance::to_credit_token` keep the crate's CPU bodies; their `*_batch` siblings above are
