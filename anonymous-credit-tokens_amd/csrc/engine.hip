@@ -1371,8 +1371,8 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
     else { if ((rc = dev_in(c, sl, 3, mem, proofs + off * pb, (size_t)m * pb, &a.proofs))) return rc; }
     if (two_slots && (rc = copy_chain_record(c, sl, false))) return rc;
     if ((rc = dev_out_begin(c, sl, 2, mem, out_token + off * 160, (size_t)m * 160, &a.out_token))) return rc;
+    HIPCK(c, hipMemsetAsync(sl.d_flags, 0, (size_t)m * 4, sl.stream));      // the kernels OR their flags in
     if (!issuance) {
-      HIPCK(c, hipMemsetAsync(sl.d_flags, 0, (size_t)m * 4, sl.stream));
       if ((rc = prof_launch(c, sl, PK_CLIENT, (uint64_t)m * c->L, [&] { launch_client_decode_com(a, sl.stream); }))) return rc;
     }
     if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_a(a, sl.stream); }))) return rc;
