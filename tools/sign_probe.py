@@ -28,7 +28,7 @@ torch.cuda.synchronize()
 print("ACT_NO_WIDE_SIGN" in os.environ and "one lane per signature" or "eight lanes per signature up to 8 192")
 row = []
 digests = []
-for n in (1, 64, 1024, 2048, 4096, 8192, 16384, 65536):
+for n in (1, 64, 1024, 2048, 4096, 8192, 16384, 24576, 32768, 49152, 65536):
     best = 1e9
     for _ in range(9):
         torch.cuda.synchronize(); t = time.perf_counter()
