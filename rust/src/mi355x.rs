@@ -7,8 +7,7 @@
 //! (src/cbor.rs:105-110, 163-169, 250-268, 422-427, 546-549, 596-602, 656-660), every `Scalar::random` is one 64-byte
 //! `fill_bytes`, and issue / refund draw only for accepted lanes (src/lib.rs:638-643, 842-846).
 //!
-//! The existing single-call signatures are kept (bottom of this file): with the feature on, those the GPU serves faster than one CPU core
-//! (`refund`, `prove_spend`, `PreRefund::to_credit_token`) are batches of one; `request`, `issue`, `PreIssuance::to_credit_token` stay on the CPU.
+//! The existing single-call signatures are kept (bottom of this file): with the feature on they are batches of one.
 use crate::{
     CreditToken, Error, IssuanceRequest, IssuanceResponse, Params, PreIssuance, PreRefund, PrivateKey, PublicKey, Refund,
     SpendProof, L,
@@ -440,17 +439,32 @@ impl PreRefund {
     }
 }
 
-// ---- the kept single-call signatures ------------------------------------------------------------------------------------
-// One item per call is latency, not throughput, and a GPU's latency is a dependent chain on ONE lane.  Measured on an MI355X box
-// (profiles/r04_single_item_latency.txt) against the C port on one of its cores (bench.py cpu_baseline.config1):
-//     request 0.59 ms vs 0.05      issue 2.7 vs 0.25      PreIssuance::to_credit_token 2.6 vs 0.21
-//     prove_spend 3.6 vs 15.5      refund 3.6 vs 17.3     PreRefund::to_credit_token 3.1 vs 5.0
-// So with the feature on, `refund`, `prove_spend` and `PreRefund::to_credit_token` become batches of one on the GPU (and merge with
-// other threads' calls: `act_node_set_coalescing` above) -- in src/lib.rs THOSE three bodies become `#[cfg(not(feature = "mi355x"))]`
-// -- while `request`, `issue` and `PreIssuance::to_credit_token` keep the crate's CPU bodies; their `*_batch` siblings above are
-// where the GPU takes over (24 M issues/s, 112 M requests/s).
+// ---- the kept single-call signatures: batches of one ------------------------------------------------------------------
+// In src/lib.rs the six existing method bodies become `#[cfg(not(feature = "mi355x"))]`; these take their place otherwise: with the
+// feature on, nothing of the protocol runs on the CPU.  One item per call is latency, not throughput, and a GPU's latency is a
+// dependent chain on a few lanes (profiles/r04_single_item_latency.txt; the C port on one core of the same box in brackets):
+//     request 0.59 ms (0.05)    issue 2.7 (0.25)    PreIssuance::to_credit_token 2.3 (0.21)
+//     prove_spend 3.6 (15.5)    refund 3.5 (17.3)   PreRefund::to_credit_token 3.0 (5.0)
+// Under load the small calls of the threads sharing this `Params` merge (`act_node_set_coalescing` above), and the `*_batch`
+// siblings are where the rates are (24 M issues/s, 112 M requests/s, 520 k refunds/s).
+#[cfg(feature = "mi355x")]
+impl PreIssuance {
+    pub fn request(&self, params: &Params, rng: impl CryptoRngCore) -> IssuanceRequest {
+        // src/lib.rs:463
+        Self::request_batch(std::slice::from_ref(self), params, rng).pop().unwrap()
+    }
+    pub fn to_credit_token(&self, params: &Params, public: &PublicKey, request: &IssuanceRequest, response: &IssuanceResponse)
+        -> Result<CreditToken, Error> {
+        // src/lib.rs:528-534
+        Self::to_credit_token_batch(std::slice::from_ref(self), params, public, std::slice::from_ref(request), std::slice::from_ref(response)).pop().unwrap()
+    }
+}
 #[cfg(feature = "mi355x")]
 impl PrivateKey {
+    pub fn issue(&self, params: &Params, request: &IssuanceRequest, c: Scalar, rng: impl CryptoRngCore) -> Result<IssuanceResponse, Error> {
+        // src/lib.rs:621-627
+        self.issue_batch(params, std::slice::from_ref(request), &[c], rng).pop().unwrap()
+    }
     pub fn refund(&self, params: &Params, spend_proof: &SpendProof, rng: impl CryptoRngCore) -> Result<Refund, Error> {
         // src/lib.rs:781-786
         self.refund_batch(params, std::slice::from_ref(spend_proof), rng).pop().unwrap()
