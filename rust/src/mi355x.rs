@@ -444,7 +444,7 @@ impl PreRefund {
 // feature on, nothing of the protocol runs on the CPU.  One item per call is latency, not throughput, and a GPU's latency is a
 // dependent chain on a few lanes (profiles/r04_single_item_latency.txt; the C port on one core of the same box in brackets):
 //     request 0.59 ms (0.05)    issue 2.7 (0.25)    PreIssuance::to_credit_token 2.3 (0.21)
-//     prove_spend 3.6 (15.5)    refund 3.5 (17.3)   PreRefund::to_credit_token 3.0 (5.0)
+//     prove_spend 3.1 (15.5)    refund 3.5 (17.3)   PreRefund::to_credit_token 3.0 (5.0)
 // Under load the small calls of the threads sharing this `Params` merge (`act_node_set_coalescing` above), and the `*_batch`
 // siblings are where the rates are (24 M issues/s, 112 M requests/s, 520 k refunds/s).
 #[cfg(feature = "mi355x")]
