@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACT_LIB_PATH") or os.path.join(_HERE, "libact_mi355x.so")   # override: tuning A/B runs only
 
 MEM_HOST, MEM_DEVICE = 0, 1
-RNG_PER_LANE, RNG_SEQUENTIAL = 0, 1
+RNG_PER_LANE, RNG_SEQUENTIAL, RNG_CALLBACK = 0, 1, 2
 TRANSCRIPT_HOST, TRANSCRIPT_DEVICE = 0, 1
 _ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO_DEVICE"}
 
@@ -33,6 +33,9 @@ EXPORTS = [
     "act_node_issue_check_batch", "act_node_issue_sign_batch", "act_node_refund_sign_batch",
     "act_node_nullifier_set_create", "act_node_nullifier_set_destroy", "act_node_nullifier_set_len", "act_node_nullifier_set_last_error",
     "act_node_nullifier_check_and_insert_batch",
+    "act_verify_spend_cbor_keys_batch", "act_node_verify_spend_cbor_keys_batch", "act_refund_sign_cbor_batch", "act_refund_cbor_batch",
+    "act_node_refund_sign_cbor_batch", "act_node_refund_cbor_batch", "act_redeem_cbor_batch", "act_node_redeem_cbor_batch",
+    "act_node_set_balance", "act_node_device_stats", "act_node_balance_state", "act_debug_set_slowdown", "act_debug_fail_next_signs",
 ]
 CBOR_TYPES = {"IssuanceRequest": 1, "IssuanceResponse": 2, "SpendProof": 3, "Refund": 4, "PrivateKey": 5, "PublicKey": 6,
               "PreIssuance": 7, "CreditToken": 8, "PreRefund": 9}
@@ -167,8 +170,63 @@ def load() -> C.CDLL:
     lib.act_node_nullifier_set_last_error.argtypes = [vp]
     lib.act_node_nullifier_set_last_error.restype = C.c_char_p
     lib.act_node_nullifier_check_and_insert_batch.argtypes = [vp, sz, u8p, sz, u8p, u8p]
+    lib.act_verify_spend_cbor_keys_batch.argtypes = [vp, sz, i32, u8p, u8p, vp, u8p, u8p, u8p]
+    lib.act_node_verify_spend_cbor_keys_batch.argtypes = [vp, sz, u8p, u8p, vp, u8p, u8p, u8p]
+    lib.act_refund_sign_cbor_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_refund_cbor_batch.argtypes = [vp, sz, i32, u8p, u8p, vp, u8p, i32, u8p, u8p]
+    lib.act_node_refund_sign_cbor_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, i32, u8p, u8p]
+    lib.act_node_refund_cbor_batch.argtypes = [vp, sz, u8p, u8p, vp, u8p, i32, u8p, u8p]
+    lib.act_redeem_cbor_batch.argtypes = [vp, vp, sz, i32, u8p, u8p, vp, u8p, i32, u8p, u8p]
+    lib.act_node_redeem_cbor_batch.argtypes = [vp, vp, sz, u8p, u8p, vp, u8p, i32, u8p, u8p]
+    lib.act_node_set_balance.argtypes = [vp, i32, i32]
+    lib.act_node_device_stats.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.act_node_balance_state.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.act_debug_set_slowdown.argtypes = [vp, C.c_uint32]
+    lib.act_debug_fail_next_signs.argtypes = [vp, i32]
     _lib = lib
     return lib
+
+
+RNG_DRAW_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class RngSource(C.Structure):
+    """act_rng_source (ACT_RNG_CALLBACK): the library draws 128 bytes per SIGNED lane through `draw`, once, after the verdicts."""
+    _fields_ = [("draw", RNG_DRAW_FN), ("rng_ctx", C.c_void_p)]
+
+
+class ReplayRng:
+    """A generator that hands out a fixed byte string (what tests/parity.rs feeds the crate); `pos` = bytes consumed so far."""
+
+    def __init__(self, data: bytes):
+        self.data, self.pos, self.draws = bytes(data), 0, []
+
+        def draw(_ctx, dst, n):
+            assert self.pos + n <= len(self.data), "generator exhausted"
+            C.memmove(dst, self.data[self.pos:self.pos + n], n)
+            self.pos += n
+            self.draws.append(n)
+        self._cb = RNG_DRAW_FN(draw)
+        self.source = RngSource(self._cb, None)
+
+    @property
+    def ptr(self):
+        return C.addressof(self.source)
+
+
+def _msgs(messages):
+    """list of byte strings -> (blob pointer, keep-alive, offsets array)"""
+    n = len(messages)
+    offs = np.zeros(n + 1, np.uint64); offs[1:] = np.cumsum([len(m) for m in messages], dtype=np.uint64)
+    p, keep = _in(b"".join(messages) + b"\0")
+    return p, keep, offs
+
+
+def _rng_arg(rng):
+    """bytes -> pointer; ReplayRng -> pointer to its act_rng_source (rng_mode must then be RNG_CALLBACK)"""
+    if isinstance(rng, ReplayRng):
+        return rng.ptr, rng
+    return _in(rng)
 
 
 def _in(x, nbytes=None):
@@ -401,7 +459,7 @@ class Engine:
     def redeem(self, nullifier_set, sk: bytes, proofs: bytes, rng: bytes, rng_mode: int = RNG_PER_LANE):
         """verify -> nullifier check-and-insert -> sign: statuses (3 = DoubleSpendError) and refunds."""
         n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
-        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _rng_arg(rng)
         self._ck(self.lib.act_redeem_batch(self.ctx, nullifier_set.h, n, MEM_HOST, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
 
@@ -422,6 +480,51 @@ class Engine:
     def verify_spend_cbor_ptr(self, sk: bytes, n: int, mem: int, p_cbor: int, p_offsets: int, p_status: int, p_kprime: int = 0):
         ps, ks = _in(sk, 64)
         self._ck(self.lib.act_verify_spend_cbor_batch(self.ctx, n, mem, ps, p_cbor, p_offsets or None, p_status, p_kprime or None))
+
+    def verify_spend_cbor_keys(self, sk: bytes, messages: list):
+        """-> (statuses, enc(K') per message, nullifier `k` per message as it stood on the wire)"""
+        n = len(messages); p0, k0, offs = _msgs(messages)
+        st = np.zeros(n, np.uint8); kp = np.zeros(32 * n, np.uint8); nul = np.zeros(32 * n, np.uint8); ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_verify_spend_cbor_keys_batch(self.ctx, n, MEM_HOST, ps, p0, offs.ctypes.data, st.ctypes.data, kp.ctypes.data, nul.ctypes.data))
+        return st.tobytes(), kp.tobytes(), nul.tobytes()
+
+    def refund_cbor(self, sk: bytes, messages: list, rng, rng_mode: int = RNG_PER_LANE):
+        """CBOR SpendProof messages in -> (statuses, list of CBOR Refund messages; b"" for a lane that was not signed)"""
+        n = len(messages); p0, k0, offs = _msgs(messages); ml = self.cbor_size("Refund")
+        st = np.zeros(n, np.uint8); out = np.zeros(ml * n, np.uint8); ps, ks = _in(sk, 64); pr, kr = _rng_arg(rng)
+        self._ck(self.lib.act_refund_cbor_batch(self.ctx, n, MEM_HOST, ps, p0, offs.ctypes.data, pr, rng_mode, out.ctypes.data, st.ctypes.data))
+        b = out.tobytes()
+        assert all(st[i] == 0 or not out[i * ml:(i + 1) * ml].any() for i in range(n)), "a failed lane's slot is not zero"
+        return st.tobytes(), [b[i * ml:(i + 1) * ml] if st[i] == 0 else b"" for i in range(n)]
+
+    def refund_sign_cbor(self, sk: bytes, kprime: bytes, status_in: bytes, rng, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(status_in); ml = self.cbor_size("Refund"); st = np.zeros(n, np.uint8); out = np.zeros(ml * n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(kprime, 32 * n); p1, k1 = _in(status_in, n); pr, kr = _rng_arg(rng)
+        self._ck(self.lib.act_refund_sign_cbor_batch(self.ctx, n, MEM_HOST, ps, p0, p1, pr, rng_mode, out.ctypes.data, st.ctypes.data))
+        b = out.tobytes()
+        return st.tobytes(), [b[i * ml:(i + 1) * ml] if st[i] == 0 else b"" for i in range(n)]
+
+    def redeem_cbor(self, nullifier_set, sk: bytes, messages: list, rng, rng_mode: int = RNG_SEQUENTIAL, raw: bool = False):
+        """wire bytes -> verify -> nullifier check-and-insert -> sign -> wire bytes.  raw=True: (rc, statuses, out bytes), no exception."""
+        n = len(messages); p0, k0, offs = _msgs(messages); ml = self.cbor_size("Refund")
+        st = np.zeros(n, np.uint8); out = np.full(ml * n, 7 if raw else 0, np.uint8); ps, ks = _in(sk, 64); pr, kr = _rng_arg(rng)
+        rc = self.lib.act_redeem_cbor_batch(self.ctx, nullifier_set.h, n, MEM_HOST, ps, p0, offs.ctypes.data, pr, rng_mode, out.ctypes.data, st.ctypes.data)
+        if raw:
+            return rc, st.tobytes(), out.tobytes()
+        self._ck(rc)
+        b = out.tobytes()
+        return st.tobytes(), [b[i * ml:(i + 1) * ml] if st[i] == 0 else b"" for i in range(n)]
+
+    def wire_ptr(self, fn: str, sk: bytes, n: int, mem: int, p_cbor: int, p_offsets: int, p_rng: int, rng_mode: int, p_out: int, p_status: int, nullifier_set=None):
+        """act_refund_cbor_batch / act_redeem_cbor_batch on raw pointers of either kind (device-memory callers)"""
+        ps, ks = _in(sk, 64)
+        if fn == "refund":
+            self._ck(self.lib.act_refund_cbor_batch(self.ctx, n, mem, ps, p_cbor, p_offsets or None, p_rng, rng_mode, p_out, p_status))
+        else:
+            self._ck(self.lib.act_redeem_cbor_batch(self.ctx, nullifier_set.h, n, mem, ps, p_cbor, p_offsets or None, p_rng, rng_mode, p_out, p_status))
+
+    def set_slowdown(self, ns_per_lane: int):
+        self._ck(self.lib.act_debug_set_slowdown(self.ctx, ns_per_lane))
 
     # ---- device-memory batch calls (raw device pointers) -----------------------------------------
     def verify_spend_dev(self, sk: bytes, n: int, d_proofs: int, d_status: int, d_kprime: int = 0):
@@ -574,7 +677,7 @@ class Node:
 
     def redeem(self, nullifier_set, sk: bytes, proofs: bytes, rng: bytes, rng_mode: int = RNG_SEQUENTIAL):
         n = len(proofs) // self.proof_bytes; out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
-        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _in(rng)
+        ps, ks = _in(sk, 64); p0, k0 = _in(proofs, self.proof_bytes * n); p1, k1 = _rng_arg(rng)
         self._ck(self.lib.act_node_redeem_batch(self.nd, nullifier_set.h, n, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
 
@@ -599,6 +702,59 @@ class Node:
         p0, k0 = _in(prerefund, 96 * n); p1, k1 = _in(proofs, self.proof_bytes * n); p2, k2 = _in(refund, 128 * n); pw, kw = _in(w, 32)
         self._ck(self.lib.act_node_refund_to_credit_token_batch(self.nd, n, p0, p1, p2, pw, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
+
+
+    def _wire(self, messages):
+        p0, k0, offs = _msgs(messages)
+        return p0, k0, offs, self.lib.act_cbor_size(self.lib.act_node_ctx(self.nd, 0), CBOR_TYPES["Refund"])
+
+    def verify_spend_cbor_keys(self, sk: bytes, messages: list):
+        n = len(messages); p0, k0, offs = _msgs(messages)
+        st = np.zeros(n, np.uint8); kp = np.zeros(32 * n, np.uint8); nul = np.zeros(32 * n, np.uint8); ps, ks = _in(sk, 64)
+        self._ck(self.lib.act_node_verify_spend_cbor_keys_batch(self.nd, n, ps, p0, offs.ctypes.data, st.ctypes.data, kp.ctypes.data, nul.ctypes.data))
+        return st.tobytes(), kp.tobytes(), nul.tobytes()
+
+    def refund_cbor(self, sk: bytes, messages: list, rng, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(messages); p0, k0, offs, ml = self._wire(messages)
+        st = np.zeros(n, np.uint8); out = np.zeros(ml * n, np.uint8); ps, ks = _in(sk, 64); pr, kr = _rng_arg(rng)
+        self._ck(self.lib.act_node_refund_cbor_batch(self.nd, n, ps, p0, offs.ctypes.data, pr, rng_mode, out.ctypes.data, st.ctypes.data))
+        b = out.tobytes()
+        return st.tobytes(), [b[i * ml:(i + 1) * ml] if st[i] == 0 else b"" for i in range(n)]
+
+    def refund_sign_cbor(self, sk: bytes, kprime: bytes, status_in: bytes, rng, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(status_in); ml = self.lib.act_cbor_size(self.lib.act_node_ctx(self.nd, 0), CBOR_TYPES["Refund"])
+        st = np.zeros(n, np.uint8); out = np.zeros(ml * n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(kprime, 32 * n); p1, k1 = _in(status_in, n); pr, kr = _rng_arg(rng)
+        self._ck(self.lib.act_node_refund_sign_cbor_batch(self.nd, n, ps, p0, p1, pr, rng_mode, out.ctypes.data, st.ctypes.data))
+        b = out.tobytes()
+        return st.tobytes(), [b[i * ml:(i + 1) * ml] if st[i] == 0 else b"" for i in range(n)]
+
+    def redeem_cbor(self, nullifier_set, sk: bytes, messages: list, rng, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(messages); p0, k0, offs, ml = self._wire(messages)
+        st = np.zeros(n, np.uint8); out = np.zeros(ml * n, np.uint8); ps, ks = _in(sk, 64); pr, kr = _rng_arg(rng)
+        self._ck(self.lib.act_node_redeem_cbor_batch(self.nd, nullifier_set.h, n, ps, p0, offs.ctypes.data, pr, rng_mode, out.ctypes.data, st.ctypes.data))
+        b = out.tobytes()
+        return st.tobytes(), [b[i * ml:(i + 1) * ml] if st[i] == 0 else b"" for i in range(n)]
+
+    def set_balance(self, weighted: bool = True, tail_64ths: int = -1):
+        self._ck(self.lib.act_node_set_balance(self.nd, 1 if weighted else 0, tail_64ths))
+
+    def device_stats(self) -> list:
+        """per context: weight (relative speed, mean 1) and what the most recent cut call gave it"""
+        out = []
+        for k in range(self.device_count()):
+            w, s = C.c_double(0), C.c_double(0); la, ca = C.c_uint64(0), C.c_uint64(0)
+            self._ck(self.lib.act_node_device_stats(self.nd, k, C.byref(w), C.byref(la), C.byref(s), C.byref(ca)))
+            out.append({"weight": w.value, "lanes": la.value, "seconds": s.value, "calls": ca.value})
+        return out
+
+    def balance_state(self) -> dict:
+        sp, tf = C.c_double(0), C.c_double(0)
+        self._ck(self.lib.act_node_balance_state(self.nd, C.byref(sp), C.byref(tf)))
+        return {"spread": sp.value, "tail_fraction": tf.value}
+
+    def ctx_handle(self, k: int):
+        return self.lib.act_node_ctx(self.nd, k)
 
 
 class NullifierSet:

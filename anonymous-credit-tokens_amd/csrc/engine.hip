@@ -19,6 +19,7 @@
 #include <vector>
 #include "kernels.h"
 #include "coalesce.h"
+#include "rng_source.h"
 #include "../../include/act_mi355x.h"
 
 using namespace act;
@@ -108,6 +109,8 @@ struct act_ctx {
   act::Combiner<struct CoReq>* co = nullptr;     // the queue of requests waiting to be merged (coalesce.h); created with the context
   uint8_t *h_co_proofs = nullptr, *h_co_rng = nullptr, *h_co_out = nullptr;   // pinned gather / scatter buffers of the leader (grow-only)
   size_t h_co_cap = 0;                 // lanes
+  std::atomic<uint32_t> debug_ns_per_lane{0};    // act_debug_set_slowdown (test hook of the node dispatcher's load balance)
+  std::atomic<int> debug_fail_signs{0};          // act_debug_fail_next_signs (test hook of the redeem failure contract)
 };
 
 namespace {
@@ -465,7 +468,11 @@ int finish_call(act_ctx* c, size_t n) {
 struct Call {
   act_ctx* c; size_t n; std::unique_lock<std::mutex> lk; bool finished = false;
   Call(act_ctx* c_, size_t n_) : c(c_), n(n_), lk(c_->mu) {}
-  int finish() { finished = true; return finish_call(c, n); }
+  void slow() const {           // act_debug_set_slowdown: this context as a slower GPU
+    const uint32_t ns = c->debug_ns_per_lane.load();
+    if (ns && n) std::this_thread::sleep_for(std::chrono::nanoseconds((uint64_t)ns * n));
+  }
+  int finish() { finished = true; slow(); return finish_call(c, n); }
   ~Call() {
     if (finished) return;
     const std::string first = c->err;
@@ -724,6 +731,7 @@ int act_build_has_ct_secret_tables(void) {
 #endif
 }
 int act_ctx_set_small_batch_max(act_ctx* c, size_t n) { if (!c) return ACT_ERR_ARG; std::lock_guard<std::mutex> lk(c->mu); c->small_max = n; return ACT_OK; }
+int act_debug_set_slowdown(act_ctx* c, uint32_t ns_per_lane) { if (!c) return ACT_ERR_ARG; c->debug_ns_per_lane.store(ns_per_lane); return ACT_OK; }
 int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
 int act_ctx_set_host_threads(act_ctx* c, int n) { if (!c || n < 0) return ACT_ERR_ARG; c->host_threads = n; return ACT_OK; }
 // copied under the context's lock into a buffer of the calling thread (another thread's failing call may rewrite c->err at any
@@ -905,8 +913,10 @@ int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], c
 
 // Proofs that arrive as CBOR wire bytes (act_verify_spend_cbor_batch, cbor_impl.inc): every chunk's messages are copied /
 // read where they are and unframed into raw records by a kernel on the chunk's own stream, in front of k_spend_prep.
-struct WireSrc { const uint8_t* cbor; const uint64_t* offsets; size_t msg_len; };
+struct WireSrc { const uint8_t* cbor; const uint64_t* offsets; size_t msg_len; uint8_t* out_nullifier; };      // out_nullifier (nullable): the caller's n*32 array for the `k` fields
 static int wire_unframe_chunk(act_ctx* c, Slot& sl, const WireSrc& w, int mem, size_t off, uint32_t m, const uint8_t** d_records);     // cbor_impl.inc
+static int copy_chain_wait(act_ctx* c, Slot& sl, bool out);        // (defined with client_batch below)
+static int copy_chain_record(act_ctx* c, Slot& sl, bool out);
 
 // ---- the small-batch schedule (spend_lanes.h) ----------------------------------------------------------------------------------
 // Every kernel of a call goes on the stream of its kind, so that the per-proof kernels run NEXT TO the range kernel instead of in
@@ -968,8 +978,10 @@ struct SmallTicket {
 };
 }  // namespace
 
+// d_ready (nullable): the proofs as records already in device memory, written by work queued on slot 0's stream (a wire-bytes call's
+// unframing kernel); `proof` / the copy in are then not used, everything else (outputs, rng) still follows `mem`
 static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proof, bool sign, const uint8_t* rng, int rng_mode, uint8_t* out_refund,
-                              uint8_t* status, uint8_t* out_kprime) {
+                              uint8_t* status, uint8_t* out_kprime, const uint8_t* d_ready = nullptr) {
   SmallTicket ticket(SmallGate::of(c->device));      // held until this call's work has left the GPU (sync_all below)
   const SpendTranscript st{c->L};
   const size_t pb = ProofLayout{c->L}.bytes(), L = (size_t)c->L;
@@ -983,7 +995,12 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   const bool host_tr = c->tr_mode == ACT_TRANSCRIPT_HOST;
   // device views of the caller's arrays (staged on slot 0 for host memory; the copies themselves go piece by piece below)
   const uint8_t* d_proofs = proof; uint8_t *d_kprime = out_kprime, *d_out = out_refund;
-  if (mem == ACT_MEM_HOST) { if ((rc = stage_reserve(c, sl, 0, n * pb))) return rc; d_proofs = sl.d_stage[0]; }
+  const bool copy_in = mem == ACT_MEM_HOST && !d_ready;
+  if (d_ready) {
+    d_proofs = d_ready;
+    if ((rc = copy_chain_record(c, sl, false))) return rc;            // the unframing kernel on slot 0's stream ...
+    HIPCK(c, hipStreamWaitEvent(s_x, sl.cp_in_ev, 0));                // ... precedes everything that hangs on SM_IN
+  } else if (copy_in) { if ((rc = stage_reserve(c, sl, 0, n * pb))) return rc; d_proofs = sl.d_stage[0]; }
   if (out_kprime && (rc = dev_out_begin(c, sl, 2, mem, out_kprime, n * 32, &d_kprime))) return rc;
   if (sign && (rc = dev_out_begin(c, sl, 4, mem, out_refund, n * 128, &d_out))) return rc;
   if (host_tr) {
@@ -1002,7 +1019,7 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   std::vector<SpendArgs> args(K);
   for (size_t k = 0; k < K; k++) {
     const size_t off = k * S, m = std::min(S, n - off);
-    if (mem == ACT_MEM_HOST) {
+    if (copy_in) {
       hipError_t ce = hipSuccess;
       if ((rc = prof_launch_on(c, sl, s_x, PK_COPY_H2D, m * pb, [&] { ce = hipMemcpyAsync(sl.d_stage[0] + off * pb, proof + off * pb, m * pb, hipMemcpyHostToDevice, s_x); }))) return rc;
       HIPCK(c, ce);
@@ -1075,7 +1092,13 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
 static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
                               int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime, const WireSrc* wire = nullptr) {
   int rc = set_key(c, sk); if (rc) return rc;
-  if (!wire && n && n <= c->small_max && n <= c->max_batch) return spend_small_locked(c, n, mem, proof, sign, rng, rng_mode, out_refund, status, out_kprime);
+  if (n && n <= c->small_max && n <= c->max_batch) {
+    if (!wire) return spend_small_locked(c, n, mem, proof, sign, rng, rng_mode, out_refund, status, out_kprime);
+    // wire bytes: all n messages are unframed on slot 0's stream, the small-batch schedule starts from those records
+    const uint8_t* d_records = nullptr;
+    if ((rc = wire_unframe_chunk(c, c->slots[0], *wire, mem, 0, (uint32_t)n, &d_records))) return rc;
+    return spend_small_locked(c, n, mem, nullptr, sign, rng, rng_mode, out_refund, status, out_kprime, d_records);
+  }
   const size_t pb = ProofLayout{c->L}.bytes();
   static const size_t host_chunk_env = [] { const char* e = getenv("ACT_HOST_CHUNK"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning knob
   // host-transcript mode: a chunk's transcripts go to the host, are hashed there and come back before its status kernel, all
@@ -1249,8 +1272,6 @@ int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const 
 
 // rng: the caller's bytes, or (seed != nullptr) expanded on the device from a 32-byte seed: lane i draws from the BLAKE3 XOF of
 // seed | u64_le(first_lane + i) (k_misc.hip k_xof_expand) -- 33 536 bytes per proof that then never cross PCIe
-static int copy_chain_wait(act_ctx* c, Slot& sl, bool out);        // (defined with client_batch below)
-static int copy_chain_record(act_ctx* c, Slot& sl, bool out);
 static int prove_spend_impl(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng, const uint8_t* seed,
                             uint64_t first_lane, uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
   Call call(c, n);

@@ -1,13 +1,14 @@
 // node.cpp — the GPUs of one node behind one handle (include/act_mi355x.h act_node_*): a batch is cut into contiguous
-// shards, one per GPU; one host thread per GPU drives that GPU's context through the single-GPU entry points; outputs
-// land in disjoint slices of the caller's arrays.  No collective, no peer traffic: lanes are independent
-// (SURVEY.md section 8e).  The one cross-shard dependency is ACT_RNG_SEQUENTIAL for issue / refund: a lane's rng slice
-// is the number of ACCEPTED lanes in front of it (/root/reference/src/lib.rs:638-643, 842-846 draw only after the proof
-// verifies), so every shard is checked first, the host counts the accepted lanes of the shards in front, and only then
-// every shard signs from its own offset into the stream -- byte for byte what one loop over one generator produces.
+// pieces, one host thread per GPU drives that GPU's context through the single-GPU entry points; outputs land in disjoint
+// slices of the caller's arrays.  No collective, no peer traffic: lanes are independent.  The one
+// cross-piece dependency is ACT_RNG_SEQUENTIAL for issue / refund: a lane's rng slice is the number of ACCEPTED lanes in front
+// of it (/root/reference/src/lib.rs:638-643, 842-846 draw only after the proof verifies), so every lane is checked first, the
+// host counts the accepted lanes in front of every piece, and only then every piece is signed from its own offset into the
+// stream -- byte for byte what one loop over one generator produces, whichever GPU a piece went to.
 // Plain host C++ over the C ABI: nothing here touches a device.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <sys/random.h>
 #include <cstring>
 #include <mutex>
@@ -15,6 +16,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/act_mi355x.h"
+#include "rng_source.h"
 
 struct act_node {
   std::vector<act_ctx*> ctx;
@@ -26,45 +28,134 @@ struct act_node {
   // and merge there with the calls of other threads (engine.hip spend_coalesced)
   std::atomic<size_t> co_max{0};
   std::atomic<unsigned> co_next{0};
+  // Load balance (all under mu).  The GPUs of a node are not equally fast -- clocks differ by several percent between devices and
+  // move with temperature -- and a call ends when its slowest GPU does.  Two mechanisms, both invisible in the output bytes:
+  //   weights   every throughput-sized call measures what each context did with its head piece; the next call cuts the heads in
+  //             proportion (weight = relative speed, mean 1, averaged over calls).  Costs nothing.
+  //   tail      the last part of the batch is not assigned in advance: it is handed out in small pieces from a cursor to whichever
+  //             context asks next, so a GPU that falls behind DURING a call is covered by the others.  Costs the per-call overhead
+  //             of a few small calls, so its size follows the finish-time spread the heads actually show:
+  //             a sixteenth of the batch while nothing is known, nothing once the heads finish together.
+  std::vector<double> weight;
+  double spread = -1;            // running average of (last - first head to finish) / mean head time; < 0 = nothing measured yet
+  bool weighted = true;
+  int tail_64ths = -1;           // act_node_set_balance: -1 = follow `spread`, 0 = no tail, k = k/64 of the batch
+  double last_tail_fraction = 0;
+  struct DevStats { uint64_t lanes = 0, calls = 0; double seconds = 0; };
+  std::vector<DevStats> last;    // what each context did in the most recent cut call
 };
 
 namespace {
 
 struct Shard { size_t off, m; };
-std::vector<Shard> cut(size_t n, size_t parts) {
-  std::vector<Shard> s(parts);
-  for (size_t k = 0; k < parts; k++) { size_t a = n * k / parts, b = n * (k + 1) / parts; s[k] = {a, b - a}; }
-  return s;
+struct Piece { size_t k, off, m; int rc; };       // lanes [off, off + m) ran (or were to run: k == SIZE_MAX) on context k with result rc
+constexpr size_t kMinBalanceLanes = 4096;         // per device and piece: below this a call is latency, not throughput
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct Plan { std::vector<Shard> head; size_t tail_off = 0, piece = 0; double tail_fraction = 0; };
+Plan make_plan(const act_node* nd, size_t n) {
+  const size_t N = nd->ctx.size();
+  Plan p; p.head.resize(N); p.tail_off = n;
+  const bool big = N > 1 && n >= N * 4 * kMinBalanceLanes;
+  size_t tail = 0;
+  if (big) {
+    double f = nd->tail_64ths >= 0 ? nd->tail_64ths / 64.0 : (nd->spread < 0 ? 1.0 / 16 : std::min(0.125, 2 * nd->spread));
+    if (f < 1.0 / 64) f = 0;
+    tail = (size_t)((double)n * f);
+    if (tail) {
+      p.piece = std::max(kMinBalanceLanes, tail / (2 * N) / 1024 * 1024);
+      tail = tail / p.piece * p.piece;
+    }
+    if (!tail) p.piece = 0;
+  }
+  const size_t body = n - tail;
+  p.tail_off = body; p.tail_fraction = n ? (double)tail / (double)n : 0;
+  bool equal = !big || !nd->weighted || nd->weight.size() != N;
+  if (!equal) { equal = true; for (double w : nd->weight) if (w != nd->weight[0]) equal = false; }
+  if (equal) { for (size_t k = 0; k < N; k++) { const size_t a = body * k / N, b = body * (k + 1) / N; p.head[k] = {a, b - a}; } return p; }
+  double total = 0, cum = 0; for (double w : nd->weight) total += w;
+  size_t a = 0;
+  for (size_t k = 0; k < N; k++) {
+    cum += nd->weight[k];
+    const size_t b = k + 1 == N ? body : std::min(body, (size_t)((double)body * (cum / total)));
+    p.head[k] = {a, b > a ? b - a : 0}; a = std::max(a, b);
+  }
+  return p;
 }
-// fn(k, shard) on one thread per GPU; first failure wins and is reported with its device
-// (the caller holds nd->mu: nd->err is only ever written under it)
+
+// fn(k, off, m): lanes [off, off + m) on context k.  One thread per GPU: its head piece, then tail pieces while there are any.
+// First failure wins and is reported with its device (the caller holds nd->mu: nd->err is only ever written under it).  A
+// context that fails stops taking pieces; the others finish the tail.  `pieces` (optional) receives what ran where, and -- with
+// k == SIZE_MAX -- whatever nobody ran because every context had failed.
 template <class F>
-int run(act_node* nd, size_t n, F fn, std::vector<int>* shard_rc = nullptr) {
-  const size_t parts = nd->ctx.size();
-  const std::vector<Shard> sh = cut(n, parts);
-  std::vector<int> rc(parts, ACT_OK);
+int run(act_node* nd, size_t n, F fn, std::vector<Piece>* pieces = nullptr) {
+  const size_t N = nd->ctx.size();
+  const Plan p = make_plan(nd, n);
+  std::atomic<size_t> cursor{p.tail_off};
+  std::vector<std::vector<Piece>> done(N);
+  std::vector<double> head_s(N, 0), all_s(N, 0);
+  auto worker = [&](size_t k) {
+    const double t0 = now_s();
+    int rc = ACT_OK;
+    if (p.head[k].m || n == 0) { rc = fn(k, p.head[k].off, p.head[k].m); done[k].push_back({k, p.head[k].off, p.head[k].m, rc}); }
+    head_s[k] = now_s() - t0;
+    while (!rc && p.piece) {
+      const size_t off = cursor.fetch_add(p.piece);
+      if (off >= n) break;
+      const size_t m = std::min(p.piece, n - off);
+      rc = fn(k, off, m);
+      done[k].push_back({k, off, m, rc});
+    }
+    all_s[k] = now_s() - t0;
+  };
   std::vector<std::thread> th;
-  for (size_t k = 1; k < parts; k++) th.emplace_back([&, k] { rc[k] = fn(k, sh[k]); });
-  rc[0] = fn(0, sh[0]);
+  for (size_t k = 1; k < N; k++) th.emplace_back(worker, k);
+  worker(0);
   for (auto& t : th) t.join();
-  if (shard_rc) *shard_rc = rc;
-  for (size_t k = 0; k < parts; k++)
-    if (rc[k]) { nd->err = "device " + std::to_string(nd->devices[k]) + ": " + act_last_error(nd->ctx[k]); return rc[k]; }
-  return ACT_OK;
+  // telemetry + what the next call's cut learns from this one
+  nd->last.assign(N, act_node::DevStats{});
+  nd->last_tail_fraction = p.tail_fraction;
+  bool measurable = N > 1 && n >= N * 4 * kMinBalanceLanes;
+  for (size_t k = 0; k < N; k++) {
+    for (const Piece& q : done[k]) { nd->last[k].lanes += q.m; nd->last[k].calls++; if (q.rc) measurable = false; }
+    nd->last[k].seconds = all_s[k];
+    if (p.head[k].m < kMinBalanceLanes || head_s[k] <= 0) measurable = false;
+  }
+  if (measurable) {
+    if (nd->weight.size() != N) nd->weight.assign(N, 1.0);
+    double mean_rate = 0, mean_t = 0, lo = head_s[0], hi = head_s[0];
+    for (size_t k = 0; k < N; k++) { mean_rate += (double)p.head[k].m / head_s[k] / N; mean_t += head_s[k] / N; lo = std::min(lo, head_s[k]); hi = std::max(hi, head_s[k]); }
+    double total = 0;
+    for (size_t k = 0; k < N; k++) { nd->weight[k] = 0.5 * nd->weight[k] + 0.5 * ((double)p.head[k].m / head_s[k] / mean_rate); total += nd->weight[k]; }
+    for (double& w : nd->weight) w *= (double)N / total;
+    const double s = (hi - lo) / mean_t;
+    nd->spread = nd->spread < 0 ? s : 0.5 * nd->spread + 0.5 * s;
+  }
+  int first_rc = ACT_OK;
+  for (size_t k = 0; k < N && !first_rc; k++)
+    for (const Piece& q : done[k])
+      if (q.rc) { nd->err = "device " + std::to_string(nd->devices[k]) + ": " + act_last_error(nd->ctx[k]); first_rc = q.rc; break; }
+  if (pieces) {
+    pieces->clear();
+    for (size_t k = 0; k < N; k++) pieces->insert(pieces->end(), done[k].begin(), done[k].end());
+    if (p.piece) for (size_t off = cursor.load(); off < n; off += p.piece) pieces->push_back({(size_t)-1, off, std::min(p.piece, n - off), first_rc ? first_rc : ACT_ERR_HIP});
+  }
+  return first_rc;
 }
 inline const uint8_t* at(const uint8_t* p, size_t off, size_t rec) { return p ? p + off * rec : nullptr; }
 inline uint8_t* at(uint8_t* p, size_t off, size_t rec) { return p ? p + off * rec : nullptr; }
 
-// accepted lanes in front of each shard (exclusive prefix over the shards)
-std::vector<size_t> accepted_before(const std::vector<Shard>& sh, const uint8_t* status) {
-  std::vector<size_t> base(sh.size(), 0);
-  size_t acc = 0;
-  for (size_t k = 0; k < sh.size(); k++) {
-    base[k] = acc;
-    for (size_t i = 0; i < sh[k].m; i++) acc += status[sh[k].off + i] == 0;
+// accepted lanes in front of any lane: counts per block of 4096 lanes, the rest counted on demand
+struct AcceptedBefore {
+  const uint8_t* status; std::vector<size_t> block;
+  AcceptedBefore(const uint8_t* st, size_t n) : status(st), block(n / 4096 + 2, 0) {
+    size_t acc = 0;
+    for (size_t i = 0; i < n; i++) { if (i % 4096 == 0) block[i / 4096] = acc; acc += st[i] == 0; }
+    for (size_t b = (n + 4095) / 4096; b < block.size(); b++) block[b] = acc;
   }
-  return base;
-}
+  size_t total() const { return block.back(); }
+  size_t operator()(size_t off) const { size_t a = block[off / 4096]; for (size_t i = off / 4096 * 4096; i < off; i++) a += status[i] == 0; return a; }
+};
 
 }  // namespace
 
@@ -75,9 +166,9 @@ int act_node_create(const uint8_t h[96], int L, const int* devices, int n_device
   act_node* nd = new act_node();
   *out = nd;      // returned even on failure so that act_node_last_error() can be read; the caller destroys it
   nd->L = L;
-  // One thread per entry: contexts on different GPUs are built at the same time (a throughput-sized context spends ~2 s
-  // constructing 47 GB of fixed-base tables); entries that name the same GPU share that GPU's tables (engine.hip table
-  // cache), so the second one waits for the first one's tables instead of building its own.
+  // One thread per entry: contexts on different GPUs are built at the same time (a throughput-sized context with wide tables spends
+  // ~2 s constructing them); entries that name the same GPU share that GPU's tables (engine.hip table cache), so the second one
+  // waits for the first one's tables instead of building its own.
   std::vector<act_ctx*> made(n_devices, nullptr);
   std::vector<int> rcs(n_devices, ACT_OK);
   std::vector<std::thread> th;
@@ -92,6 +183,7 @@ int act_node_create(const uint8_t h[96], int L, const int* devices, int n_device
     return rcs[bad];
   }
   for (int k = 0; k < n_devices; k++) { nd->ctx.push_back(made[k]); nd->devices.push_back(devices[k]); }
+  nd->weight.assign(n_devices, 1.0); nd->last.assign(n_devices, act_node::DevStats{});
   return ACT_OK;
 }
 void act_node_destroy(act_node* nd) {
@@ -119,6 +211,29 @@ int act_node_set_host_threads(act_node* nd, int per_gpu) {
   for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_host_threads(c, per_gpu); if (rc) return rc; }
   return ACT_OK;
 }
+int act_node_set_balance(act_node* nd, int weighted, int tail_64ths) {
+  if (!nd || tail_64ths < -1 || tail_64ths > 32) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  nd->weighted = weighted != 0; nd->tail_64ths = tail_64ths;
+  if (!nd->weighted) nd->weight.assign(nd->ctx.size(), 1.0);
+  return ACT_OK;
+}
+int act_node_balance_state(act_node* nd, double* spread, double* tail_fraction) {
+  if (!nd) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  if (spread) *spread = nd->spread;
+  if (tail_fraction) *tail_fraction = nd->last_tail_fraction;
+  return ACT_OK;
+}
+int act_node_device_stats(act_node* nd, int k, double* weight, uint64_t* last_lanes, double* last_seconds, uint64_t* last_calls) {
+  if (!nd || k < 0 || k >= (int)nd->ctx.size()) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  if (weight) *weight = nd->weight[k];
+  if (last_lanes) *last_lanes = nd->last[k].lanes;
+  if (last_seconds) *last_seconds = nd->last[k].seconds;
+  if (last_calls) *last_calls = nd->last[k].calls;
+  return ACT_OK;
+}
 // verify / refund-sign calls of at most `max_proofs_per_call` proofs are not cut over the GPUs (a one-proof call has nothing to cut):
 // each goes to one context -- the next one, round robin -- and merges there with the small calls other threads make at the same time
 int act_node_set_coalescing(act_node* nd, size_t max_proofs_per_call) {
@@ -132,28 +247,28 @@ int act_node_set_coalescing(act_node* nd, size_t max_proofs_per_call) {
 int act_node_request_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
   if (!nd || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_request_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(pre, s.off, 64), at(rng, s.off, 128), at(out_req, s.off, 128));
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_request_batch(nd->ctx[k], m, ACT_MEM_HOST, at(pre, off, 64), at(rng, off, 128), at(out_req, off, 128));
   });
 }
 
 int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* req, const uint8_t* c, const uint8_t* rng,
                          int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!nd || !sk || (n && (!req || !c || !rng || !out_resp || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
-    return run(nd, n, [&](size_t k, Shard s) {
-      return act_issue_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(req, s.off, 128), at(c, s.off, 32),
-                             rng_mode == ACT_RNG_PER_LANE ? at(rng, s.off, 128) : rng, rng_mode, at(out_resp, s.off, 160), status + s.off);
+    return run(nd, n, [&](size_t k, size_t off, size_t m) {
+      return act_issue_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(req, off, 128), at(c, off, 32),
+                             rng_mode == ACT_RNG_PER_LANE ? at(rng, off, 128) : rng, rng_mode, at(out_resp, off, 160), status + off);
     });
-  if (rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  int rc = run(nd, n, [&](size_t k, Shard s) { return act_issue_check_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(req, s.off, 128), status + s.off); });
+  int rc = run(nd, n, [&](size_t k, size_t off, size_t m) { return act_issue_check_batch(nd->ctx[k], m, ACT_MEM_HOST, at(req, off, 128), status + off); });
   if (rc) return rc;
-  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status);
   const std::vector<uint8_t> checked(status, status + n);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_issue_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(req, s.off, 128), at(c, s.off, 32), checked.data() + s.off, rng + base[k] * 128,
-                                ACT_RNG_SEQUENTIAL, at(out_resp, s.off, 160), status + s.off);
+  const AcceptedBefore before(checked.data(), n);
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_issue_sign_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(req, off, 128), at(c, off, 32), checked.data() + off, rng + before(off) * 128,
+                                ACT_RNG_SEQUENTIAL, at(out_resp, off, 160), status + off);
   });
 }
 
@@ -168,7 +283,7 @@ int act_node_issue_check_batch(act_node* nd, size_t n, const uint8_t* req, uint8
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
-  return run(nd, n, [&](size_t k, Shard s) { return act_issue_check_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(req, s.off, 128), status + s.off); });
+  return run(nd, n, [&](size_t k, size_t off, size_t m) { return act_issue_check_batch(nd->ctx[k], m, ACT_MEM_HOST, at(req, off, 128), status + off); });
 }
 int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* req, const uint8_t* c, const uint8_t* status_in,
                               const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
@@ -181,43 +296,58 @@ int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], cons
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
-  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
   const std::vector<uint8_t> checked(status_in, status_in + n);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_issue_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(req, s.off, 128), at(c, s.off, 32), checked.data() + s.off,
-                                rng + (rng_mode == ACT_RNG_PER_LANE ? s.off : base[k]) * 128, rng_mode, at(out_resp, s.off, 160), status + s.off);
+  const AcceptedBefore before(checked.data(), n);
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_issue_sign_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(req, off, 128), at(c, off, 32), checked.data() + off,
+                                rng + (rng_mode == ACT_RNG_PER_LANE ? off : before(off)) * 128, rng_mode, at(out_resp, off, 160), status + off);
   });
 }
+// refund signatures as records (out_rec = 128) or as CBOR Refund messages (cbor: out_rec = act_cbor_size(REFUND)); rng already resolved
 static int refund_sign_locked(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
-                              int rng_mode, uint8_t* out_refund, uint8_t* status, std::vector<int>* shard_rc) {
-  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status_in);
+                              int rng_mode, bool cbor, uint8_t* out, uint8_t* status, std::vector<Piece>* pieces) {
   const std::vector<uint8_t> checked(status_in, status_in + n);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_refund_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(kprime, s.off, 32), checked.data() + s.off,
-                                 rng + (rng_mode == ACT_RNG_PER_LANE ? s.off : base[k]) * 128, rng_mode, at(out_refund, s.off, 128), status + s.off);
-  }, shard_rc);
+  const AcceptedBefore before(checked.data(), n);
+  const size_t out_rec = cbor ? act_cbor_size(nd->ctx[0], ACT_CBOR_REFUND) : 128;
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    const uint8_t* r = rng + (rng_mode == ACT_RNG_PER_LANE ? off : before(off)) * 128;
+    return cbor ? act_refund_sign_cbor_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(kprime, off, 32), checked.data() + off, r, rng_mode, at(out, off, out_rec), status + off)
+                : act_refund_sign_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(kprime, off, 32), checked.data() + off, r, rng_mode, at(out, off, out_rec), status + off);
+  }, pieces);
 }
-int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
-                               int rng_mode, uint8_t* out_refund, uint8_t* status) {
-  if (!nd || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
-  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+static size_t count_zero(const uint8_t* st, size_t n) { size_t a = 0; for (size_t i = 0; i < n; i++) a += st[i] == 0; return a; }
+static int refund_sign_any(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
+                           int rng_mode, bool cbor, uint8_t* out, uint8_t* status) {
+  if (!nd || !sk || !rng || (n && (!kprime || !status_in || !out || !status))) return ACT_ERR_ARG;
+  act::DrawnRng drawn;
+  if (!cbor && rng_mode == ACT_RNG_CALLBACK) return ACT_ERR_ARG;      // (the record-level halves take bytes: include/act_mi355x.h)
+  int rc = drawn.resolve(rng, rng_mode, rng_mode == ACT_RNG_CALLBACK ? count_zero(status_in, n) : 0); if (rc) return rc;
   if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {
     act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    const int rc = act_refund_sign_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out_refund, status);
+    rc = cbor ? act_refund_sign_cbor_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out, status)
+              : act_refund_sign_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out, status);
     if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
-  return refund_sign_locked(nd, n, sk, kprime, status_in, rng, rng_mode, out_refund, status, nullptr);
+  return refund_sign_locked(nd, n, sk, kprime, status_in, rng, rng_mode, cbor, out, status, nullptr);
+}
+int act_node_refund_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
+                               int rng_mode, uint8_t* out_refund, uint8_t* status) {
+  return refund_sign_any(nd, n, sk, kprime, status_in, rng, rng_mode, false, out_refund, status);
+}
+int act_node_refund_sign_cbor_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng,
+                                    int rng_mode, uint8_t* out_refund_cbor, uint8_t* status) {
+  return refund_sign_any(nd, n, sk, kprime, status_in, rng, rng_mode, true, out_refund_cbor, status);
 }
 
 int act_node_issuance_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
                                             const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
   if (!nd || !w || (n && (!pre || !req || !resp || !out_token || !status))) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_issuance_to_credit_token_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(pre, s.off, 64), w, at(req, s.off, 128), at(resp, s.off, 160),
-                                              at(out_token, s.off, 160), status + s.off);
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_issuance_to_credit_token_batch(nd->ctx[k], m, ACT_MEM_HOST, at(pre, off, 64), w, at(req, off, 128), at(resp, off, 160),
+                                              at(out_token, off, 160), status + off);
   });
 }
 
@@ -226,9 +356,9 @@ int act_node_prove_spend_batch(act_node* nd, size_t n, const uint8_t* token, con
   if (!nd || (n && (!token || !s_ || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]), rb = act_prove_rng_bytes(nd->ctx[0]);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_prove_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(token, s.off, 160), at(s_, s.off, 32), at(rng, s.off, rb), at(out_proof, s.off, pb),
-                                 at(out_prerefund, s.off, 96), status + s.off);
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_prove_spend_batch(nd->ctx[k], m, ACT_MEM_HOST, at(token, off, 160), at(s_, off, 32), at(rng, off, rb), at(out_proof, off, pb),
+                                 at(out_prerefund, off, 96), status + off);
   });
 }
 
@@ -237,9 +367,9 @@ int act_node_prove_spend_seeded_batch(act_node* nd, size_t n, const uint8_t* tok
   if (!nd || !seed || (n && (!token || !s_ || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
-  return run(nd, n, [&](size_t k, Shard s) {      // lane numbers are global: a shard starts at first_lane + its offset, whatever the number of GPUs
-    return act_prove_spend_seeded_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(token, s.off, 160), at(s_, s.off, 32), seed, first_lane + s.off, at(out_proof, s.off, pb),
-                                        at(out_prerefund, s.off, 96), status + s.off);
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {      // lane numbers are global: a piece starts at first_lane + its offset, whichever GPU takes it
+    return act_prove_spend_seeded_batch(nd->ctx[k], m, ACT_MEM_HOST, at(token, off, 160), at(s_, off, 32), seed, first_lane + off, at(out_proof, off, pb),
+                                        at(out_prerefund, off, 96), status + off);
   });
 }
 
@@ -253,47 +383,65 @@ int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], co
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_verify_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(proof, s.off, pb), status + s.off, at(out_kprime, s.off, 32));
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_verify_spend_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(proof, off, pb), status + off, at(out_kprime, off, 32));
   });
 }
 
-// wire bytes: shard k takes messages [n k / N, n (k+1) / N); offsets are absolute into `cbor`, so every shard gets the same base
+// wire bytes: a piece takes messages [off, off + m); offsets are absolute into `cbor`, so every piece gets the same base
+int act_node_verify_spend_cbor_keys_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* cbor, const uint64_t* offsets, uint8_t* status,
+                                          uint8_t* out_kprime, uint8_t* out_nullifier) {
+  if (!nd || !sk || (n && (!cbor || !status))) return ACT_ERR_ARG;
+  const size_t ml = act_cbor_size(nd->ctx[0], ACT_CBOR_SPEND_PROOF);
+  if (n && n <= nd->co_max.load()) {          // a call this small has nothing to cut: one context, round robin, no node lock
+    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    const int rc = act_verify_spend_cbor_keys_batch(c, n, ACT_MEM_HOST, sk, cbor, offsets, status, out_kprime, out_nullifier);
+    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    return rc;
+  }
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_verify_spend_cbor_keys_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, offsets ? cbor : cbor + off * ml, offsets ? offsets + off : nullptr,
+                                            status + off, at(out_kprime, off, 32), at(out_nullifier, off, 32));
+  });
+}
 int act_node_verify_spend_cbor_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* cbor, const uint64_t* offsets, uint8_t* status,
                                      uint8_t* out_kprime) {
-  if (!nd || !sk || (n && (!cbor || !status))) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> node_lock(nd->mu);
-  const size_t ml = act_cbor_size(nd->ctx[0], ACT_CBOR_SPEND_PROOF);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_verify_spend_cbor_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, offsets ? cbor : cbor + s.off * ml, offsets ? offsets + s.off : nullptr,
-                                       status + s.off, at(out_kprime, s.off, 32));
-  });
+  return act_node_verify_spend_cbor_keys_batch(nd, n, sk, cbor, offsets, status, out_kprime, nullptr);
 }
 
 int act_node_refund_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
                           uint8_t* out_refund, uint8_t* status) {
   if (!nd || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
-    return run(nd, n, [&](size_t k, Shard s) {
-      return act_refund_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(proof, s.off, pb), rng_mode == ACT_RNG_PER_LANE ? at(rng, s.off, 128) : rng,
-                              rng_mode, at(out_refund, s.off, 128), status + s.off);
+    return run(nd, n, [&](size_t k, size_t off, size_t m) {
+      return act_refund_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(proof, off, pb), rng_mode == ACT_RNG_PER_LANE ? at(rng, off, 128) : rng,
+                              rng_mode, at(out_refund, off, 128), status + off);
     });
-  if (rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  // phase 1: verification on every shard, keeping enc(K') (32 bytes per lane) -- the only thing the signature needs
+  // phase 1: verification of every lane, keeping enc(K') (32 bytes per lane) -- the only thing the signature needs
   std::vector<uint8_t> kprime(n * 32);
-  int rc = run(nd, n, [&](size_t k, Shard s) {
-    return act_verify_spend_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, at(proof, s.off, pb), status + s.off, kprime.data() + s.off * 32);
+  int rc = run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_verify_spend_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, at(proof, off, pb), status + off, kprime.data() + off * 32);
   });
   if (rc) return rc;
-  const std::vector<size_t> base = accepted_before(cut(n, nd->ctx.size()), status);
-  const std::vector<uint8_t> checked(status, status + n);
-  // phase 2: X_A = g + K', then the BBS signature (src/lib.rs:846-868), each shard from its own offset into the stream
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_refund_sign_batch(nd->ctx[k], s.m, ACT_MEM_HOST, sk, kprime.data() + s.off * 32, checked.data() + s.off, rng + base[k] * 128, ACT_RNG_SEQUENTIAL,
-                                 at(out_refund, s.off, 128), status + s.off);
-  });
+  // phase 2: X_A = g + K', then the BBS signature (src/lib.rs:846-868), each piece from its own offset into the stream
+  return refund_sign_locked(nd, n, sk, kprime.data(), status, rng, ACT_RNG_SEQUENTIAL, false, out_refund, status, nullptr);
+}
+
+// wire bytes in, wire bytes out: verification of every message first (all verdicts are then known), then the signatures framed as
+// CBOR Refund messages -- ACT_RNG_SEQUENTIAL / ACT_RNG_CALLBACK hand their bytes to the signed lanes in lane order
+int act_node_refund_cbor_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* cbor, const uint64_t* offsets, const uint8_t* rng,
+                               int rng_mode, uint8_t* out_refund_cbor, uint8_t* status) {
+  if (!nd || !sk || !rng || (n && (!cbor || !out_refund_cbor || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL && rng_mode != ACT_RNG_CALLBACK) return ACT_ERR_ARG;
+  if (n == 0) return ACT_OK;
+  std::vector<uint8_t> kprime(n * 32), verdict(n);
+  int rc = act_node_verify_spend_cbor_keys_batch(nd, n, sk, cbor, offsets, verdict.data(), kprime.data(), nullptr);
+  if (rc) return rc;
+  return refund_sign_any(nd, n, sk, kprime.data(), verdict.data(), rng, rng_mode, true, out_refund_cbor, status);
 }
 
 int act_node_refund_to_credit_token_batch(act_node* nd, size_t n, const uint8_t* prerefund, const uint8_t* proof, const uint8_t* refund,
@@ -301,9 +449,9 @@ int act_node_refund_to_credit_token_batch(act_node* nd, size_t n, const uint8_t*
   if (!nd || !w || (n && (!prerefund || !proof || !refund || !out_token || !status))) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
-  return run(nd, n, [&](size_t k, Shard s) {
-    return act_refund_to_credit_token_batch(nd->ctx[k], s.m, ACT_MEM_HOST, at(prerefund, s.off, 96), at(proof, s.off, pb), at(refund, s.off, 128), w,
-                                            at(out_token, s.off, 160), status + s.off);
+  return run(nd, n, [&](size_t k, size_t off, size_t m) {
+    return act_refund_to_credit_token_batch(nd->ctx[k], m, ACT_MEM_HOST, at(prerefund, off, 96), at(proof, off, pb), at(refund, off, 128), w,
+                                            at(out_token, off, 160), status + off);
   });
 }
 
@@ -475,37 +623,54 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set* ns, size_t
 }
 }  // extern "C"
 
-// The issuer's whole redemption step over the GPUs of a node (act_redeem_batch's meaning, include/act_mi355x.h): verification on
-// every shard, the node-level nullifier set over the whole batch in lane order (verdicts as skip mask), then the signatures --
-// ACT_RNG_SEQUENTIAL draws only for lanes that are signed, from one stream, exactly as the sequential loop would.
+// The issuer's whole redemption step over the GPUs of a node (act_redeem_batch's meaning, include/act_mi355x.h): verification of
+// every lane, the node-level nullifier set over the whole batch in lane order (verdicts as skip mask), then the signatures --
+// ACT_RNG_SEQUENTIAL / ACT_RNG_CALLBACK draw only for lanes that are signed, from one stream, exactly as the sequential loop would.
+// Records in / records out (act_node_redeem_batch) and wire bytes in / wire bytes out (act_node_redeem_cbor_batch) share this body.
 // Failures after verification never lose a decision (same contract as act_redeem_batch): a device of the nullifier set that
 // fails leaves ITS lanes ACT_STATUS_NULLIFIER_UNDETERMINED (not recorded, not signed) while every other lane is finished; a GPU
-// that fails while signing leaves the lanes of ITS shard that were to be signed ACT_STATUS_RECORDED_UNSIGNED (nullifier recorded,
-// refund owed); status[] and out_refund[] are complete for all other lanes and the error code says that something was left over.
-extern "C" int act_node_redeem_batch(act_node* nd, act_node_nullifier_set* set, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng,
-                                     int rng_mode, uint8_t* out_refund, uint8_t* status) {
-  if (!nd || !set || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
-  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+// that fails while signing leaves the lanes of ITS pieces that were to be signed ACT_STATUS_RECORDED_UNSIGNED (nullifier recorded,
+// refund owed); status[] and the output are complete for all other lanes and the error code says that something was left over.
+static int node_redeem(act_node* nd, act_node_nullifier_set* set, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* cbor,
+                       const uint64_t* offsets, const uint8_t* rng, int rng_mode, uint8_t* out, uint8_t* status) {
+  const bool wire = cbor != nullptr;
+  if (!nd || !set || !sk || !rng || (n && ((!proof && !cbor) || !out || !status))) return ACT_ERR_ARG;
+  if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL && rng_mode != ACT_RNG_CALLBACK) return ACT_ERR_ARG;
   if (n == 0) return ACT_OK;
-  const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
-  std::vector<uint8_t> kprime(n * 32), verdict(n), spent(n);
-  int rc = act_node_verify_spend_batch(nd, n, sk, proof, verdict.data(), kprime.data());
+  const size_t pb = act_spend_proof_bytes(nd->ctx[0]), out_rec = wire ? act_cbor_size(nd->ctx[0], ACT_CBOR_REFUND) : 128;
+  std::vector<uint8_t> kprime(n * 32), verdict(n), spent(n), nul(wire ? n * 32 : 0);
+  int rc = wire ? act_node_verify_spend_cbor_keys_batch(nd, n, sk, cbor, offsets, verdict.data(), kprime.data(), nul.data())
+                : act_node_verify_spend_batch(nd, n, sk, proof, verdict.data(), kprime.data());
   if (rc) return rc;
-  const int rc_null = act_node_nullifier_check_and_insert_batch(set, n, proof, pb, verdict.data(), spent.data());
+  const int rc_null = act_node_nullifier_check_and_insert_batch(set, n, wire ? nul.data() : proof, wire ? 32 : pb, verdict.data(), spent.data());
   for (size_t i = 0; i < n; i++)
     if (verdict[i] == 0 && spent[i]) verdict[i] = spent[i] == 1 ? ACT_STATUS_DOUBLE_SPEND : ACT_STATUS_NULLIFIER_UNDETERMINED;
+  // the caller's generator is touched only now, and only for the lanes that are signed
+  act::DrawnRng drawn;
+  int rc_sign = drawn.resolve(rng, rng_mode, rng_mode == ACT_RNG_CALLBACK ? count_zero(verdict.data(), n) : 0);
   std::lock_guard<std::mutex> node_lock(nd->mu);
-  std::vector<int> shard_rc;
-  const int rc_sign = refund_sign_locked(nd, n, sk, kprime.data(), verdict.data(), rng, rng_mode, out_refund, status, &shard_rc);
+  std::vector<Piece> pieces;
+  if (!rc_sign) rc_sign = refund_sign_locked(nd, n, sk, kprime.data(), verdict.data(), rng, rng_mode, wire, out, status, &pieces);
+  else pieces.push_back({(size_t)-1, 0, n, rc_sign});
   if (rc_sign) {
-    const std::vector<Shard> sh = cut(n, nd->ctx.size());
-    for (size_t k = 0; k < sh.size(); k++) {
-      if (!shard_rc[k]) continue;
-      for (size_t i = sh[k].off; i < sh[k].off + sh[k].m; i++) status[i] = verdict[i] == 0 ? ACT_STATUS_RECORDED_UNSIGNED : verdict[i];
-      memset(out_refund + sh[k].off * 128, 0, sh[k].m * 128);
+    for (const Piece& q : pieces) {
+      if (!q.rc) continue;
+      for (size_t i = q.off; i < q.off + q.m; i++) status[i] = verdict[i] == 0 ? ACT_STATUS_RECORDED_UNSIGNED : verdict[i];
+      memset(out + q.off * out_rec, 0, q.m * out_rec);
     }
     return rc_sign;
   }
   if (rc_null) nd->err = std::string("nullifier set: ") + act_node_nullifier_set_last_error(set);
   return rc_null;
+}
+extern "C" int act_node_redeem_batch(act_node* nd, act_node_nullifier_set* set, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng,
+                                     int rng_mode, uint8_t* out_refund, uint8_t* status) {
+  if (n && !proof) return ACT_ERR_ARG;
+  return node_redeem(nd, set, n, sk, proof, nullptr, nullptr, rng, rng_mode, out_refund, status);
+}
+extern "C" int act_node_redeem_cbor_batch(act_node* nd, act_node_nullifier_set* set, size_t n, const uint8_t sk[64], const uint8_t* cbor, const uint64_t* offsets,
+                                          const uint8_t* rng, int rng_mode, uint8_t* out_refund_cbor, uint8_t* status) {
+  if (n && !cbor) return ACT_ERR_ARG;
+  static const uint8_t none = 0;
+  return node_redeem(nd, set, n, sk, nullptr, cbor ? cbor : &none, offsets, rng, rng_mode, out_refund_cbor, status);
 }

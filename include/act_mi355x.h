@@ -69,6 +69,14 @@ extern "C" {
 
 #define ACT_RNG_PER_LANE 0
 #define ACT_RNG_SEQUENTIAL 1
+/* The crate's `impl CryptoRngCore` itself, for the calls that say they take it (the wire-level and redeem entry points below): `rng`
+ * points to an act_rng_source instead of bytes.  The library calls draw(rng_ctx, dst, 128 * k) ONCE per call, from the calling
+ * thread, after every verdict is known, k = the number of lanes that will be signed -- the generator is advanced by exactly what a
+ * sequential loop over refund() would have drawn (src/lib.rs:842-852: e, alpha only after the checks), and the slices go to the
+ * signed lanes in lane order like ACT_RNG_SEQUENTIAL.  The drawn bytes are wiped before the call returns. */
+#define ACT_RNG_CALLBACK 2
+typedef void (*act_rng_draw_fn)(void *rng_ctx, uint8_t *dst, size_t len);
+typedef struct act_rng_source { act_rng_draw_fn draw; void *rng_ctx; } act_rng_source;
 
 #define ACT_TRANSCRIPT_HOST 0    /* BLAKE3 of every transcript on host threads (src/transcript.rs stays on the host) */
 #define ACT_TRANSCRIPT_DEVICE 1  /* the same bytes hashed by the device BLAKE3 kernel; no D2H/H2D inside a batch */
@@ -223,8 +231,9 @@ int act_refund_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64],
 
 /* Node-level dispatch: the GPUs of one node behind one handle.  act_node_create builds one context per
  * entry of devices[] (the same device may be listed more than once: each entry is its own context, stream set and
- * workspace).  Every act_node_*_batch call cuts its batch into n_devices contiguous shards (shard k = lanes
- * [n*k/N, n*(k+1)/N)), runs shard k on context k from its own host thread through the single-GPU entry point of the same
+ * workspace).  Every act_node_*_batch call cuts its batch into contiguous pieces (one per context, shard k = lanes
+ * [n*k/N, n*(k+1)/N), for batches below 16384 lanes per GPU; see "Load balance" below for larger ones), runs every piece on a
+ * context from that context's own host thread through the single-GPU entry point of the same
  * name, and writes outputs into the matching slices of the caller's arrays: no collective, no peer traffic.  All bulk
  * pointers are host memory.  ACT_RNG_SEQUENTIAL stays exact across shards -- the bytes of one sequential loop over one
  * generator (src/lib.rs:638-643, 842-846 draw only for accepted lanes): all shards are checked first, the host counts
@@ -241,6 +250,20 @@ act_ctx *act_node_ctx(act_node *node, int k);                  /* context k, e.g
 const char *act_node_last_error(const act_node *node);
 int act_node_set_transcript_mode(act_node *node, int mode);
 int act_node_set_host_threads(act_node *node, int per_gpu);    /* host BLAKE3 workers of every context */
+/* Load balance.  The GPUs of a node are not equally fast (clocks differ by several percent between devices and move with
+ * temperature) and a call ends when its slowest GPU does, so the cut is not n/N: (1) every throughput-sized call -- at least
+ * 16384 lanes per GPU -- measures what each context did with its piece and the next call cuts in proportion (weights: relative
+ * speed, mean 1); (2) the last part of such a batch is not assigned in advance but handed out in small pieces (>= 4096 lanes) to
+ * whichever GPU asks next, its size following the finish-time spread the previous calls showed: a sixteenth of the batch while
+ * nothing is known, nothing once the GPUs finish together (a tail costs a few small calls).  Neither changes a byte of the output:
+ * a lane's result depends on its inputs and its rng slice, never on the GPU that computed it.
+ *   act_node_set_balance     weighted = 0 turns (1) off (equal cut); tail_64ths = -1 adaptive (default), 0 = no tail, k = k/64 of the batch
+ *   act_node_device_stats    context k: its weight, and lanes / seconds / calls it was given in the most recent cut call
+ *   act_node_balance_state   finish-time spread of the heads (running average, relative to their mean; < 0 = not measured yet) and the
+ *                            fraction of the last call that went through the tail */
+int act_node_set_balance(act_node *node, int weighted, int tail_64ths);
+int act_node_device_stats(act_node *node, int k, double *weight, uint64_t *last_lanes, double *last_seconds, uint64_t *last_calls);
+int act_node_balance_state(act_node *node, double *spread, double *tail_fraction);
 /* act_ctx_set_coalescing on every context, and: act_node_verify_spend_batch / _refund_sign_batch / _issue_check_batch / _issue_sign_batch calls of at most
  * max_proofs_per_call proofs are no longer cut over the GPUs under the handle's lock -- each goes to one context (round robin) and
  * merges there with the small calls other threads make on the same handle at the same time.  What the Rust binding's single-item
@@ -312,6 +335,29 @@ int act_verify_spend_cbor_batch(act_ctx *ctx, size_t n, int mem, const uint8_t s
                                 uint8_t *status, uint8_t *out_kprime);
 int act_node_verify_spend_cbor_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
                                      uint8_t *status, uint8_t *out_kprime);
+/* The same, also returning what the rest of a redemption needs: out_nullifier (nullable) n*32 = the `k` field of every message as it
+ * stood on the wire (unreduced; the nullifier sets reduce mod l themselves), zero for a message that did not parse. */
+int act_verify_spend_cbor_keys_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
+                                     uint8_t *status, uint8_t *out_kprime, uint8_t *out_nullifier);
+int act_node_verify_spend_cbor_keys_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
+                                          uint8_t *status, uint8_t *out_kprime, uint8_t *out_nullifier);
+
+/* Wire bytes in, wire bytes out: what a server does with the bytes a client sent (SpendProof::from_cbor, src/cbor.rs:276-408;
+ * PrivateKey::refund, src/lib.rs:781-869; Refund::to_cbor, src/cbor.rs:421-433) without a SpendProof, a RistrettoPoint or a Refund
+ * ever existing on the host.  Message i in, message i out: out_refund_cbor holds n slots of act_cbor_size(ctx, ACT_CBOR_REFUND)
+ * bytes (141), the canonical Refund message of an accepted lane, all zero for any other lane.
+ *   act_refund_sign_cbor_batch   act_refund_sign_batch + framing: the BBS signature for lanes with status_in == 0 from enc(K')
+ *   act_refund_cbor_batch        act_verify_spend_cbor_batch, then the above; status as act_verify_spend_cbor_batch
+ * rng / rng_mode: ACT_RNG_PER_LANE, ACT_RNG_SEQUENTIAL (both halves see every verdict before a slice is assigned, so SEQUENTIAL is the
+ * sequential loop's byte stream) or ACT_RNG_CALLBACK.  The node forms cut the batch over the GPUs like every act_node_* call. */
+int act_refund_sign_cbor_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *kprime, const uint8_t *status_in,
+                               const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
+int act_refund_cbor_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
+                          const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
+int act_node_refund_sign_cbor_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *kprime, const uint8_t *status_in,
+                                    const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
+int act_node_refund_cbor_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
+                               const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
 
 /* Nullifier set: the double-spend database the crate leaves to the caller (src/lib.rs:741-745; `HashSet<Scalar>` with
  * "is_spent? reject : insert" per spend in src/tests.rs:29-50, examples/act.rs:10-30), as a hash set in one GPU's HBM.
@@ -376,6 +422,14 @@ int act_redeem_batch(act_ctx *ctx, act_nullifier_set *set, size_t n, int mem, co
                      const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
 int act_node_redeem_batch(act_node *node, act_node_nullifier_set *set, size_t n, const uint8_t sk[64], const uint8_t *proof,
                           const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
+/* The redemption step on wire bytes: act_redeem_batch with CBOR SpendProof messages in (as act_verify_spend_cbor_batch) and CBOR Refund
+ * messages out (as act_refund_cbor_batch) -- the loop of examples/act.rs:62-73 for a server that holds bytes.  status[i] additionally
+ * takes the wire codes 255 / ACT_STATUS_CBOR_MALFORMED / ACT_STATUS_CBOR_STRUCTURE; failure semantics as above.
+ * All four redeem entry points accept ACT_RNG_CALLBACK: the draw happens after the nullifier step, for the lanes that are signed. */
+int act_redeem_cbor_batch(act_ctx *ctx, act_nullifier_set *set, size_t n, int mem, const uint8_t sk[64], const uint8_t *cbor,
+                          const uint64_t *offsets, const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
+int act_node_redeem_cbor_batch(act_node *node, act_node_nullifier_set *set, size_t n, const uint8_t sk[64], const uint8_t *cbor,
+                               const uint64_t *offsets, const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
 
 /* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
@@ -385,6 +439,12 @@ int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *ou
  * host inputs (tokens, PreIssuance, rng), the signer's nonces, the prover's r3 / r* / k* terms and the per-proof Pippenger
  * buckets -- all of which every entry point clears before it returns (the crate's ZeroizeOnDrop, src/lib.rs:160,362,393). */
 int act_debug_secret_residue(act_ctx *ctx, size_t *nonzero_bytes);
+/* Debug / test hook: every batch call on this context additionally sleeps ns_per_lane nanoseconds per lane while it holds the
+ * context: a GPU that is slower than its neighbours, for the load-balance tests of the node dispatcher.  0 = off. */
+int act_debug_set_slowdown(act_ctx *ctx, uint32_t ns_per_lane);
+/* Debug / test hook: the signature step of the next `count` act_redeem_batch / act_redeem_cbor_batch calls on this context fails after
+ * the nullifiers have been recorded (the failure ACT_STATUS_RECORDED_UNSIGNED exists for; no input can provoke it). */
+int act_debug_fail_next_signs(act_ctx *ctx, int count);
 /* Debug / test hook: out[i] = enc(scalars[i] * points[i]) (`RistrettoPoint * Scalar`, e.g. src/lib.rs:791) computed by the
  * engine's production variable-base chain, decode and encode; status[i] = 255 and a zero record when points[i] is not a
  * canonical encoding.  Exists so that third-party known answers can be replayed on the device one operation at a time

@@ -10,6 +10,7 @@
 //   every context counts its calls and lanes (act_mock_lanes) so that the test can see all of them were used
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -20,7 +21,7 @@
 #include <vector>
 #include "../../include/act_mi355x.h"
 
-struct act_ctx { int device; int L; std::atomic<size_t> lanes{0}; std::string err; };     // (lanes: calls that bypass the node's lock run on several threads)
+struct act_ctx { int device; int L; std::atomic<size_t> lanes{0}; std::string err; std::atomic<unsigned> ns_per_lane{0}; };     // (lanes: calls that bypass the node's lock run on several threads)
 struct act_nullifier_set { std::set<std::vector<uint8_t>> keys; std::string err; int device = 0; };
 // failure injection (error-path tests): the device whose nullifier set / whose signature step fails, -1 = none
 static int g_fail_null_device = -1, g_fail_sign_device = -1;
@@ -37,6 +38,9 @@ size_t act_spend_proof_bytes(const act_ctx*) { return kPB; }
 size_t act_prove_rng_bytes(const act_ctx*) { return 256; }
 size_t act_mock_lanes(const act_ctx* c) { return c->lanes; }
 void act_mock_fail(int null_device, int sign_device) { g_fail_null_device = null_device; g_fail_sign_device = sign_device; }
+// a context as a slower GPU: every verification call sleeps ns_per_lane per lane (load-balance tests)
+void act_mock_slow(act_ctx* c, unsigned ns_per_lane) { c->ns_per_lane = ns_per_lane; }
+static void mock_work(act_ctx* c, size_t n) { c->lanes += n; const unsigned ns = c->ns_per_lane; if (ns) std::this_thread::sleep_for(std::chrono::nanoseconds((uint64_t)ns * n)); }
 
 static void emit(uint8_t* out, size_t rec, const uint8_t* in, const uint8_t* rng) { memset(out, 0, rec); memcpy(out, in, 8); if (rng) memcpy(out + 8, rng, rec - 8 < 120 ? rec - 8 : 120); }
 
@@ -79,19 +83,24 @@ int act_prove_spend_seeded_batch(act_ctx* c, size_t n, int, const uint8_t* tok, 
   return ACT_OK;
 }
 int act_verify_spend_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* proof, uint8_t* status, uint8_t* kp) {
-  c->lanes += n;
+  mock_work(c, n);
   for (size_t i = 0; i < n; i++) { status[i] = (proof[kPB * i] & 1) ? 7 : 0; if (kp) { memset(kp + 32 * i, 0, 32); if (!status[i]) memcpy(kp + 32 * i, proof + kPB * i, 8); } }
   return ACT_OK;
 }
-size_t act_cbor_size(const act_ctx*, int) { return kPB + 3; }       // mock wire message: 3 framing bytes + the record
-int act_verify_spend_cbor_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* cbor, const uint64_t* offsets, uint8_t* status, uint8_t* kp) {
-  c->lanes += n;
+// mock wire messages: a SpendProof is 3 framing bytes + the record; a Refund is 0xa4 + the 128-byte mock record
+size_t act_cbor_size(const act_ctx*, int type) { return type == ACT_CBOR_REFUND ? 129 : kPB + 3; }
+int act_verify_spend_cbor_keys_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* cbor, const uint64_t* offsets, uint8_t* status, uint8_t* kp, uint8_t* nul) {
+  mock_work(c, n);
   for (size_t i = 0; i < n; i++) {
     const uint8_t* m = cbor + (offsets ? offsets[i] : i * (kPB + 3)) + 3;
     status[i] = (m[0] & 1) ? 7 : 0;
     if (kp) { memset(kp + 32 * i, 0, 32); if (!status[i]) memcpy(kp + 32 * i, m, 8); }
+    if (nul) memcpy(nul + 32 * i, m, 32);                 // the record's first 32 bytes are its nullifier
   }
   return ACT_OK;
+}
+int act_verify_spend_cbor_batch(act_ctx* c, size_t n, int mem, const uint8_t* sk, const uint8_t* cbor, const uint64_t* offsets, uint8_t* status, uint8_t* kp) {
+  return act_verify_spend_cbor_keys_batch(c, n, mem, sk, cbor, offsets, status, kp, nullptr);
 }
 int act_refund_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* proof, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status) {
   return sign_like(c, n, proof, kPB, nullptr, 7, rng, mode, out, 128, status);
@@ -99,6 +108,13 @@ int act_refund_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* p
 int act_refund_sign_batch(act_ctx* c, size_t n, int, const uint8_t*, const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status) {
   if (c->device == g_fail_sign_device) { c->err = "mock: signature step failed"; return ACT_ERR_HIP; }
   return sign_like(c, n, kprime, 32, status_in, 7, rng, mode, out, 128, status);      // K' carries the record's 8-byte tag
+}
+int act_refund_sign_cbor_batch(act_ctx* c, size_t n, int mem, const uint8_t* sk, const uint8_t* kprime, const uint8_t* status_in, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status) {
+  std::vector<uint8_t> rec(128 * n + 1);
+  const int rc = act_refund_sign_batch(c, n, mem, sk, kprime, status_in, rng, mode, rec.data(), status);
+  if (rc) return rc;
+  for (size_t i = 0; i < n; i++) { memset(out + 129 * i, 0, 129); if (!status[i]) { out[129 * i] = 0xa4; memcpy(out + 129 * i + 1, rec.data() + 128 * i, 128); } }
+  return ACT_OK;
 }
 int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int, const uint8_t* prer, const uint8_t* proof, const uint8_t* refund, const uint8_t*, uint8_t* out, uint8_t* status) {
   c->lanes += n; for (size_t i = 0; i < n; i++) { emit(out + 160 * i, 160, prer + 96 * i, refund + 128 * i); out[159 + 160 * i] = proof[kPB * i]; status[i] = 0; } return ACT_OK;

@@ -312,3 +312,44 @@ def test_single_item_issues_from_many_threads_merge_on_a_node_handle(engine_fact
         assert merged[i] == alone[i], i
         so, resp = octx.issue(sk, items[i], scb(10 + i), shake("ni-r%d" % i, 128))
         assert alone[i][1][0] == so == (1 if i % 6 == 0 else 0) and alone[i][2] == resp
+
+
+def test_slow_context_is_relieved_and_bytes_do_not_change(engine_factory, bench_params):
+    """Load balance of the node dispatcher on real contexts: three contexts, one of them made slower by the test
+    hook.  In the first call the others take the tail pieces; the weights that call leaves behind give the slow context a
+    smaller head in the second; statuses, K' and (ACT_RNG_SEQUENTIAL, cut into pieces) refunds equal one context's."""
+    from act_amd import capi
+    L, distinct, reps = 8, 4096, 48
+    n = distinct * reps
+    eng = engine_factory(bench_params, L, max_batch=16384)
+    sk = eng.private_key_random(shake("lb-sk", 64))
+    pre = eng.pre_issuance_random(shake("lb-pre", 128 * distinct)); req = eng.request(pre, shake("lb-rq", 128 * distinct))
+    st, resp = eng.issue(sk, req, b"".join(scb(1000 + i) for i in range(distinct)), shake("lb-ir", 128 * distinct))
+    st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i % 200) for i in range(distinct)), shake("lb-pr", eng.prove_rng_bytes * distinct))
+    assert st == bytes(distinct)
+    pb = eng.proof_bytes
+    tampered = bytearray(proofs)
+    for i in range(0, distinct, 97):
+        tampered[pb * i + 33] ^= 1
+    batch = bytes(tampered) * reps
+    rng = shake("lb-rr", 128 * distinct) * reps
+    want_v = eng.verify_spend(sk, batch, True)
+    want_r = eng.refund(sk, batch, rng, capi.RNG_SEQUENTIAL)
+    node = capi.Node(bench_params, L, devices=(0, 0, 0), max_batch=16384)
+    try:
+        node.lib.act_debug_set_slowdown(node.ctx_handle(1), 1000)      # 1 us per lane on top of context 1's calls
+        assert node.verify_spend(sk, batch, True) == want_v
+        s1, b1 = node.device_stats(), node.balance_state()
+        assert sum(d["lanes"] for d in s1) == n and abs(b1["tail_fraction"] - 1 / 16) < 0.01 and b1["spread"] > 0.2, (s1, b1)
+        assert s1[1]["calls"] == 1 and s1[0]["calls"] + s1[2]["calls"] == 2 + 3, s1           # the three tail pieces went to the fast contexts
+        assert s1[1]["weight"] < 0.9 < s1[0]["weight"], s1
+        assert node.refund(sk, batch, rng, capi.RNG_SEQUENTIAL) == want_r                       # verify pass + sign pass, both cut by the weights
+        assert node.verify_spend(sk, batch, True) == want_v
+        s2 = node.device_stats()
+        assert s2[1]["lanes"] < 0.9 * s2[0]["lanes"] and sum(d["lanes"] for d in s2) == n, s2
+        node.set_balance(False, 0)
+        assert node.verify_spend(sk, batch) == want_v[0]
+        assert [d["lanes"] for d in node.device_stats()] == [n // 3] * 3
+    finally:
+        node.close()

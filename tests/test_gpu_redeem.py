@@ -163,10 +163,9 @@ def test_redeem_failures_keep_every_decision(engine_factory, oracle, bench_param
     big.close()
     # (b) signature step fails (test hook): recorded, unsigned
     ns = capi.NullifierSet(1000)
-    monkeypatch.setenv("ACT_TEST_FAIL_REDEEM_SIGN", "1")
+    assert eng.lib.act_debug_fail_next_signs(eng.ctx, 1) == 0
     st = np.zeros(n, np.uint8); out = np.full(128 * n, 7, np.uint8)
     rc = eng.lib.act_redeem_batch(eng.ctx, ns.h, n, capi.MEM_HOST, skb.ctypes.data, pr.ctypes.data, rg.ctypes.data, capi.RNG_SEQUENTIAL, out.ctypes.data, st.ctypes.data)
-    monkeypatch.delenv("ACT_TEST_FAIL_REDEEM_SIGN")
     assert rc != 0 and b"signature step" in eng.lib.act_last_error(eng.ctx)
     assert list(st) == [251 if w == 0 else w for w in want[0]] and not out.any()
     assert len(ns) == sum(1 for w in want[0] if w == 0)                 # the nullifiers ARE recorded ...

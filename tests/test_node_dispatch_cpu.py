@@ -273,3 +273,181 @@ def test_seeded_prover_lane_numbers_are_global(lib, ndev):
         assert proof.raw[PB * i:PB * i + 8] == tok[160 * i:160 * i + 8]
         assert proof.raw[PB * i + 8:PB * i + 16] == seed[:8] and int.from_bytes(proof.raw[PB * i + 16:PB * i + 24], "little") == 1000 + i
     lib.act_node_destroy(nd)
+
+
+class _Replay:
+    """act_rng_source over a fixed byte string; records every draw the dispatcher makes"""
+
+    def __init__(self, data):
+        self.data, self.pos, self.draws = data, 0, []
+        FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+
+        def draw(_ctx, dst, n):
+            C.memmove(dst, self.data[self.pos:self.pos + n], n)
+            self.pos += n
+            self.draws.append(n)
+
+        class Src(C.Structure):
+            _fields_ = [("draw", FN), ("ctx", C.c_void_p)]
+        self._fn = FN(draw)
+        self.src = Src(self._fn, None)
+
+    @property
+    def ptr(self):
+        return C.cast(C.pointer(self.src), C.c_void_p)
+
+
+@pytest.mark.parametrize("ndev", [1, 3, 8])
+def test_wire_level_calls_and_the_generator_callback(lib, ndev):
+    """act_node_refund_cbor_batch / act_node_redeem_cbor_batch: wire bytes in, wire bytes out over the shards; ACT_RNG_CALLBACK draws
+    once, after the verdicts (redeem: after the nullifier step), exactly 128 bytes per lane that is signed -- the state a sequential
+    loop would leave the caller's generator in -- and gives the same bytes as ACT_RNG_SEQUENTIAL over that stream."""
+    n = 57
+    nd = make_node(lib, ndev)
+    recs = bytearray(records(n, PB, 500 + ndev))
+    recs[PB * 9:PB * 10] = recs[PB * 4:PB * 5]                       # lane 9 repeats lane 4
+    recs = bytes(recs)
+    ML, RL = PB + 3, 129
+    msgs = b"".join(b"\xa1\x01\x58" + recs[PB * i:PB * (i + 1)] for i in range(n))
+    offs = (C.c_uint64 * (n + 1))(*[ML * i for i in range(n + 1)])
+    rrng = records(n, 128, 21)
+    verdict = [7 if recs[PB * i] & 1 else 0 for i in range(n)]
+    acc = sum(1 for v in verdict if v == 0)
+
+    def check(out, st, want_status, stream):
+        cur = 0
+        for i in range(n):
+            assert st.raw[i] == want_status[i], (i, st.raw[i], want_status[i])
+            slot = out.raw[RL * i:RL * (i + 1)]
+            if want_status[i]:
+                assert slot == bytes(RL)
+                continue
+            assert slot[0] == 0xa4 and slot[1:9] == recs[PB * i:PB * i + 8] and slot[9:17] == stream[128 * cur:128 * cur + 8], i
+            cur += 1
+        return cur
+
+    # refund: sequential bytes, then the same through the callback
+    out = C.create_string_buffer(RL * n); st = C.create_string_buffer(n)
+    assert lib.act_node_refund_cbor_batch(nd, C.c_size_t(n), bytes(64), msgs, offs, rrng, 1, out, st) == 0
+    assert check(out, st, verdict, rrng) == acc
+    g = _Replay(rrng)
+    out2 = C.create_string_buffer(RL * n); st2 = C.create_string_buffer(n)
+    assert lib.act_node_refund_cbor_batch(nd, C.c_size_t(n), bytes(64), msgs, None, g.ptr, 2, out2, st2) == 0
+    assert out2.raw == out.raw and st2.raw == st.raw
+    assert g.draws == [128 * acc] and g.pos == 128 * acc, g.draws
+    # per-lane rng: lane i owns slice i
+    out3 = C.create_string_buffer(RL * n); st3 = C.create_string_buffer(n)
+    assert lib.act_node_refund_cbor_batch(nd, C.c_size_t(n), bytes(64), msgs, offs, rrng, 0, out3, st3) == 0
+    for i in range(n):
+        if verdict[i] == 0:
+            assert out3.raw[RL * i + 9:RL * i + 17] == rrng[128 * i:128 * i + 8]
+    # the halves: keys (K', nullifier) then sign + frame
+    stv = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n); nul = C.create_string_buffer(32 * n)
+    assert lib.act_node_verify_spend_cbor_keys_batch(nd, C.c_size_t(n), bytes(64), msgs, offs, stv, kp, nul) == 0
+    assert stv.raw == bytes(verdict) and nul.raw == b"".join(recs[PB * i:PB * i + 32] for i in range(n))
+    out4 = C.create_string_buffer(RL * n); st4 = C.create_string_buffer(n)
+    assert lib.act_node_refund_sign_cbor_batch(nd, C.c_size_t(n), bytes(64), kp.raw, stv.raw, rrng, 1, out4, st4) == 0
+    assert out4.raw == out.raw and st4.raw == st.raw
+
+    # redeem on wire bytes: the repeat is a double spend iff its first occurrence was accepted; the generator is drawn for signed lanes only
+    ns = C.c_void_p(); devs = (C.c_int * 2)(0, 1)
+    assert lib.act_node_nullifier_set_create(devs, 2, C.c_size_t(1000), None, C.byref(ns)) == 0
+    want = list(verdict)
+    if verdict[4] == 0:
+        want[9] = 3
+    signed = sum(1 for v in want if v == 0)
+    g = _Replay(rrng)
+    out5 = C.create_string_buffer(RL * n); st5 = C.create_string_buffer(n)
+    assert lib.act_node_redeem_cbor_batch(nd, ns, C.c_size_t(n), bytes(64), msgs, offs, g.ptr, 2, out5, st5) == 0
+    assert check(out5, st5, want, rrng) == signed and g.draws == [128 * signed]
+    assert lib.act_node_nullifier_set_len(ns) == signed
+    # a second submission of the same messages: every accepted lane is now a double spend, nothing is drawn
+    g2 = _Replay(rrng)
+    assert lib.act_node_redeem_cbor_batch(nd, ns, C.c_size_t(n), bytes(64), msgs, offs, g2.ptr, 2, out5, st5) == 0
+    assert st5.raw == bytes(3 if v == 0 else v for v in verdict) and out5.raw == bytes(RL * n) and g2.draws == []
+    # the record-level redeem takes the generator too
+    ns2 = C.c_void_p()
+    assert lib.act_node_nullifier_set_create(devs, 2, C.c_size_t(1000), None, C.byref(ns2)) == 0
+    g3 = _Replay(rrng)
+    out6 = C.create_string_buffer(128 * n); st6 = C.create_string_buffer(n)
+    assert lib.act_node_redeem_batch(nd, ns2, C.c_size_t(n), bytes(64), recs, g3.ptr, 2, out6, st6) == 0
+    assert st6.raw == bytes(want) and g3.pos == 128 * signed
+    for i in range(n):
+        assert out6.raw[128 * i:128 * (i + 1)] == (bytes(128) if want[i] else check_rec(recs, rrng, want, i))
+    lib.act_node_nullifier_set_destroy(ns); lib.act_node_nullifier_set_destroy(ns2)
+    lib.act_node_destroy(nd)
+
+
+def check_rec(recs, stream, want, i):
+    """the mock's Refund record of signed lane i under a sequential stream"""
+    cur = sum(1 for j in range(i) if want[j] == 0)
+    return recs[PB * i:PB * i + 8] + stream[128 * cur:128 * cur + 120]
+
+
+def test_load_balance_slow_context_gets_fewer_lanes(lib):
+    """A context that is slower than its neighbours: with the dynamic tail the others take pieces off it during the FIRST call; the
+    weights it leaves behind cut the next call's heads in proportion; the output never changes."""
+    lib.act_mock_slow.argtypes = [C.c_void_p, C.c_uint]
+    lib.act_node_device_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    lib.act_node_balance_state.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    ndev, n = 3, 3 * 65536
+    proofs = records_fast(n, PB, 5)
+    sk = bytes(64)
+
+    def stats(nd):
+        out = []
+        for k in range(ndev):
+            w, s = C.c_double(0), C.c_double(0); la, ca = C.c_uint64(0), C.c_uint64(0)
+            assert lib.act_node_device_stats(nd, k, C.byref(w), C.byref(la), C.byref(s), C.byref(ca)) == 0
+            out.append((w.value, la.value, s.value, ca.value))
+        return out
+
+    ref_nd = make_node(lib, 1)
+    want_st = C.create_string_buffer(n); want_kp = C.create_string_buffer(32 * n)
+    assert lib.act_node_verify_spend_batch(ref_nd, C.c_size_t(n), sk, proofs, want_st, want_kp) == 0
+    lib.act_node_destroy(ref_nd)
+
+    nd = make_node(lib, ndev)
+    for k in range(ndev):
+        lib.act_mock_slow(lib.act_node_ctx(nd, k), 300 if k == 1 else 100)         # context 1 is three times slower
+    st = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
+    assert lib.act_node_verify_spend_batch(nd, C.c_size_t(n), sk, proofs, st, kp) == 0
+    assert st.raw == want_st.raw and kp.raw == want_kp.raw
+    s1 = stats(nd)
+    sp, tf = C.c_double(0), C.c_double(0)
+    assert lib.act_node_balance_state(nd, C.byref(sp), C.byref(tf)) == 0
+    assert sum(x[1] for x in s1) == n
+    assert abs(tf.value - 1 / 16) < 0.01 and sp.value > 0.3                           # nothing known: a sixteenth through the tail; the spread is seen
+    assert s1[1][3] == 1 and s1[0][3] > 1 and s1[2][3] > 1, s1                       # the slow context got no tail piece, the others took them
+    assert s1[1][0] < 0.8 < 1.05 < s1[0][0], s1                                      # weights after one call
+    # second call: heads cut by the weights
+    assert lib.act_node_verify_spend_batch(nd, C.c_size_t(n), sk, proofs, st, kp) == 0
+    assert st.raw == want_st.raw and kp.raw == want_kp.raw
+    s2 = stats(nd)
+    assert s2[1][1] < 0.8 * s2[0][1] and sum(x[1] for x in s2) == n, s2
+    # the cut can be pinned: equal shares, no tail
+    assert lib.act_node_set_balance(nd, 0, 0) == 0
+    assert lib.act_node_verify_spend_batch(nd, C.c_size_t(n), sk, proofs, st, kp) == 0
+    assert st.raw == want_st.raw and [x[1] for x in stats(nd)] == [n // 3] * 3 and [x[3] for x in stats(nd)] == [1, 1, 1]
+    # SEQUENTIAL signatures over pieces: the stream position of a piece is the number of accepted lanes in front of it
+    assert lib.act_node_set_balance(nd, 1, 8) == 0
+    rng = records_fast(n, 128, 6)
+    out = C.create_string_buffer(128 * n); st2 = C.create_string_buffer(n)
+    assert lib.act_node_refund_batch(nd, C.c_size_t(n), sk, proofs, rng, 1, out, st2) == 0
+    one = make_node(lib, 1)
+    out1 = C.create_string_buffer(128 * n); st1 = C.create_string_buffer(n)
+    assert lib.act_node_refund_batch(one, C.c_size_t(n), sk, proofs, rng, 1, out1, st1) == 0
+    assert out.raw == out1.raw and st2.raw == st1.raw
+    lib.act_node_destroy(one)
+    lib.act_node_destroy(nd)
+
+
+def records_fast(n, rec, seed):
+    """like records(), vectorised: first byte random, then the 7-byte lane number, then random filler"""
+    import numpy as np
+    g = np.random.default_rng(seed)
+    a = g.integers(0, 256, (n, rec), dtype=np.uint8)
+    idx = np.arange(n, dtype=np.uint64)
+    for b in range(7):
+        a[:, 1 + b] = (idx >> np.uint64(8 * b)).astype(np.uint8)
+    return a.tobytes()
