@@ -98,12 +98,14 @@ struct act_ctx {
   std::vector<std::pair<float, float>> prof_iv[PK_COUNT];          // [start, end) of every launch, ms since prof_base
   // small-batch schedule (spend_small_locked): four more streams, the events that tie its streams together, per-proof scratch
   hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool aux_used = false;               // the running call has put work on the aux streams: finish_call waits for them before it wipes
   std::vector<hipEvent_t> sm_ev;       // SM_EVENTS per sub-chunk, created on first use, kept
   uint32_t* d_small = nullptr; size_t d_small_cap = 0, d_small_dirty = 0;      // bytes
-  size_t small_max = 8192;             // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
+  std::atomic<size_t> small_max{8192}; // (atomic: merged callers read it without the context's lock)  calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
   double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
+  double host_wait_s = 0, host_hash_s = 0; uint64_t host_hash_bytes = 0; // act_ctx_host_hash_stats: the calling thread's time in hash_end since the last reset
   // coalescing of concurrent callers' small verify / refund calls (act_ctx_set_coalescing; spend_coalesced below)
   std::atomic<size_t> co_req_max{0};   // 0 = off; else: calls of at most this many proofs from host memory may be merged
   act::Combiner<struct CoReq>* co = nullptr;     // the queue of requests waiting to be merged (coalesce.h); created with the context
@@ -259,11 +261,13 @@ int hash_end(act_ctx* c, Slot& sl, uint32_t stride, uint32_t len, uint32_t n) {
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   for (int k = 0; k < HASH_PIECES; k++) {
     size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
-    double t0 = trace ? now() : 0;
+    const double t0 = now();
     HIPCK(c, hipEventSynchronize(sl.h_ev[k]));
-    double t1 = trace ? now() : 0;
+    const double t1 = now();
     if (i1 > i0) host_hash_many(c, sl.h_tr + i0 * stride, stride, len, i1 - i0, sl.h_xof + i0 * 16);
-    if (trace) { t_wait += t1 - t0; t_hash += now() - t1; }
+    const double t2 = now();
+    t_wait += t1 - t0; t_hash += t2 - t1;
+    c->host_wait_s += t1 - t0; c->host_hash_s += t2 - t1; c->host_hash_bytes += (uint64_t)(i1 - i0) * len;      // act_ctx_host_hash_stats
   }
   if (trace && len > 1024) {
     n_msgs += n;
@@ -292,8 +296,14 @@ int decode_one(act_ctx* c, const uint8_t enc[32], ge* out) {
   *out = ge_load(host);
   return ACT_OK;
 }
+// equality of two byte strings in time that does not depend on where they differ (private keys are compared: cache hit, merging)
+inline bool ct_equal(const uint8_t* a, const uint8_t* b, size_t n) {
+  uint32_t d = 0;
+  for (size_t i = 0; i < n; i++) d |= (uint32_t)(a[i] ^ b[i]);
+  return d == 0;
+}
 int set_key(act_ctx* c, const uint8_t sk[64]) {
-  if (c->sk_valid && memcmp(c->sk_cached, sk, 64) == 0) return ACT_OK;
+  if (c->sk_valid && ct_equal(c->sk_cached, sk, 64)) return ACT_OK;
   // nothing of the cached key changes unless the whole new key is good (a rejected w must not leave its x behind)
   uint32_t w[8]; memcpy(w, sk, 32);
   ge wpt;
@@ -406,13 +416,20 @@ int streams_overlap_probe(act_ctx* c, int* overlap) {
   *overlap = std::max(t1, t2) < 1.6f * (ticks / 1e5f) ? 1 : 0;
   return ACT_OK;
 }
+// On a GPU that other work is using (other contexts being created, eight ranks on one device) a single probe can read as "no
+// overlap" although the streams are fine: the verdict is the best of three.
+int streams_overlap_probe3(act_ctx* c, int* overlap) {
+  *overlap = 0;
+  for (int t = 0; t < 3 && !*overlap; t++) { int rc = streams_overlap_probe(c, overlap); if (rc) return rc; }
+  return ACT_OK;
+}
 // ... and if they share a queue, slot 1 moves to a stream of another priority: the runtime keeps a separate set of hardware queues
 // per priority, so the two cannot alias whatever else the process has created.  What is left is reported by
 // act_ctx_streams_overlap() and documented for the embedding process (GPU_MAX_HW_QUEUES).
 int streams_settle(act_ctx* c) {
   static const bool skip = getenv("ACT_NO_STREAM_PROBE") != nullptr;
   if (skip) { c->streams_overlap = -1; return ACT_OK; }
-  int ov = 0, rc = streams_overlap_probe(c, &ov); if (rc) return rc;
+  int ov = 0, rc = streams_overlap_probe3(c, &ov); if (rc) return rc;
   if (!ov) {
     int least = 0, greatest = 0;
     HIPCK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -423,7 +440,7 @@ int streams_settle(act_ctx* c) {
       HIPCK(c, hipStreamSynchronize(c->slots[1].stream));
       HIPCK(c, hipStreamDestroy(c->slots[1].stream));
       c->slots[1].stream = s;
-      if ((rc = streams_overlap_probe(c, &ov))) return rc;
+      if ((rc = streams_overlap_probe3(c, &ov))) return rc;
     }
   }
   c->streams_overlap = ov;
@@ -443,6 +460,9 @@ int sync_all(act_ctx* c) {
 // Only the extent this call touched is cleared: n lanes (at most max_batch) of the per-proof buffers.
 int finish_call(act_ctx* c, size_t n) {
   const size_t lanes = std::min(n, c->max_batch);
+  // a small-batch call that returned early (a HIP error half way through its schedule) may still have kernels on the aux streams
+  // writing d_small and the slot buffers: nothing is wiped under them
+  if (c->aux_used) { c->aux_used = false; for (hipStream_t a : c->aux) if (a) HIPCK(c, hipStreamSynchronize(a)); }
   for (Slot& sl : c->slots) {
     for (int i = 0; i < Slot::N_STAGE; i++)
       if (sl.d_stage_dirty[i]) { HIPCK(c, hipMemsetAsync(sl.d_stage[i], 0, sl.d_stage_dirty[i], sl.stream)); sl.d_stage_dirty[i] = 0; }
@@ -620,24 +640,25 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   HIPCK(c, hipMemcpyAsync(ok, d_ok, 16, hipMemcpyDeviceToHost, s0));
   HIPCK(c, hipStreamSynchronize(s0));
   if (!(ok[0] && ok[1] && ok[2] && ok[3])) { c->err = "h1/h2/h3 is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
-  // Window widths: 16 bits everywhere by default (128 MiB per base).  In contexts sized for throughput the two bases the
-  // range kernel multiplies (h1, h3: 48 of its table additions per proof-bit) get 24-bit windows, 23.6 GB each of the 288 GB
-  // -- but only when the device has that much to spare: free memory after this context's workspace must cover the tables
-  // that are not already shared on this device plus a reserve for what is allocated later (staging buffers of host-memory
-  // callers grow on demand: up to ~7 GB for a 65536-lane prover chunk).  ACT_FB_WIDE_BITS=16 turns the wide tables off,
-  // ACT_FB_WIDE_BITS=<n> picks another width, ACT_FB_ALL_WIDE=1 widens g and h2 as well (prover-heavy deployments).
+  // Window widths: 16 bits everywhere (128 MiB per base) unless the device is plainly being used for nothing but this.  The two bases
+  // the range kernel multiplies (h1, h3: 48 of its table additions per proof-bit) gain +3 % verifies/s from 24-bit windows, which cost
+  // 23.6 GB each -- 47 GB for 3 %.  A context therefore takes them only when it is sized for throughput (max_batch >= 65536) AND at
+  // least 128 GB of the device are still free after its own workspace (a 288 GB MI355X running one or two such contexts; never a GPU
+  // shared with other tenants), or when asked: ACT_FB_WIDE_BITS=24 (any width 4..24; needs the tables' size + 16 GB free),
+  // ACT_FB_WIDE_BITS=16 = never, ACT_FB_ALL_WIDE=1 widens g and h2 as well (prover-heavy deployments).  Tables of one width on one
+  // device are shared by all contexts of the process, so the second context pays nothing either way.
   {
     static const int wide_env = [] { const char* e = getenv("ACT_FB_WIDE_BITS"); return e ? atoi(e) : 0; }();
     static const bool all_wide = getenv("ACT_FB_ALL_WIDE") != nullptr;
-    int wide = wide_env ? wide_env : (c->max_batch >= 32768 ? 24 : FB_WBITS);
+    int wide = wide_env ? wide_env : (c->max_batch >= 65536 ? 24 : FB_WBITS);
     if (wide < 4 || wide > 24) wide = FB_WBITS;
     for (int b = 0; b < 4; b++) c->fb_bits[b] = (b == BASE_H1 || b == BASE_H3 || all_wide) ? wide : FB_WBITS;
     if (wide > FB_WBITS) {
       size_t need = 0, free_b = 0, total_b = 0;
       for (int b = 0; b < 4; b++)
         if (c->fb_bits[b] > FB_WBITS && !table_cached(device, enc + 32 * b, c->fb_bits[b])) need += fb_table_words((uint32_t)c->fb_bits[b]) * 4;
-      const size_t reserve = (size_t)16 << 30;
-      if (need && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + reserve)) {
+      const size_t floor_free = wide_env ? need + ((size_t)16 << 30) : std::max(need + ((size_t)16 << 30), (size_t)128 << 30);
+      if (need && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < floor_free)) {
         (void)hipGetLastError();
         for (int b = 0; b < 4; b++) c->fb_bits[b] = FB_WBITS;
       }
@@ -730,10 +751,19 @@ int act_build_has_ct_secret_tables(void) {
   return 0;
 #endif
 }
-int act_ctx_set_small_batch_max(act_ctx* c, size_t n) { if (!c) return ACT_ERR_ARG; std::lock_guard<std::mutex> lk(c->mu); c->small_max = n; return ACT_OK; }
+int act_ctx_set_small_batch_max(act_ctx* c, size_t n) { if (!c) return ACT_ERR_ARG; c->small_max.store(n); return ACT_OK; }
 int act_debug_set_slowdown(act_ctx* c, uint32_t ns_per_lane) { if (!c) return ACT_ERR_ARG; c->debug_ns_per_lane.store(ns_per_lane); return ACT_OK; }
 int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
 int act_ctx_set_host_threads(act_ctx* c, int n) { if (!c || n < 0) return ACT_ERR_ARG; c->host_threads = n; return ACT_OK; }
+int act_ctx_host_hash_stats(act_ctx* c, double* wait_s, double* hash_s, uint64_t* bytes, int reset) {
+  if (!c) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (wait_s) *wait_s = c->host_wait_s;
+  if (hash_s) *hash_s = c->host_hash_s;
+  if (bytes) *bytes = c->host_hash_bytes;
+  if (reset) { c->host_wait_s = c->host_hash_s = 0; c->host_hash_bytes = 0; }
+  return ACT_OK;
+}
 // copied under the context's lock into a buffer of the calling thread (another thread's failing call may rewrite c->err at any
 // moment); valid until this thread's next act_last_error call
 const char* act_last_error(const act_ctx* c) {
@@ -947,9 +977,14 @@ static int small_prepare(act_ctx* c, size_t n, size_t subs) {
   while (c->sm_ev.size() < subs * SM_EVENTS) { hipEvent_t e; HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->sm_ev.push_back(e); }
   const size_t per_proof = ((size_t)PREP_BUCKET_SETS * BUCKET_WORDS + (size_t)PART_POINTS * GE_WORDS) * 4;
   if (n * per_proof > c->d_small_cap) {
-    const size_t cap = std::min(c->max_batch, std::max<size_t>(c->small_max, n)) * per_proof;
+    const size_t cap = std::min(c->max_batch, std::max<size_t>(c->small_max.load(), n)) * per_proof;
     if (c->d_small) { HIPCK(c, hipMemset(c->d_small, 0, c->d_small_cap)); HIPCK(c, hipFree(c->d_small)); c->d_small = nullptr; c->d_small_cap = 0; }
     HIPCK(c, hipMalloc(&c->d_small, cap)); c->d_small_cap = cap;
+    // starts clean like the other secret-bearing buffers (the allocator may hand back freed memory).  On a stream of this context and
+    // waited for: a plain hipMemset goes to the null stream, which the context's non-blocking streams do not wait for -- it could land
+    // in the middle of the role kernels that are about to fill this buffer.
+    HIPCK(c, hipMemsetAsync(c->d_small, 0, cap, c->slots[0].stream));
+    HIPCK(c, hipStreamSynchronize(c->slots[0].stream));
   }
   c->d_small_dirty = std::max(c->d_small_dirty, n * per_proof);
   return ACT_OK;
@@ -989,6 +1024,7 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   const size_t S = sub_env ? sub_env : std::max<size_t>(64, ((size_t)1 << 20) / L);        // measured (profiles/r04_small_sweep.txt): sub-chunks of one round lose to one launch
   const size_t K = (n + S - 1) / S;
   int rc = small_prepare(c, n, K); if (rc) return rc;
+  c->aux_used = true;
   Slot& sl = c->slots[0];
   hipStream_t s_bits = sl.stream, s_tail = c->slots[1].stream, s_a = c->aux[0], s_b = c->aux[1], s_e = c->aux[2], s_x = c->aux[3];
   auto ev = [&](size_t k, int what) { return c->sm_ev[k * SM_EVENTS + what]; };
@@ -1092,7 +1128,7 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
 static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
                               int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime, const WireSrc* wire = nullptr) {
   int rc = set_key(c, sk); if (rc) return rc;
-  if (n && n <= c->small_max && n <= c->max_batch) {
+  if (n && n <= c->small_max.load() && n <= c->max_batch) {
     if (!wire) return spend_small_locked(c, n, mem, proof, sign, rng, rng_mode, out_refund, status, out_kprime);
     // wire bytes: all n messages are unframed on slot 0's stream, the small-batch schedule starts from those records
     const uint8_t* d_records = nullptr;
@@ -1244,10 +1280,11 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
 }
 
 static int spend_coalesced(act_ctx* c, CoReq& r) {
-  const size_t cap = std::max<size_t>(c->co_req_max.load(), std::min<size_t>(c->max_batch, c->small_max ? c->small_max : c->max_batch));   // lanes per merged call
+  const size_t sm = c->small_max.load();
+  const size_t cap = std::max<size_t>(c->co_req_max.load(), std::min<size_t>(c->max_batch, sm ? sm : c->max_batch));   // lanes per merged call
   // the oldest request decides key and kind; every queued request of the same key and kind joins (coalesce.h)
   return c->co->submit(r, cap,
-                       [](const CoReq& a, const CoReq& b) { return a.kind == b.kind && (!a.sk || memcmp(a.sk, b.sk, 64) == 0); },
+                       [](const CoReq& a, const CoReq& b) { return a.kind == b.kind && (!a.sk || ct_equal(a.sk, b.sk, 64)); },
                        [c](const std::vector<CoReq*>& batch, size_t total) { return co_run(c, batch, total); });
 }
 
@@ -1551,6 +1588,8 @@ int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
     regions.emplace_back(sl.d_d01, c->max_batch * 3 * GE_WORDS * 4);
     regions.emplace_back(sl.d_buckets, c->max_batch * PREP_BUCKET_SETS * BUCKET_WORDS * 4);
   }
+  if (c->d_small) regions.emplace_back(c->d_small, c->d_small_cap);      // the small-batch schedule's partial sums and bucket sets (what single-item calls use)
+  if (c->h_co_rng) for (size_t i = 0; i < c->h_co_cap * 128; i++) nz += c->h_co_rng[i] != 0;      // the merged calls' pinned rng gather buffer (host memory)
   for (auto& r : regions) total += r.second;
   if (total > ((size_t)1 << 30)) { c->err = "act_debug_secret_residue: context too large to read back (use a small max_batch)"; return ACT_ERR_ARG; }
   std::vector<uint8_t> buf;

@@ -334,6 +334,9 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+NOMINAL_MAD_PEAK = 256 * 4 * 16 * 2.4e9      # 256 CUs x 4 SIMDs x 16 lanes, one v_mad_u64_u32 per lane and clock, 2.4 GHz
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as a CHILD process (torch.distributed.run), before this
     process has imported torch or touched HIP (a process that has initialised the GPU must not exec or fork GPU users on this
@@ -442,6 +445,7 @@ def main():
         torch.cuda.synchronize()      # the engine runs on its own streams: inputs written by torch must be complete first
         for _ in range(warmup):
             step()
+        eng.host_hash_stats(reset=True)
         eng.prof_reset(); eng.prof_enable(True)        # HIP events on the engine's own streams (torch events cannot see them)
         barrier()
         t0 = time.perf_counter()
@@ -450,22 +454,27 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         eng.prof_enable(False)
+        hs = eng.host_hash_stats(reset=True)
+        loc = {"elapsed": elapsed}                # this rank's own clock around the region (the line reports the max over ranks)
+        loc.update({"host_hash_busy_fraction": round(hs["hash_s"] / elapsed, 4), "host_wait_for_device_fraction": round(hs["wait_s"] / elapsed, 4),
+                                 "transcripts_over_pcie_GBps": round(hs["bytes"] / elapsed / 1e9, 2), "host_hash_GBps_while_hashing": round(hs["bytes"] / hs["hash_s"] / 1e9, 2) if hs["hash_s"] else None,
+                                 "host_threads": eng.lib.act_host_usable_cpus()})
         if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert os.environ.get("ACT_BENCH_NO_CHECK") or torch.equal(status[:m], expect[:m]), "verification statuses wrong"
-        return elapsed, eng.prof()
+        return elapsed, eng.prof(), loc
 
     # N = 1: one region.  N > 1: strong scaling = ONE batch of 2^batch_log2 over the whole node (the metric as BASELINE.json words
     # it) and weak scaling = every rank its own 2^batch_log2 proofs; --scaling picks which is `value`, both are printed.
     scaling = "weak" if world == 1 else ("strong" if args.scaling == "auto" else args.scaling)
-    weak_elapsed, weak_prof = timed_region(n, args.steps, args.warmup)
+    weak_elapsed, weak_prof, weak_loc = timed_region(n, args.steps, args.warmup)
     strong = None
     if world > 1:
         n_s = n // world
         status.zero_()
-        s_elapsed, s_prof = timed_region(n_s, args.steps, args.warmup)
+        s_elapsed, s_prof, s_loc = timed_region(n_s, args.steps, args.warmup)
         strong = {"value": world * n_s * args.steps / s_elapsed, "unit": "verifies/s", "ms_per_step": 1e3 * s_elapsed / args.steps, "batch_total": world * n_s,
                   "batch_per_gpu": n_s, "launch_chunks_per_gpu": -(-n_s // args.max_batch), "scaling": "strong",
                   "what": "BASELINE.json's metric as worded: ONE 2^%d batch over the whole node, contiguous shards of 2^%d / %d proofs per rank, no collective"
@@ -475,15 +484,23 @@ def main():
         other = capi.TRANSCRIPT_DEVICE if tr_mode == capi.TRANSCRIPT_HOST else capi.TRANSCRIPT_HOST
         eng.set_transcript_mode(other)
         status.zero_()
-        o_elapsed, _ = timed_region(n_s, max(1, args.steps // 2), 1)
+        o_elapsed, _, _ = timed_region(n_s, max(1, args.steps // 2), 1)
         eng.set_transcript_mode(tr_mode)
         strong["other_transcript_mode"] = {"transcript": "device BLAKE3" if other == capi.TRANSCRIPT_DEVICE else "host BLAKE3",
                                            "value": world * n_s * max(1, args.steps // 2) / o_elapsed, "unit": "verifies/s",
                                            "ms_per_step": 1e3 * o_elapsed / max(1, args.steps // 2)}
     if scaling == "strong":
-        elapsed, prof, n_rank = s_elapsed, s_prof, n_s
+        elapsed, prof, n_rank, loc = s_elapsed, s_prof, n_s, s_loc
     else:
-        elapsed, prof, n_rank = weak_elapsed, weak_prof, n
+        elapsed, prof, n_rank, loc = weak_elapsed, weak_prof, n, weak_loc
+    # what every rank saw in the region that became `value` (N > 1: gathered on rank 0): the first thing to look at when the 1 -> 8
+    # curve bends -- a slow GPU (clock, k_spend_bits busy), a starved host side (hash_busy_fraction near 1), or the link
+    mine = rank_report(capi, eng, local, prof, loc, args.steps, n_rank, L)
+    per_rank = [mine]
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine, group=ctl)
+        per_rank = gathered
 
     out = None
     if rank == 0:
@@ -524,6 +541,10 @@ def main():
                        "sharding": ("one batch cut into contiguous shards, one per rank, no collective" if scaling == "strong" else "independent batches per rank, no collective"),
                        "input_generation_s": round(t_gen, 2), "prove_spend_proofs_per_s": round(distinct / t_prove) if t_prove else None},
         }
+        if world > 1:
+            out["per_rank"] = per_rank
+        else:
+            out["rank_report"] = per_rank[0]
         if strong:
             out["strong"] = strong
             out["weak"] = {"value": world * n * args.steps / weak_elapsed, "unit": "verifies/s", "ms_per_step": 1e3 * weak_elapsed / args.steps, "batch_per_gpu": n,
@@ -539,6 +560,9 @@ def main():
         bits_rate = bits_mad_per_proof * proofs_per_launch / launch_s if launch_s else 0.0
         roof = {"bound": "valu-int-mad", "kernel": "k_spend_bits",
                 "achieved": bits_rate, "peak": peak_mad, "unit": "lane multiply-accumulates (v_mad_u64_u32) per second", "frac": bits_rate / peak_mad,
+                "frac_vs_nominal_2p4GHz": bits_rate / NOMINAL_MAD_PEAK,
+                "peak_note": "peak = the in-process probe (%.2f GHz x 16 384 lanes: what the power governor gives a sustained integer load on this box); "
+                             "frac_vs_nominal_2p4GHz prices the same work against 16 384 lanes x the 2.4 GHz peak engine clock of MI355X_MICROARCH.md" % (peak_mad / 16384 / 1e9),
                 "traffic": None,
                 "avg_launch_ms": 1e3 * launch_s, "launches_per_step": launches_per_step,
                 "avg_launch_ms_x_launches_per_step": 1e3 * launch_s * launches_per_step,
@@ -615,10 +639,30 @@ def main():
         dist.destroy_process_group()
 
 
-def timed(fn, sync):
-    fn(); sync()                       # warm-up (buffers grow, pinned staging is allocated)
-    t = time.perf_counter(); fn(); sync()
-    return time.perf_counter() - t
+EXTRA_SAMPLES = 3
+
+
+def rank_report(capi, eng, device, prof, loc, steps, n_rank, L):
+    """One rank's view of its timed region: its own wall time, the clock its GPU gives a sustained integer load (the roofline probe),
+    how long k_spend_bits was executing, how busy the host side of the host-transcript mode was, and the PCIe traffic of that mode."""
+    peak, _ = capi.ubench_mad(device)
+    bits = prof.get("k_spend_bits", {"busy_ms": 0.0, "launches": 0})
+    elapsed_s = loc["elapsed"]
+    rep = {"rank": int(os.environ.get("RANK", "0")), "device": device, "ms_per_step": round(1e3 * elapsed_s / steps, 2), "proofs_per_step": n_rank,
+           "verifies_per_s": round(n_rank * steps / elapsed_s), "probe_clock_ghz": round(peak / 16384 / 1e9, 3),
+           "k_spend_bits_busy_ms_per_step": round(bits["busy_ms"] / steps, 2), "k_spend_bits_busy_fraction": round(bits["busy_ms"] / 1e3 / elapsed_s, 4)}
+    rep.update({k: v for k, v in loc.items() if k != "elapsed"})
+    return rep
+
+
+def timed(fn, sync, reps=EXTRA_SAMPLES):
+    """median of `reps` timed runs after one warm-up run (buffers grow, pinned staging is allocated)"""
+    fn(); sync()
+    ts = []
+    for _ in range(reps):
+        t = time.perf_counter(); fn(); sync()
+        ts.append(time.perf_counter() - t)
+    return sorted(ts)[len(ts) // 2]
 
 
 def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinct):
@@ -626,7 +670,7 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     n = dev.shape[0]
     m = min(1 << args.extra_log2, n)
     sync = torch.cuda.synchronize
-    ex = {"proofs_each": m}
+    ex = {"proofs_each": m, "samples": "every rate below is the median of %d timed runs after one warm-up run (call_latency_ms: of 7)" % EXTRA_SAMPLES}
     st = torch.zeros(m, dtype=torch.uint8, device="cuda")
     stf = torch.zeros(n, dtype=torch.uint8, device="cuda")
     # (0) the round-1..3 headline: the same batch with the transcripts hashed by the device BLAKE3 kernel (nothing crosses PCIe)
@@ -635,7 +679,7 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     dt = timed(lambda: eng.verify_spend_dev(sk, n, dev.data_ptr(), stf.data_ptr()), sync)
     assert torch.equal(stf, expect)
     ex["hbm_device_transcripts"] = {"value": n / dt, "unit": "verifies/s", "proofs": n,
-                                    "what": "ACT_TRANSCRIPT_DEVICE over the whole 2^%d batch, proofs in HBM: byte-identical transcripts hashed on the GPU (one step after a warm-up step)" % args.batch_log2}
+                                    "what": "ACT_TRANSCRIPT_DEVICE over the whole 2^%d batch, proofs in HBM: byte-identical transcripts hashed on the GPU" % args.batch_log2}
     # (0b) what tiling flatters: the round-1/2 input, 4 096 distinct proofs x256 (every 65 536-proof launch holds each proof 16
     #      times, so the scalar-addressed reads of the 24-bit tables hit in L2 / Infinity Cache)
     if distinct == n and n >= 8192:
@@ -645,7 +689,7 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
         sync()
         dt = timed(lambda: eng.verify_spend_dev(sk, n, tiled.data_ptr(), stf.data_ptr()), sync)
         assert torch.equal(stf, t_exp)
-        ex["tiled_4096"] = {"value": n / dt, "unit": "verifies/s", "proofs": n, "what": "device transcripts, 4 096 distinct proofs tiled x%d (one step after a warm-up step)" % (n // 4096)}
+        ex["tiled_4096"] = {"value": n / dt, "unit": "verifies/s", "proofs": n, "what": "device transcripts, 4 096 distinct proofs tiled x%d" % (n // 4096)}
         del tiled
     del stf
     # (1) host transcripts on a quarter-size batch: pipeline fill and drain are a larger share
@@ -763,6 +807,34 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     assert torch.equal(st, expect[:m])
     assert bool((rf[expect[:m] != 0] == 0).all()) and bool((rf[expect[:m] == 0].any(dim=1)).all())
     ex["refund"] = {"value": m / dt, "unit": "refunds/s", "what": "verify + BBS re-sign, device transcripts, HBM-resident, ACT_RNG_PER_LANE"}
+    # (4b) the server's path on wire bytes: CBOR SpendProof messages in, CBOR Refund messages out --
+    #      SpendProof::from_cbor + refund + Refund::to_cbor per message in the crate.  Device memory, then pinned host memory.
+    try:
+        import ctypes as C
+        ml_in, ml_out = eng.cbor_size("SpendProof"), eng.cbor_size("Refund")
+        msgs = torch.empty(m * ml_in, dtype=torch.uint8, device="cuda"); outm = torch.zeros(m * ml_out, dtype=torch.uint8, device="cuda")
+        sync()
+        eng._ck(eng.lib.act_cbor_encode_batch(eng.ctx, capi.CBOR_TYPES["SpendProof"], m, capi.MEM_DEVICE, dev.data_ptr(), msgs.data_ptr()))
+        dt = timed(lambda: eng.wire_ptr("refund", sk, m, capi.MEM_DEVICE, msgs.data_ptr(), 0, rng.data_ptr(), capi.RNG_PER_LANE, outm.data_ptr(), st.data_ptr()), sync)
+        assert torch.equal(st, expect[:m])
+        # the framed refunds carry the records of (4): payloads at 4 + 35 f of every 141-byte message
+        om = outm.view(m, ml_out)
+        ok = expect[:m] == 0
+        assert all(torch.equal(om[ok][:, 4 + 35 * f:36 + 35 * f], rf[ok][:, 32 * f:32 * f + 32]) for f in range(4)) and bool((om[~ok] == 0).all())
+        wire = {"device_memory": {"value": m / dt, "unit": "messages/s"}}
+        mh = min(m, 1 << 17)
+        hm = torch.empty(mh * ml_in, dtype=torch.uint8, pin_memory=True); hm.copy_(msgs[:mh * ml_in]); sync()
+        ho = torch.zeros(mh * ml_out, dtype=torch.uint8, pin_memory=True); hst = torch.zeros(mh, dtype=torch.uint8, pin_memory=True)
+        hr = torch.empty(mh * 128, dtype=torch.uint8, pin_memory=True); hr.copy_(rng[:mh].flatten()); sync()
+        dt = timed(lambda: eng.wire_ptr("refund", sk, mh, capi.MEM_HOST, hm.data_ptr(), 0, hr.data_ptr(), capi.RNG_PER_LANE, ho.data_ptr(), hst.data_ptr()), sync)
+        assert torch.equal(hst, expect[:mh].cpu()) and torch.equal(ho, outm[:mh * ml_out].cpu())
+        wire["pinned_host_memory"] = {"value": mh / dt, "unit": "messages/s", "messages": mh, "pcie_GBps": mh * ml_in / dt / 1e9}
+        wire["what"] = ("act_refund_cbor_batch: %d canonical CBOR SpendProof messages (%d B) -> verify -> sign -> CBOR Refund messages (%d B), ACT_RNG_PER_LANE, device transcripts; "
+                        "compare `refund` above (records in HBM)" % (m, ml_in, ml_out))
+        ex["wire_refund"] = wire
+        del msgs, outm, hm, ho
+    except Exception as e:          # an accessory measurement must never cost the line
+        ex["wire_refund"] = {"error": repr(e)}
     # (5) BASELINE config 2: 2^16 DISTINCT verifies at L = 64
     if L == 128:
         e64 = capi.Engine(h, 64, device=local, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
@@ -823,6 +895,10 @@ def node_host_path(args, capi, torch, np, sk, dev, expect, h, devices, L, PB):
                        "host transcripts = the library default (src/transcript.rs on the process's shared worker pool, %d usable host threads); `value` = pageable, host transcripts"
                        % (list(devices), usable_cores()))
         res["host_pool"] = capi.host_pool_stats()
+        # how the dispatcher cut the last call over the devices (load balance: INTEGRATION.md section 7)
+        res["per_device"] = [dict(d, device=devices[k], verifies_per_s=round(d["lanes"] / d["seconds"]) if d["seconds"] else None) for k, d in enumerate(node.device_stats())]
+        res["per_device_lanes"] = [d["lanes"] for d in res["per_device"]]
+        res["balance"] = node.balance_state()
     finally:
         node.close()
     return res
@@ -870,6 +946,12 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
            "kernel_ms_per_65536_proofs": {k: round(v["busy_ms"] / v["launches"], 3) for k, v in prof.items() if k.startswith("k_prove")},
            "prove_spend_proofs_per_s_wall": round(n_proofs / t_prove) if t_prove else None}
     out.update(rnd)
+    out["frac_vs_nominal_2p4GHz"] = rate / NOMINAL_MAD_PEAK
+    if ct:
+        out["note"] = ("the work counted here is the ADDRESS-FREE formulation's own: 37 table additions per fixed-base product (64-entry windows picked on the matrix "
+                       "cores) where addressed 16-/24-bit tables need 16 / 11 -- the fast build makes the same proofs at 2.1 x the rate.  So `frac` says how well the "
+                       "kernel runs the constant-time algorithm (the price the reference's `subtle` / dalek table scans pay too), not how close prove_spend is to the "
+                       "fewest field operations it could be done with")
     f_valu = rate / peak_mad
     out["bound"], out["frac"] = "valu-int-mad", f_valu
     if rnd.get("random_128B_read_GBps_measured") and not ct:

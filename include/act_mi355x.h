@@ -107,16 +107,19 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
 
 /* A context = Params (h1,h2,h3 with their device-resident fixed-base tables, cf. the three
  * RistrettoBasepointTables of src/lib.rs:222-229) + the range-proof width L (src/lib.rs:116; 128 is the
- * crate's value, 1..128 accepted) + one GPU.  max_batch bounds the records per internal launch and
- * thereby the workspace: about 200 KB per record at L = 128 (1.6 KB per range-proof bit), times two
- * pipeline slots, plus the fixed-base tables, which the contexts of a process on one GPU with the same Params share: 0.5 GB with
- * 16-bit windows; from max_batch 32768 up h1 and h3 get 24-bit windows (47 GB, built in about 2 s, +3 % verifies/s) provided at
- * least 16 GB of the device would stay free afterwards (otherwise, or with ACT_FB_WIDE_BITS=16 in the environment, 16 bits).
- * 0 = default = 65536 (27 GB of workspace at L = 128), from which size on the
- * throughput of every entry point is flat; 16384 costs about 5 % of the verify rate and two thirds
- * of the issue/request rate.  Batches of any length are accepted and processed in such chunks.  max_batch > 2^22 is
- * refused (ACT_ERR_ARG).  On failure *out still receives a context whose only use is act_last_error() and
- * act_ctx_destroy(). */
+ * crate's value, 1..128 accepted) + one GPU.  max_batch bounds the records per internal launch and thereby the workspace.
+ * What a context costs in HBM at L = 128:
+ *     workspace      about 200 KB per record of max_batch per pipeline slot, two slots:  max_batch 65536 -> 27 GB, 16384 -> 6.8 GB,
+ *                    4096 -> 1.7 GB; staging buffers of host-memory callers grow on demand on top (up to ~7 GB for a 65536-lane
+ *                    prover chunk)
+ *     tables         0.5 GB (16-bit windows for g, h1, h2, h3 + the matrix-core images), shared by all contexts of the process on
+ *                    that GPU with the same Params
+ *     wide tables    +47 GB (24-bit windows for h1 and h3, built in about 2 s, +3 % verifies/s), taken ONLY by a context with
+ *                    max_batch >= 65536 on a device that still has 128 GB free after the workspace -- i.e. a GPU that serves
+ *                    nothing else -- or on request (ACT_FB_WIDE_BITS=24 in the environment; =16 never)
+ * 0 = default = 65536, from which size on the throughput of every entry point is flat; 16384 costs about 5 % of the verify rate and
+ * two thirds of the issue/request rate.  Batches of any length are accepted and processed in such chunks.  max_batch > 2^22 is
+ * refused (ACT_ERR_ARG).  On failure *out still receives a context whose only use is act_last_error() and act_ctx_destroy(). */
 int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act_ctx **out);
 void act_ctx_destroy(act_ctx *ctx);
 int act_ctx_set_transcript_mode(act_ctx *ctx, int mode);    /* default ACT_TRANSCRIPT_HOST */
@@ -126,6 +129,10 @@ int act_ctx_set_transcript_mode(act_ctx *ctx, int mode);    /* default ACT_TRANS
  * when they hash alone; nthreads > 0 caps the share of this context, 0 = no cap.  ACT_NUMA=1 pins worker k to the k-th CPU of the
  * process's affinity mask. */
 int act_ctx_set_host_threads(act_ctx *ctx, int nthreads);
+/* Telemetry of the host-transcript mode on this context since the last reset: seconds its calling thread spent waiting for
+ * transcript pieces to arrive from the device, seconds it spent hashing them (with its share of the pool), bytes hashed.  hash_s over
+ * the wall time of the calls = how close the host side is to being the bottleneck (bench.py reports it per rank at N > 1). */
+int act_ctx_host_hash_stats(act_ctx *ctx, double *wait_s, double *hash_s, uint64_t *bytes, int reset);
 int act_host_usable_cpus(void);                             /* CPUs the process may use (affinity mask, cgroup quota) = pool size */
 /* The pool's hashing entry point (what the host-transcript mode calls; pure host code, usable and tested without a GPU):
  * xof[16*i ..] = first 64 XOF bytes of BLAKE3(msgs + i*stride, len), i < n; max_threads as nthreads above. */
@@ -175,7 +182,7 @@ int act_ctx_set_coalescing(act_ctx *ctx, size_t max_proofs_per_call);
  * the fast build; an issuer gains nothing from it. */
 int act_build_has_ct_secret_tables(void);
 /* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
- * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 when max_batch >= 32768 and the device has the memory (see above) */
+ * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 in a throughput-sized context on an otherwise empty device (see act_ctx_create) */
 int act_ctx_fixed_base_bits(const act_ctx *ctx, int base);
 /* Text of the last failure on this handle.  Every *_last_error function copies the text under the handle's lock into a buffer of
  * the CALLING THREAD (another thread's failing call may be rewriting it), valid until that thread asks again. */

@@ -15,14 +15,27 @@ use crate::{
 use curve25519_dalek::{ristretto::CompressedRistretto, RistrettoPoint, Scalar};
 use rand_core::CryptoRngCore;
 use std::ffi::CStr;
-use std::os::raw::{c_char, c_int};
+use std::os::raw::{c_char, c_int, c_void};
 use std::sync::OnceLock;
 
 #[repr(C)]
 pub struct ActNode {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct ActNodeNullifierSet {
+    _private: [u8; 0],
+}
+/// `act_rng_source` (include/act_mi355x.h): the caller's generator handed to the library, which draws 128 bytes per lane it signs --
+/// once, after every verdict is known -- so the generator ends where a sequential loop over `refund` would have left it.
+#[repr(C)]
+pub struct ActRngSource {
+    draw: unsafe extern "C" fn(rng_ctx: *mut c_void, dst: *mut u8, len: usize),
+    rng_ctx: *mut c_void,
+}
 const ACT_RNG_SEQUENTIAL: c_int = 1;
+const ACT_RNG_CALLBACK: c_int = 2;
+const REFUND_CBOR_BYTES: usize = 141; // act_cbor_size(ctx, ACT_CBOR_REFUND): A4, then four times (key, 58 20, 32 bytes)
 const PROOF_FIELDS: usize = 14 + 4 * L;
 const PROOF_BYTES: usize = 32 * PROOF_FIELDS; // 16 832
 const PROVE_RNG_BYTES: usize = 64 * (4 * L + 12); // 33 536: draw order of src/lib.rs:978-1058
@@ -48,9 +61,30 @@ extern "C" {
                                   rng: *const u8, rng_mode: c_int, out_refund: *mut u8, status: *mut u8) -> c_int;
     fn act_node_refund_to_credit_token_batch(node: *mut ActNode, n: usize, prerefund: *const u8, proof: *const u8, refund: *const u8,
                                              w: *const u8, out_token: *mut u8, status: *mut u8) -> c_int;
+    // wire bytes in, wire bytes out (src/cbor.rs:276-408, src/lib.rs:781-869, src/cbor.rs:421-433) and the redemption step
+    // (examples/act.rs:62-73); `rng` with ACT_RNG_CALLBACK points to an ActRngSource
+    fn act_node_verify_spend_cbor_batch(node: *mut ActNode, n: usize, sk: *const u8, cbor: *const u8, offsets: *const u64,
+                                        status: *mut u8, out_kprime: *mut u8) -> c_int;
+    fn act_node_refund_cbor_batch(node: *mut ActNode, n: usize, sk: *const u8, cbor: *const u8, offsets: *const u64,
+                                  rng: *const u8, rng_mode: c_int, out_refund_cbor: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_redeem_batch(node: *mut ActNode, set: *mut ActNodeNullifierSet, n: usize, sk: *const u8, proof: *const u8,
+                             rng: *const u8, rng_mode: c_int, out_refund: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_redeem_cbor_batch(node: *mut ActNode, set: *mut ActNodeNullifierSet, n: usize, sk: *const u8, cbor: *const u8,
+                                  offsets: *const u64, rng: *const u8, rng_mode: c_int, out_refund_cbor: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_nullifier_set_create(devices: *const c_int, n_devices: c_int, capacity_per_device: usize, salt: *const u8,
+                                     out: *mut *mut ActNodeNullifierSet) -> c_int;
+    fn act_node_nullifier_set_destroy(set: *mut ActNodeNullifierSet);
+    fn act_node_nullifier_set_len(set: *const ActNodeNullifierSet) -> usize;
+    fn act_node_nullifier_set_last_error(set: *const ActNodeNullifierSet) -> *const c_char;
+    fn act_node_device_stats(node: *mut ActNode, k: c_int, weight: *mut f64, last_lanes: *mut u64, last_seconds: *mut f64, last_calls: *mut u64) -> c_int;
 }
 
-/// All GPUs of the node behind one handle (contiguous shards, no collective).
+/// ACT_MI355X_DEVICES = "0,1,2,3,4,5,6,7" (default: device 0)
+fn devices_from_env() -> Vec<c_int> {
+    std::env::var("ACT_MI355X_DEVICES").map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect()).unwrap_or_else(|_| vec![0])
+}
+
+/// All GPUs of the node behind one handle (contiguous pieces, load-balanced, no collective).
 ///
 /// How `Params` (src/lib.rs:222-229, `#[derive(Clone)]`) carries it: add the field
 /// `#[cfg(feature = "mi355x")] gpu: GpuSlot` and nothing else -- `GpuSlot` below is `Clone` (a clone starts EMPTY and builds its own
@@ -64,8 +98,10 @@ extern "C" {
 /// guarantee lives in the library, not in a promise by the caller.  Small calls (the single-item API) do better than queue: they
 /// merge into one launch with the small calls of other threads (`act_node_set_coalescing`, set in `Gpu::new`).
 pub struct Gpu(*mut ActNode);
-// SAFETY: the handle is only ever passed to act_node_* entry points, each of which locks it (csrc/node.cpp `node_lock`);
-// act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies it under
+// SAFETY: the handle is only ever passed to act_node_* entry points.  Calls that are cut over the GPUs take the node's lock
+// (csrc/node.cpp `node_lock`); calls small enough to merge (act_node_set_coalescing) bypass it and are serialised by the lock of the
+// one context they go to and by that context's request combiner (csrc/coalesce.h) -- either way no two threads are ever inside the
+// same context's buffers.  act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies it under
 // the handle's lock into a buffer of the CALLING thread (valid until this thread asks again), so `check` below never reads a
 // string another thread's failing call is rewriting.
 unsafe impl Send for Gpu {}
@@ -96,15 +132,12 @@ impl Gpu {
         h[..32].copy_from_slice(params.h1.basepoint().compress().as_bytes());
         h[32..64].copy_from_slice(params.h2.basepoint().compress().as_bytes());
         h[64..].copy_from_slice(params.h3.basepoint().compress().as_bytes());
-        // ACT_MI355X_DEVICES = "0,1,2,3,4,5,6,7" (default: device 0)
-        let devices: Vec<c_int> = std::env::var("ACT_MI355X_DEVICES")
-            .map(|s| s.split(',').filter_map(|d| d.trim().parse().ok()).collect())
-            .unwrap_or_else(|_| vec![0]);
+        let devices = devices_from_env();
         // The library never touches the process environment.  A service with many HIP streams exports GPU_MAX_HW_QUEUES=8 before its
         // first HIP call; the engine measures whether its two pipeline streams overlap either way.
-        // ACT_MI355X_MAX_BATCH: records per internal launch.  Unset = the library default (65 536: 29 GB of workspace per GPU and,
-        // where the device has the memory to spare, 47 GB of 24-bit fixed-base tables built in ~2 s, all GPUs concurrently);
-        // a service that only ever sees small batches sets e.g. 4096 (1.8 GB, 16-bit tables, 0.02 s).
+        // ACT_MI355X_MAX_BATCH: records per internal launch.  Unset = the library default, 65 536: 27 GB of workspace per GPU
+        // (+ 0.5 GB of tables; + 47 GB of 24-bit tables for +3 % ONLY on a GPU that still has 128 GB free, i.e. one that serves
+        // nothing else -- include/act_mi355x.h act_ctx_create).  A service that only ever sees small batches sets e.g. 4096 (1.7 GB).
         let max_batch: usize = std::env::var("ACT_MI355X_MAX_BATCH").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
         let mut node = std::ptr::null_mut();
         let rc = unsafe { act_node_create(h.as_ptr(), L as c_int, devices.as_ptr(), devices.len() as c_int, max_batch, &mut node) };
@@ -171,6 +204,65 @@ fn draw(rng: &mut impl CryptoRngCore, count: usize) -> Vec<u8> {
         rng.fill_bytes(chunk);
     }
     buf
+}
+
+// Marshalling is the expensive part of the struct-level batch API: a `RistrettoPoint` becomes 32 bytes by `compress()` (one inverse
+// square root, ~4 us on one core) and comes back by `decompress()` (another).  A SpendProof holds 130 points: ~0.5 ms of compress per
+// proof = ~2 000 proofs/s per core in front of an engine that verifies ~514 000/s per GPU (INTEGRATION.md section 6 has the measured
+// figures).  So records are written and read on `std::thread::scope` workers, one slice of the batch each; a server that can should
+// use the wire-level calls further down (`refund_cbor_batch`), where no point is ever built on the host.
+fn workers_for(items: usize) -> usize {
+    let cpus = std::thread::available_parallelism().map(|n| n.get()).unwrap_or(1);
+    cpus.min(items / 8).max(1) // fewer than 8 items per worker is not worth a thread
+}
+/// `rec_bytes` per item, written by `write(item, out)` (which appends exactly `rec_bytes`), on scoped worker threads.
+fn marshal<T: Sync>(items: &[T], rec_bytes: usize, write: impl Fn(&T, &mut Vec<u8>) + Sync) -> Vec<u8> {
+    let n = items.len();
+    let workers = workers_for(n);
+    if workers == 1 {
+        let mut out = Vec::with_capacity(n * rec_bytes);
+        items.iter().for_each(|it| write(it, &mut out));
+        return out;
+    }
+    let per = (n + workers - 1) / workers;
+    let parts: Vec<Vec<u8>> = std::thread::scope(|sc| {
+        let handles: Vec<_> = items
+            .chunks(per)
+            .map(|chunk| {
+                let write = &write;
+                sc.spawn(move || {
+                    let mut out = Vec::with_capacity(chunk.len() * rec_bytes);
+                    chunk.iter().for_each(|it| write(it, &mut out));
+                    out
+                })
+            })
+            .collect();
+        handles.into_iter().map(|h| h.join().expect("marshalling worker")).collect()
+    });
+    let mut out = Vec::with_capacity(n * rec_bytes);
+    parts.iter().for_each(|p| out.extend_from_slice(p));
+    out
+}
+/// The reverse: `n` results from `rec_bytes`-sized records + statuses, `read(record)` on scoped worker threads.
+fn unmarshal<T: Send>(records: &[u8], rec_bytes: usize, status: &[u8], read: impl Fn(&[u8]) -> T + Sync) -> Vec<Result<T, Error>> {
+    let n = status.len();
+    let one = |i: usize| if status[i] == 0 { Ok(read(&records[rec_bytes * i..rec_bytes * (i + 1)])) } else { Err(status_to_error(status[i])) };
+    let workers = workers_for(n);
+    if workers == 1 {
+        return (0..n).map(one).collect();
+    }
+    let per = (n + workers - 1) / workers;
+    let parts: Vec<Vec<Result<T, Error>>> = std::thread::scope(|sc| {
+        let handles: Vec<_> = (0..n)
+            .step_by(per)
+            .map(|lo| {
+                let one = &one;
+                sc.spawn(move || (lo..(lo + per).min(n)).map(one).collect::<Vec<_>>())
+            })
+            .collect();
+        handles.into_iter().map(|h| h.join().expect("unmarshalling worker")).collect()
+    });
+    parts.into_iter().flatten().collect()
 }
 
 impl PrivateKey {
@@ -334,8 +426,7 @@ impl PrivateKey {
     /// lanes only (:846, :852), then the BBS signature on K' (:848-868).
     pub fn refund_batch(&self, params: &Params, proofs: &[SpendProof], mut rng: impl CryptoRngCore) -> Vec<Result<Refund, Error>> {
         let n = proofs.len();
-        let mut rec = Vec::with_capacity(n * PROOF_BYTES);
-        proofs.iter().for_each(|p| p.write_record(&mut rec));
+        let rec = marshal(proofs, PROOF_BYTES, |p, out| p.write_record(out)); // 130 compress() per proof: on all cores
         let sk = self.record();
         let gpu = params.gpu();
         let (mut checked, mut kprime) = (vec![0u8; n], vec![0u8; 32 * n]);
@@ -347,7 +438,7 @@ impl PrivateKey {
             act_node_refund_sign_batch(gpu.0, n, sk.as_ptr(), kprime.as_ptr(), checked.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL,
                                        out.as_mut_ptr(), status.as_mut_ptr())
         });
-        (0..n).map(|i| if status[i] == 0 { Ok(Refund::from_record(&out[128 * i..128 * i + 128])) } else { Err(status_to_error(status[i])) }).collect()
+        unmarshal(&out, 128, &status, Refund::from_record)
     }
 }
 
@@ -357,8 +448,8 @@ impl CreditToken {
         -> Vec<(SpendProof, PreRefund)> {
         let n = tokens.len();
         assert_eq!(charges.len(), n);
-        let (mut tok, mut s) = (Vec::with_capacity(160 * n), Vec::with_capacity(32 * n));
-        tokens.iter().for_each(|t| t.write_record(&mut tok));
+        let tok = marshal(tokens, 160, |t, out| t.write_record(out));
+        let mut s = Vec::with_capacity(32 * n);
         charges.iter().for_each(|c| put_s(&mut s, c));
         let rng_bytes = draw(&mut rng, (4 * L + 12) * n);
         debug_assert_eq!(rng_bytes.len(), PROVE_RNG_BYTES * n);
@@ -367,11 +458,22 @@ impl CreditToken {
         gpu.check(unsafe {
             act_node_prove_spend_batch(gpu.0, n, tok.as_ptr(), s.as_ptr(), rng_bytes.as_ptr(), proofs.as_mut_ptr(), prer.as_mut_ptr(), status.as_mut_ptr())
         });
-        (0..n).map(|i| {
-            let p = &prer[96 * i..96 * i + 96]; // r | k | m (src/cbor.rs:656-660)
-            (SpendProof::from_record(&proofs[PROOF_BYTES * i..PROOF_BYTES * (i + 1)]), PreRefund { r: get_s(p, 0), k: get_s(p, 1), m: get_s(p, 2) })
-        }).collect()
+        proofs_out(&proofs, &prer)
     }
+}
+
+/// (proof records, PreRefund records) -> structs; 130 `decompress()` per proof, on scoped worker threads
+fn proofs_out(proofs: &[u8], prer: &[u8]) -> Vec<(SpendProof, PreRefund)> {
+    let n = prer.len() / 96;
+    let zeros = vec![0u8; n]; // prove_spend has no failing lanes: every status is Ok
+    let ps = unmarshal(proofs, PROOF_BYTES, &zeros, SpendProof::from_record);
+    ps.into_iter()
+        .enumerate()
+        .map(|(i, p)| {
+            let r = &prer[96 * i..96 * i + 96]; // r | k | m (src/cbor.rs:656-660)
+            (p.unwrap_or_else(|_| unreachable!()), PreRefund { r: get_s(r, 0), k: get_s(r, 1), m: get_s(r, 2) })
+        })
+        .collect()
 }
 
 /// The generator `prove_spend_seeded_batch` gives lane `lane`: the BLAKE3 XOF of `seed | lane.to_le_bytes()`, read sequentially.
@@ -400,18 +502,15 @@ impl CreditToken {
         -> Vec<(SpendProof, PreRefund)> {
         let n = tokens.len();
         assert_eq!(charges.len(), n);
-        let (mut tok, mut s) = (Vec::with_capacity(160 * n), Vec::with_capacity(32 * n));
-        tokens.iter().for_each(|t| t.write_record(&mut tok));
+        let tok = marshal(tokens, 160, |t, out| t.write_record(out));
+        let mut s = Vec::with_capacity(32 * n);
         charges.iter().for_each(|c| put_s(&mut s, c));
         let (mut proofs, mut prer, mut status) = (vec![0u8; PROOF_BYTES * n], vec![0u8; 96 * n], vec![0u8; n]);
         let gpu = params.gpu();
         gpu.check(unsafe {
             act_node_prove_spend_seeded_batch(gpu.0, n, tok.as_ptr(), s.as_ptr(), seed.as_ptr(), first_lane, proofs.as_mut_ptr(), prer.as_mut_ptr(), status.as_mut_ptr())
         });
-        (0..n).map(|i| {
-            let p = &prer[96 * i..96 * i + 96];
-            (SpendProof::from_record(&proofs[PROOF_BYTES * i..PROOF_BYTES * (i + 1)]), PreRefund { r: get_s(p, 0), k: get_s(p, 1), m: get_s(p, 2) })
-        }).collect()
+        proofs_out(&proofs, &prer)
     }
 }
 
@@ -421,14 +520,14 @@ impl PreRefund {
         -> Vec<Result<CreditToken, Error>> {
         let n = pres.len();
         assert!(proofs.len() == n && refunds.len() == n);
-        let (mut pre, mut rec, mut rf) = (Vec::with_capacity(96 * n), Vec::with_capacity(PROOF_BYTES * n), Vec::with_capacity(128 * n));
+        let (mut pre, mut rf) = (Vec::with_capacity(96 * n), Vec::with_capacity(128 * n));
         for i in 0..n {
             put_s(&mut pre, &pres[i].r);
             put_s(&mut pre, &pres[i].k);
             put_s(&mut pre, &pres[i].m);
-            proofs[i].write_record(&mut rec);
             refunds[i].write_record(&mut rf);
         }
+        let rec = marshal(proofs, PROOF_BYTES, |p, out| p.write_record(out));
         let w = public_key.w.compress();
         let (mut out, mut status) = (vec![0u8; 160 * n], vec![0u8; n]);
         let gpu = params.gpu();
@@ -437,6 +536,207 @@ impl PreRefund {
         });
         (0..n).map(|i| if status[i] == 0 { Ok(CreditToken::from_record(&out[160 * i..160 * i + 160])) } else { Err(status_to_error(status[i])) }).collect()
     }
+}
+
+// ---- wire bytes in, wire bytes out ---------------------------------------------------------------------------------------
+// A server does not receive `SpendProof`s, it receives bytes.  The loop it runs today --
+//     let proof = SpendProof::from_cbor(&msg)?;  let refund = key.refund(&params, &proof, &mut rng)?;  refund.to_cbor()
+// (src/cbor.rs:276-408, src/lib.rs:781-869, src/cbor.rs:421-433) -- builds 130 RistrettoPoints per message on the host only to
+// have them compressed again for the GPU.  These calls hand the bytes over as they came: no point, no scalar, no `SpendProof` and
+// no `Refund` ever exists on the host; message i in, message i out.
+
+/// What a lane of a wire-level call can come back with instead of bytes.
+#[derive(Debug, PartialEq)]
+pub enum WireError {
+    /// `CborError::Ciborium`: not well-formed CBOR
+    Malformed,
+    /// `CborError::InvalidStructure`: not a map, a field missing, wrong shape or length
+    InvalidStructure,
+    /// `CborError::InvalidValue`: a point that is not a canonical Ristretto encoding
+    InvalidValue,
+    /// the message decoded; `refund` (or the nullifier store: `DoubleSpendError`) rejected it
+    Protocol(Error),
+    /// redeem only, and only together with an engine failure: verified, but the nullifier store could not answer -- NOT recorded,
+    /// NOT signed, safe to resubmit (include/act_mi355x.h ACT_STATUS_NULLIFIER_UNDETERMINED)
+    NullifierUndetermined,
+    /// redeem only, and only together with an engine failure: the nullifier IS recorded and the signature step failed -- the refund
+    /// is owed: sign it (`refund`), never redeem it again (ACT_STATUS_RECORDED_UNSIGNED)
+    RecordedUnsigned,
+}
+fn status_to_wire_error(s: u8) -> WireError {
+    match s {
+        254 => WireError::Malformed,
+        253 => WireError::InvalidStructure,
+        255 => WireError::InvalidValue,
+        252 => WireError::NullifierUndetermined,
+        251 => WireError::RecordedUnsigned,
+        other => WireError::Protocol(status_to_error(other)),
+    }
+}
+
+/// The caller's generator as the library's draw callback.  dalek draws a `Scalar::random` with one `fill_bytes(&mut [u8; 64])`;
+/// so does this, 64 bytes at a time, so that generators that are not plain byte streams still see the calls they would have seen.
+/// (A panic inside `fill_bytes` cannot unwind through the C frames: the process aborts.)
+unsafe extern "C" fn draw_trampoline<R: CryptoRngCore>(rng_ctx: *mut c_void, dst: *mut u8, len: usize) {
+    let rng = &mut *(rng_ctx as *mut R);
+    let buf = std::slice::from_raw_parts_mut(dst, len);
+    for chunk in buf.chunks_mut(64) {
+        rng.fill_bytes(chunk);
+    }
+}
+fn rng_source<R: CryptoRngCore>(rng: &mut R) -> ActRngSource {
+    ActRngSource { draw: draw_trampoline::<R>, rng_ctx: rng as *mut R as *mut c_void }
+}
+
+/// `msgs` gathered into one buffer + offsets (what the C ABI takes).  The copy is 18 KB per message at memcpy speed; a server that
+/// already holds its messages in one buffer calls the `*_blob` forms and skips it.
+fn gather(msgs: &[&[u8]]) -> (Vec<u8>, Vec<u64>) {
+    let total: usize = msgs.iter().map(|m| m.len()).sum();
+    let mut offsets = Vec::with_capacity(msgs.len() + 1);
+    let mut blob = Vec::with_capacity(total + 1);
+    offsets.push(0u64);
+    for m in msgs {
+        blob.extend_from_slice(m);
+        offsets.push(blob.len() as u64);
+    }
+    blob.push(0); // never an empty allocation: the library wants a non-null pointer
+    (blob, offsets)
+}
+fn refund_messages(out: &[u8], status: &[u8]) -> Vec<Result<Vec<u8>, WireError>> {
+    status
+        .iter()
+        .enumerate()
+        .map(|(i, &s)| if s == 0 { Ok(out[REFUND_CBOR_BYTES * i..REFUND_CBOR_BYTES * (i + 1)].to_vec()) } else { Err(status_to_wire_error(s)) })
+        .collect()
+}
+
+impl PrivateKey {
+    /// `msgs.iter().map(|m| SpendProof::from_cbor(m).map(|p| self.refund(params, &p, &mut rng)).map(|r| r.to_cbor()))` as ONE call:
+    /// CBOR `SpendProof` messages in, CBOR `Refund` messages out, byte for byte what that loop returns, `rng` left where it leaves
+    /// it (e, alpha are drawn for accepted lanes only, in lane order, after all verdicts: src/lib.rs:842-852).
+    pub fn refund_cbor_batch(&self, params: &Params, msgs: &[&[u8]], rng: impl CryptoRngCore) -> Vec<Result<Vec<u8>, WireError>> {
+        let (blob, offsets) = gather(msgs);
+        self.refund_cbor_blob(params, &blob, &offsets, rng)
+    }
+    /// The same over messages that already lie in one buffer: message i = `blob[offsets[i]..offsets[i + 1]]`.
+    pub fn refund_cbor_blob(&self, params: &Params, blob: &[u8], offsets: &[u64], mut rng: impl CryptoRngCore) -> Vec<Result<Vec<u8>, WireError>> {
+        assert!(!offsets.is_empty() && *offsets.last().unwrap() as usize <= blob.len());
+        let n = offsets.len() - 1;
+        let sk = self.record();
+        let gpu = params.gpu();
+        let src = rng_source(&mut rng);
+        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES * n + 1], vec![0u8; n + 1]);
+        gpu.check(unsafe {
+            act_node_refund_cbor_batch(gpu.0, n, sk.as_ptr(), blob.as_ptr(), offsets.as_ptr(), &src as *const ActRngSource as *const u8,
+                                       ACT_RNG_CALLBACK, out.as_mut_ptr(), status.as_mut_ptr())
+        });
+        refund_messages(&out, &status[..n])
+    }
+    /// Verdicts only (`refund` up to the challenge check, src/lib.rs:787-844) for CBOR `SpendProof` messages.
+    pub fn verify_spend_cbor_batch(&self, params: &Params, msgs: &[&[u8]]) -> Vec<Result<(), WireError>> {
+        let (blob, offsets) = gather(msgs);
+        let n = msgs.len();
+        let sk = self.record();
+        let gpu = params.gpu();
+        let mut status = vec![0u8; n + 1];
+        gpu.check(unsafe { act_node_verify_spend_cbor_batch(gpu.0, n, sk.as_ptr(), blob.as_ptr(), offsets.as_ptr(), status.as_mut_ptr(), std::ptr::null_mut()) });
+        status[..n].iter().map(|&s| if s == 0 { Ok(()) } else { Err(status_to_wire_error(s)) }).collect()
+    }
+}
+
+// ---- the redemption step (examples/act.rs:62-73) ------------------------------------------------------------------------------
+/// The double-spend database the crate leaves to the caller (src/lib.rs:741-745; `HashSet<Scalar>` in src/tests.rs:29-50 and
+/// examples/act.rs:10-30) as a hash set in the HBM of the node's GPUs: one set per GPU, a nullifier owned by exactly one of them.
+pub struct GpuNullifierStore(*mut ActNodeNullifierSet);
+// SAFETY: every entry point that takes the set locks it (csrc/node.cpp act_node_nullifier_check_and_insert_batch); destroy runs from Drop.
+unsafe impl Send for GpuNullifierStore {}
+unsafe impl Sync for GpuNullifierStore {}
+impl Drop for GpuNullifierStore {
+    fn drop(&mut self) {
+        unsafe { act_node_nullifier_set_destroy(self.0) }
+    }
+}
+impl GpuNullifierStore {
+    /// `capacity_per_device`: nullifiers each GPU's share must be able to hold (32 bytes + 4 per slot, load factor 1/2).
+    pub fn new(capacity_per_device: usize) -> Self {
+        let devices = devices_from_env();
+        let mut set = std::ptr::null_mut();
+        // salt = null: the routing and slot hashes are keyed with 16 bytes from the OS -- clients choose their nullifiers
+        let rc = unsafe { act_node_nullifier_set_create(devices.as_ptr(), devices.len() as c_int, capacity_per_device, std::ptr::null(), &mut set) };
+        if rc != 0 {
+            let msg = if set.is_null() { String::new() } else { unsafe { CStr::from_ptr(act_node_nullifier_set_last_error(set)) }.to_string_lossy().into_owned() };
+            panic!("act_node_nullifier_set_create failed ({rc}): {msg}");
+        }
+        GpuNullifierStore(set)
+    }
+    pub fn len(&self) -> usize {
+        unsafe { act_node_nullifier_set_len(self.0) }
+    }
+    pub fn is_empty(&self) -> bool {
+        self.len() == 0
+    }
+}
+
+/// Outcome of a redeem call.  `engine_failure` is set when a GPU or the store failed AFTER verification: every lane still has its
+/// decision (`WireError::NullifierUndetermined` / `RecordedUnsigned` name the lanes that were left over) -- nothing is lost, nothing
+/// may be blindly resubmitted (include/act_mi355x.h, act_redeem_batch).
+pub struct Redeemed<T> {
+    pub lanes: Vec<Result<T, WireError>>,
+    pub engine_failure: Option<String>,
+}
+
+impl PrivateKey {
+    /// The server loop of examples/act.rs:62-73 over a batch of wire messages --
+    ///     from_cbor -> refund's checks -> `if store.is_used(k) { DoubleSpendError } else { store.mark_used(k) }` -> sign -> to_cbor
+    /// -- with the meaning of that loop run in lane order (a nullifier repeated inside the batch is a double spend from its second
+    /// occurrence on; a proof that does not verify cannot burn a nullifier) and `rng` drawn for exactly the lanes that are signed.
+    pub fn redeem_cbor_batch(&self, params: &Params, store: &GpuNullifierStore, msgs: &[&[u8]], mut rng: impl CryptoRngCore) -> Redeemed<Vec<u8>> {
+        let (blob, offsets) = gather(msgs);
+        let n = msgs.len();
+        let sk = self.record();
+        let gpu = params.gpu();
+        let src = rng_source(&mut rng);
+        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES * n + 1], vec![0u8; n + 1]);
+        let rc = unsafe {
+            act_node_redeem_cbor_batch(gpu.0, store.0, n, sk.as_ptr(), blob.as_ptr(), offsets.as_ptr(), &src as *const ActRngSource as *const u8,
+                                       ACT_RNG_CALLBACK, out.as_mut_ptr(), status.as_mut_ptr())
+        };
+        let engine_failure = if rc != 0 { Some(unsafe { CStr::from_ptr(act_node_last_error(gpu.0)) }.to_string_lossy().into_owned()) } else { None };
+        Redeemed { lanes: refund_messages(&out, &status[..n]), engine_failure }
+    }
+    /// The same over `SpendProof`s (marshalled on all cores: 130 `compress()` per proof).
+    pub fn redeem_batch(&self, params: &Params, store: &GpuNullifierStore, proofs: &[SpendProof], mut rng: impl CryptoRngCore) -> Redeemed<Refund> {
+        let n = proofs.len();
+        let rec = marshal(proofs, PROOF_BYTES, |p, out| p.write_record(out));
+        let sk = self.record();
+        let gpu = params.gpu();
+        let src = rng_source(&mut rng);
+        let (mut out, mut status) = (vec![0u8; 128 * n + 1], vec![0u8; n + 1]);
+        let rc = unsafe {
+            act_node_redeem_batch(gpu.0, store.0, n, sk.as_ptr(), rec.as_ptr(), &src as *const ActRngSource as *const u8, ACT_RNG_CALLBACK,
+                                  out.as_mut_ptr(), status.as_mut_ptr())
+        };
+        let engine_failure = if rc != 0 { Some(unsafe { CStr::from_ptr(act_node_last_error(gpu.0)) }.to_string_lossy().into_owned()) } else { None };
+        let lanes = (0..n).map(|i| if status[i] == 0 { Ok(Refund::from_record(&out[128 * i..128 * i + 128])) } else { Err(status_to_wire_error(status[i])) }).collect();
+        Redeemed { lanes, engine_failure }
+    }
+}
+
+/// What the node dispatcher knows about its GPUs (load balance: include/act_mi355x.h "Load balance"): per device its weight
+/// (relative speed, mean 1) and the lanes / seconds / calls of the most recent cut call.
+pub fn gpu_device_stats(params: &Params) -> Vec<(f64, u64, f64, u64)> {
+    let gpu = params.gpu();
+    let mut out = Vec::new();
+    let mut k = 0;
+    loop {
+        let (mut w, mut lanes, mut secs, mut calls) = (0f64, 0u64, 0f64, 0u64);
+        if unsafe { act_node_device_stats(gpu.0, k, &mut w, &mut lanes, &mut secs, &mut calls) } != 0 {
+            break;
+        }
+        out.push((w, lanes, secs, calls));
+        k += 1;
+    }
+    out
 }
 
 // ---- the kept single-call signatures: batches of one ------------------------------------------------------------------

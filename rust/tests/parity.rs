@@ -1,4 +1,5 @@
-//! tests/parity.rs — the unmodified crate against its MI355X batch siblings, byte for byte.
+//! tests/parity.rs — the unmodified crate against its MI355X batch siblings, byte for byte (needs a GPU; the GPU-free half of the
+//! pin -- the crate against the committed fixtures -- is tests/golden.rs).
 //!
 //! UNCOMPILED / UNRUN in the authoring environment (no Rust toolchain there; rust/README.md).  Run on a box with a GPU:
 //!     ACT_MI355X_LIB_DIR=.../anonymous-credit-tokens_amd cargo test --features mi355x --test parity
@@ -122,4 +123,86 @@ fn lifecycle_batch_equals_sequential_loop() {
         let want = seq_p[i].1.to_credit_token_reference(&params, &proofs[i], seq_r[i].as_ref().unwrap(), sk.public()).unwrap();
         assert_eq!(want.to_cbor().unwrap(), t2[j].as_ref().unwrap().to_cbor().unwrap());
     }
+}
+
+/// Wire bytes in, wire bytes out: `refund_cbor_batch` / `redeem_cbor_batch` against the server loop they replace
+/// (`SpendProof::from_cbor` -> nullifier store -> `refund` -> `Refund::to_cbor`; examples/act.rs:62-73), including the state the
+/// caller's generator is left in and the messages `from_cbor` rejects.
+#[test]
+fn wire_level_calls_equal_the_server_loop() {
+    use std::collections::HashSet;
+    const N: usize = 12;
+    let params = Params::new("bench-org", "bench-service", "bench-env", "2024-01-01");
+    let sk = PrivateKey::random(ReplayRng::new(1, 64));
+    // N tokens of 50 credits, spends of 0..N credits; everything on this side is the crate's own code path
+    let mut msgs: Vec<Vec<u8>> = Vec::new();
+    for i in 0..N {
+        let pre = PreIssuance::random(ReplayRng::new(200 + i as u64, 128));
+        let req = pre.request_reference(&params, ReplayRng::new(300 + i as u64, 128));
+        let resp = sk.issue_reference(&params, &req, Scalar::from(50u128), ReplayRng::new(400 + i as u64, 128)).unwrap();
+        let tok = pre.to_credit_token_reference(&params, sk.public(), &req, &resp).unwrap();
+        let (proof, _) = tok.prove_spend_reference(&params, Scalar::from(i as u128), ReplayRng::new(500 + i as u64, 64 * (4 * L + 12)));
+        msgs.push(proof.to_cbor().unwrap());
+    }
+    let flip = |m: &mut Vec<u8>, at: usize| m[at] ^= 1;
+    flip(&mut msgs[2], 4 + 34 + 5);             // a bit of the charge `s` (key 2): parses, InvalidClientSpendProof
+    msgs[3].truncate(100);                      // cut short: CborError::Ciborium
+    msgs[4][0] = 0x80;                          // an array where the map should be: CborError::InvalidStructure
+    msgs[5] = msgs[1].clone();                  // a second submission of message 1: a double spend for redeem
+    let mut loose = vec![0xbfu8];               // message 6 again as an indefinite-length map: same content, not canonical
+    loose.extend_from_slice(&msgs[6][1..]);
+    loose.push(0xff);
+    msgs[6] = loose;
+    let refs: Vec<&[u8]> = msgs.iter().map(|m| m.as_slice()).collect();
+
+    // refund: the loop, then the one call; same bytes, same generator position
+    let (mut a, mut b) = (ReplayRng::new(7, 128 * N), ReplayRng::new(7, 128 * N));
+    let seq: Vec<Result<Vec<u8>, ()>> = refs.iter().map(|m| match SpendProof::from_cbor(m) {
+        Err(_) => Err(()),
+        Ok(p) => sk.refund_reference(&params, &p, &mut a).map(|r| r.to_cbor().unwrap()).map_err(|_| ()),
+    }).collect();
+    let bat = sk.refund_cbor_batch(&params, &refs, &mut b);
+    assert_eq!(a.pos, b.pos, "128 bytes per ACCEPTED message, drawn after the verdicts");
+    for i in 0..N {
+        match (&seq[i], &bat[i]) {
+            (Ok(x), Ok(y)) => assert_eq!(x, y, "message {i}"),
+            (Err(()), Err(_)) => {}
+            _ => panic!("message {i}: accept/reject differs"),
+        }
+    }
+    assert_eq!(bat[2], Err(WireError::Protocol(Error::InvalidClientSpendProof)));
+    assert_eq!(bat[3], Err(WireError::Malformed));
+    assert_eq!(bat[4], Err(WireError::InvalidStructure));
+    assert!(bat[5].is_ok() && bat[6].is_ok());
+
+    // redeem: the same loop with the example's nullifier store in front of refund
+    let (mut a, mut b) = (ReplayRng::new(8, 128 * N), ReplayRng::new(8, 128 * N));
+    let mut used: HashSet<[u8; 32]> = HashSet::new();
+    let seq: Vec<Result<Vec<u8>, Option<Error>>> = refs.iter().map(|m| {
+        let p = SpendProof::from_cbor(m).map_err(|_| None::<Error>)?;
+        // the engine verifies BEFORE it records (a proof that does not verify must not burn a nullifier); for valid proofs the
+        // example's order (mark, then refund) gives the same result
+        let mut probe = a.clone();
+        if sk.refund_reference(&params, &p, &mut probe).is_err() {
+            return sk.refund_reference(&params, &p, &mut a).map(|r| r.to_cbor().unwrap()).map_err(Some);
+        }
+        if !used.insert(p.nullifier().to_bytes()) {
+            return Err(Some(Error::DoubleSpendError));
+        }
+        sk.refund_reference(&params, &p, &mut a).map(|r| r.to_cbor().unwrap()).map_err(Some)
+    }).collect();
+    let store = GpuNullifierStore::new(1 << 16);
+    let red = sk.redeem_cbor_batch(&params, &store, &refs, &mut b);
+    assert!(red.engine_failure.is_none());
+    assert_eq!(a.pos, b.pos, "128 bytes per SIGNED message");
+    assert_eq!(store.len(), used.len());
+    for i in 0..N {
+        match (&seq[i], &red.lanes[i]) {
+            (Ok(x), Ok(y)) => assert_eq!(x, y, "message {i}"),
+            (Err(Some(e)), Err(WireError::Protocol(f))) => assert_eq!(e, f, "message {i}"),
+            (Err(None), Err(WireError::Malformed | WireError::InvalidStructure | WireError::InvalidValue)) => {}
+            _ => panic!("message {i}: outcome differs"),
+        }
+    }
+    assert_eq!(red.lanes[5], Err(WireError::Protocol(Error::DoubleSpendError)));
 }

@@ -3,6 +3,7 @@
 // the limb-size discipline (ACT_FE_BOUNDS) and the BLAKE3 code against the oracle without a GPU.
 // Never linked into libact_mi355x.so; the product has no CPU compute path.
 #include <cstring>
+#include <ctime>
 #include <vector>
 #define ACT_FE_BOUNDS 1
 #define ACT_FB_WBITS 6   /* host test of the window logic: small tables (43 windows x 64 entries) */
@@ -57,6 +58,22 @@ void hc_sc_invert(const uint8_t* a, uint8_t* o) { sc_out(o, sc_invert(sc_in(a)))
 int hc_decode_encode(const uint8_t* a, uint8_t* o) {
   uint32_t w[8], r[8]; ld(w, a); ge p; bool ok = ristretto_decode(p, w);
   if (ok) { ristretto_encode(r, p); st(o, r); } else memset(o, 0, 32);
+  return ok;
+}
+// Marshalling bound of a struct-level binding: seconds for `reps` passes of decoding / encoding `count`
+// points on this core -- what RistrettoPoint::decompress / compress cost a host that builds 130 of them per SpendProof.
+int hc_time_point_codec(const uint8_t* enc, int count, int reps, double* s_decode, double* s_encode, uint8_t* out_check) {
+  std::vector<ge> pts(count);
+  uint32_t w[8], r[8], acc[8] = {0};
+  auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; };
+  double t0 = now();
+  int ok = 1;
+  for (int k = 0; k < reps; k++) for (int i = 0; i < count; i++) { ld(w, enc + 32 * i); ok &= (int)ristretto_decode(pts[i], w); }
+  double t1 = now();
+  for (int k = 0; k < reps; k++) for (int i = 0; i < count; i++) { ristretto_encode(r, pts[i]); for (int j = 0; j < 8; j++) acc[j] ^= r[j] + (uint32_t)k; }
+  double t2 = now();
+  *s_decode = t1 - t0; *s_encode = t2 - t1;
+  st(out_check, acc);       // keeps the encodings alive
   return ok;
 }
 void hc_from_uniform(const uint8_t* a, uint8_t* o) { uint32_t w[16], r[8]; memcpy(w, a, 64); ge p = ristretto_from_uniform(w); ristretto_encode(r, p); st(o, r); }

@@ -207,8 +207,12 @@ def test_config5_lifecycles_streamed_from_pinned_host_memory(bench_params, oracl
                 else:
                     ck(timed("prove_spend", lambda: lib.act_node_prove_spend_batch(nd, chunk, ptr(bufs["tok"]), sb.ctypes.data, ptr(self.r_pr), ptr(bufs["proof"]), ptr(bufs["prer"]), ptr(st))))
                 assert int(st.sum()) == 0
+                cut_prove = (node.device_stats(), node.balance_state())
                 ck(timed("refund", lambda: lib.act_node_refund_batch(nd, chunk, skb, ptr(bufs["proof"]), ptr(r128["rr"]), capi.RNG_PER_LANE, ptr(bufs["rf"]), ptr(st))))
-                assert int(st.sum()) == 0, "every honest spend must be refunded (chunk %d)" % c
+                if int(st.sum()) != 0:      # say where: which lanes, and how the dispatcher had cut the call
+                    bad = np.nonzero(st.numpy())[0]
+                    raise AssertionError("every honest spend must be refunded (chunk %d): %d lanes rejected, first %d last %d, statuses %s; cut of the refund: %s %s; of prove_spend: %s"
+                                         % (c, len(bad), bad[0], bad[-1], sorted(set(st.numpy()[bad].tolist())), node.device_stats(), node.balance_state(), cut_prove))
                 ck(timed("refund_to_credit_token", lambda: lib.act_node_refund_to_credit_token_batch(nd, chunk, ptr(bufs["prer"]), ptr(bufs["proof"]), ptr(bufs["rf"]), wb, ptr(bufs["tok2"]), ptr(st))))
                 assert int(st.sum()) == 0
                 # final balances: the new token carries c - s; its nullifier k is the fresh k* of the spend, not the old one

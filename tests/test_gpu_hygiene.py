@@ -29,6 +29,17 @@ def test_no_secret_residue_after_any_call(bench_params, mode):
     st, tok2 = eng.refund_to_credit_token(prer, proofs, rf, sk[32:]); assert eng.secret_residue() == 0
     assert st == bytes(N)
     st, out = eng.debug_scalarmult(proofs[64:96] * 3, sk[:32] * 3); assert eng.secret_residue() == 0
+    # calls that fit one launch take the small-batch schedule (what every single-item call of the Rust binding is): its scratch --
+    # (e_bar - x gamma) A' partial sums, role B's bucket sets -- is part of what is read back; so is the merged calls' rng gather buffer
+    pb = eng.proof_bytes
+    for k in (1, 4):
+        assert eng.verify_spend(sk, proofs[:pb * k]) == bytes(k) and eng.secret_residue() == 0
+        st, rf1 = eng.refund(sk, proofs[:pb * k], shake("hy-rr", 128 * k)); assert rf1 == rf[:128 * k] and eng.secret_residue() == 0
+    eng.set_coalescing(4)
+    st, rf1 = eng.refund(sk, proofs[:pb * 2], shake("hy-rr", 128 * 2)); assert rf1 == rf[:128 * 2] and eng.secret_residue() == 0
+    msgs = eng.cbor_encode("SpendProof", proofs[:pb * 3])
+    st, out = eng.refund_cbor(sk, msgs, shake("hy-rr", 128 * 3), capi.RNG_SEQUENTIAL); assert st == bytes(3) and eng.secret_residue() == 0
+    eng.set_coalescing(0)
     # staging that has to grow (a larger batch than any before) frees the old buffers only after clearing them, and the
     # results are still right
     pre2 = eng.pre_issuance_random(shake("hy-pre2", 128 * 40)); req2 = eng.request(pre2, shake("hy-rq2", 128 * 40))

@@ -37,3 +37,12 @@ for name, f in calls:
     for _ in range(9):
         t = time.perf_counter(); f(); ts.append(time.perf_counter() - t)
     print("  %-26s %.2f" % (name, 1e3 * sorted(ts)[4]))
+# where a single-item call's time goes: the kernels' own durations (HIP events on the engine's streams) against the wall time
+if len(sys.argv) > 2 and sys.argv[2] == "kernels":
+    print("per call: wall ms, then the kernels / copies the engine timed (ms, launches)")
+    for name, f in calls:
+        eng.prof_reset(); eng.prof_enable(True)
+        t = time.perf_counter(); f(); wall = time.perf_counter() - t
+        eng.prof_enable(False)
+        pr = eng.prof()
+        print("  %-26s %.2f   %s" % (name, 1e3 * wall, "  ".join("%s %.3f x%d" % (k, v["ms"], v["launches"]) for k, v in pr.items())))
