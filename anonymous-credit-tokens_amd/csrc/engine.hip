@@ -49,6 +49,10 @@ struct PendingProf { int id; hipEvent_t e0, e1; uint64_t lanes; };
 // One workspace slot: a stream plus every per-chunk device buffer.  Two slots let chunk i+1's kernels (and the
 // host-side hashing of chunk i in host-transcript mode) overlap chunk i's low-occupancy head/tail kernels.
 constexpr int HASH_PIECES = 8;
+constexpr size_t TINY_MAX = 64;                 // lanes of a "tiny" call (one kernel, one copy each way: request_tiny ...)
+constexpr size_t TINY_BYTES = (size_t)64 << 10; // its pinned + device buffers: inputs (secrets among them) in the first half, outputs in the second
+constexpr size_t TINY_OUT = TINY_BYTES / 2;
+constexpr size_t GROUP_CTR_WORDS = 1024;        // groups of 64 lanes per launch of a role-block kernel (launches of at most 8 192 lanes use 128)
 struct Slot {
   hipStream_t stream = nullptr;
   uint8_t *d_tr = nullptr, *d_trs = nullptr, *d_status = nullptr;
@@ -111,6 +115,10 @@ struct act_ctx {
   act::Combiner<struct CoReq>* co = nullptr;     // the queue of requests waiting to be merged (coalesce.h); created with the context
   uint8_t *h_co_proofs = nullptr, *h_co_rng = nullptr, *h_co_out = nullptr;   // pinned gather / scatter buffers of the leader (grow-only)
   size_t h_co_cap = 0;                 // lanes
+  // tiny calls (at most TINY_MAX lanes: the crate's one-item call shape): one pinned + one device buffer, one copy each way, one kernel
+  uint8_t *d_tiny = nullptr, *h_tiny = nullptr;
+  uint32_t* d_group_ctr = nullptr;     // one word per group of 64 lanes (k_sign_fused ...: which role block arrives last), zero between launches
+  uint8_t* d_tiny_tr = nullptr;        // TINY_MAX "request" transcripts of the fused issue kernel
   std::atomic<uint32_t> debug_ns_per_lane{0};    // act_debug_set_slowdown (test hook of the node dispatcher's load balance)
   std::atomic<int> debug_fail_signs{0};          // act_debug_fail_next_signs (test hook of the redeem failure contract)
 };
@@ -367,6 +375,10 @@ bool table_cached(int device, const uint8_t enc[32], int bits) {
 int workspace_alloc(act_ctx* c) {
   const SpendTranscript st{c->L};
   size_t B = c->max_batch;
+  HIPCK(c, hipMalloc(&c->d_group_ctr, GROUP_CTR_WORDS * 4));
+  HIPCK(c, hipMemset(c->d_group_ctr, 0, GROUP_CTR_WORDS * 4));
+  HIPCK(c, hipMalloc(&c->d_tiny_tr, TINY_MAX * SMALL_TR_STRIDE));
+  HIPCK(c, hipDeviceSynchronize());
   for (Slot& sl : c->slots) {
     HIPCK(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
     HIPCK(c, hipMalloc(&sl.d_tr, B * st.stride()));
@@ -543,7 +555,18 @@ int prepare_rng_slots(act_ctx* c, Slot& sl, uint32_t m, size_t off, int mem, con
   return ACT_OK;
 }
 
+// counters of the role-block kernels (which block of a group arrives last): a set per slot, because the two slots' launches overlap
+uint32_t* group_counters(act_ctx* c, const Slot& sl) { return c->d_group_ctr + (size_t)(&sl - c->slots) * (GROUP_CTR_WORDS / 2); }
+// (tiny calls: see request_tiny further down)  ACT_NO_FUSED_TINY=1 keeps the multi-launch paths (A/B; the tests compare the two)
+bool tiny_enabled() { static const bool off = getenv("ACT_NO_FUSED_TINY") != nullptr; return !off; }
 int sign_phase(act_ctx* c, Slot& sl, uint32_t m, int label, const uint8_t* d_rng, const uint8_t* d_camount, uint8_t* d_out) {
+  if (m <= TINY_MAX && tiny_enabled()) {
+    // tiny calls: phase A, the transcript's BLAKE3 (one chunk, in the kernel: same bytes as either transcript mode) and phase B in
+    // ONE launch, the five transcript points on three wavefronts (k_sign.hip k_sign_fused); nothing secret reaches global memory
+    SignFusedArgs f{}; f.P = c->P; f.K = c->key; f.n = m; f.label = label; f.xa = sl.d_xa; f.rng_slot = sl.d_slot; f.c_amount = d_camount;
+    f.status_in = sl.d_status; f.rng = d_rng; f.out = d_out; f.status = sl.d_status; f.trs = sl.d_trs; f.group_counter = group_counters(c, sl); f.pbk = sl.d_buckets;
+    return prof_launch(c, sl, PK_SIGN_A, m, [&] { launch_sign_fused(f, false, sl.stream); });
+  }
   SignArgs s{}; s.P = c->P; s.K = c->key; s.n = m; s.label = label; s.xa = sl.d_xa; s.status = sl.d_status; s.rng_slot = sl.d_slot;
   s.rng = d_rng; s.c_amount = d_camount; s.trs = sl.d_trs; s.state = sl.d_state; s.xof = sl.d_xof; s.out = d_out; s.pbk = sl.d_buckets;
   int rc;
@@ -728,6 +751,10 @@ void act_ctx_destroy(act_ctx* c) {
   for (hipStream_t& a : c->aux) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
   for (hipEvent_t e : c->sm_ev) (void)hipEventDestroy(e);
   if (c->d_small) { (void)hipMemset(c->d_small, 0, c->d_small_cap); (void)hipFree(c->d_small); }
+  if (c->d_tiny) { (void)hipMemset(c->d_tiny, 0, TINY_BYTES); (void)hipFree(c->d_tiny); }
+  if (c->d_group_ctr) (void)hipFree(c->d_group_ctr);
+  if (c->d_tiny_tr) (void)hipFree(c->d_tiny_tr);
+  if (c->h_tiny) { memset(c->h_tiny, 0, TINY_BYTES); (void)hipHostFree(c->h_tiny); }
   for (uint8_t* p : {c->h_co_proofs, c->h_co_rng, c->h_co_out}) if (p) (void)hipHostFree(p);
   for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
@@ -805,10 +832,49 @@ int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* 
   return call.finish();
 }
 
+// Tiny calls.  The crate's entry points take ONE item (src/lib.rs:463, 528, 621, 781, 972, 1217); for the cheap ones the GPU's answer
+// time is fixed cost -- three launches, copies from pageable memory, the wipe -- as much as arithmetic.  Calls of at most TINY_MAX
+// lanes gather their inputs in a pinned buffer, cross PCIe once each way, and run ONE kernel that hashes its (single-chunk) transcript
+// itself -- the device BLAKE3 of blake3_hd.h whatever the context's transcript mode: same bytes -- and zeroes its staged inputs when
+// done.  ACT_NO_FUSED_TINY=1 keeps the two-phase path (A/B, and the tests compare the two).
+static int tiny_buffers(act_ctx* c) {
+  if (c->d_tiny) return ACT_OK;
+  HIPCK(c, hipMalloc(&c->d_tiny, TINY_BYTES));
+  HIPCK(c, hipHostMalloc(&c->h_tiny, TINY_BYTES, hipHostMallocDefault));
+  HIPCK(c, hipMemsetAsync(c->d_tiny, 0, TINY_BYTES, c->slots[0].stream));
+  HIPCK(c, hipStreamSynchronize(c->slots[0].stream));
+  memset(c->h_tiny, 0, TINY_BYTES);
+  return ACT_OK;
+}
+static void wipe_host(uint8_t* p, size_t n) { volatile uint8_t* q = p; for (size_t i = 0; i < n; i++) q[i] = 0; }
+
+static int request_tiny(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
+  Slot& sl = c->slots[0];
+  RequestArgs a{}; a.P = c->P; a.n = (uint32_t)n;
+  int rc;
+  if (mem == ACT_MEM_DEVICE) {
+    a.pre = pre; a.rng = rng; a.out = out_req;
+    if ((rc = prof_launch(c, sl, PK_REQUEST_A, n, [&] { launch_request_fused(a, sl.stream); }))) return rc;
+    HIPCK(c, hipStreamSynchronize(sl.stream));
+    return prof_collect(c, sl);
+  }
+  if ((rc = tiny_buffers(c))) return rc;
+  memcpy(c->h_tiny, pre, 64 * n); memcpy(c->h_tiny + 64 * n, rng, 128 * n);
+  HIPCK(c, hipMemcpyAsync(c->d_tiny, c->h_tiny, 192 * n, hipMemcpyHostToDevice, sl.stream));
+  a.pre = c->d_tiny; a.rng = c->d_tiny + 64 * n; a.out = c->d_tiny + TINY_OUT; a.wipe_inputs = 1;
+  if ((rc = prof_launch(c, sl, PK_REQUEST_A, n, [&] { launch_request_fused(a, sl.stream); }))) return rc;
+  HIPCK(c, hipMemcpyAsync(c->h_tiny + TINY_OUT, c->d_tiny + TINY_OUT, 128 * n, hipMemcpyDeviceToHost, sl.stream));
+  HIPCK(c, hipStreamSynchronize(sl.stream));
+  memcpy(out_req, c->h_tiny + TINY_OUT, 128 * n);
+  wipe_host(c->h_tiny, 192 * n);
+  return prof_collect(c, sl);
+}
+
 int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
   if (!c || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
   Call call(c, 0);
   HIPCK(c, hipSetDevice(c->device));
+  if (n && n <= TINY_MAX && tiny_enabled()) { int rc = request_tiny(c, n, mem, pre, rng, out_req); return rc ? rc : call.finish(); }
   Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
@@ -825,6 +891,40 @@ int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const u
   return call.finish();
 }
 
+// PrivateKey::issue over at most TINY_MAX lanes whose rng slices do not depend on each other's verdicts: the PoK check and the signature
+// side by side in ONE kernel (k_sign.hip k_sign_fused<true>), one copy each way
+static int issue_tiny(act_ctx* c, size_t n, int mem, const uint8_t* req, const uint8_t* camt, const uint8_t* rng, uint8_t* out_resp, uint8_t* status) {
+  Slot& sl = c->slots[0];
+  SignFusedArgs f{}; f.P = c->P; f.K = c->key; f.n = (uint32_t)n; f.label = LABEL_RESPOND; f.point_stride = 128;
+  f.pbk = sl.d_buckets; f.trs = sl.d_trs; f.trs_req = c->d_tiny_tr; f.group_counter = group_counters(c, sl);
+#if defined(ACT_TINY_TIMING)
+  static unsigned long long* d_dbg = nullptr;
+  if (!d_dbg) { HIPCK(c, hipMalloc(&d_dbg, 16 * 8 * 8)); }
+  HIPCK(c, hipMemsetAsync(d_dbg, 0, 16 * 8 * 8, sl.stream));
+  f.dbg = d_dbg;
+  struct Dump { act_ctx* c; Slot& sl; ~Dump() { unsigned long long h[128]; if (hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) { unsigned long long t0 = ~0ull; for (int i = 0; i < 128; i++) if (h[i] && h[i] < t0) t0 = h[i]; for (int r = 0; r < 10; r++) { fprintf(stderr, "[tiny timing] role %d:", r); for (int k = 0; k < 8; k++) fprintf(stderr, " %8.1f", h[r * 8 + k] ? (double)(h[r * 8 + k] - t0) / 100.0 : -1.0); fprintf(stderr, "  us\n"); } } } } dump{c, sl};
+#endif
+  int rc;
+  if (mem == ACT_MEM_DEVICE) {
+    f.point = req; f.c_amount = camt; f.rng = rng; f.out = out_resp; f.status = status;
+    if ((rc = prof_launch(c, sl, PK_SIGN_A, n, [&] { launch_sign_fused(f, true, sl.stream); }))) return rc;
+    HIPCK(c, hipStreamSynchronize(sl.stream));
+    return prof_collect(c, sl);
+  }
+  if ((rc = tiny_buffers(c))) return rc;
+  uint8_t* h = c->h_tiny;
+  memcpy(h, req, 128 * n); memcpy(h + 128 * n, camt, 32 * n); memcpy(h + 160 * n, rng, 128 * n);
+  HIPCK(c, hipMemcpyAsync(c->d_tiny, h, 288 * n, hipMemcpyHostToDevice, sl.stream));
+  f.point = c->d_tiny; f.c_amount = c->d_tiny + 128 * n; f.rng = c->d_tiny + 160 * n; f.wipe_rng = 1;
+  f.out = c->d_tiny + TINY_OUT; f.status = c->d_tiny + TINY_OUT + 160 * n;
+  if ((rc = prof_launch(c, sl, PK_SIGN_A, n, [&] { launch_sign_fused(f, true, sl.stream); }))) return rc;
+  HIPCK(c, hipMemcpyAsync(h + TINY_OUT, c->d_tiny + TINY_OUT, 161 * n, hipMemcpyDeviceToHost, sl.stream));
+  HIPCK(c, hipStreamSynchronize(sl.stream));
+  memcpy(out_resp, h + TINY_OUT, 160 * n); memcpy(status, h + TINY_OUT + 160 * n, n);
+  wipe_host(h, 288 * n);                                        // (the device copies were zeroed by the kernel)
+  return prof_collect(c, sl);
+}
+
 int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
                     int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!c || !sk || (n && (!req || !camt || !rng || !out_resp || !status))) return ACT_ERR_ARG;
@@ -832,6 +932,10 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
   Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
+  if (n && n <= TINY_MAX && n <= c->max_batch && (rng_mode == ACT_RNG_PER_LANE || n == 1) && tiny_enabled()) {
+    rc = issue_tiny(c, n, mem, req, camt, rng, out_resp, status);
+    return rc ? rc : call.finish();
+  }
   size_t cursor = 0, chunk = 0;
   // chunks alternate between the two slots; with device transcripts and per-lane rng nothing in a chunk waits for the
   // host, so two chunks are in flight (the per-proof kernels put only one wavefront per SIMD on the GPU per chunk)
@@ -1334,7 +1438,7 @@ static int prove_spend_impl(act_ctx* c, size_t n, int mem, const uint8_t* token,
     size_t off = sched[i].first; uint32_t m = (uint32_t)sched[i].second;
     ms[i % depth] = m; offs[i % depth] = off;
     a = ProveArgs{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.half = sl.d_buckets; a.state = sl.d_state;
-    a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status;
+    a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.group_counter = group_counters(c, sl);
     int rc;
     if ((rc = dev_in(c, sl, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, s + off * 32, (size_t)m * 32, &a.s))) return rc;
@@ -1446,10 +1550,14 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
     if (!issuance) {
       if ((rc = prof_launch(c, sl, PK_CLIENT, (uint64_t)m * c->L, [&] { launch_client_decode_com(a, sl.stream); }))) return rc;
     }
+    a.group_counter = group_counters(c, sl);
+    a.fused = (m <= TINY_MAX && tiny_enabled()) ? 1 : 0;          // tiny calls: phase A, the hash and phase B in one launch (k_client.hip)
     if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_a(a, sl.stream); }))) return rc;
-    uint32_t len = c->P.prefix_len[label] + 40u * (issuance ? 7u : 6u);
-    if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, len, m))) return rc;
-    if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_b(a, sl.stream); }))) return rc;
+    if (!a.fused) {
+      uint32_t len = c->P.prefix_len[label] + 40u * (issuance ? 7u : 6u);
+      if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, len, m))) return rc;
+      if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_b(a, sl.stream); }))) return rc;
+    }
     if ((rc = dev_out_end(c, sl, mem, out_token + off * 160, a.out_token, (size_t)m * 160))) return rc;
     if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
     if (!two_slots && (rc = sync_all(c))) return rc;
@@ -1588,6 +1696,7 @@ int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
     regions.emplace_back(sl.d_d01, c->max_batch * 3 * GE_WORDS * 4);
     regions.emplace_back(sl.d_buckets, c->max_batch * PREP_BUCKET_SETS * BUCKET_WORDS * 4);
   }
+  if (c->d_tiny) { regions.emplace_back(c->d_tiny, TINY_OUT); for (size_t i = 0; i < TINY_OUT; i++) nz += c->h_tiny[i] != 0; }      // staged inputs of the tiny calls (device + pinned)
   if (c->d_small) regions.emplace_back(c->d_small, c->d_small_cap);      // the small-batch schedule's partial sums and bucket sets (what single-item calls use)
   if (c->h_co_rng) for (size_t i = 0; i < c->h_co_cap * 128; i++) nz += c->h_co_rng[i] != 0;      // the merged calls' pinned rng gather buffer (host memory)
   for (auto& r : regions) total += r.second;

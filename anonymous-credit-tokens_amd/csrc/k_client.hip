@@ -64,33 +64,56 @@ __global__ void __launch_bounds__(64, 2) k_client_a(ClientArgs a) {
   a.flags[p] = flags;
 }
 
-// The same for SHORT launches, eight lanes per item: k_client_a is three variable-base chains, a Horner sum (refund) and four
-// encodings in one lane (2.6 - 3.0 ms for one item).  Here
-//     lane 0   z A, then Y_A = z A - gamma X_A (the second term from lane 1)      lane 1   X_A, then -gamma X_A
-//     lane 2   Y_g = (z - gamma e) g - gamma w                                     lane 3   X_g = e g + w
-//     lane 4   X_A once more, to encode it (lane 1 is busy with its chain)         lanes 5-7 idle
-// Same group elements, same bytes.  The flags word is OR-ed (lanes 0 and 1 decode), so the caller clears it first.
-__global__ void __launch_bounds__(256) k_client_a_wide(ClientArgs a) {
-  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, p = gid >> 3, role = gid & 7;
+// The same for SHORT launches, four BLOCKS of one wavefront per 64 items (blockIdx.y = role, lane = item): k_client_a is three
+// variable-base chains, a Horner sum (refund) and four encodings in one lane (2.6 - 3.0 ms for one item).  Here
+//     role 0   z A                          role 1   X_A, then -gamma X_A
+//     role 2   Y_g = (z - gamma e) g - gamma w                                        role 3   X_g = e g + w, and X_A once more, to encode it
+// and the block of a group that ARRIVES LAST (a counter per group) sums Y_A = z A - gamma X_A from the two partial points the
+// roles left in their bucket areas and encodes it; for tiny calls (`fused`) it goes on to hash the transcript (one BLAKE3 chunk,
+// the routine of k_hash_xof) and to do what k_client_b does -- the whole method in one launch.  Same group elements, same bytes.
+// (Round 4 had the roles on LANES of one wavefront, which executes divergent lanes one after the other: the three chains took
+// 3 x 0.7 ms.  Wavefronts of ONE block can land on one SIMD and then run at a fraction of their speed each -- 0.9 or 2.0 ms from
+// call to call, profiles/r05_tiny_ab.txt; separate workgroups go to separate CUs.)  The flags word is OR-ed, so the caller clears it.
+__device__ __forceinline__ bool client_group_last_arrival(uint32_t* counter, uint32_t roles) {
+  __shared__ uint32_t ticket;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = atomicAdd(counter, 1u);
+  __syncthreads();
+  const bool last = ticket == roles - 1u;
+  if (last) { __threadfence(); if (threadIdx.x == 0) *counter = 0u; }
+  return last;
+}
+__global__ void __launch_bounds__(64) k_client_a_wide(ClientArgs a) {
+  const uint32_t role = blockIdx.y, lane = threadIdx.x, p = blockIdx.x * 64 + lane;
   const bool live = p < a.n;
   const int L = a.P.L;
   const bool issuance = a.label == LABEL_RESPOND;
-  ge pt = ge_identity();
-  sc e = sc_zero(), c = sc_zero();
-  uint32_t wa[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (live && role <= 4) {
-    const uint8_t* resp = a.resp + (size_t)p * (issuance ? 160 : 128);
-    e = load_sc(resp + 32); const sc gamma = load_sc(resp + 64), z = load_sc(resp + 96);
+  const uint8_t* resp = a.resp + (size_t)(live ? p : 0) * (issuance ? 160 : 128);
+  uint8_t* tr = a.trs + (size_t)(live ? p : 0) * SMALL_TR_STRIDE;
+  uint8_t* el = tr + a.P.prefix_len[a.label] + (issuance ? 40 : 0);
+  // after [c] | e: A (slot 1) | X_A (2) | X_g (3) | Y_A (4) | Y_g (5)
+  uint32_t enc[8];
+  uint32_t* part = a.pbk + (size_t)(live ? p : 0) * PREP_BUCKET_SETS * BUCKET_WORDS;      // sets 0 and 1: the roles' bucket areas, then their results
+  if (live) {
+    const sc e = load_sc(resp + 32), gamma = load_sc(resp + 64), z = load_sc(resp + 96);
     const sc ng = sc_neg(gamma);
-    uint32_t* bk = a.pbk + ((size_t)p * PREP_BUCKET_SETS + (role < 3 ? role : 0)) * BUCKET_WORDS;
+    uint32_t* bk = part + (size_t)(role < 3 ? role : 0) * BUCKET_WORDS;
+    sc c = sc_zero();
     if (issuance) c = load_sc(resp + 128);
-    load8(wa, resp);
+    uint32_t wa[8]; load8(wa, resp);
     if (role == 0) {
       ge A; if (!ristretto_decode(A, wa)) atomicOr(a.flags + p, FLAG_UNDECODABLE);
       ge acc[1] = {ge_identity()}; sc s1[1] = {z};
       chain_b<1>(acc, A, s1, bk);                                                              // z A
-      pt = acc[0];
-    } else if (role == 1 || role == 4) {
+      ge_store(bk, acc[0]);
+      // (bytes, not tr_put_prefix's word stores: the word behind the prefix belongs to an element another block may be writing)
+      const uint8_t* pre = reinterpret_cast<const uint8_t*>(a.P.prefix[a.label]);
+      for (uint32_t i = 0; i < a.P.prefix_len[a.label]; i++) tr[i] = pre[i];
+      if (issuance) tr_put_bytes(tr + a.P.prefix_len[a.label], c.v);
+      tr_put_bytes(el, e.v);
+      tr_put_bytes(el + 40, wa);
+    } else if (role == 1 || role == 3) {
       ge xa;
       if (issuance) {
         uint32_t wk[8]; load8(wk, a.req + (size_t)p * 128);
@@ -101,39 +124,39 @@ __global__ void __launch_bounds__(256) k_client_a_wide(ClientArgs a) {
         for (int j = L - 1; j >= 0; j--) { kp = ge_double(kp); kp = ge_madd(kp, niels_load(a.coords + ((size_t)p * L + j) * NIELS_WORDS)); }
         xa = ge_add(kp, ge_basepoint());
       }
-      if (role == 4) pt = xa;
-      else { ge acc[1] = {ge_identity()}; sc s2[1] = {ng}; chain_b<1>(acc, xa, s2, bk); pt = acc[0]; }   // - gamma X_A   (:540 / :1233)
-    } else if (role == 2) {
+      if (role == 3) {
+        ristretto_encode(enc, xa); tr_put_bytes(el + 40 * 2, enc);
+        ristretto_encode(enc, ge_add(fixed_base_acc(ge_identity(), a.P.tab[BASE_G], e), a.w)); tr_put_bytes(el + 40 * 3, enc);   // X_g (:537 / :1232)
+      } else { ge acc[1] = {ge_identity()}; sc s2[1] = {ng}; chain_b<1>(acc, xa, s2, bk); ge_store(bk, acc[0]); }   // - gamma X_A   (:540 / :1233)
+    } else {
       ge yg[1] = {fixed_base_acc(ge_identity(), a.P.tab[BASE_G], sc_sub(z, sc_mul(gamma, e)))};
       sc s2[1] = {ng}; chain_b<1>(yg, a.w, s2, bk);                                            // - gamma w     (:541 / :1234)
-      pt = yg[0];
-    } else {
-      pt = ge_add(fixed_base_acc(ge_identity(), a.P.tab[BASE_G], e), a.w);                     // X_g (:537 / :1232)
+      ristretto_encode(enc, yg[0]); tr_put_bytes(el + 40 * 5, enc);
     }
   }
-  // - gamma X_A travels from lane 1 of the group to lane 0 (every lane of the wavefront takes part in the shuffles)
-  ge p1;
-  const int src = (int)((threadIdx.x & 63u & ~7u) + 1u);
-#pragma unroll
-  for (int i = 0; i < FE_LIMBS; i++) {
-    p1.X.v[i] = (uint32_t)__shfl((int)pt.X.v[i], src); p1.Y.v[i] = (uint32_t)__shfl((int)pt.Y.v[i], src);
-    p1.Z.v[i] = (uint32_t)__shfl((int)pt.Z.v[i], src); p1.T.v[i] = (uint32_t)__shfl((int)pt.T.v[i], src);
-  }
-  if (!live || role > 4 || role == 1) return;
-  if (role == 0) pt = ge_add(pt, p1);                                                          // Y_A
-  uint8_t* tr = a.trs + (size_t)p * SMALL_TR_STRIDE;
-  uint8_t* el = tr + a.P.prefix_len[a.label] + (issuance ? 40 : 0);
-  // after [c] | e: A (slot 1) | X_A (2) | X_g (3) | Y_A (4) | Y_g (5)
-  uint32_t enc[8];
-  ristretto_encode(enc, pt);
-  const int slot = role == 4 ? 2 : role == 3 ? 3 : role == 0 ? 4 : 5;
-  tr_put_bytes(el + 40 * slot, enc);
-  if (role == 0) {
-    tr_put_prefix(tr, a.P, a.label);
-    if (issuance) tr_put_bytes(tr + a.P.prefix_len[a.label], c.v);
-    tr_put_bytes(el, e.v);
-    tr_put_bytes(el + 40, wa);
-  }
+  if (!client_group_last_arrival(a.group_counter + blockIdx.x, 4u)) return;
+  if (!live) return;
+  ristretto_encode(enc, ge_add(ge_load(part), ge_load(part + BUCKET_WORDS)));                  // Y_A = z A - gamma X_A
+  tr_put_bytes(el + 40 * 4, enc);
+  if (!a.fused) return;
+  // ---- tiny calls: the transcript's hash and k_client_b's part, here --------------------------------------------------------------
+  uint32_t w[16];
+  b3_hash_xof64(w, reinterpret_cast<const uint32_t*>(tr), a.P.prefix_len[a.label] + 40u * (issuance ? 7u : 6u));
+  const sc gamma = load_sc(resp + 64);
+  const uint32_t flags = __atomic_load_n(a.flags + p, __ATOMIC_RELAXED);
+  uint8_t stt = 0;
+  if (flags & FLAG_UNDECODABLE) stt = 255;
+  else if (!sc_equal(sc_from_wide_words(w), gamma)) stt = issuance ? 2 : 4;   // InvalidIssuanceResponseProof / InvalidRefundProof
+  a.status[p] = stt;
+  uint8_t* out = a.out_token + (size_t)p * 160;
+  if (stt) { for (int i = 0; i < 160; i += 32) zero8(out + i); return; }
+  const uint8_t* pre = a.pre + (size_t)p * (issuance ? 64 : 96);              // CreditToken { a, e, k, r, c } (:554-560 / :1246-1252); pre = r | k (| m)
+  uint32_t t[8];
+  load8(t, resp); store8(out, t);
+  store_sc(out + 32, load_sc(resp + 32));
+  store_sc(out + 64, load_sc(pre + 32));
+  store_sc(out + 96, load_sc(pre));
+  store_sc(out + 128, issuance ? load_sc(resp + 128) : load_sc(pre + 64));
 }
 
 __global__ void __launch_bounds__(256) k_client_b(ClientArgs a) {
@@ -170,7 +193,7 @@ constexpr uint32_t CLIENT_WIDE_MAX = 8192;
 void launch_client_a(const ClientArgs& a, hipStream_t s) {
   if (!a.n) return;
   static const bool no_wide = getenv("ACT_NO_WIDE_CLIENT") != nullptr;     // A/B knob
-  if (a.n <= CLIENT_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_client_a_wide, dim3((a.n * 8 + 255) / 256), dim3(256), 0, s, a);
+  if (a.n <= CLIENT_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_client_a_wide, dim3((a.n + 63) / 64, 4), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_client_a, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }
 void launch_client_b(const ClientArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_client_b, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }

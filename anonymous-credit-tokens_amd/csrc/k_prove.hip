@@ -9,21 +9,30 @@ __global__ void __launch_bounds__(64, 2) k_prove_head(ProveArgs a) {
   ACT_SECRET_FB(fb, a.P);
   prove_head_lane(a, blockIdx.x * 64 + threadIdx.x, fb);
 }
-// The same head for SHORT launches, eight lanes per proof.  prove_head_lane is ~15 000 dependent field operations in one lane (a
-// two-scalar chain on A, fifteen fixed-base products, four encodings): 4.2 ms however few proofs there are -- and the crate's
-// prove_spend takes ONE token (src/lib.rs:972-977).  Its pieces are independent until A1 is summed, so:
-//     lane 0   A' = (r1 r2) A                  lane 1   P1 = (e' r1 r2) A       (a doubling chain each instead of a shared one)
-//     lane 2   B_bar                           lane 3   the fixed-base part of A1 = e' A' + r2' B_bar; A1 = that + P1 (from lane 1)
-//     lane 4   A2                              lanes 5-7   the three h2 terms of bit 0 (d0, d1, d2)
-// Every lane makes ONE product per base (the matrix-core look-up wants all 64 lanes of a wavefront: lanes without a term multiply by
-// zero).  Same group elements, hence the same bytes (tests: every small prove_spend call goes through here).
-__global__ void __launch_bounds__(256) k_prove_head_wide(ProveArgs a) {
+// The same head for SHORT launches, eight BLOCKS of one wavefront per 64 proofs (blockIdx.y = role, lane = proof).  prove_head_lane is
+// ~15 000 dependent field operations in one lane (a two-scalar chain on A, fifteen fixed-base products, four encodings): 4.2 ms however
+// few proofs there are -- and the crate's prove_spend takes ONE token (src/lib.rs:972-977).  Its pieces are independent until A1 is summed:
+//     role 0   A' = (r1 r2) A                  role 1   P1 = (e' r1 r2) A       (a doubling chain each instead of a shared one)
+//     role 2   B_bar                           role 3   the fixed-base part of A1 = e' A' + r2' B_bar
+//     role 4   A2                              roles 5-7   the three h2 terms of bit 0 (d0, d1, d2)
+// and the block of a group that ARRIVES LAST (a counter per group) adds A1 = (role 3's part) + P1 and encodes it.  Roles 2-7 make one
+// product per base (the matrix-core look-up wants all 64 lanes of a wavefront: lanes past the batch multiply by zero), roles 5-7 on
+// h2 only.  Same group elements, hence the same bytes (tests: every small prove_spend call goes through here).  Round 4 had the roles
+// on LANES of one wavefront -- the kernel was a chain plus four products in sequence, 1.95 ms for one proof; the wavefronts of ONE
+// block may land on one SIMD and then share it (0.9 or 2.0 ms from call to call: profiles/r05_tiny_ab.txt); separate workgroups go
+// to separate CUs.
+__global__ void __launch_bounds__(64) k_prove_head_wide(ProveArgs a) {
+  __shared__ uint32_t ticket;
   ACT_SECRET_FB(fb, a.P);
-  const uint32_t gid = blockIdx.x * 256 + threadIdx.x, p = gid >> 3, role = gid & 7;
+  const uint32_t role = blockIdx.y, lane = threadIdx.x, p = blockIdx.x * 64 + lane;      // role is uniform over the block
   const bool live = p < a.n;
   const int L = a.P.L;
   const ProofLayout pl{L}; const SpendTranscript st{L};
   RngView rv{a.rng + (size_t)(live ? p : 0) * rng_bytes(L), L};
+  uint8_t* rec = a.proof + (size_t)(live ? p : 0) * pl.bytes();
+  uint8_t* el = a.tr + (size_t)(live ? p : 0) * a.tr_stride + 184;
+  uint32_t* park_p1 = a.half + ((size_t)(live ? p : 0) * 2 + 1) * BUCKET_WORDS;          // role 1's bucket area, then its result
+  uint32_t* park_f3 = a.half + ((size_t)a.n * 2 + (live ? p : 0)) * BUCKET_WORDS;        // (the half-point area holds max(L, 3) such areas per proof)
   sc k = sc_zero(), s = sc_zero(), r1 = sc_zero();
   sc sg = sc_zero(), sh1 = sc_zero(), sh2 = sc_zero(), sh3 = sc_zero();      // this lane's scalar on g, h1, h2, h3
   ge pt = ge_identity();
@@ -52,37 +61,43 @@ __global__ void __launch_bounds__(256) k_prove_head_wide(ProveArgs a) {
       sh2 = sc_half(role == 5 ? k_star : role == 6 ? rv.k0_prime() : sc_sub(rv.w0(), sc_mul(rv.gamma_i(0), k_star)));
     }
   }
-  ge f = ge_identity();
-  fb.stage(BASE_G);  f = fb.mul(f, BASE_G, sg);
-  fb.stage(BASE_H1); f = fb.mul(f, BASE_H1, sh1);
-  fb.stage(BASE_H2); f = fb.mul(f, BASE_H2, sh2);
-  fb.stage(BASE_H3); f = fb.mul(f, BASE_H3, sh3);
-  // P1 travels from lane 1 of the group to lane 3 (every lane of the wavefront takes part in the shuffles)
-  ge p1;
-  const int src = (int)((threadIdx.x & 63u & ~7u) + 1u);
-#pragma unroll
-  for (int i = 0; i < FE_LIMBS; i++) {
-    p1.X.v[i] = (uint32_t)__shfl((int)pt.X.v[i], src); p1.Y.v[i] = (uint32_t)__shfl((int)pt.Y.v[i], src);
-    p1.Z.v[i] = (uint32_t)__shfl((int)pt.Z.v[i], src); p1.T.v[i] = (uint32_t)__shfl((int)pt.T.v[i], src);
+  if (role >= 2) {                                             // uniform over the block: whole wavefronts multiply, or none of their lanes
+    ge f = ge_identity();
+    if (role <= 4) { fb.stage(BASE_G);  f = fb.mul(f, BASE_G, sg); fb.stage(BASE_H1); f = fb.mul(f, BASE_H1, sh1); }
+    fb.stage(BASE_H2); f = fb.mul(f, BASE_H2, sh2);
+    if (role <= 4) { fb.stage(BASE_H3); f = fb.mul(f, BASE_H3, sh3); }
+    pt = f;
   }
-  if (!live) return;
-  if (role >= 5) { ge_store(a.d3 + ((size_t)p * 3 + (role - 5)) * GE_WORDS, f); return; }
-  if (role >= 2) pt = role == 3 ? ge_add(f, p1) : f;
-  uint8_t* rec = a.proof + (size_t)p * pl.bytes();
-  uint8_t* el = a.tr + (size_t)p * a.tr_stride + 184;
   uint32_t enc[8];
-  ristretto_encode(enc, pt);
-  if (role == 0) {
-    tr_put_prefix(a.tr + (size_t)p * a.tr_stride, a.P, LABEL_SPEND);
-    tr_put_aligned(el + 40 * st.el_k(), k.v);
-    store_sc(rec + 32 * pl.k(), k); store_sc(rec + 32 * pl.s(), s);
-    tr_put_aligned(el + 40 * st.el_a_prime(), enc); store8(rec + 32 * pl.a_prime(), enc);
-    const sc r3 = sc_invert(r1);                                                // :992
-    uint32_t* stt = a.state + (size_t)p * 24;
-    for (int i = 0; i < 8; i++) stt[i] = r3.v[i];
-  } else if (role == 2) { tr_put_aligned(el + 40 * st.el_b_bar(), enc); store8(rec + 32 * pl.b_bar(), enc); }
-  else if (role == 3) tr_put_aligned(el + 40 * st.el_a1(), enc);
-  else if (role == 4) tr_put_aligned(el + 40 * st.el_a2(), enc);
+  if (live) {
+    if (role >= 5) ge_store(a.d3 + ((size_t)p * 3 + (role - 5)) * GE_WORDS, pt);
+    else if (role == 1) ge_store(park_p1, pt);
+    else if (role == 3) ge_store(park_f3, pt);
+    else {
+      ristretto_encode(enc, pt);
+      if (role == 0) {
+        tr_put_prefix(a.tr + (size_t)p * a.tr_stride, a.P, LABEL_SPEND);
+        tr_put_aligned(el + 40 * st.el_k(), k.v);
+        store_sc(rec + 32 * pl.k(), k); store_sc(rec + 32 * pl.s(), s);
+        tr_put_aligned(el + 40 * st.el_a_prime(), enc); store8(rec + 32 * pl.a_prime(), enc);
+        const sc r3 = sc_invert(r1);                                                // :992
+        uint32_t* stt = a.state + (size_t)p * 24;
+        for (int i = 0; i < 8; i++) stt[i] = r3.v[i];
+      } else if (role == 2) { tr_put_aligned(el + 40 * st.el_b_bar(), enc); store8(rec + 32 * pl.b_bar(), enc); }
+      else tr_put_aligned(el + 40 * st.el_a2(), enc);                               // role 4
+    }
+  }
+  // the last block of the group to arrive sums A1
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) ticket = atomicAdd(a.group_counter + blockIdx.x, 1u);
+  __syncthreads();
+  if (ticket != 7u) return;
+  __threadfence();
+  if (threadIdx.x == 0) a.group_counter[blockIdx.x] = 0u;
+  if (!live) return;
+  ristretto_encode(enc, ge_add(ge_load(park_f3), ge_load(park_p1)));
+  tr_put_aligned(el + 40 * st.el_a1(), enc);
 }
 __global__ void __launch_bounds__(256, 2) k_prove_bits(ProveArgs a) {
   ACT_SECRET_FB_LDS(fb, a.P);
@@ -103,7 +118,7 @@ constexpr uint32_t PROVE_WIDE_MAX = 8192;
 void launch_prove_head(const ProveArgs& a, hipStream_t s) {
   if (!a.n) return;
   static const bool no_wide = getenv("ACT_NO_WIDE_PROVE") != nullptr;     // A/B knob
-  if (a.n <= PROVE_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_prove_head_wide, dim3((a.n * 8 + 255) / 256), dim3(256), 0, s, a);
+  if (a.n <= PROVE_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_prove_head_wide, dim3((a.n + 63) / 64, 8), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_prove_head, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }
 void launch_prove_bits(const ProveArgs& a, hipStream_t s) {

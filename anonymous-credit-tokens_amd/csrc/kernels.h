@@ -119,6 +119,25 @@ struct SignArgs {
   uint32_t* pbk;             // n * 2 * BUCKET_WORDS: per-proof Pippenger buckets (msm.h chain_b)
 };
 
+// k_sign_fused (k_sign.hip): the whole signature -- and, with `check`, the request's PoK check beside it -- in one kernel, for tiny calls
+struct SignFusedArgs {
+  DevParams P; DevKey K;
+  uint32_t n; int label;
+  const uint8_t* point; uint32_t point_stride;     // IssuanceRequest records (K first, 128 B) or enc(K') (32 B); CHECK needs the records
+  const uint32_t* xa;                              // or (!CHECK, nullable) X_A itself, n * GE_WORDS: then `point` is not read
+  const uint32_t* rng_slot;                        // nullable: lane p draws from slice rng_slot[p] instead of p
+  const uint8_t* c_amount;                         // n * 32 (issue) or null (refund)
+  const uint8_t* status_in;                        // !CHECK: verdicts of the check phase; lanes with a non-zero byte are not signed
+  const uint8_t* rng;                              // lane p's 128 bytes at rng + 128 p
+  uint8_t* out; uint8_t* status;
+  uint32_t* pbk;                                   // n * PREP_BUCKET_SETS * BUCKET_WORDS: sets 0, 1 = the check's chain_b, set 2 = the quarters of A and Y_A
+  uint8_t* trs;                                    // n * SMALL_TR_STRIDE: the "respond" / "refund" transcripts the roles assemble
+  uint8_t* trs_req;                                // CHECK: n * SMALL_TR_STRIDE "request" transcripts
+  uint32_t* group_counter;                         // one word per group of 64 lanes, zero between launches: which block arrives last
+  int wipe_rng;                                    // rng is the engine's staged copy: zero it when done
+  unsigned long long* dbg;                         // -DACT_TINY_TIMING builds only: 8 time stamps per role
+};
+
 // X_A for the sign-only entry points: from K of the request (+ c h1) or from enc(K') of a verified spend proof
 struct SignXaArgs {
   DevParams P;
@@ -151,6 +170,7 @@ struct RequestArgs {
   uint8_t* trs;
   const uint32_t* xof;
   uint8_t* out;              // n * 128
+  int wipe_inputs;           // k_request_fused: pre / rng are the engine's staged copies -- zero them when done
 };
 
 // CreditToken::prove_spend (src/lib.rs:972-1152)
@@ -169,6 +189,7 @@ struct ProveArgs {
   uint8_t* proof;            // n * 32*(14+4L)
   uint8_t* prerefund;        // n * 96
   uint8_t* status;
+  uint32_t* group_counter;   // k_prove_head_wide: one word per group of 64 proofs, zero between launches (which role block arrives last)
 };
 // PreIssuance::to_credit_token (src/lib.rs:528-562) / PreRefund::to_credit_token (:1217-1253)
 struct ClientArgs {
@@ -186,7 +207,9 @@ struct ClientArgs {
   const uint32_t* xof;
   uint8_t* out_token;        // n * 160
   uint8_t* status;
-  uint32_t* pbk;             // n * 2 * BUCKET_WORDS (msm.h chain_b)
+  uint32_t* pbk;             // n * PREP_BUCKET_SETS * BUCKET_WORDS (msm.h chain_b); the wide kernel also parks two partial points there
+  uint32_t* group_counter;   // wide kernel: one word per group of 64 items, zero between launches (which role block arrives last)
+  int fused;                 // wide kernel, tiny calls: the last block also hashes the transcript and does k_client_b's part
 };
 
 struct HashArgs { const uint8_t* msg; uint32_t stride; uint32_t len; uint32_t n; uint32_t* xof; const uint32_t* len_per_lane; };
@@ -222,10 +245,12 @@ void launch_spend_finish(const SpendArgs& a, hipStream_t s);
 void launch_sign_a(const SignArgs& a, hipStream_t s);
 void launch_sign_b(const SignArgs& a, hipStream_t s);
 void launch_sign_xa(const SignXaArgs& a, hipStream_t s);
+void launch_sign_fused(const SignFusedArgs& a, bool check, hipStream_t s);
 void launch_issue_a(const IssueArgs& a, hipStream_t s);
 void launch_issue_check(const IssueArgs& a, hipStream_t s);
 void launch_request_a(const RequestArgs& a, hipStream_t s);
 void launch_request_b(const RequestArgs& a, hipStream_t s);
+void launch_request_fused(const RequestArgs& a, hipStream_t s);      // a.n <= any: 64 requests per block of four wavefronts, hash in-kernel (tiny calls)
 void launch_prove_head(const ProveArgs& a, hipStream_t s);
 void launch_prove_bits(const ProveArgs& a, hipStream_t s);
 void launch_prove_enc(const ProveArgs& a, hipStream_t s);

@@ -641,18 +641,19 @@ __device__ ge fixed_base_acc_mf(ge acc, const uint8_t* tab_mf, const sc& s);    
 #endif
 
 // acc[a] += s[a] * N with no secret-dependent address and no secret-dependent branch: chain<NACC> with every addition executed
+// `steps` < 127: the scalars are known to fit 2 (steps - 1) bits (the last step takes the recoding's carry): chain_ct_piece below
 template <int NACC>
-ACT_HD void chain_ct(ge* acc, const ge& N, const sc* s) {
+ACT_HD void chain_ct(ge* acc, const ge& N, const sc* s, int steps = 127) {
   uint32_t w[NACC][8], carry[NACC];
   for (int a = 0; a < NACC; a++) { carry[a] = 0; for (int i = 0; i < 8; i++) w[a][i] = s[a].v[i]; }
   ge_cached idc; idc.YpX = fe_one(); idc.YmX = fe_one(); idc.Z = fe_one(); idc.T2d = fe_zero();
   ge P = N;
 #pragma unroll 1
-  for (int step = 0; step < 127; step++) {
+  for (int step = 0; step < steps; step++) {
     ge_cached c1 = ge_to_cached(P);
     ge Q = ge_double(P);
     ge_cached c2 = ge_to_cached(Q);
-    if (step < 126) P = ge_double(Q);
+    if (step < steps - 1) P = ge_double(Q);
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
       digit4 d = next_digit4(w[a], carry[a]);
@@ -666,6 +667,21 @@ ACT_HD void chain_ct(ge* acc, const ge& N, const sc* s) {
       acc[a] = ge_add_cached(acc[a], q);
     }
   }
+}
+// One QUARTER of s * N, for latency: s = sum_i 2^(64 i) s_i with 64-bit s_i, so s N = sum_i s_i (2^(64 i) N) and the four terms are
+// independent -- four wavefronts each double N 64 i times and then run 33 chain steps instead of one running 127 (the longest does
+// 192 doublings + 33 steps: ~0.55 of the whole chain's multiplications).  Same group element once the four are added; still no
+// secret-dependent address or branch.  For single-item calls, where the chip is empty and the chain IS the answer time.
+ACT_HD ge chain_ct_quarter(const ge& N, const sc& s, int i) {
+  ge P = N;
+#pragma unroll 1
+  for (int d = 0; d < 64 * i; d++) P = ge_double(P);
+  sc piece = sc_zero();
+  piece.v[0] = s.v[2 * i]; piece.v[1] = s.v[2 * i + 1];
+  ge acc[1] = {ge_identity()};
+  sc sp[1] = {piece};
+  chain_ct<1>(acc, P, sp, 33);
+  return acc[0];
 }
 #if defined(ACT_CT_SECRET_TABLES)
 template <int NACC> ACT_HD void chain_s(ge* acc, const ge& N, const sc* s, uint32_t*) { chain_ct<NACC>(acc, N, s); }

@@ -142,19 +142,57 @@ ACT_HD sc sc_mul(const sc& a, const sc& b) { uint32_t t[16]; bn_mul<8, 8>(t, a.v
 ACT_HD sc sc_muladd(const sc& a, const sc& b, const sc& c) { return sc_add(sc_mul(a, b), c); }
 ACT_HD bool sc_equal(const sc& a, const sc& b) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i]; return d == 0; }
 ACT_HD bool sc_is_zero(const sc& a) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i]; return d == 0; }
-// a^(l-2); 0 -> 0 (Scalar::invert, src/lib.rs:645, 849, 992)
+// ---- Scalar::invert (src/lib.rs:645, 849, 992): a^(l-2), 0 -> 0 ----------------------------------------------------------------
+// 253 squarings + 73 multiplications.  Through sc_mul (schoolbook product, then the three-stage fold of sc_reduce512 with its
+// conditional subtractions) that was 0.5 - 0.6 ms of one wavefront -- a third of a single-item `issue` (profiles/r05_tiny_timing.txt)
+// and a fifth of k_sign_a.  Inside the exponentiation the operands stay in Montgomery form (R = 2^256): one CIOS pass per product,
+// 8 x (8 + 1 + 5) multiply-accumulates (l = 2^252 + c has three zero words), no subtraction until the end -- R = 16 l, so operands
+// below 2 l give results below 2 l: (a b + m l) / R < (4 l^2 + R l) / R < 2 l.
+ACT_HD void sc_mont_mul(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]) {
+  constexpr uint32_t NPRIME = 0x12547e1bu;      // -l^-1 mod 2^32
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { c += (uint64_t)a[j] * b[i] + t[j]; t[j] = (uint32_t)c; c >>= 32; }
+    t[8] += (uint32_t)c;                         // (t < 2^287 throughout: nine words)
+    const uint32_t m = t[0] * NPRIME;
+    c = ((uint64_t)m * sc_l_word(0) + t[0]) >> 32;                    // the low word becomes zero
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      c += t[j];
+      if (j < 4 || j == 7) c += (uint64_t)m * sc_l_word(j);           // words 4, 5, 6 of l are zero
+      t[j - 1] = (uint32_t)c; c >>= 32;
+    }
+    c += t[8];
+    t[7] = (uint32_t)c; t[8] = (uint32_t)(c >> 32);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) out[i] = t[i];     // < 2 l < 2^254: t[8] is zero
+}
 ACT_HD sc sc_invert(const sc& a) {
-  // l - 2 as words
-  uint32_t e[8];
+  constexpr uint32_t R2[8] = {0x449c0f01u, 0xa40611e3u, 0x68859347u, 0xd00e1ba7u, 0x17f5be65u, 0xceec73d2u, 0x7c309a3du, 0x0399411bu};      // R^2 mod l
+  constexpr uint32_t R1[8] = {0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};      // R mod l
+  uint32_t e[8];                                 // l - 2
 #pragma unroll
   for (int i = 0; i < 8; i++) e[i] = sc_l_word(i);
   e[0] -= 2u;
-  sc acc = sc_one();
+  uint32_t am[8], acc[8], r2[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) { r2[i] = R2[i]; acc[i] = R1[i]; }
+  sc_mont_mul(am, a.v, r2);                      // a R
   for (int i = 252; i >= 0; i--) {
-    acc = sc_mul(acc, acc);
-    if ((e[i >> 5] >> (i & 31)) & 1u) acc = sc_mul(acc, a);
+    sc_mont_mul(acc, acc, acc);
+    if ((e[i >> 5] >> (i & 31)) & 1u) sc_mont_mul(acc, acc, am);
   }
-  return acc;
+  uint32_t one[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  sc r;
+  sc_mont_mul(r.v, acc, one);                    // out of Montgomery form: < 2 l
+  sc_cond_sub_l(r.v, 1);
+  return r;
 }
 
 }  // namespace act
