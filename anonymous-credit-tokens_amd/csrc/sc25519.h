@@ -143,54 +143,73 @@ ACT_HD sc sc_muladd(const sc& a, const sc& b, const sc& c) { return sc_add(sc_mu
 ACT_HD bool sc_equal(const sc& a, const sc& b) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i]; return d == 0; }
 ACT_HD bool sc_is_zero(const sc& a) { uint32_t d = 0; for (int i = 0; i < 8; i++) d |= a.v[i]; return d == 0; }
 // ---- Scalar::invert (src/lib.rs:645, 849, 992): a^(l-2), 0 -> 0 ----------------------------------------------------------------
-// 253 squarings + 73 multiplications.  Through sc_mul (schoolbook product, then the three-stage fold of sc_reduce512 with its
-// conditional subtractions) that was 0.5 - 0.6 ms of one wavefront -- a third of a single-item `issue` (profiles/r05_tiny_timing.txt)
-// and a fifth of k_sign_a.  Inside the exponentiation the operands stay in Montgomery form (R = 2^256): one CIOS pass per product,
-// 8 x (8 + 1 + 5) multiply-accumulates (l = 2^252 + c has three zero words), no subtraction until the end -- R = 16 l, so operands
-// below 2 l give results below 2 l: (a b + m l) / R < (4 l^2 + R l) / R < 2 l.
-ACT_HD void sc_mont_mul(uint32_t out[8], const uint32_t a[8], const uint32_t b[8]) {
-  constexpr uint32_t NPRIME = 0x12547e1bu;      // -l^-1 mod 2^32
-  uint32_t t[9];
+// 253 squarings + 73 multiplications.  Through sc_mul (schoolbook product on 32-bit words with a carry per step, then the three-stage
+// fold of sc_reduce512 with its conditional subtractions) that was 0.5 - 0.6 ms of one wavefront -- a third of a single-item
+// `issue` (profiles/r05_tiny_timing.txt) and a fifth of k_sign_a.  Inside the exponentiation the operands are kept the way the
+// field elements are (fe25519.h): ten limbs of 26 bits, so that a column of the product -- ten 52-bit terms, plus ten more from
+// the reduction -- is a plain 64-bit sum of v_mad_u64_u32 results with no carry anywhere, and in Montgomery form (R = 2^260): the
+// reduction is ten more passes of six multiply-accumulates (l = 2^252 + c has four zero limbs).  R > 2^7 l, so operands below
+// 2 l give results below 2 l and nothing is subtracted until the end.
+constexpr int SCM_LIMBS = 10;
+constexpr uint32_t SCM_MASK = (1u << 26) - 1u;
+ACT_HD uint32_t scm_l(int i) {
+  constexpr uint32_t Lm[SCM_LIMBS] = {0x0f5d3edu, 0x098c697u, 0x1cd6581u, 0x37a8bdeu, 0x014def9u, 0u, 0u, 0u, 0u, 0x0040000u};
+  return Lm[i];
+}
+// out = a b R^-1 mod l (lazily: < 2 l), limbs < 2^26
+ACT_HD void scm_mul(uint32_t out[SCM_LIMBS], const uint32_t a[SCM_LIMBS], const uint32_t b[SCM_LIMBS]) {
+  constexpr uint32_t NPRIME = 0x2547e1bu;        // -l^-1 mod 2^26
+  uint64_t col[2 * SCM_LIMBS];
 #pragma unroll
-  for (int i = 0; i < 9; i++) t[i] = 0u;
+  for (int k = 0; k < 2 * SCM_LIMBS; k++) col[k] = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t c = 0;
+  for (int i = 0; i < SCM_LIMBS; i++)
 #pragma unroll
-    for (int j = 0; j < 8; j++) { c += (uint64_t)a[j] * b[i] + t[j]; t[j] = (uint32_t)c; c >>= 32; }
-    t[8] += (uint32_t)c;                         // (t < 2^287 throughout: nine words)
-    const uint32_t m = t[0] * NPRIME;
-    c = ((uint64_t)m * sc_l_word(0) + t[0]) >> 32;                    // the low word becomes zero
+    for (int j = 0; j < SCM_LIMBS; j++) col[i + j] += (uint64_t)a[i] * b[j];
 #pragma unroll
-    for (int j = 1; j < 8; j++) {
-      c += t[j];
-      if (j < 4 || j == 7) c += (uint64_t)m * sc_l_word(j);           // words 4, 5, 6 of l are zero
-      t[j - 1] = (uint32_t)c; c >>= 32;
-    }
-    c += t[8];
-    t[7] = (uint32_t)c; t[8] = (uint32_t)(c >> 32);
+  for (int i = 0; i < SCM_LIMBS; i++) {
+    const uint32_t m = ((uint32_t)col[i] * NPRIME) & SCM_MASK;
+#pragma unroll
+    for (int j = 0; j < SCM_LIMBS; j++) if (j < 5 || j == 9) col[i + j] += (uint64_t)m * scm_l(j);      // limbs 5..8 of l are zero
+    col[i + 1] += col[i] >> 26;                  // the low 26 bits of col[i] are zero now
   }
 #pragma unroll
-  for (int i = 0; i < 8; i++) out[i] = t[i];     // < 2 l < 2^254: t[8] is zero
+  for (int k = SCM_LIMBS; k < 2 * SCM_LIMBS - 1; k++) { col[k + 1] += col[k] >> 26; out[k - SCM_LIMBS] = (uint32_t)col[k] & SCM_MASK; }
+  out[SCM_LIMBS - 1] = (uint32_t)col[2 * SCM_LIMBS - 1];       // value < 2 l < 2^254: fits its 26 bits
 }
 ACT_HD sc sc_invert(const sc& a) {
-  constexpr uint32_t R2[8] = {0x449c0f01u, 0xa40611e3u, 0x68859347u, 0xd00e1ba7u, 0x17f5be65u, 0xceec73d2u, 0x7c309a3du, 0x0399411bu};      // R^2 mod l
-  constexpr uint32_t R1[8] = {0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu};      // R mod l
+  constexpr uint32_t R2[SCM_LIMBS] = {0x152d13bu, 0x274997au, 0x1bea69fu, 0x358f1c5u, 0x3687604u, 0x16f9972u, 0x33d217fu, 0x0f73bb1u, 0x37c309au, 0x0025046u};      // R^2 mod l
+  constexpr uint32_t R1[SCM_LIMBS] = {0x321e6edu, 0x3d22f59u, 0x067e45au, 0x0eead6bu, 0x335e51bu, 0x3fffffau, 0x3ffffffu, 0x3ffffffu, 0x3ffffffu, 0x003ffffu};      // R mod l
   uint32_t e[8];                                 // l - 2
 #pragma unroll
   for (int i = 0; i < 8; i++) e[i] = sc_l_word(i);
   e[0] -= 2u;
-  uint32_t am[8], acc[8], r2[8];
+  uint32_t al[SCM_LIMBS], am[SCM_LIMBS], acc[SCM_LIMBS], r2[SCM_LIMBS];
 #pragma unroll
-  for (int i = 0; i < 8; i++) { r2[i] = R2[i]; acc[i] = R1[i]; }
-  sc_mont_mul(am, a.v, r2);                      // a R
-  for (int i = 252; i >= 0; i--) {
-    sc_mont_mul(acc, acc, acc);
-    if ((e[i >> 5] >> (i & 31)) & 1u) sc_mont_mul(acc, acc, am);
+  for (int i = 0; i < SCM_LIMBS; i++) {          // 8 x 32 bits -> 10 x 26 bits
+    const int bit = 26 * i, w = bit >> 5, sh = bit & 31;
+    uint32_t v = a.v[w] >> sh;
+    if (sh > 6 && w + 1 < 8) v |= a.v[w + 1] << (32 - sh);
+    al[i] = v & SCM_MASK;
+    r2[i] = R2[i]; acc[i] = R1[i];
   }
-  uint32_t one[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  scm_mul(am, al, r2);                           // a R
+  for (int i = 252; i >= 0; i--) {
+    scm_mul(acc, acc, acc);
+    if ((e[i >> 5] >> (i & 31)) & 1u) scm_mul(acc, acc, am);
+  }
+  uint32_t one[SCM_LIMBS] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+  uint32_t o[SCM_LIMBS];
+  scm_mul(o, acc, one);                          // out of Montgomery form: < 2 l
   sc r;
-  sc_mont_mul(r.v, acc, one);                    // out of Montgomery form: < 2 l
+#pragma unroll
+  for (int w = 0; w < 8; w++) {                  // 10 x 26 bits -> 8 x 32 bits
+    const int bit = 32 * w, i = bit / 26, sh = bit % 26;
+    uint32_t v = o[i] >> sh;
+    if (i + 1 < SCM_LIMBS) v |= o[i + 1] << (26 - sh);
+    if (sh > 20 && i + 2 < SCM_LIMBS) v |= o[i + 2] << (52 - sh);
+    r.v[w] = v;
+  }
   sc_cond_sub_l(r.v, 1);
   return r;
 }

@@ -161,6 +161,15 @@ int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
  * Threads with a context each may make such calls at the same time; two of them run on a device at once, the others wait their
  * turn inside the call (more active streams than that and the driver time-slices the process's queues: INTEGRATION.md). */
 int act_ctx_set_small_batch_max(act_ctx *ctx, size_t n);
+/* Tiny calls -- at most 64 lanes, the crate's own one-item call shape (src/lib.rs:463, 528, 621, 781, 1217).  Their answer time is a
+ * dependent chain plus fixed cost, so act_request_batch, act_issue_batch (ACT_RNG_PER_LANE, or one lane), the signing half of every
+ * issue / refund call and the two to_credit_token calls run such a call as ONE kernel: the independent pieces of the method on
+ * separate workgroups (a signature's two variable-base products cut into quarters), the block that arrives last assembling the
+ * transcript, hashing it -- these transcripts are a single BLAKE3 chunk; the routine is the one ACT_TRANSCRIPT_DEVICE runs, so the
+ * bytes are those of either transcript mode -- and finishing the record; inputs cross PCIe in one copy from a pinned buffer, which
+ * the kernel zeroes itself.  One item, MI355X: request 0.28 ms (was 0.58), issue 1.2 (2.7), PreIssuance::to_credit_token 1.2 (2.3),
+ * PreRefund::to_credit_token 1.6 (3.0), refund 3.3 (3.7), prove_spend 2.5 (3.2): profiles/r05_single_item_latency.txt.
+ * ACT_NO_FUSED_TINY=1 in the environment keeps the multi-launch paths (same bytes; tests/test_gpu_tiny.py compares). */
 /* Several threads, ONE context, one proof per call -- what a server built on the crate's single-item API does with the context the
  * Rust binding keeps inside `Params`.  Such callers queue on the context (a call is ~1.7 ms whatever its size: ~600 calls/s between
  * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch, act_refund_batch, act_refund_sign_batch, act_issue_check_batch and
