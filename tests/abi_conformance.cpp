@@ -7,6 +7,7 @@
 //
 //   g++ -std=c++17 -Iinclude tests/abi_conformance.cpp -o conf -Lanonymous-credit-tokens_amd -lact_mi355x ...
 //   ./conf fixture.bin
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -104,6 +105,51 @@ int main(int argc, char** argv) {
   rc = act_node_refund_batch(node, n, sk.data(), proof_in.data(), refund_rng.data(), ACT_RNG_SEQUENTIAL, o_rf.data(), st.data());
   if (rc) { fprintf(stderr, "act_node_refund_batch -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
   expect("act_node_refund_batch (sequential rng)", o_rf, seq_refund);
+  // wire bytes in, wire bytes out: the proofs as SpendProof::to_cbor would send them, the refunds as
+  // Refund::to_cbor frames them -- sequential bytes, then the generator itself as a draw callback (what rust/src/mi355x.rs passes)
+  {
+    const size_t ml = act_cbor_size(ctx, ACT_CBOR_SPEND_PROOF), rl = act_cbor_size(ctx, ACT_CBOR_REFUND);
+    if (rl != 141) { fprintf(stderr, "Refund message size %zu\n", rl); return 4; }
+    bytes msgs(n * ml);
+    CK(act_cbor_encode_batch(ctx, ACT_CBOR_SPEND_PROOF, n, ACT_MEM_HOST, proof_in.data(), msgs.data()));
+    bytes want(n * rl, 0);
+    for (size_t i = 0; i < n; i++) {
+      if (status[i]) continue;
+      uint8_t* m = want.data() + i * rl;
+      *m++ = 0xa4;
+      for (int f = 0; f < 4; f++) { *m++ = (uint8_t)(f + 1); *m++ = 0x58; *m++ = 0x20; memcpy(m, seq_refund.data() + i * 128 + 32 * f, 32); m += 32; }
+    }
+    bytes o_msgs(n * rl, 7);
+    rc = act_node_refund_cbor_batch(node, n, sk.data(), msgs.data(), nullptr, refund_rng.data(), ACT_RNG_SEQUENTIAL, o_msgs.data(), st.data());
+    if (rc) { fprintf(stderr, "act_node_refund_cbor_batch -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
+    expect("act_node_refund_cbor_batch (sequential rng)", o_msgs, want); expect("  status", st, status);
+    struct Gen { const bytes* stream; size_t pos; int draws; } gen{&refund_rng, 0, 0};
+    act_rng_source src{[](void* g_, uint8_t* dst, size_t len) { Gen* g = static_cast<Gen*>(g_); memcpy(dst, g->stream->data() + g->pos, len); g->pos += len; g->draws++; }, &gen};
+    std::fill(o_msgs.begin(), o_msgs.end(), 7);
+    rc = act_node_refund_cbor_batch(node, n, sk.data(), msgs.data(), nullptr, reinterpret_cast<const uint8_t*>(&src), ACT_RNG_CALLBACK, o_msgs.data(), st.data());
+    if (rc) { fprintf(stderr, "act_node_refund_cbor_batch (callback) -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
+    expect("act_node_refund_cbor_batch (generator callback)", o_msgs, want);
+    size_t accepted = 0; for (size_t i = 0; i < n; i++) accepted += status[i] == 0;
+    if (gen.draws != 1 || gen.pos != 128 * accepted) { fprintf(stderr, "callback drew %zu bytes in %d calls, want %zu in 1\n", gen.pos, gen.draws, 128 * accepted); g_fail++; }
+    else printf("ok  the generator was asked once, for 128 bytes per accepted message (%zu)\n", gen.pos);
+    // the redemption step on wire bytes: every accepted nullifier is fresh the first time, spent the second
+    act_node_nullifier_set* nset = nullptr;
+    const int ndev[2] = {0, 0};
+    rc = act_node_nullifier_set_create(ndev, 2, 1024, nullptr, &nset);
+    if (rc) { fprintf(stderr, "act_node_nullifier_set_create -> %d\n", rc); return 3; }
+    gen = Gen{&refund_rng, 0, 0};
+    rc = act_node_redeem_cbor_batch(node, nset, n, sk.data(), msgs.data(), nullptr, reinterpret_cast<const uint8_t*>(&src), ACT_RNG_CALLBACK, o_msgs.data(), st.data());
+    if (rc) { fprintf(stderr, "act_node_redeem_cbor_batch -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
+    expect("act_node_redeem_cbor_batch (first submission)", o_msgs, want); expect("  status", st, status);
+    if (act_node_nullifier_set_len(nset) != accepted) { fprintf(stderr, "nullifier set holds %zu, want %zu\n", act_node_nullifier_set_len(nset), accepted); g_fail++; }
+    gen = Gen{&refund_rng, 0, 0};
+    rc = act_node_redeem_cbor_batch(node, nset, n, sk.data(), msgs.data(), nullptr, reinterpret_cast<const uint8_t*>(&src), ACT_RNG_CALLBACK, o_msgs.data(), st.data());
+    bytes spent = status; for (size_t i = 0; i < n; i++) if (!spent[i]) spent[i] = ACT_STATUS_DOUBLE_SPEND;
+    if (rc) { fprintf(stderr, "act_node_redeem_cbor_batch (second) -> %d\n", rc); return 3; }
+    expect("act_node_redeem_cbor_batch (second submission: double spends)", st, spent); expect("  no refunds", o_msgs, bytes(n * rl, 0));
+    if (gen.pos != 0) { fprintf(stderr, "a rejected batch drew %zu bytes\n", gen.pos); g_fail++; }
+    act_node_nullifier_set_destroy(nset);
+  }
   act_node_destroy(node);
 
   // failure path from C: a context is returned for its error text and must be destroyed by the caller
