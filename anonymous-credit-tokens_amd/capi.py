@@ -35,7 +35,7 @@ EXPORTS = [
     "act_node_nullifier_check_and_insert_batch",
     "act_verify_spend_cbor_keys_batch", "act_node_verify_spend_cbor_keys_batch", "act_refund_sign_cbor_batch", "act_refund_cbor_batch",
     "act_node_refund_sign_cbor_batch", "act_node_refund_cbor_batch", "act_redeem_cbor_batch", "act_node_redeem_cbor_batch",
-    "act_ctx_host_hash_stats", "act_node_set_balance", "act_node_device_stats", "act_node_balance_state", "act_debug_set_slowdown", "act_debug_fail_next_signs",
+    "act_ctx_host_hash_stats", "act_ctx_set_tiny_calls", "act_node_set_balance", "act_node_device_stats", "act_node_balance_state", "act_debug_set_slowdown", "act_debug_fail_next_signs",
 ]
 CBOR_TYPES = {"IssuanceRequest": 1, "IssuanceResponse": 2, "SpendProof": 3, "Refund": 4, "PrivateKey": 5, "PublicKey": 6,
               "PreIssuance": 7, "CreditToken": 8, "PreRefund": 9}
@@ -179,6 +179,7 @@ def load() -> C.CDLL:
     lib.act_redeem_cbor_batch.argtypes = [vp, vp, sz, i32, u8p, u8p, vp, u8p, i32, u8p, u8p]
     lib.act_node_redeem_cbor_batch.argtypes = [vp, vp, sz, u8p, u8p, vp, u8p, i32, u8p, u8p]
     lib.act_ctx_host_hash_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), i32]
+    lib.act_ctx_set_tiny_calls.argtypes = [vp, i32]
     lib.act_node_set_balance.argtypes = [vp, i32, i32]
     lib.act_node_device_stats.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     lib.act_node_balance_state.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -529,6 +530,10 @@ class Engine:
         w, hs, b = C.c_double(0), C.c_double(0), C.c_uint64(0)
         self._ck(self.lib.act_ctx_host_hash_stats(self.ctx, C.byref(w), C.byref(hs), C.byref(b), 1 if reset else 0))
         return {"wait_s": w.value, "hash_s": hs.value, "bytes": b.value}
+
+    def set_tiny_calls(self, on: bool):
+        """calls of at most 64 lanes as one kernel with the transcript hashed in it (default) or the multi-launch paths"""
+        self._ck(self.lib.act_ctx_set_tiny_calls(self.ctx, 1 if on else 0))
 
     def set_slowdown(self, ns_per_lane: int):
         self._ck(self.lib.act_debug_set_slowdown(self.ctx, ns_per_lane))

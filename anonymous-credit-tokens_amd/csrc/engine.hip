@@ -72,6 +72,15 @@ struct Slot {
   size_t last_spend_lanes = 0;
 };
 
+// The context's last error text, under a lock of ITS OWN: act_last_error() must not wait behind a batch call that holds the context
+// for seconds, and a failing call on one thread must not tear the string another thread is copying.
+struct ErrText {
+  mutable std::mutex m; std::string s;
+  ErrText& operator=(const std::string& v) { std::lock_guard<std::mutex> lk(m); s = v; return *this; }
+  ErrText& operator=(const char* v) { std::lock_guard<std::mutex> lk(m); s = v; return *this; }
+  std::string get() const { std::lock_guard<std::mutex> lk(m); return s; }
+  operator std::string() const { return get(); }
+};
 struct CoReq;       // a small call waiting to be merged with others (defined with the entry points that merge)
 struct act_ctx {
   int device = 0, L = 128;
@@ -82,7 +91,7 @@ struct act_ctx {
   int depth = 2;                       // chunks in flight (act_ctx_set_pipeline_depth): 2 = both slots, 1 = strictly one after the other
   int host_threads = 0;
   int streams_overlap = -1;            // 1 = the two slots' streams run side by side (measured at creation), 0 = they share a hardware queue
-  std::string err;
+  ErrText err;
   Slot slots[2];
   std::mutex mu;                       // every batch entry point holds it: calls on one context are serialised, whatever thread they come from
   uint32_t* d_tables[4] = {nullptr, nullptr, nullptr, nullptr};     // shared with the other contexts of this device (table cache below)
@@ -117,6 +126,7 @@ struct act_ctx {
   size_t h_co_cap = 0;                 // lanes
   // tiny calls (at most TINY_MAX lanes: the crate's one-item call shape): one pinned + one device buffer, one copy each way, one kernel
   uint8_t *d_tiny = nullptr, *h_tiny = nullptr;
+  std::atomic<bool> tiny_on{true};     // act_ctx_set_tiny_calls
   uint32_t* d_group_ctr = nullptr;     // one word per group of 64 lanes (k_sign_fused ...: which role block arrives last), zero between launches
   uint8_t* d_tiny_tr = nullptr;        // TINY_MAX "request" transcripts of the fused issue kernel
   std::atomic<uint32_t> debug_ns_per_lane{0};    // act_debug_set_slowdown (test hook of the node dispatcher's load balance)
@@ -509,6 +519,8 @@ struct Call {
     if (finished) return;
     const std::string first = c->err;
     (void)hipSetDevice(c->device);
+    // a call that failed half way may have left a role-block kernel's arrival counters mid-count: the next launch must find zeros
+    if (c->d_group_ctr) { for (Slot& sl : c->slots) if (sl.stream) (void)hipStreamSynchronize(sl.stream); (void)hipMemset(c->d_group_ctr, 0, GROUP_CTR_WORDS * 4); (void)hipDeviceSynchronize(); }
     (void)finish_call(c, n);
     if (!first.empty()) c->err = first;
   }
@@ -558,9 +570,9 @@ int prepare_rng_slots(act_ctx* c, Slot& sl, uint32_t m, size_t off, int mem, con
 // counters of the role-block kernels (which block of a group arrives last): a set per slot, because the two slots' launches overlap
 uint32_t* group_counters(act_ctx* c, const Slot& sl) { return c->d_group_ctr + (size_t)(&sl - c->slots) * (GROUP_CTR_WORDS / 2); }
 // (tiny calls: see request_tiny further down)  ACT_NO_FUSED_TINY=1 keeps the multi-launch paths (A/B; the tests compare the two)
-bool tiny_enabled() { static const bool off = getenv("ACT_NO_FUSED_TINY") != nullptr; return !off; }
+bool tiny_enabled(const act_ctx* c) { static const bool off = getenv("ACT_NO_FUSED_TINY") != nullptr; return !off && c->tiny_on.load(); }
 int sign_phase(act_ctx* c, Slot& sl, uint32_t m, int label, const uint8_t* d_rng, const uint8_t* d_camount, uint8_t* d_out) {
-  if (m <= TINY_MAX && tiny_enabled()) {
+  if (m <= TINY_MAX && tiny_enabled(c)) {
     // tiny calls: phase A, the transcript's BLAKE3 (one chunk, in the kernel: same bytes as either transcript mode) and phase B in
     // ONE launch, the five transcript points on three wavefronts (k_sign.hip k_sign_fused); nothing secret reaches global memory
     SignFusedArgs f{}; f.P = c->P; f.K = c->key; f.n = m; f.label = label; f.xa = sl.d_xa; f.rng_slot = sl.d_slot; f.c_amount = d_camount;
@@ -779,6 +791,7 @@ int act_build_has_ct_secret_tables(void) {
 #endif
 }
 int act_ctx_set_small_batch_max(act_ctx* c, size_t n) { if (!c) return ACT_ERR_ARG; c->small_max.store(n); return ACT_OK; }
+int act_ctx_set_tiny_calls(act_ctx* c, int on) { if (!c) return ACT_ERR_ARG; c->tiny_on.store(on != 0); return ACT_OK; }
 int act_debug_set_slowdown(act_ctx* c, uint32_t ns_per_lane) { if (!c) return ACT_ERR_ARG; c->debug_ns_per_lane.store(ns_per_lane); return ACT_OK; }
 int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
 int act_ctx_set_host_threads(act_ctx* c, int n) { if (!c || n < 0) return ACT_ERR_ARG; c->host_threads = n; return ACT_OK; }
@@ -791,12 +804,12 @@ int act_ctx_host_hash_stats(act_ctx* c, double* wait_s, double* hash_s, uint64_t
   if (reset) { c->host_wait_s = c->host_hash_s = 0; c->host_hash_bytes = 0; }
   return ACT_OK;
 }
-// copied under the context's lock into a buffer of the calling thread (another thread's failing call may rewrite c->err at any
-// moment); valid until this thread's next act_last_error call
+// copied (under the text's own lock, not the context's: a running batch call does not delay it) into a buffer of the calling thread --
+// another thread's failing call may rewrite c->err at any moment; valid until this thread's next act_last_error call
 const char* act_last_error(const act_ctx* c) {
   if (!c) return "null context";
   thread_local std::string mine;
-  { std::lock_guard<std::mutex> lk(const_cast<act_ctx*>(c)->mu); mine = c->err; }
+  mine = c->err.get();
   return mine.c_str();
 }
 size_t act_spend_proof_bytes(const act_ctx* c) { return ProofLayout{c->L}.bytes(); }
@@ -874,7 +887,7 @@ int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const u
   if (!c || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
   Call call(c, 0);
   HIPCK(c, hipSetDevice(c->device));
-  if (n && n <= TINY_MAX && tiny_enabled()) { int rc = request_tiny(c, n, mem, pre, rng, out_req); return rc ? rc : call.finish(); }
+  if (n && n <= TINY_MAX && tiny_enabled(c)) { int rc = request_tiny(c, n, mem, pre, rng, out_req); return rc ? rc : call.finish(); }
   Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
@@ -932,7 +945,7 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
   Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
-  if (n && n <= TINY_MAX && n <= c->max_batch && (rng_mode == ACT_RNG_PER_LANE || n == 1) && tiny_enabled()) {
+  if (n && n <= TINY_MAX && n <= c->max_batch && (rng_mode == ACT_RNG_PER_LANE || n == 1) && tiny_enabled(c)) {
     rc = issue_tiny(c, n, mem, req, camt, rng, out_resp, status);
     return rc ? rc : call.finish();
   }
@@ -1551,7 +1564,7 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
       if ((rc = prof_launch(c, sl, PK_CLIENT, (uint64_t)m * c->L, [&] { launch_client_decode_com(a, sl.stream); }))) return rc;
     }
     a.group_counter = group_counters(c, sl);
-    a.fused = (m <= TINY_MAX && tiny_enabled()) ? 1 : 0;          // tiny calls: phase A, the hash and phase B in one launch (k_client.hip)
+    a.fused = (m <= TINY_MAX && tiny_enabled(c)) ? 1 : 0;          // tiny calls: phase A, the hash and phase B in one launch (k_client.hip)
     if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_a(a, sl.stream); }))) return rc;
     if (!a.fused) {
       uint32_t len = c->P.prefix_len[label] + 40u * (issuance ? 7u : 6u);

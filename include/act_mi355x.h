@@ -169,7 +169,10 @@ int act_ctx_set_small_batch_max(act_ctx *ctx, size_t n);
  * bytes are those of either transcript mode -- and finishing the record; inputs cross PCIe in one copy from a pinned buffer, which
  * the kernel zeroes itself.  One item, MI355X: request 0.28 ms (was 0.58), issue 1.2 (2.7), PreIssuance::to_credit_token 1.2 (2.3),
  * PreRefund::to_credit_token 1.6 (3.0), refund 3.3 (3.7), prove_spend 2.5 (3.2): profiles/r05_single_item_latency.txt.
- * ACT_NO_FUSED_TINY=1 in the environment keeps the multi-launch paths (same bytes; tests/test_gpu_tiny.py compares). */
+ * act_ctx_set_tiny_calls(ctx, 0) (or ACT_NO_FUSED_TINY=1 in the environment) keeps the multi-launch paths, whose transcripts follow
+ * the context's transcript mode -- a deployment that wants every hash on the host, whatever the call size (same bytes either way;
+ * tests/test_gpu_tiny.py compares). */
+int act_ctx_set_tiny_calls(act_ctx *ctx, int on);           /* default 1 */
 /* Several threads, ONE context, one proof per call -- what a server built on the crate's single-item API does with the context the
  * Rust binding keeps inside `Params`.  Such callers queue on the context (a call is ~1.7 ms whatever its size: ~600 calls/s between
  * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch, act_refund_batch, act_refund_sign_batch, act_issue_check_batch and

@@ -24,6 +24,12 @@ def test_tiny_calls_equal_the_oracle_and_the_multi_launch_path(engine_factory, o
     assert req_big == octx.request_batch(pre, rq, 4)
     for n in (1, 2, 63, 64, 65):
         assert eng.request(pre[:64 * n], rq[:128 * n]) == req_big[:128 * n], n
+    eng.set_tiny_calls(False)                                  # the multi-launch path at the same sizes: same bytes
+    try:
+        for n in (1, 5, 64):
+            assert eng.request(pre[:64 * n], rq[:128 * n]) == req_big[:128 * n], n
+    finally:
+        eng.set_tiny_calls(True)
     # device memory
     d = lambda b: torch.from_numpy(np.frombuffer(b, np.uint8).copy()).cuda()
     d_pre, d_rq = d(pre[:64 * 5]), d(rq[:128 * 5]); d_out = torch.zeros(128 * 5, dtype=torch.uint8, device="cuda")
