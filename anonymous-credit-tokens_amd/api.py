@@ -96,6 +96,36 @@ class ByteStreamRng:
         self.pos += n
 
 
+def _wire_error(status: int):
+    """lane status of a wire-level call -> the error the crate's two calls would have produced"""
+    return CborError({254: 1, 253: 2, 255: 3}[status]) if status in (253, 254, 255) else Error(status)
+
+
+def _draw_signed(rng, n_lanes: int, run):
+    """The wire-level calls take the generator itself (ACT_RNG_CALLBACK): the library draws 128 bytes per lane it SIGNS, once, after
+    every verdict is known.  `rng.fill_bytes(k)` is called with exactly that many bytes."""
+    import ctypes as C
+
+    def draw(_ctx, dst, n):
+        if n:
+            C.memmove(dst, rng.fill_bytes(n), n)
+    cb = capi.RNG_DRAW_FN(draw)
+    src = capi.RngSource(cb, None)
+    holder = type("Src", (), {"ptr": C.addressof(src), "keep": (cb, src)})()
+    return run(_CallbackRng(holder), capi.RNG_CALLBACK)
+
+
+class _CallbackRng(capi.ReplayRng):
+    """adapter: a capi.ReplayRng-shaped object (what capi._rng_arg accepts) around an arbitrary act_rng_source"""
+
+    def __init__(self, holder):
+        self._holder = holder
+
+    @property
+    def ptr(self):
+        return self._holder.ptr
+
+
 def scalar(v) -> bytes:
     """Scalar::from(u128) / canonical 32-byte little-endian scalar."""
     if isinstance(v, (bytes, bytearray)):
@@ -205,6 +235,22 @@ class PrivateKey(_Cbor):
         pb = b"".join(p.record for p in proofs)
         st, out = _draw_accepting(rng, len(proofs), lambda rb, mode: e.redeem(db.set, self.record, pb, rb, mode))
         return [Refund(out[128 * i:128 * i + 128]) if st[i] == 0 else Error(st[i]) for i in range(len(proofs))]
+
+    # ---- wire bytes in, wire bytes out (rust/src/mi355x.rs refund_cbor_batch / redeem_cbor_batch) ----------
+    def refund_cbor_batch(self, params: Params, msgs: Sequence[bytes], rng, nbits: int = L) -> list:
+        """`[SpendProof::from_cbor(m).and_then(|p| self.refund(params, &p, rng)).map(to_cbor) for m in msgs]` as one call: entry i is
+        the CBOR Refund message, a CborError (from_cbor's) or an Error (refund's); `rng` is drawn for the accepted messages only, in
+        message order, after all verdicts (src/lib.rs:842-852)."""
+        e = params.engine(nbits)
+        st, out = _draw_signed(rng, len(msgs), lambda src, mode: e.refund_cbor(self.record, list(msgs), src, mode))
+        return [out[i] if st[i] == 0 else _wire_error(st[i]) for i in range(len(msgs))]
+
+    def redeem_cbor_batch(self, params: Params, db: "NullifierDb", msgs: Sequence[bytes], rng, nbits: int = L) -> list:
+        """The server loop of examples/act.rs:62-73 on wire bytes: from_cbor, refund's checks, the nullifier store (DoubleSpendError),
+        the signature, to_cbor."""
+        e = params.engine(nbits)
+        st, out = _draw_signed(rng, len(msgs), lambda src, mode: e.redeem_cbor(db.set, self.record, list(msgs), src, mode))
+        return [out[i] if st[i] == 0 else _wire_error(st[i]) for i in range(len(msgs))]
 
     def verify_spend_batch(self, params: Params, proofs: Sequence["SpendProof"]) -> bytes:
         nbits = proofs[0].nbits if proofs else L

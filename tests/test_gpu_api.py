@@ -197,6 +197,37 @@ def test_redeem_batch_and_nullifier_db(env):              # examples/act.rs:62-7
     assert db.spend(fresh.nullifier()) is True and db.spend(fresh.nullifier()) is False and len(db) == 5
 
 
+def test_wire_level_api(env):                             # rust/src/mi355x.rs refund_cbor_batch / redeem_cbor_batch; examples/act.rs:62-73
+    """Bytes in, bytes out: the messages a client sends (`SpendProof::to_cbor`), the messages it gets back (`Refund::to_cbor`), the
+    crate's two error families per lane, and a generator that is drawn for signed lanes only."""
+    api, params, rng, sk = env
+    toks = [issue_token(api, params, rng, sk, 30) for _ in range(5)]
+    spends = [t.prove_spend(params, 4 + i, rng) for i, t in enumerate(toks)]
+    msgs = [p.to_cbor(params) for p, _ in spends]
+    bad = bytearray(msgs[1]); bad[40] ^= 1                          # the charge: parses, InvalidClientSpendProof
+    wire = [msgs[0], bytes(bad), msgs[2][:200], b"\x80", msgs[3], msgs[0], msgs[4]]
+    stream = api.ByteStreamRng(os.urandom(128 * len(wire)))
+    res = sk.refund_cbor_batch(params, wire, stream)
+    kinds = [type(r).__name__ if not isinstance(r, bytes) else "bytes" for r in res]
+    assert kinds == ["bytes", "Error", "CborError", "CborError", "bytes", "bytes", "bytes"], kinds
+    assert res[1].name == "InvalidClientSpendProof" and res[2].name == "Ciborium" and res[3].name == "InvalidStructure"
+    assert stream.pos == 128 * 4                                    # drawn for the four signed messages only
+    assert len(res[0]) == 141 and res[0] != res[5]                  # the same proof signed twice: two different nonces
+    # what came back is what the struct-level call gives for the same bytes of the generator
+    again = api.ByteStreamRng(stream.data)
+    want = sk.refund_batch(params, [spends[0][0], api.SpendProof.from_cbor(bytes(bad), params), spends[3][0], spends[0][0], spends[4][0]], again)
+    assert [r.to_cbor(params) for r in want if isinstance(r, api.Refund)] == [res[0], res[4], res[5], res[6]]
+    # the client accepts the refund it unpacks from the wire
+    new = spends[4][1].to_credit_token(params, spends[4][0], api.Refund.from_cbor(res[6], params), sk.public())
+    assert api.scalar_to_u128(new.credits()) == 30 - 8
+    # redeem on wire bytes: the repeat of message 0 is now a double spend
+    db = api.NullifierDb(1 << 10)
+    stream = api.ByteStreamRng(os.urandom(128 * len(wire)))
+    red = sk.redeem_cbor_batch(params, db, wire, stream)
+    assert [isinstance(r, bytes) for r in red] == [True, False, False, False, True, False, True]
+    assert red[5].name == "DoubleSpendError" and len(db) == 3 and stream.pos == 128 * 3
+
+
 def test_roofline_probes_run(engine_factory, bench_params):
     """The library's three roofline probes (bench.py: the MAD issue rate; the random 128-byte read rate on a fresh allocation and on a
     context's own table) return sane numbers."""
