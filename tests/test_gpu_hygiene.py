@@ -20,6 +20,9 @@ def test_no_secret_residue_after_any_call(bench_params, mode):
     req = eng.request(pre, shake("hy-rq", 128 * N)); assert eng.secret_residue() == 0
     st, resp = eng.issue(sk, req, scb(40) * N, shake("hy-ir", 128 * N), capi.RNG_SEQUENTIAL); assert eng.secret_residue() == 0
     assert st == bytes(N)
+    # tiny calls (at most 64 lanes): one kernel, inputs staged through the context's pinned + device buffers, which the kernel zeroes itself
+    st1, resp1 = eng.issue(sk, req, scb(40) * N, shake("hy-ir", 128 * N), capi.RNG_PER_LANE); assert st1 == bytes(N) and resp1 == resp and eng.secret_residue() == 0
+    st1, resp1 = eng.issue(sk, req[:128], scb(40), shake("hy-ir", 128), capi.RNG_SEQUENTIAL); assert resp1 == resp[:160] and eng.secret_residue() == 0
     st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp); assert eng.secret_residue() == 0
     st, proofs, prer = eng.prove_spend(tok, scb(7) * N, shake("hy-pr", eng.prove_rng_bytes * N)); assert eng.secret_residue() == 0
     assert st == bytes(N)
