@@ -987,10 +987,33 @@ struct CoReq {
 };
 static int spend_coalesced(act_ctx* c, CoReq& r);
 
+static int tiny_buffers(act_ctx* c);
+static void wipe_host(uint8_t* p, size_t n);
 static int issue_check_impl(act_ctx* c, size_t n, int mem, const uint8_t* req, uint8_t* status) {
   Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc; size_t chunk = 0;
+  if (n && n <= TINY_MAX && n <= c->max_batch && tiny_enabled(c)) {
+    // the PoK check of a tiny call as ONE kernel (k_sign_fused's check role on its own): K1, the 266-byte transcript, its BLAKE3, the verdict
+    Slot& sl = c->slots[0];
+    SignFusedArgs f{}; f.P = c->P; f.n = (uint32_t)n; f.label = LABEL_RESPOND; f.point_stride = 128; f.check_only = 1;
+    f.pbk = sl.d_buckets; f.trs = sl.d_trs; f.trs_req = c->d_tiny_tr; f.group_counter = group_counters(c, sl);
+    if (mem == ACT_MEM_DEVICE) { f.point = req; f.status = status; }
+    else {
+      if ((rc = tiny_buffers(c))) return rc;
+      memcpy(c->h_tiny, req, 128 * n);
+      HIPCK(c, hipMemcpyAsync(c->d_tiny, c->h_tiny, 128 * n, hipMemcpyHostToDevice, sl.stream));
+      f.point = c->d_tiny; f.status = c->d_tiny + TINY_OUT; f.wipe_rng = 1;
+    }
+    if ((rc = prof_launch(c, sl, PK_ISSUE_A, n, [&] { launch_sign_fused(f, true, sl.stream); }))) return rc;
+    if (mem == ACT_MEM_HOST) {
+      HIPCK(c, hipMemcpyAsync(c->h_tiny + TINY_OUT, c->d_tiny + TINY_OUT, n, hipMemcpyDeviceToHost, sl.stream));
+      HIPCK(c, hipStreamSynchronize(sl.stream));
+      memcpy(status, c->h_tiny + TINY_OUT, n);
+      wipe_host(c->h_tiny, 128 * n);
+    }
+    return call.finish();
+  }
   for (size_t off = 0; off < n; off += c->max_batch, chunk++) {
     Slot& sl = c->slots[chunk % c->depth];
     if (chunk >= (size_t)c->depth) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }

@@ -294,7 +294,9 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
       uint32_t w[16];
       b3_hash_xof64(w, reinterpret_cast<const uint32_t*>(t1), a.P.prefix_len[LABEL_REQUEST] + 80u);
       a.status[p] = !ok ? (uint8_t)255 : sc_equal(sc_from_wide_words(w), gamma) ? (uint8_t)0 : (uint8_t)1;      // Error::InvalidIssuanceRequestProof (:638-640)
+      if (a.check_only && a.wipe_rng) { uint8_t* q = const_cast<uint8_t*>(rec); for (uint32_t i = 0; i < a.point_stride; i += 32) zero8(q + i); }
     }
+    if (a.check_only) return;                                  // act_issue_check_batch on a tiny call: this role is the whole launch
   } else if (role == R_M) {
     IssuerFb fb{a.P};                                          // the whole wavefront multiplies: lanes that do not sign by zero
     const ge xg = ge_add(fb.mul(ge_identity(), BASE_G, e), a.K.w);   // X_g = e g + w (:646 / :851)
@@ -358,6 +360,7 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
 }
 void launch_sign_fused(const SignFusedArgs& a, bool check, hipStream_t s) {
   if (!a.n) return;
+  if (check && a.check_only) { hipLaunchKernelGGL(k_sign_fused<true>, dim3((a.n + 63) / 64, 1), dim3(64), 0, s, a); return; }
   if (check) hipLaunchKernelGGL(k_sign_fused<true>, dim3((a.n + 63) / 64, 10), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_sign_fused<false>, dim3((a.n + 63) / 64, 9), dim3(64), 0, s, a);
 }

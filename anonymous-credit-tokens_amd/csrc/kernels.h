@@ -134,6 +134,7 @@ struct SignFusedArgs {
   uint8_t* trs;                                    // n * SMALL_TR_STRIDE: the "respond" / "refund" transcripts the roles assemble
   uint8_t* trs_req;                                // CHECK: n * SMALL_TR_STRIDE "request" transcripts
   uint32_t* group_counter;                         // one word per group of 64 lanes, zero between launches: which block arrives last
+  int check_only;                                  // CHECK: only the check role runs (act_issue_check_batch): status out, no signature
   int wipe_rng;                                    // rng is the engine's staged copy: zero it when done
   unsigned long long* dbg;                         // -DACT_TINY_TIMING builds only: 8 time stamps per role
 };

@@ -62,7 +62,11 @@ def test_tiny_calls_equal_the_oracle_and_the_multi_launch_path(engine_factory, o
         assert {0, 1, 255} <= set(big[0])
     # the halves: check, then sign with exactly the accepted lanes' bytes
     for n in (1, 9, 64):
-        st = capi_issue_check(eng, bad[:128 * n])
+        st = capi_issue_check(eng, bad[:128 * n])                # (one kernel: k_sign_fused's check role on its own)
+        assert st == big[0][:n]
+        d_rq2 = d(bad[:128 * n]); d_st = torch.full((n,), 9, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        eng._ck(eng.lib.act_issue_check_batch(eng.ctx, n, capi.MEM_DEVICE, d_rq2.data_ptr(), d_st.data_ptr()))
+        assert d_st.cpu().numpy().tobytes() == st and d_rq2.cpu().numpy().tobytes() == bad[:128 * n]
         acc = sum(1 for v in st if v == 0)
         got = capi_issue_sign(eng, sk, bad[:128 * n], cam[:32 * n], st, irng[:128 * acc])
         assert got == eng.issue(sk, bad[:128 * n], cam[:32 * n], irng, capi.RNG_SEQUENTIAL)
