@@ -189,6 +189,22 @@ int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
   sl.d_stage_cap[slot] = bytes; sl.d_stage_dirty[slot] = bytes;
   return ACT_OK;
 }
+// Host memory the device can read in place: hipHostMalloc / hipHostRegister memory is mapped into the device's address space, and the
+// spend-proof kernels read every proof byte once or twice, spread over the kernels' whole run time -- 9 GB/s at full rate, a fraction
+// of the link.  Reading in place takes the staging copy out from in front of a single-chunk call's first kernel (tools/
+// midsize_probe.py: 4 096 proofs 11.9 -> 10.5 ms, 16 384: 39.6 -> 35.9; what the same call takes from HBM: 10.1 / 35.3).  Only for PUBLIC
+// inputs (proofs, wire bytes): secrets keep their staged, wiped copies.  Returns the device address of p, or null (pageable memory,
+// a range that leaves its allocation, memory pinned under another device, or ACT_NO_MAPPED_READS set).
+const uint8_t* mapped_view(const act_ctx* c, const uint8_t* p, size_t bytes) {
+  static const bool off = getenv("ACT_NO_MAPPED_READS") != nullptr;
+  if (off || !p || !bytes) return nullptr;
+  hipPointerAttribute_t a0{}, a1{};
+  if (hipPointerGetAttributes(&a0, p) != hipSuccess || hipPointerGetAttributes(&a1, p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost || !a0.devicePointer || !a1.devicePointer) return nullptr;
+  if (a0.device != c->device || a1.device != c->device) return nullptr;      // pinned while another device was current: staged as before
+  if ((const uint8_t*)a1.devicePointer - (const uint8_t*)a0.devicePointer != (ptrdiff_t)(bytes - 1)) return nullptr;
+  return (const uint8_t*)a0.devicePointer;
+}
 // device view of `bytes` of caller memory: the pointer itself (device memory) or a staged H2D copy
 int dev_in(act_ctx* c, Slot& sl, int slot, int mem, const uint8_t* p, size_t bytes, const uint8_t** out) {
   if (mem == ACT_MEM_DEVICE || bytes == 0) { *out = p; return ACT_OK; }
@@ -1171,12 +1187,15 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   const bool host_tr = c->tr_mode == ACT_TRANSCRIPT_HOST;
   // device views of the caller's arrays (staged on slot 0 for host memory; the copies themselves go piece by piece below)
   const uint8_t* d_proofs = proof; uint8_t *d_kprime = out_kprime, *d_out = out_refund;
-  const bool copy_in = mem == ACT_MEM_HOST && !d_ready;
+  bool copy_in = mem == ACT_MEM_HOST && !d_ready;
   if (d_ready) {
     d_proofs = d_ready;
     if ((rc = copy_chain_record(c, sl, false))) return rc;            // the unframing kernel on slot 0's stream ...
     HIPCK(c, hipStreamWaitEvent(s_x, sl.cp_in_ev, 0));                // ... precedes everything that hangs on SM_IN
-  } else if (copy_in) { if ((rc = stage_reserve(c, sl, 0, n * pb))) return rc; d_proofs = sl.d_stage[0]; }
+  } else if (copy_in) {
+    if (const uint8_t* v = mapped_view(c, proof, n * pb)) { d_proofs = v; copy_in = false; }      // pinned host memory: read in place
+    else { if ((rc = stage_reserve(c, sl, 0, n * pb))) return rc; d_proofs = sl.d_stage[0]; }
+  }
   if (out_kprime && (rc = dev_out_begin(c, sl, 2, mem, out_kprime, n * 32, &d_kprime))) return rc;
   if (sign && (rc = dev_out_begin(c, sl, 4, mem, out_refund, n * 128, &d_out))) return rc;
   if (host_tr) {
@@ -1276,6 +1295,8 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
     return spend_small_locked(c, n, mem, nullptr, sign, rng, rng_mode, out_refund, status, out_kprime, d_records);
   }
   const size_t pb = ProofLayout{c->L}.bytes();
+  const uint8_t* proof_view = (mem == ACT_MEM_HOST && !wire) ? mapped_view(c, proof, n * pb) : nullptr;      // pinned: the kernels read the proofs in place
+  const bool in_host = mem == ACT_MEM_HOST && !proof_view;       // the proofs travel through the staging buffers
   static const size_t host_chunk_env = [] { const char* e = getenv("ACT_HOST_CHUNK"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning knob
   // host-transcript mode: a chunk's transcripts go to the host, are hashed there and come back before its status kernel, all
   // of which only overlaps with compute if there are other chunks to compute: long batches use full-size chunks (the
@@ -1283,7 +1304,7 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
   const size_t host_chunk = host_chunk_env ? host_chunk_env : (n >= 8 * c->max_batch ? c->max_batch : (size_t)16384);
   const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
   static const int stagger_env = [] { const char* e = getenv("ACT_STAGGER"); return e ? atoi(e) : -1; }();      // tuning knob: force on / off
-  const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (mem == ACT_MEM_HOST || c->tr_mode == ACT_TRANSCRIPT_HOST);
+  const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (in_host || c->tr_mode == ACT_TRANSCRIPT_HOST);
   // Chunk schedule.  Full-size chunks are the kernels' best size, but whenever a call moves data over PCIe the pipeline has a
   // head (nothing computes until the first chunk's proofs have arrived and its per-proof kernel has run) and a tail (the
   // last chunk's transcripts travel to the host, are hashed and come back with nothing left to overlap): measured 44 ms and
@@ -1300,7 +1321,7 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
     // A call that fits one or a few chunks and reads its proofs from host memory (device transcripts: nothing else crosses PCIe):
     // as one chunk its 16.8 KB per proof arrive before anything computes (19 ms of a 148 ms call over 65 536 proofs).  A proof
     // takes ~0.3 us to arrive and ~1.95 us to verify, so a first chunk of an eighth of the call hides the arrival of the rest.
-    else if (c->tr_mode == ACT_TRANSCRIPT_DEVICE && mem == ACT_MEM_HOST && !taper_off && n >= 4096 && n < 4 * chunk_len) {
+    else if (c->tr_mode == ACT_TRANSCRIPT_DEVICE && in_host && !taper_off && n >= 4096 && n < 4 * chunk_len) {
       const size_t h = std::min(n, std::max<size_t>(2048, (n / 8 + 1023) / 1024 * 1024));
       if (h < n) { head = {h}; left -= h; }
     }
@@ -1320,6 +1341,7 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
     ch.stagger = stagger;
     int r;
     if (wire) { if ((r = wire_unframe_chunk(c, sl, *wire, mem, ch.off, ch.m, &ch.d_proofs))) return r; }
+    else if (proof_view) ch.d_proofs = proof_view + ch.off * pb;
     else if ((r = dev_in(c, sl, 0, mem, proof + ch.off * pb, (size_t)ch.m * pb, &ch.d_proofs))) return r;
     if (out_kprime && (r = dev_out_begin(c, sl, 2, mem, out_kprime + ch.off * 32, (size_t)ch.m * 32, &ch.d_kprime))) return r;
     if (sign && (r = dev_out_begin(c, sl, 4, mem, out_refund + ch.off * 128, (size_t)ch.m * 128, &ch.d_out))) return r;
