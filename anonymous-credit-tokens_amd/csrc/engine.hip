@@ -1588,7 +1588,8 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
   size_t chunk = std::min(c->max_batch, std::max<size_t>(16384, (n / 4 + 1023) / 1024 * 1024));      // (below 16 384 lanes the kernels no longer fill the chip)
   // (issuance: 352 B per lane, nothing to hide)
   static const bool taper_off = getenv("ACT_NO_TAPER") != nullptr;      // A/B knob, read once
-  const bool two_slots = mem == ACT_MEM_HOST && !issuance && c->depth > 1 && n > chunk && !taper_off;
+  const uint8_t* proofs_view = (!issuance && mem == ACT_MEM_HOST) ? mapped_view(c, proofs, n * pb) : nullptr;      // pinned: the SpendProofs (public, 16.8 KB each) are read in place
+  const bool two_slots = mem == ACT_MEM_HOST && !issuance && !proofs_view && c->depth > 1 && n > chunk && !taper_off;
   if (!two_slots) chunk = c->max_batch;
   size_t k = 0;
   for (size_t off = 0; off < n; off += chunk, k++) {
@@ -1601,6 +1602,7 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
     if ((rc = dev_in(c, sl, 0, mem, pre + off * pre_b, (size_t)m * pre_b, &a.pre))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, resp + off * resp_b, (size_t)m * resp_b, &a.resp))) return rc;
     if (issuance) { if ((rc = dev_in(c, sl, 3, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc; }
+    else if (proofs_view) a.proofs = proofs_view + off * pb;
     else { if ((rc = dev_in(c, sl, 3, mem, proofs + off * pb, (size_t)m * pb, &a.proofs))) return rc; }
     if (two_slots && (rc = copy_chain_record(c, sl, false))) return rc;
     if ((rc = dev_out_begin(c, sl, 2, mem, out_token + off * 160, (size_t)m * 160, &a.out_token))) return rc;

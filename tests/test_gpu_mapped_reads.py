@@ -64,4 +64,25 @@ def test_pinned_host_proofs_are_read_in_place(engine_factory, oracle, bench_para
     assert _h2d_bytes(eng) < len(blob)
     assert (st.numpy().tobytes(), kp.numpy().tobytes()) == ref
     eng.set_small_batch_max(8192)
+    # the client's side: PreRefund::to_credit_token reads the same SpendProofs (its own, public) from pinned memory in place
+    from conftest import scb
+    M = 70
+    pre = eng.pre_issuance_random(shake("mr2-pre", 128 * M)); req = eng.request(pre, shake("mr2-rq", 128 * M))
+    s0, resp = eng.issue(sk, req, b"".join(scb(90 + i) for i in range(M)), shake("mr2-ir", 128 * M))
+    s0, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+    s0, pr, prer = eng.prove_spend(tok, b"".join(scb(i) for i in range(M)), shake("mr2-pr", eng.prove_rng_bytes * M))
+    s0, rf = eng.refund(sk, pr, shake("mr2-rr", 128 * M))
+    assert s0 == bytes(M)
+    rf = bytearray(rf); rf[128 * 4 + 70] ^= 1; rf = bytes(rf)
+    ref = eng.refund_to_credit_token(prer, pr, rf, sk[32:])
+    assert len(set(ref[0])) == 2 and ref[0][4] != 0
+    pin_of = lambda b: torch.from_numpy(np.frombuffer(b, np.uint8).copy()).pin_memory()
+    t_prer, t_pr, t_rf = pin_of(prer), pin_of(pr), pin_of(rf)
+    t_out = torch.zeros(160 * M, dtype=torch.uint8).pin_memory(); t_st = torch.full((M,), 9, dtype=torch.uint8).pin_memory()
+    pw, kw = capi._in(sk[32:], 32)
+    eng.prof_reset(); eng.prof_enable(True)
+    eng._ck(eng.lib.act_refund_to_credit_token_batch(eng.ctx, M, capi.MEM_HOST, t_prer.data_ptr(), t_pr.data_ptr(), t_rf.data_ptr(), pw, t_out.data_ptr(), t_st.data_ptr()))
+    eng.prof_enable(False)
+    assert _h2d_bytes(eng) < M * pb
+    assert (t_st.numpy().tobytes(), t_out.numpy().tobytes()) == ref
     assert eng.secret_residue() == 0
