@@ -1121,7 +1121,8 @@ static int copy_chain_record(act_ctx* c, Slot& sl, bool out);
 // that.  So the default sub-chunk is 2^20 lanes (8 192 proofs at L = 128) = the schedule's size limit, and larger calls keep the
 // two-slot pipeline of 65 536-proof chunks (one lane per proof is the cheaper form once a launch fills the chip: DESIGN.md section 8).
 // Scratch of the roles lives in d_small, wiped like every other key-dependent buffer (finish_call).
-enum { SM_IN = 0, SM_A, SM_C, SM_JOIN, SM_TAIL, SM_BITS, SM_READY, SM_D2H, SM_EVENTS };
+enum { SM_IN = 0, SM_A, SM_C, SM_JOIN, SM_TAIL, SM_BITS, SM_READY, SM_D2H, SM_K, SM_SPEC, SM_EVENTS };
+constexpr size_t SPEC_PARK_BYTES = (size_t)TINY_MAX * PREP_BUCKET_SETS * BUCKET_WORDS * 4;      // k_sign_fused parks in set 2 of a lane's three
 static int small_prepare(act_ctx* c, size_t n, size_t subs) {
   if (!c->aux[0]) {
     int least = 0, greatest = 0;
@@ -1132,8 +1133,9 @@ static int small_prepare(act_ctx* c, size_t n, size_t subs) {
   }
   while (c->sm_ev.size() < subs * SM_EVENTS) { hipEvent_t e; HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->sm_ev.push_back(e); }
   const size_t per_proof = ((size_t)PREP_BUCKET_SETS * BUCKET_WORDS + (size_t)PART_POINTS * GE_WORDS) * 4;
-  if (n * per_proof > c->d_small_cap) {
-    const size_t cap = std::min(c->max_batch, std::max<size_t>(c->small_max.load(), n)) * per_proof;
+  if (n * per_proof + SPEC_PARK_BYTES > c->d_small_cap) {
+    // (+ in front: where a tiny refund's signature, computed beside the verification, parks its partial points: spend_small_locked)
+    const size_t cap = std::min(c->max_batch, std::max<size_t>(c->small_max.load(), n)) * per_proof + SPEC_PARK_BYTES;
     if (c->d_small) { HIPCK(c, hipMemset(c->d_small, 0, c->d_small_cap)); HIPCK(c, hipFree(c->d_small)); c->d_small = nullptr; c->d_small_cap = 0; }
     HIPCK(c, hipMalloc(&c->d_small, cap)); c->d_small_cap = cap;
     // starts clean like the other secret-bearing buffers (the allocator may hand back freed memory).  On a stream of this context and
@@ -1142,7 +1144,7 @@ static int small_prepare(act_ctx* c, size_t n, size_t subs) {
     HIPCK(c, hipMemsetAsync(c->d_small, 0, cap, c->slots[0].stream));
     HIPCK(c, hipStreamSynchronize(c->slots[0].stream));
   }
-  c->d_small_dirty = std::max(c->d_small_dirty, n * per_proof);
+  c->d_small_dirty = std::max(c->d_small_dirty, n * per_proof + SPEC_PARK_BYTES);
   return ACT_OK;
 }
 // At most SMALL_IN_FLIGHT small-batch calls run on one device at a time, whatever number of contexts (threads of a server) issue
@@ -1211,6 +1213,25 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     }
   }
   HIPCK(c, hipMemsetAsync(sl.d_flags, 0, n * 4, s_x));               // every kernel ORs its flags in
+  // A tiny refund signs BESIDE its verification: X_A = g + K' exists as soon as k_spend_tail has run (1.3 ms into a 1.9 ms call), and the
+  // signature's dependent chain (X_A -> (e+x)^-1 -> the quartered products, 0.8 ms) then runs on the tail's stream while the range
+  // kernel, the encodings and the hash finish; only the last step (add the quarters, encode, hash, z: k_sign_fused phase 2) waits for
+  // the verdict.  A lane's e, alpha are read before its verdict is known, which is observable only if the slice a lane draws depends
+  // on other lanes' verdicts: ACT_RNG_PER_LANE or a single lane (as PrivateKey::issue's tiny path, k_sign.hip).  A rejected lane's
+  // partial points are zeroed by the finish like everybody's; its record is zero.
+  const bool spec_sign = sign && K == 1 && n <= TINY_MAX && tiny_enabled(c) && (rng_mode == ACT_RNG_PER_LANE || (rng_mode == ACT_RNG_SEQUENTIAL && n == 1));
+  SignFusedArgs sf{};
+  if (spec_sign) {
+    const uint8_t* d_rng = rng;
+    if (mem == ACT_MEM_HOST) {
+      if ((rc = stage_reserve(c, sl, 3, n * 128))) return rc;
+      HIPCK(c, hipMemcpyAsync(sl.d_stage[3], rng, n * 128, hipMemcpyHostToDevice, s_tail));
+      d_rng = sl.d_stage[3];
+    }
+    launch_iota(sl.d_slot, (uint32_t)n, 0u, s_tail);
+    sf.P = c->P; sf.K = c->key; sf.n = (uint32_t)n; sf.label = LABEL_REFUND; sf.xa = sl.d_xa; sf.rng_slot = sl.d_slot; sf.rng = d_rng;
+    sf.status_in = sl.d_status; sf.status = sl.d_status; sf.out = d_out; sf.trs = sl.d_trs; sf.pbk = c->d_small; sf.group_counter = group_counters(c, sl);
+  }
   std::vector<SpendArgs> args(K);
   for (size_t k = 0; k < K; k++) {
     const size_t off = k * S, m = std::min(S, n - off);
@@ -1225,7 +1246,8 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     a.coords = sl.d_coords + off * L * NIELS_WORDS; a.d01 = sl.d_d01 + off * 2 * GE_WORDS; a.buckets = sl.d_buckets + off * L * BUCKET_WORDS;
     a.xa = sl.d_xa + off * GE_WORDS; a.flags = sl.d_flags + off; a.xof = sl.d_xof + off * 16; a.status = sl.d_status + off;
     a.kprime_enc = d_kprime ? d_kprime + off * 32 : nullptr; a.naf = sl.d_naf + off * NAF_WORDS; a.dig = sl.d_dig + off * L * 8;
-    a.pbk = c->d_small + off * PREP_BUCKET_SETS * BUCKET_WORDS; a.part = c->d_small + n * PREP_BUCKET_SETS * BUCKET_WORDS + off * PART_POINTS * GE_WORDS;
+    uint32_t* const small0 = c->d_small + SPEC_PARK_BYTES / 4;
+    a.pbk = small0 + off * PREP_BUCKET_SETS * BUCKET_WORDS; a.part = small0 + n * PREP_BUCKET_SETS * BUCKET_WORDS + off * PART_POINTS * GE_WORDS;
     for (hipStream_t s : {s_a, s_b, s_tail}) HIPCK(c, hipStreamWaitEvent(s, ev(k, SM_IN), 0));
     if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 4, s_a); }))) return rc;      // C1: digits and h2 terms of the range kernel
     HIPCK(c, hipEventRecord(ev(k, SM_C), s_a));
@@ -1237,8 +1259,20 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_JOIN, m, [&] { launch_spend_prep_role(a, 3, s_b); }))) return rc;
     HIPCK(c, hipEventRecord(ev(k, SM_JOIN), s_b));
     if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_COORDS, m * L, [&] { launch_spend_coords(a, s_tail); }))) return rc;
-    if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, m, [&] { launch_spend_tail(a, s_tail); }))) return rc;
-    HIPCK(c, hipEventRecord(ev(k, SM_TAIL), s_tail));
+    if (!spec_sign) {
+      if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, m, [&] { launch_spend_tail(a, s_tail); }))) return rc;
+      HIPCK(c, hipEventRecord(ev(k, SM_TAIL), s_tail));
+    } else {
+      // the tail in two launches: the signature's roles follow K' / X_A on this stream while C is made on the copy stream (idle by now)
+      if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, m, [&] { launch_spend_tail_k(a, s_tail); }))) return rc;
+      HIPCK(c, hipEventRecord(ev(k, SM_K), s_tail));
+      HIPCK(c, hipStreamWaitEvent(s_x, ev(k, SM_K), 0));
+      if ((rc = prof_launch_on(c, sl, s_x, PK_SPEND_TAIL, m, [&] { launch_spend_tail_c(a, s_x); }))) return rc;
+      HIPCK(c, hipEventRecord(ev(k, SM_TAIL), s_x));
+      sf.phase = 1;
+      if ((rc = prof_launch_on(c, sl, s_tail, PK_SIGN_A, m, [&] { launch_sign_fused(sf, false, s_tail); }))) return rc;
+      HIPCK(c, hipEventRecord(ev(k, SM_SPEC), s_tail));
+    }
     HIPCK(c, hipStreamWaitEvent(s_bits, ev(k, SM_C), 0));               // implies SM_IN
     if ((rc = prof_launch_on(c, sl, s_bits, PK_SPEND_BITS, (uint64_t)m * L, [&] { launch_spend_bits(a, s_bits); }))) return rc;
     HIPCK(c, hipEventRecord(ev(k, SM_BITS), s_bits));
@@ -1272,7 +1306,12 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_IN), 0));
   sl.last_spend_lanes = n; c->last_spend_slot = 0;
   if (out_kprime && (rc = dev_out_end(c, sl, mem, out_kprime, d_kprime, n * 32))) return rc;
-  if (sign) {
+  if (spec_sign) {
+    HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_SPEC), 0));
+    sf.phase = 2;
+    if ((rc = prof_launch(c, sl, PK_SIGN_B, n, [&] { launch_sign_fused(sf, false, sl.stream); }))) return rc;
+    if ((rc = dev_out_end(c, sl, mem, out_refund, d_out, n * 128))) return rc;
+  } else if (sign) {
     const uint8_t* d_rng; size_t cursor = 0;
     if ((rc = prepare_rng_slots(c, sl, (uint32_t)n, 0, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
     if ((rc = sign_phase(c, sl, (uint32_t)n, LABEL_REFUND, d_rng, nullptr, d_out))) return rc;

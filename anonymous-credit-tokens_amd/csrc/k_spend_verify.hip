@@ -42,6 +42,14 @@ __global__ void __launch_bounds__(64, 2) k_spend_tail(SpendArgs a) {
   uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p < a.n) spend_tail_lane(a, p);
 }
+__global__ void __launch_bounds__(64, 2) k_spend_tail_k(SpendArgs a) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p < a.n) spend_tail_k_lane(a, p);
+}
+__global__ void __launch_bounds__(64, 2) k_spend_tail_c(SpendArgs a) {
+  uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p < a.n) spend_tail_c_lane(a, p);
+}
 
 __global__ void __launch_bounds__(256) k_spend_finish(SpendArgs a) {
   uint32_t p = blockIdx.x * 256 + threadIdx.x;
@@ -83,6 +91,8 @@ void launch_spend_enc_small(const SpendArgs& a, hipStream_t s) {
   size_t threads = ((size_t)a.n * a.P.L * 2 + ENC_BATCH_SMALL - 1) / ENC_BATCH_SMALL;
   hipLaunchKernelGGL(k_spend_enc_small, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
 }
+void launch_spend_tail_k(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail_k, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
+void launch_spend_tail_c(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail_c, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
 void launch_spend_tail(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
 void launch_spend_finish(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_finish, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 

@@ -288,6 +288,13 @@ ACT_HD void spend_tail_lane(const SpendArgs& a, uint32_t p) {
   spend_tail_c(a, p, kp, spend_tail_fixed(a, p));
   spend_tail_xa(a, p, kp);
 }
+// The same in two kernels, for the call that signs beside its verification (engine.hip spend_small_locked): X_A leaves after the
+// Horner run -- 0.5 ms into a 1.25 ms lane -- and the signature's chain starts there; C follows from K' = X_A - g.
+ACT_HD void spend_tail_k_lane(const SpendArgs& a, uint32_t p) { spend_tail_xa(a, p, spend_tail_horner(a, p, 0, a.P.L, 0)); }
+ACT_HD void spend_tail_c_lane(const SpendArgs& a, uint32_t p) {
+  const ge kp = ge_add(ge_load(a.xa + (size_t)p * GE_WORDS), ge_neg(ge_basepoint()));
+  spend_tail_c(a, p, kp, spend_tail_fixed(a, p));
+}
 
 ACT_HD void spend_finish_lane(const SpendArgs& a, uint32_t p) {
   const ProofLayout pl{a.P.L};
