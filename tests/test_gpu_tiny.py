@@ -93,6 +93,21 @@ def test_tiny_calls_equal_the_oracle_and_the_multi_launch_path(engine_factory, o
             assert (so, ro) == (got[0][i], got[1][128 * i:128 * i + 128]), (rng_mode, i)
             cur += so == 0
         assert set(got[0]) == {0, 6, 7}
+    # one proof per call (the crate's call shape; the signature is computed beside the verification in either rng convention), an
+    # accepted, a rejected and an identity-A' proof; then the same from device memory
+    for i in (0, 2, 5):
+        for rng_mode in (capi.RNG_PER_LANE, capi.RNG_SEQUENTIAL):
+            so, ro = octx.refund(sk, t[pb * i:pb * i + pb], rrng[:128])
+            assert eng.refund(sk, t[pb * i:pb * i + pb], rrng[:128], rng_mode) == (bytes([so]), ro), (i, rng_mode)
+    d_p, d_r = d(t), d(rrng); d_o = torch.full((128 * M,), 7, dtype=torch.uint8, device="cuda"); d_s = torch.full((M,), 9, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    eng.refund_dev(sk, M, d_p.data_ptr(), d_r.data_ptr(), capi.RNG_PER_LANE, d_o.data_ptr(), d_s.data_ptr())
+    assert (d_s.cpu().numpy().tobytes(), d_o.cpu().numpy().tobytes()) == eng.refund(sk, t, rrng, capi.RNG_PER_LANE)
+    eng.set_tiny_calls(False)                                  # the signature behind the verification: same bytes
+    try:
+        assert eng.refund(sk, t, rrng, capi.RNG_PER_LANE) == (d_s.cpu().numpy().tobytes(), d_o.cpu().numpy().tobytes())
+    finally:
+        eng.set_tiny_calls(True)
     st, rf = eng.refund(sk, proofs, rrng)
     got = eng.refund_to_credit_token(prer, proofs, rf, sk[32:])
     for i in range(M):
