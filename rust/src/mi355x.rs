@@ -57,6 +57,10 @@ extern "C" {
     fn act_node_prove_spend_seeded_batch(node: *mut ActNode, n: usize, token: *const u8, s: *const u8, seed: *const u8, first_lane: u64,
                                          out_proof: *mut u8, out_prerefund: *mut u8, status: *mut u8) -> c_int;
     fn act_node_verify_spend_batch(node: *mut ActNode, n: usize, sk: *const u8, proof: *const u8, status: *mut u8, out_kprime: *mut u8) -> c_int;
+    fn act_node_issue_batch(node: *mut ActNode, n: usize, sk: *const u8, req: *const u8, c: *const u8, rng: *const u8, rng_mode: c_int,
+                            out_resp: *mut u8, status: *mut u8) -> c_int;
+    fn act_node_refund_batch(node: *mut ActNode, n: usize, sk: *const u8, proof: *const u8, rng: *const u8, rng_mode: c_int,
+                             out_refund: *mut u8, status: *mut u8) -> c_int;
     fn act_node_refund_sign_batch(node: *mut ActNode, n: usize, sk: *const u8, kprime: *const u8, status_in: *const u8,
                                   rng: *const u8, rng_mode: c_int, out_refund: *mut u8, status: *mut u8) -> c_int;
     fn act_node_refund_to_credit_token_batch(node: *mut ActNode, n: usize, prerefund: *const u8, proof: *const u8, refund: *const u8,
@@ -768,6 +772,31 @@ impl PrivateKey {
     pub fn refund(&self, params: &Params, spend_proof: &SpendProof, rng: impl CryptoRngCore) -> Result<Refund, Error> {
         // src/lib.rs:781-786
         self.refund_batch(params, std::slice::from_ref(spend_proof), rng).pop().unwrap()
+    }
+    /// `refund` in ONE call to the library, the signature computed beside the verification (2.2 ms instead of ~3.0 for one proof):
+    /// e and alpha are drawn BEFORE the verdict is known.  The refund is the one `refund` returns for the same generator; the one
+    /// difference is on the error path -- the crate draws nothing for a rejected proof (src/lib.rs:787-846), this draws 128 bytes
+    /// whatever the verdict.  For callers whose generator is the operating system's, that is no difference at all.
+    pub fn refund_eager(&self, params: &Params, spend_proof: &SpendProof, mut rng: impl CryptoRngCore) -> Result<Refund, Error> {
+        let mut rec = Vec::with_capacity(PROOF_BYTES);
+        spend_proof.write_record(&mut rec);
+        let rng_bytes = draw(&mut rng, 2);
+        let (sk, gpu) = (self.record(), params.gpu());
+        let (mut out, mut status) = ([0u8; 128], [0u8; 1]);
+        gpu.check(unsafe { act_node_refund_batch(gpu.0, 1, sk.as_ptr(), rec.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr()) });
+        if status[0] == 0 { Ok(Refund::from_record(&out)) } else { Err(status_to_error(status[0])) }
+    }
+    /// `issue` in one call, the signature beside the request's proof of knowledge (1.25 ms instead of ~2.0); the same remark as
+    /// `refund_eager`: 128 bytes are drawn before the check of src/lib.rs:629-640, not after it.
+    pub fn issue_eager(&self, params: &Params, request: &IssuanceRequest, c: Scalar, mut rng: impl CryptoRngCore) -> Result<IssuanceResponse, Error> {
+        let (mut req, mut cb) = (Vec::with_capacity(128), Vec::with_capacity(32));
+        request.write_record(&mut req);
+        put_s(&mut cb, &c);
+        let rng_bytes = draw(&mut rng, 2);
+        let (sk, gpu) = (self.record(), params.gpu());
+        let (mut out, mut status) = ([0u8; 160], [0u8; 1]);
+        gpu.check(unsafe { act_node_issue_batch(gpu.0, 1, sk.as_ptr(), req.as_ptr(), cb.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr()) });
+        if status[0] == 0 { Ok(IssuanceResponse::from_record(&out)) } else { Err(status_to_error(status[0])) }
     }
 }
 #[cfg(feature = "mi355x")]
