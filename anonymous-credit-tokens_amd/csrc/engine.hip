@@ -74,11 +74,22 @@ struct Slot {
 
 // The context's last error text, under a lock of ITS OWN: act_last_error() must not wait behind a batch call that holds the context
 // for seconds, and a failing call on one thread must not tear the string another thread is copying.
+// The text of a handle's last failure.  A handle is shared between threads, and "last" must mean the calling thread's own last
+// failing call, not whichever thread failed most recently: every assignment is also kept in a slot of the assigning thread, which
+// act_last_error prefers; a caller whose request was merged into another thread's call is handed the leader's text (CoReq::err).
 struct ErrText {
   mutable std::mutex m; std::string s;
-  ErrText& operator=(const std::string& v) { std::lock_guard<std::mutex> lk(m); s = v; return *this; }
-  ErrText& operator=(const char* v) { std::lock_guard<std::mutex> lk(m); s = v; return *this; }
-  std::string get() const { std::lock_guard<std::mutex> lk(m); return s; }
+  struct Mine { const ErrText* of = nullptr; std::string text; };
+  static Mine& mine() { thread_local Mine t; return t; }
+  void keep(const std::string& v) const { Mine& t = mine(); t.of = this; t.text = v; }
+  ErrText& operator=(const std::string& v) { { std::lock_guard<std::mutex> lk(m); s = v; } keep(v); return *this; }
+  ErrText& operator=(const char* v) { return *this = std::string(v); }
+  std::string get() const {
+    const Mine& t = mine();
+    if (t.of == this && !t.text.empty()) return t.text;
+    std::lock_guard<std::mutex> lk(m); return s;
+  }
+  void forget_mine() const { Mine& t = mine(); if (t.of == this) t.text.clear(); }      // a new call of this thread on this handle begins
   operator std::string() const { return get(); }
 };
 struct CoReq;       // a small call waiting to be merged with others (defined with the entry points that merge)
@@ -525,7 +536,7 @@ int finish_call(act_ctx* c, size_t n) {
 // successful one does.  On the failure path the wipe is best effort and the first error is the one reported.
 struct Call {
   act_ctx* c; size_t n; std::unique_lock<std::mutex> lk; bool finished = false;
-  Call(act_ctx* c_, size_t n_) : c(c_), n(n_), lk(c_->mu) {}
+  Call(act_ctx* c_, size_t n_) : c(c_), n(n_), lk(c_->mu) { c->err.forget_mine(); }
   void slow() const {           // act_debug_set_slowdown: this context as a slower GPU
     const uint32_t ns = c->debug_ns_per_lane.load();
     if (ns && n) std::this_thread::sleep_for(std::chrono::nanoseconds((uint64_t)ns * n));
@@ -1000,6 +1011,7 @@ struct CoReq {
   const uint8_t* camt; const uint8_t* status_in; const uint8_t* rng; bool rng_if_accepted;
   uint8_t* out; uint8_t* status; uint8_t* out_kprime;
   int rc = ACT_OK; bool done = false;
+  std::string err;                        // rc != 0: the merged call's error text, for this caller's act_last_error
 };
 static int spend_coalesced(act_ctx* c, CoReq& r);
 
@@ -1468,8 +1480,10 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
                         sign ? h_out : nullptr, h_st, want_kp ? h_kp : nullptr);
   if (sign) memset(c->h_co_rng, 0, total * 128);        // signing nonces' seeds: not left in a long-lived buffer
   off = 0;
+  const std::string why = rc ? c->err.get() : std::string();
   for (CoReq* q : batch) {
     q->rc = rc;
+    if (rc) q->err = why;
     if (!rc) {
       memcpy(q->status, h_st + off, q->n);
       if (q->out_kprime) memcpy(q->out_kprime, h_kp + off * 32, q->n * 32);
@@ -1484,9 +1498,12 @@ static int spend_coalesced(act_ctx* c, CoReq& r) {
   const size_t sm = c->small_max.load();
   const size_t cap = std::max<size_t>(c->co_req_max.load(), std::min<size_t>(c->max_batch, sm ? sm : c->max_batch));   // lanes per merged call
   // the oldest request decides key and kind; every queued request of the same key and kind joins (coalesce.h)
-  return c->co->submit(r, cap,
-                       [](const CoReq& a, const CoReq& b) { return a.kind == b.kind && (!a.sk || ct_equal(a.sk, b.sk, 64)); },
-                       [c](const std::vector<CoReq*>& batch, size_t total) { return co_run(c, batch, total); });
+  c->err.forget_mine();
+  const int rc = c->co->submit(r, cap,
+                               [](const CoReq& a, const CoReq& b) { return a.kind == b.kind && (!a.sk || ct_equal(a.sk, b.sk, 64)); },
+                               [c](const std::vector<CoReq*>& batch, size_t total) { return co_run(c, batch, total); });
+  if (rc && !r.err.empty()) c->err.keep(r.err);        // the merged call ran on another thread: its text, for THIS thread's act_last_error
+  return rc;
 }
 
 int act_ctx_set_coalescing(act_ctx* c, size_t max_proofs_per_call) {

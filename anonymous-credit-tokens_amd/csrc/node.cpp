@@ -45,6 +45,15 @@ struct act_node {
   std::vector<DevStats> last;    // what each context did in the most recent cut call
 };
 
+// A node handle's last error is the CALLING THREAD's last failure on it where there is one (threads share the handle; small calls do
+// not even take its lock): every write also lands in a slot of the writing thread, which act_node_last_error prefers.
+namespace {
+struct NodeErrMine { const void* of = nullptr; std::string text; };
+NodeErrMine& node_err_mine() { thread_local NodeErrMine t; return t; }
+void set_node_err(act_node* nd, const std::string& text) { nd->err = text; NodeErrMine& t = node_err_mine(); t.of = nd; t.text = text; }      // caller holds nd->mu
+void small_call_err(act_node* nd, act_ctx* c) { const std::string text = act_last_error(c); std::lock_guard<std::mutex> node_lock(nd->mu); set_node_err(nd, text); }
+}  // namespace
+
 namespace {
 
 struct Shard { size_t off, m; };
@@ -134,7 +143,7 @@ int run(act_node* nd, size_t n, F fn, std::vector<Piece>* pieces = nullptr) {
   int first_rc = ACT_OK;
   for (size_t k = 0; k < N && !first_rc; k++)
     for (const Piece& q : done[k])
-      if (q.rc) { nd->err = "device " + std::to_string(nd->devices[k]) + ": " + act_last_error(nd->ctx[k]); first_rc = q.rc; break; }
+      if (q.rc) { set_node_err(nd, "device " + std::to_string(nd->devices[k]) + ": " + act_last_error(nd->ctx[k])); first_rc = q.rc; break; }
   if (pieces) {
     pieces->clear();
     for (size_t k = 0; k < N; k++) pieces->insert(pieces->end(), done[k].begin(), done[k].end());
@@ -198,6 +207,8 @@ act_ctx* act_node_ctx(act_node* nd, int k) { return (nd && k >= 0 && k < (int)nd
 const char* act_node_last_error(const act_node* nd) {
   if (!nd) return "null node";
   thread_local std::string mine;
+  const NodeErrMine& t = node_err_mine();
+  if (t.of == nd && !t.text.empty()) { mine = t.text; return mine.c_str(); }      // this thread's own last failure on this handle
   { std::lock_guard<std::mutex> lk(const_cast<act_node*>(nd)->mu); mine = nd->err; }
   return mine.c_str();
 }
@@ -279,7 +290,7 @@ int act_node_issue_check_batch(act_node* nd, size_t n, const uint8_t* req, uint8
   if (n && n <= nd->co_max.load()) {          // small enough to merge with other threads' calls: one context, no node lock
     act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
     const int rc = act_issue_check_batch(c, n, ACT_MEM_HOST, req, status);
-    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    if (rc) small_call_err(nd, c);
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
@@ -292,7 +303,7 @@ int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], cons
   if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {
     act_ctx* cx = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
     const int rc = act_issue_sign_batch(cx, n, ACT_MEM_HOST, sk, req, c, status_in, rng, rng_mode, out_resp, status);
-    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(cx); }
+    if (rc) small_call_err(nd, cx);
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
@@ -326,7 +337,7 @@ static int refund_sign_any(act_node* nd, size_t n, const uint8_t sk[64], const u
     act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
     rc = cbor ? act_refund_sign_cbor_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out, status)
               : act_refund_sign_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out, status);
-    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    if (rc) small_call_err(nd, c);
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
@@ -378,7 +389,7 @@ int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], co
   if (n && n <= nd->co_max.load()) {
     act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
     const int rc = act_verify_spend_batch(c, n, ACT_MEM_HOST, sk, proof, status, out_kprime);
-    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    if (rc) small_call_err(nd, c);
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
@@ -396,7 +407,7 @@ int act_node_verify_spend_cbor_keys_batch(act_node* nd, size_t n, const uint8_t 
   if (n && n <= nd->co_max.load()) {          // a call this small has nothing to cut: one context, round robin, no node lock
     act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
     const int rc = act_verify_spend_cbor_keys_batch(c, n, ACT_MEM_HOST, sk, cbor, offsets, status, out_kprime, out_nullifier);
-    if (rc) { std::lock_guard<std::mutex> node_lock(nd->mu); nd->err = act_last_error(c); }
+    if (rc) small_call_err(nd, c);
     return rc;
   }
   std::lock_guard<std::mutex> node_lock(nd->mu);
@@ -660,7 +671,7 @@ static int node_redeem(act_node* nd, act_node_nullifier_set* set, size_t n, cons
     }
     return rc_sign;
   }
-  if (rc_null) nd->err = std::string("nullifier set: ") + act_node_nullifier_set_last_error(set);
+  if (rc_null) set_node_err(nd, std::string("nullifier set: ") + act_node_nullifier_set_last_error(set));
   return rc_null;
 }
 extern "C" int act_node_redeem_batch(act_node* nd, act_node_nullifier_set* set, size_t n, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng,

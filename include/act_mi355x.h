@@ -200,8 +200,9 @@ int act_build_has_ct_secret_tables(void);
 /* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
  * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 in a throughput-sized context on an otherwise empty device (see act_ctx_create) */
 int act_ctx_fixed_base_bits(const act_ctx *ctx, int base);
-/* Text of the last failure on this handle.  Every *_last_error function copies the text under the handle's lock into a buffer of
- * the CALLING THREAD (another thread's failing call may be rewriting it), valid until that thread asks again. */
+/* Text of the CALLING THREAD's last failure on this handle (of the handle's most recent failure if this thread has had none): a
+ * handle is shared between threads, and a caller whose small call was merged into another thread's launch gets that launch's text.
+ * Every *_last_error function copies the text into a buffer of the calling thread, valid until that thread asks again. */
 const char *act_last_error(const act_ctx *ctx);
 size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
 size_t act_prove_rng_bytes(const act_ctx *ctx);             /* 64*(4L+12) */

@@ -451,3 +451,37 @@ def records_fast(n, rec, seed):
     for b in range(7):
         a[:, 1 + b] = (idx >> np.uint64(8 * b)).astype(np.uint8)
     return a.tobytes()
+
+
+def test_node_last_error_is_the_calling_threads_own(lib):
+    """threads share a node handle; act_node_last_error must give a thread the text of ITS last failing call, not of
+    whichever thread failed last.  A thread that never failed on the handle sees the handle's most recent text."""
+    import threading
+    lib.act_node_last_error.restype = C.c_char_p
+    n, ndev = 64, 2
+    recs = records(n, PB, 91); rrng = records(n, 128, 92)
+    nd = make_node(lib, ndev)
+    devs = (C.c_int * ndev)(*range(ndev))
+
+    def failing_call(null_dev, sign_dev):
+        ns = C.c_void_p()
+        assert lib.act_node_nullifier_set_create(devs, ndev, C.c_size_t(4 * n), b"0123456789abcdef", C.byref(ns)) == 0
+        lib.act_mock_fail(null_dev, sign_dev)
+        out = C.create_string_buffer(128 * n); st = C.create_string_buffer(n)
+        rc = lib.act_node_redeem_batch(nd, ns, C.c_size_t(n), bytes(64), recs, rrng, 0, out, st)
+        lib.act_mock_fail(-1, -1)
+        lib.act_node_nullifier_set_destroy(ns)
+        return rc
+
+    assert failing_call(-1, 1) != 0
+    assert b"signature step" in lib.act_node_last_error(nd)
+    seen = {}
+
+    def other():
+        seen["before"] = lib.act_node_last_error(nd)          # never failed here: the handle's latest
+        seen["rc"] = failing_call(0, -1)
+        seen["after"] = lib.act_node_last_error(nd)
+    t = threading.Thread(target=other); t.start(); t.join()
+    assert b"signature step" in seen["before"] and seen["rc"] != 0 and b"nullifier set" in seen["after"]
+    assert b"signature step" in lib.act_node_last_error(nd)   # this thread's own failure, not the other thread's later one
+    lib.act_node_destroy(nd)
