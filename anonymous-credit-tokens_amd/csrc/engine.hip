@@ -203,8 +203,8 @@ int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
 // Host memory the device can read in place: hipHostMalloc / hipHostRegister memory is mapped into the device's address space, and the
 // spend-proof kernels read every proof byte once or twice, spread over the kernels' whole run time -- 9 GB/s at full rate, a fraction
 // of the link.  Reading in place takes the staging copy out from in front of a single-chunk call's first kernel (tools/
-// midsize_probe.py: 4 096 proofs 11.9 -> 10.5 ms, 16 384: 39.6 -> 35.9; what the same call takes from HBM: 10.1 / 35.3).  Only for PUBLIC
-// inputs (proofs, wire bytes): secrets keep their staged, wiped copies.  Returns the device address of p, or null (pageable memory,
+// midsize_probe.py: 4 096 proofs 11.9 -> 10.5 ms, 16 384: 39.6 -> 35.9; what the same call takes from HBM: 10.1 / 35.3).  Only for proof
+// RECORDS (public, read in 2 KiB-contiguous wavefront loads): wire bytes and secrets keep their staged (secrets: wiped) copies.  Returns the device address of p, or null (pageable memory,
 // a range that leaves its allocation, memory pinned under another device, or ACT_NO_MAPPED_READS set).
 const uint8_t* mapped_view(const act_ctx* c, const uint8_t* p, size_t bytes) {
   static const bool off = getenv("ACT_NO_MAPPED_READS") != nullptr;

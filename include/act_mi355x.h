@@ -48,10 +48,10 @@
  * point takes the context's lock, so a context shared between host threads serves them one at a time; different contexts
  * (e.g. one per GPU) run concurrently (batches shard across GPUs with no collective).  Contexts of one process on the
  * same GPU with the same Params share one set of fixed-base tables.
- * Host memory may be pageable or pinned.  Spend proofs and SpendProof wire bytes (public inputs) that lie in pinned memory
- * (hipHostMalloc / hipHostRegister under the context's device) are read by the kernels in place over the link -- no staging copy in
- * front of the first kernel; a caller must therefore not write to them while the call runs.  Everything else, and pageable memory,
- * is staged through the context's own buffers, which are wiped when the call ends.  (ACT_NO_MAPPED_READS=1: always stage.)
+ * Host memory may be pageable or pinned.  Spend-proof RECORDS (public inputs) that lie in pinned memory (hipHostMalloc /
+ * hipHostRegister under the context's device) are read by the kernels in place over the link -- no staging copy in front of the
+ * first kernel; a caller must therefore not write to them while the call runs.  Everything else (wire bytes included), and pageable
+ * memory, is staged through the context's own buffers, which are wiped when the call ends.  (ACT_NO_MAPPED_READS=1: always stage.)
  * There is no CPU fallback: without a HIP device every entry point fails.
  */
 #ifndef ACT_MI355X_H
