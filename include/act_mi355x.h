@@ -214,7 +214,9 @@ int act_pre_issuance_random_batch(act_ctx *ctx, size_t n, int mem, const uint8_t
 
 /* PreIssuance::request: pre n*64, rng n*128 -> req n*128 */
 int act_request_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *pre, const uint8_t *rng, uint8_t *out_req);
-/* PrivateKey::issue: req n*128, c n*32, rng (n or #accepted)*128 -> resp n*160, status n */
+/* PrivateKey::issue: req n*128, c n*32, rng (n or #accepted)*128 -> resp n*160, status n.  ACT_RNG_SEQUENTIAL with n == 1: the buffer
+ * must hold its 128 bytes WHATEVER the verdict -- a one-lane call computes the signature beside the check and reads the slice first
+ * (the bytes of a rejected lane go nowhere).  A caller that must not even hold bytes for a rejected item uses the two halves below. */
 int act_issue_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *req, const uint8_t *c,
                     const uint8_t *rng, int rng_mode, uint8_t *out_resp, uint8_t *status);
 /* PreIssuance::to_credit_token: pre n*64, w 32 (host), req n*128, resp n*160 -> token n*160, status n */
@@ -233,7 +235,8 @@ int act_prove_spend_seeded_batch(act_ctx *ctx, size_t n, int mem, const uint8_t 
 /* spend-proof verification only (src/lib.rs:787-844): proof -> status n; out_kprime (nullable) n*32 = enc(K') */
 int act_verify_spend_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof,
                            uint8_t *status, uint8_t *out_kprime);
-/* PrivateKey::refund: proof, rng (n or #accepted)*128 -> refund n*128, status n */
+/* PrivateKey::refund: proof, rng (n or #accepted)*128 -> refund n*128, status n.  As for act_issue_batch: a one-lane ACT_RNG_SEQUENTIAL
+ * call needs its 128 bytes present whatever the verdict (the signature is computed beside the verification). */
 int act_refund_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof, const uint8_t *rng,
                      int rng_mode, uint8_t *out_refund, uint8_t *status);
 /* PreRefund::to_credit_token: prerefund n*96, proof, refund n*128, w 32 (host) -> token n*160, status n */
