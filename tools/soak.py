@@ -92,7 +92,36 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
         eng.set_coalescing(0)
         if errs:
             raise errs[0]
+    # ACT_SOAK_TINY=1: the same proofs once more as refunds of 1 - 64 proofs -- the calls whose signature is computed beside the
+    # verification (engine.hip spend_small_locked) -- per-lane rng from pageable memory, from pinned memory read in place, and one-proof
+    # calls with the sequential convention; every answer against the batch answers above and, for one-proof calls, the oracle
+    tiny_note = ""
+    if os.environ.get("ACT_SOAK_TINY"):
+        import numpy as np, torch
+        eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
+        st2_b, rf_b = eng.refund(sk, t, rrng)
+        pin_p = torch.from_numpy(np.frombuffer(t, np.uint8).copy()).pin_memory(); pin_r = torch.from_numpy(np.frombuffer(rrng, np.uint8).copy()).pin_memory()
+        p_sk, _k = capi._in(sk, 64)
+        i = calls = 0
+        while i < n:
+            k = min(n - i, r.choice((1, 1, 1, 2, 3, 7, 33, 64))); calls += 1
+            how = r.randrange(3)
+            if how == 0:
+                got = eng.refund(sk, t[pb * i:pb * (i + k)], rrng[128 * i:128 * (i + k)], capi.RNG_PER_LANE)
+            elif how == 1:
+                o_rf = torch.zeros(128 * k, dtype=torch.uint8).pin_memory(); o_st = torch.full((k,), 9, dtype=torch.uint8).pin_memory()
+                eng._ck(eng.lib.act_refund_batch(eng.ctx, k, capi.MEM_HOST, p_sk, pin_p.data_ptr() + pb * i, pin_r.data_ptr() + 128 * i, capi.RNG_PER_LANE, o_rf.data_ptr(), o_st.data_ptr()))
+                got = (o_st.numpy().tobytes(), o_rf.numpy().tobytes())
+            else:
+                k = 1
+                got = eng.refund(sk, t[pb * i:pb * (i + 1)], rrng[128 * i:128 * (i + 1)], capi.RNG_SEQUENTIAL)
+                so, ro = octx.refund(sk, t[pb * i:pb * (i + 1)], rrng[128 * i:128 * (i + 1)])
+                assert got == (bytes([so]), ro), ("one-proof refund vs oracle", L, i)
+            assert got == (st2_b[i:i + k], rf_b[128 * i:128 * (i + k)]), ("tiny refund", L, i, k, how)
+            i += k
+        assert eng.secret_residue() == 0
+        tiny_note = "; %d refunds of 1 - 64 proofs (signature beside the verification; pageable / pinned-in-place / sequential one-proof) == the batch answers" % calls
     hist = {}
     for s_ in st_o: hist[s_] = hist.get(s_, 0) + 1
-    print("L=%d: %d proofs, statuses %s: engine == oracle (both transcript modes, refunds sampled)%s" % (L, n, dict(sorted(hist.items())), "; %d merged small calls from %d threads == the batch answers" % (len(cuts), T) if T else ""))
+    print("L=%d: %d proofs, statuses %s: engine == oracle (both transcript modes, refunds sampled)%s" % (L, n, dict(sorted(hist.items())), ("; %d merged small calls from %d threads == the batch answers" % (len(cuts), T) if T else "") + tiny_note))
     eng.close()
