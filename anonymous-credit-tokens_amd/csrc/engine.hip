@@ -1188,6 +1188,10 @@ struct SmallTicket {
 static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proof, bool sign, const uint8_t* rng, int rng_mode, uint8_t* out_refund,
                               uint8_t* status, uint8_t* out_kprime, const uint8_t* d_ready = nullptr) {
   SmallTicket ticket(SmallGate::of(c->device));      // held until this call's work has left the GPU (sync_all below)
+  // ACT_SMALL_TRACE=1 (diagnostics): host-side time stamps of this schedule on stderr -- enqueue, wait, outputs
+  static const bool small_trace = getenv("ACT_SMALL_TRACE") != nullptr;
+  const auto t_in = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count(); };
   const SpendTranscript st{c->L};
   const size_t pb = ProofLayout{c->L}.bytes(), L = (size_t)c->L;
   static const size_t sub_env = [] { const char* e = getenv("ACT_SMALL_SUB"); return e ? (size_t)atol(e) : (size_t)0; }();      // tuning knob: proofs per sub-chunk
@@ -1330,7 +1334,10 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     if ((rc = dev_out_end(c, sl, mem, out_refund, d_out, n * 128))) return rc;
   }
   if ((rc = copy_status_out(c, sl, mem, status, (uint32_t)n))) return rc;
-  return sync_all(c);
+  const double t_enq = small_trace ? since() : 0;
+  rc = sync_all(c);
+  if (small_trace) fprintf(stderr, "small n=%zu sign=%d: enqueued after %.0f us, GPU done after %.0f us\n", n, (int)sign, t_enq, since());
+  return rc;
 }
 
 // verify (sign == false) or refund (sign == true), two-slot software pipeline: stage 1 of chunk i+1 is enqueued before
