@@ -83,3 +83,36 @@ def test_pinned_host_proofs_are_read_in_place(engine_factory, oracle, bench_para
     assert _h2d_bytes(eng) < M * pb
     assert (t_st.numpy().tobytes(), t_out.numpy().tobytes()) == ref
     assert eng.secret_residue() == 0
+
+
+def test_registered_host_memory_is_read_in_place_too(engine_factory, oracle, bench_params):
+    """hipHostRegister on an ordinary allocation (what a server would do with its receive buffers): mapped, so read in place; the same
+    buffer after hipHostUnregister is pageable again and is staged.  Same verdicts either way."""
+    import ctypes as C
+    from act_amd import capi
+    L = 8
+    eng = engine_factory(bench_params, L, max_batch=96, transcript=1)
+    octx = oracle.ctx(bench_params, L)
+    sk = octx.private_key_random(shake("mr-sk", 64))
+    N = 48
+    proofs = bytearray(_proofs(eng, sk, N, "mr3"))
+    pb = eng.proof_bytes
+    proofs[pb * 7 + 33] ^= 1
+    want = octx.verify_spend_batch(sk, bytes(proofs), 4)
+    buf = np.frombuffer(bytes(proofs), np.uint8).copy()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]; hip.hipHostUnregister.argtypes = [C.c_void_p]
+    assert hip.hipHostRegister(buf.ctypes.data, buf.nbytes, 0) == 0
+    try:
+        st = np.full(N, 9, np.uint8)
+        eng.prof_reset(); eng.prof_enable(True)
+        eng.verify_spend_ptr(sk, N, capi.MEM_HOST, buf.ctypes.data, st.ctypes.data)
+        eng.prof_enable(False)
+        assert st.tobytes() == want and _h2d_bytes(eng) < N * pb
+    finally:
+        assert hip.hipHostUnregister(buf.ctypes.data) == 0
+    st = np.full(N, 9, np.uint8)
+    eng.prof_reset(); eng.prof_enable(True)
+    eng.verify_spend_ptr(sk, N, capi.MEM_HOST, buf.ctypes.data, st.ctypes.data)
+    eng.prof_enable(False)
+    assert st.tobytes() == want and _h2d_bytes(eng) >= N * pb
