@@ -1134,7 +1134,8 @@ static int copy_chain_record(act_ctx* c, Slot& sl, bool out);
 // two-slot pipeline of 65 536-proof chunks (one lane per proof is the cheaper form once a launch fills the chip: DESIGN.md section 8).
 // Scratch of the roles lives in d_small, wiped like every other key-dependent buffer (finish_call).
 enum { SM_IN = 0, SM_A, SM_C, SM_JOIN, SM_TAIL, SM_BITS, SM_READY, SM_D2H, SM_K, SM_SPEC, SM_EVENTS };
-constexpr size_t SPEC_PARK_BYTES = (size_t)TINY_MAX * PREP_BUCKET_SETS * BUCKET_WORDS * 4;      // k_sign_fused parks in set 2 of a lane's three
+constexpr size_t SPEC_HELD_OFF = (size_t)TINY_MAX * PREP_BUCKET_SETS * BUCKET_WORDS * 4;        // k_sign_fused parks in set 2 of a lane's three ...
+constexpr size_t SPEC_PARK_BYTES = SPEC_HELD_OFF + (size_t)TINY_MAX * 128;                        // ... and the finished records wait here for their verdicts
 static int small_prepare(act_ctx* c, size_t n, size_t subs) {
   if (!c->aux[0]) {
     int least = 0, greatest = 0;
@@ -1200,7 +1201,11 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   int rc = small_prepare(c, n, K); if (rc) return rc;
   c->aux_used = true;
   Slot& sl = c->slots[0];
-  hipStream_t s_bits = sl.stream, s_tail = c->slots[1].stream, s_a = c->aux[0], s_b = c->aux[1], s_e = c->aux[2], s_x = c->aux[3];
+  // One sub-chunk (every call unless ACT_SMALL_SUB cuts finer): the range kernel's own line -- digits, range kernel, encodings, hash,
+  // verdict -- runs IN ORDER on one stream; a dependency between streams costs 20 - 50 us of event latency each, and this line is the
+  // call's critical path (tools/small_batch_timeline.py).  Only the per-proof kernels, which run beside it, meet it through events.
+  const bool inorder = K == 1;
+  hipStream_t s_bits = sl.stream, s_tail = c->slots[1].stream, s_a = c->aux[0], s_b = c->aux[1], s_e = inorder ? sl.stream : c->aux[2], s_x = c->aux[3];
   auto ev = [&](size_t k, int what) { return c->sm_ev[k * SM_EVENTS + what]; };
   const bool host_tr = c->tr_mode == ACT_TRANSCRIPT_HOST;
   // device views of the caller's arrays (staged on slot 0 for host memory; the copies themselves go piece by piece below)
@@ -1230,9 +1235,9 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   }
   HIPCK(c, hipMemsetAsync(sl.d_flags, 0, n * 4, s_x));               // every kernel ORs its flags in
   // A tiny refund signs BESIDE its verification: X_A = g + K' exists as soon as k_spend_tail has run (1.3 ms into a 1.9 ms call), and the
-  // signature's dependent chain (X_A -> (e+x)^-1 -> the quartered products, 0.8 ms) then runs on the tail's stream while the range
-  // kernel, the encodings and the hash finish; only the last step (add the quarters, encode, hash, z: k_sign_fused phase 2) waits for
-  // the verdict.  A lane's e, alpha are read before its verdict is known, which is observable only if the slice a lane draws depends
+  // WHOLE signature (X_A -> (e+x)^-1 -> the quartered products -> encodings, hash, z: k_sign_fused phase 3, 1.0 ms) then runs on the
+  // tail's stream while the range kernel, the encodings and the hash finish; the records wait in a buffer of the context's and a copy
+  // kernel hands out those the verdicts allow (launch_sign_commit), zeroing the rest and the buffer.  A lane's e, alpha are read before its verdict is known, which is observable only if the slice a lane draws depends
   // on other lanes' verdicts: ACT_RNG_PER_LANE or a single lane (as PrivateKey::issue's tiny path, k_sign.hip).  A rejected lane's
   // partial points are zeroed by the finish like everybody's; its record is zero.
   const bool spec_sign = sign && K == 1 && n <= TINY_MAX && tiny_enabled(c) && (rng_mode == ACT_RNG_PER_LANE || (rng_mode == ACT_RNG_SEQUENTIAL && n == 1));
@@ -1246,7 +1251,8 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     }
     launch_iota(sl.d_slot, (uint32_t)n, 0u, s_tail);
     sf.P = c->P; sf.K = c->key; sf.n = (uint32_t)n; sf.label = LABEL_REFUND; sf.xa = sl.d_xa; sf.rng_slot = sl.d_slot; sf.rng = d_rng;
-    sf.status_in = sl.d_status; sf.status = sl.d_status; sf.out = d_out; sf.trs = sl.d_trs; sf.pbk = c->d_small; sf.group_counter = group_counters(c, sl);
+    sf.status_in = sl.d_status; sf.status = sl.d_status; sf.out = reinterpret_cast<uint8_t*>(c->d_small) + SPEC_HELD_OFF; sf.trs = sl.d_trs; sf.pbk = c->d_small;
+    sf.group_counter = group_counters(c, sl); sf.phase = 3;
   }
   std::vector<SpendArgs> args(K);
   for (size_t k = 0; k < K; k++) {
@@ -1265,8 +1271,13 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     uint32_t* const small0 = c->d_small + SPEC_PARK_BYTES / 4;
     a.pbk = small0 + off * PREP_BUCKET_SETS * BUCKET_WORDS; a.part = small0 + n * PREP_BUCKET_SETS * BUCKET_WORDS + off * PART_POINTS * GE_WORDS;
     for (hipStream_t s : {s_a, s_b, s_tail}) HIPCK(c, hipStreamWaitEvent(s, ev(k, SM_IN), 0));
-    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 4, s_a); }))) return rc;      // C1: digits and h2 terms of the range kernel
-    HIPCK(c, hipEventRecord(ev(k, SM_C), s_a));
+    if (inorder) {
+      HIPCK(c, hipStreamWaitEvent(s_bits, ev(k, SM_IN), 0));
+      if ((rc = prof_launch_on(c, sl, s_bits, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 4, s_bits); }))) return rc;      // C1: digits and h2 terms of the range kernel
+    } else {
+      if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 4, s_a); }))) return rc;
+      HIPCK(c, hipEventRecord(ev(k, SM_C), s_a));
+    }
     if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 5, s_a); }))) return rc;      // C2: the fixed-base part of A2
     if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_A, m, [&] { launch_spend_prep_role(a, 0, s_a); }))) return rc;
     HIPCK(c, hipEventRecord(ev(k, SM_A), s_a));
@@ -1285,14 +1296,13 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
       HIPCK(c, hipStreamWaitEvent(s_x, ev(k, SM_K), 0));
       if ((rc = prof_launch_on(c, sl, s_x, PK_SPEND_TAIL, m, [&] { launch_spend_tail_c(a, s_x); }))) return rc;
       HIPCK(c, hipEventRecord(ev(k, SM_TAIL), s_x));
-      sf.phase = 1;
       if ((rc = prof_launch_on(c, sl, s_tail, PK_SIGN_A, m, [&] { launch_sign_fused(sf, false, s_tail); }))) return rc;
       HIPCK(c, hipEventRecord(ev(k, SM_SPEC), s_tail));
     }
-    HIPCK(c, hipStreamWaitEvent(s_bits, ev(k, SM_C), 0));               // implies SM_IN
+    if (!inorder) HIPCK(c, hipStreamWaitEvent(s_bits, ev(k, SM_C), 0));               // implies SM_IN
     if ((rc = prof_launch_on(c, sl, s_bits, PK_SPEND_BITS, (uint64_t)m * L, [&] { launch_spend_bits(a, s_bits); }))) return rc;
     HIPCK(c, hipEventRecord(ev(k, SM_BITS), s_bits));
-    HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_BITS), 0));
+    if (!inorder) HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_BITS), 0));
     if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_ENC, (uint64_t)m * L * 2, [&] { launch_spend_enc_small(a, s_e); }))) return rc;
     HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_JOIN), 0)); HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_TAIL), 0));
     if (!host_tr) {
@@ -1318,14 +1328,15 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     }
   // everything of this call joins slot 0's stream, which carries what is left: outputs, the signatures, the wipe (finish_call)
   hipStream_t last = host_tr ? s_x : s_e;
-  HIPCK(c, hipEventRecord(ev(0, SM_IN), last));                        // (the events of sub-chunk 0 have all been consumed)
-  HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_IN), 0));
+  if (last != s_bits) {
+    HIPCK(c, hipEventRecord(ev(0, SM_IN), last));                      // (the events of sub-chunk 0 have all been consumed)
+    HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_IN), 0));
+  }
   sl.last_spend_lanes = n; c->last_spend_slot = 0;
   if (out_kprime && (rc = dev_out_end(c, sl, mem, out_kprime, d_kprime, n * 32))) return rc;
   if (spec_sign) {
     HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_SPEC), 0));
-    sf.phase = 2;
-    if ((rc = prof_launch(c, sl, PK_SIGN_B, n, [&] { launch_sign_fused(sf, false, sl.stream); }))) return rc;
+    if ((rc = prof_launch(c, sl, PK_SIGN_B, n, [&] { launch_sign_commit(sl.d_status, sf.out, d_out, (uint32_t)n, 128u, sl.stream); }))) return rc;
     if ((rc = dev_out_end(c, sl, mem, out_refund, d_out, n * 128))) return rc;
   } else if (sign) {
     const uint8_t* d_rng; size_t cursor = 0;

@@ -265,6 +265,7 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
   const int phase = CHECK ? 0 : a.phase;
   const uint32_t role = phase == 2 ? (uint32_t)ROLES : blockIdx.y + (CHECK ? 0u : 1u);        // uniform over the block
   const bool in = p < a.n;
+  const bool spec = phase == 3;                                // roles + finish like phase 0, but for every lane and without looking at a verdict
   const bool sign = in && (CHECK || phase != 0 || a.status_in[in ? p : 0] == 0);
   const uint8_t* rec = a.point ? a.point + (size_t)(in ? p : 0) * a.point_stride : nullptr;
   const uint8_t* rng = a.rng + (size_t)((in && a.rng_slot) ? a.rng_slot[p] : (in ? p : 0)) * 128;
@@ -328,13 +329,13 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
   }
   ACT_STAMP(3);
   if (phase == 1) return;                                      // (the finish is a launch of its own, behind the verification's last kernel)
-  if (phase == 0 && !group_last_arrival(a.group_counter + blockIdx.x, CHECK ? (uint32_t)ROLES : (uint32_t)ROLES - 1u)) return;
+  if (phase != 2 && !group_last_arrival(a.group_counter + blockIdx.x, CHECK ? (uint32_t)ROLES : (uint32_t)ROLES - 1u)) return;
   ACT_STAMP(4);
   // ---- the last block of the group to arrive: A and Y_A from their quarters, the hash, z, the record ------------------------------
   if (!in) return;
   const int rec_out = a.label == LABEL_RESPOND ? 160 : 128;
   uint8_t* out = a.out + (size_t)p * rec_out;
-  const uint8_t v = __atomic_load_n(a.status + p, __ATOMIC_RELAXED);      // (written by another block of this launch)
+  const uint8_t v = spec ? (uint8_t)0 : __atomic_load_n(a.status + p, __ATOMIC_RELAXED);      // (written by another block of this launch)
   if (v == 0) {
     uint32_t enc_a[8];
     ge sa = ge_load(park), sy = ge_load(park + 4 * GE_WORDS);
@@ -359,6 +360,21 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
     if (rec) { q = const_cast<uint8_t*>(rec); for (uint32_t i = 0; i < a.point_stride; i += 32) zero8(q + i); }
     if (a.c_amount) zero8(const_cast<uint8_t*>(a.c_amount) + (size_t)p * 32);
   }
+}
+// a signature computed before its verdict (k_sign_fused phase 3) is handed out, or not
+__global__ void __launch_bounds__(64) k_sign_commit(const uint8_t* status, uint8_t* held, uint8_t* out, uint32_t n, uint32_t rec_bytes) {
+  const uint32_t p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n) return;
+  const bool ok = status[p] == 0;
+  for (uint32_t i = 0; i < rec_bytes; i += 16) {
+    uint4* h = reinterpret_cast<uint4*>(held + (size_t)p * rec_bytes + i);
+    const uint4 v = *h;
+    *reinterpret_cast<uint4*>(out + (size_t)p * rec_bytes + i) = ok ? v : make_uint4(0, 0, 0, 0);
+    *h = make_uint4(0, 0, 0, 0);
+  }
+}
+void launch_sign_commit(const uint8_t* status, uint8_t* held, uint8_t* out, uint32_t n, uint32_t rec_bytes, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_sign_commit, dim3((n + 63) / 64), dim3(64), 0, s, status, held, out, n, rec_bytes);
 }
 void launch_sign_fused(const SignFusedArgs& a, bool check, hipStream_t s) {
   if (!a.n) return;

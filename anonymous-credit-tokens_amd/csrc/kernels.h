@@ -135,8 +135,10 @@ struct SignFusedArgs {
   uint8_t* trs_req;                                // CHECK: n * SMALL_TR_STRIDE "request" transcripts
   uint32_t* group_counter;                         // one word per group of 64 lanes, zero between launches: which block arrives last
   int check_only;                                  // CHECK: only the check role runs (act_issue_check_batch): status out, no signature
-  int phase;                                       // !CHECK: 0 = roles, then the last block to arrive finishes; 1 = roles only, for EVERY lane (the verdicts
-                                                   // are not known yet: a tiny refund signs beside its verification); 2 = the finish only, by the verdicts in `status`
+  int phase;                                       // !CHECK: 0 = roles, then the last block to arrive finishes, for the lanes status_in accepts; 3 = the same for
+                                                   // EVERY lane, `status` neither read nor written (the verdicts are not known yet: a tiny refund signs beside its
+                                                   // verification, into a buffer of the engine's; launch_sign_commit hands out what the verdicts allow);
+                                                   // 1 = roles only, every lane; 2 = the finish only, by the verdicts in `status` (the two halves of 3)
   int wipe_rng;                                    // rng is the engine's staged copy: zero it when done
   unsigned long long* dbg;                         // -DACT_TINY_TIMING builds only: 8 time stamps per role
 };
@@ -244,6 +246,7 @@ void launch_spend_coords(const SpendArgs& a, hipStream_t s);
 void launch_spend_bits(const SpendArgs& a, hipStream_t s);
 void launch_spend_enc(const SpendArgs& a, hipStream_t s);
 void launch_spend_tail(const SpendArgs& a, hipStream_t s);
+void launch_sign_commit(const uint8_t* status, uint8_t* held, uint8_t* out, uint32_t n, uint32_t rec_bytes, hipStream_t s);      // out[p] = status[p] == 0 ? held[p] : 0; held wiped
 void launch_spend_tail_k(const SpendArgs& a, hipStream_t s);      // the tail in two launches: K', X_A ...
 void launch_spend_tail_c(const SpendArgs& a, hipStream_t s);      // ... then C (spend_lanes.h spend_tail_k_lane / spend_tail_c_lane)
 void launch_spend_finish(const SpendArgs& a, hipStream_t s);
