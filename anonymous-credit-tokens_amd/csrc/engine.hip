@@ -1235,7 +1235,7 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
   }
   HIPCK(c, hipMemsetAsync(sl.d_flags, 0, n * 4, s_x));               // every kernel ORs its flags in
   // A tiny refund signs BESIDE its verification: X_A = g + K' exists as soon as k_spend_tail has run (1.3 ms into a 1.9 ms call), and the
-  // WHOLE signature (X_A -> (e+x)^-1 -> the quartered products -> encodings, hash, z: k_sign_fused phase 3, 1.0 ms) then runs on the
+  // WHOLE signature (X_A -> (e+x)^-1 -> the quartered products -> encodings, hash, z: k_sign_fused with before_verdict, 1.0 ms) then runs on the
   // tail's stream while the range kernel, the encodings and the hash finish; the records wait in a buffer of the context's and a copy
   // kernel hands out those the verdicts allow (launch_sign_commit), zeroing the rest and the buffer.  A lane's e, alpha are read before its verdict is known, which is observable only if the slice a lane draws depends
   // on other lanes' verdicts: ACT_RNG_PER_LANE or a single lane (as PrivateKey::issue's tiny path, k_sign.hip).  A rejected lane's
@@ -1252,7 +1252,7 @@ static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proo
     launch_iota(sl.d_slot, (uint32_t)n, 0u, s_tail);
     sf.P = c->P; sf.K = c->key; sf.n = (uint32_t)n; sf.label = LABEL_REFUND; sf.xa = sl.d_xa; sf.rng_slot = sl.d_slot; sf.rng = d_rng;
     sf.status_in = sl.d_status; sf.status = sl.d_status; sf.out = reinterpret_cast<uint8_t*>(c->d_small) + SPEC_HELD_OFF; sf.trs = sl.d_trs; sf.pbk = c->d_small;
-    sf.group_counter = group_counters(c, sl); sf.phase = 3;
+    sf.group_counter = group_counters(c, sl); sf.before_verdict = 1;
   }
   std::vector<SpendArgs> args(K);
   for (size_t k = 0; k < K; k++) {

@@ -262,11 +262,10 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
   // roles: 0 = the check; 1..4 = the quarters of A; 5..8 = the quarters of Y_A (msm.h chain_ct_quarter); 9 = X_g, Y_g, X_A and the
   // transcript's head
   enum { R_CHECK = 0, R_A0 = 1, R_Y0 = 5, R_M = 9, ROLES = 10 };
-  const int phase = CHECK ? 0 : a.phase;
-  const uint32_t role = phase == 2 ? (uint32_t)ROLES : blockIdx.y + (CHECK ? 0u : 1u);        // uniform over the block
+  const uint32_t role = blockIdx.y + (CHECK ? 0u : 1u);        // uniform over the block
   const bool in = p < a.n;
-  const bool spec = phase == 3;                                // roles + finish like phase 0, but for every lane and without looking at a verdict
-  const bool sign = in && (CHECK || phase != 0 || a.status_in[in ? p : 0] == 0);
+  const bool spec = !CHECK && a.before_verdict;                // every lane is signed, no verdict is looked at (see kernels.h)
+  const bool sign = in && (CHECK || spec || a.status_in[in ? p : 0] == 0);
   const uint8_t* rec = a.point ? a.point + (size_t)(in ? p : 0) * a.point_stride : nullptr;
   const uint8_t* rng = a.rng + (size_t)((in && a.rng_slot) ? a.rng_slot[p] : (in ? p : 0)) * 128;
   sc e = sc_zero(), alpha = sc_zero();
@@ -316,7 +315,7 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
       if (!dec_ok && !CHECK) a.status[p] = 255;                  // (with CHECK the check role says so)
       ristretto_encode(enc, xa); tr_put_bytes(el2 + 40 * 2, enc);
     }
-  } else if (sign && phase != 2) {
+  } else if (sign) {
     bool dec_ok;
     const ge xa = sign_fused_xa(a, p, rec, dec_ok);
     ACT_STAMP(1);
@@ -328,8 +327,7 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
     ge_store(park + (size_t)(role - R_A0) * GE_WORDS, chain_ct_quarter(xa, is_a ? inv : sc_mul(alpha, inv), q));
   }
   ACT_STAMP(3);
-  if (phase == 1) return;                                      // (the finish is a launch of its own, behind the verification's last kernel)
-  if (phase != 2 && !group_last_arrival(a.group_counter + blockIdx.x, CHECK ? (uint32_t)ROLES : (uint32_t)ROLES - 1u)) return;
+  if (!group_last_arrival(a.group_counter + blockIdx.x, CHECK ? (uint32_t)ROLES : (uint32_t)ROLES - 1u)) return;
   ACT_STAMP(4);
   // ---- the last block of the group to arrive: A and Y_A from their quarters, the hash, z, the record ------------------------------
   if (!in) return;
@@ -361,7 +359,7 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
     if (a.c_amount) zero8(const_cast<uint8_t*>(a.c_amount) + (size_t)p * 32);
   }
 }
-// a signature computed before its verdict (k_sign_fused phase 3) is handed out, or not
+// a signature computed before its verdict (k_sign_fused with before_verdict) is handed out, or not
 __global__ void __launch_bounds__(64) k_sign_commit(const uint8_t* status, uint8_t* held, uint8_t* out, uint32_t n, uint32_t rec_bytes) {
   const uint32_t p = blockIdx.x * 64 + threadIdx.x;
   if (p >= n) return;
@@ -380,7 +378,7 @@ void launch_sign_fused(const SignFusedArgs& a, bool check, hipStream_t s) {
   if (!a.n) return;
   if (check && a.check_only) { hipLaunchKernelGGL(k_sign_fused<true>, dim3((a.n + 63) / 64, 1), dim3(64), 0, s, a); return; }
   if (check) hipLaunchKernelGGL(k_sign_fused<true>, dim3((a.n + 63) / 64, 10), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(k_sign_fused<false>, dim3((a.n + 63) / 64, a.phase == 2 ? 1 : 9), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(k_sign_fused<false>, dim3((a.n + 63) / 64, 9), dim3(64), 0, s, a);
 }
 
 // ---- PreIssuance::request for TINY calls: the whole method in ONE kernel -------------------------------------------------------

@@ -135,10 +135,9 @@ struct SignFusedArgs {
   uint8_t* trs_req;                                // CHECK: n * SMALL_TR_STRIDE "request" transcripts
   uint32_t* group_counter;                         // one word per group of 64 lanes, zero between launches: which block arrives last
   int check_only;                                  // CHECK: only the check role runs (act_issue_check_batch): status out, no signature
-  int phase;                                       // !CHECK: 0 = roles, then the last block to arrive finishes, for the lanes status_in accepts; 3 = the same for
-                                                   // EVERY lane, `status` neither read nor written (the verdicts are not known yet: a tiny refund signs beside its
-                                                   // verification, into a buffer of the engine's; launch_sign_commit hands out what the verdicts allow);
-                                                   // 1 = roles only, every lane; 2 = the finish only, by the verdicts in `status` (the two halves of 3)
+  int before_verdict;                              // !CHECK: EVERY lane is signed and `status` is neither read nor written -- the verdicts are not known yet: a tiny
+                                                   // refund signs beside its verification, into a buffer of the engine's; launch_sign_commit then hands out
+                                                   // what the verdicts allow (engine.hip spend_small_locked)
   int wipe_rng;                                    // rng is the engine's staged copy: zero it when done
   unsigned long long* dbg;                         // -DACT_TINY_TIMING builds only: 8 time stamps per role
 };
