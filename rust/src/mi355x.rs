@@ -105,9 +105,9 @@ pub struct Gpu(*mut ActNode);
 // SAFETY: the handle is only ever passed to act_node_* entry points.  Calls that are cut over the GPUs take the node's lock
 // (csrc/node.cpp `node_lock`); calls small enough to merge (act_node_set_coalescing) bypass it and are serialised by the lock of the
 // one context they go to and by that context's request combiner (csrc/coalesce.h) -- either way no two threads are ever inside the
-// same context's buffers.  act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies it under
-// the handle's lock into a buffer of the CALLING thread (valid until this thread asks again), so `check` below never reads a
-// string another thread's failing call is rewriting.
+// same context's buffers.  act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies the
+// CALLING thread's own last failure on the handle (kept per thread by the library) into a buffer of that thread, valid until it asks
+// again, so `check` below neither reads a string another thread's failing call is rewriting nor reports another thread's error.
 unsafe impl Send for Gpu {}
 unsafe impl Sync for Gpu {}
 impl Drop for Gpu {
