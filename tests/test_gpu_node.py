@@ -111,8 +111,8 @@ def test_check_then_sign_equals_one_call(engine_factory, bench_params):
 def test_bench_two_ranks_on_one_device():
     """`python bench.py --gpus 2` run DIRECTLY, the way the driver runs it: the bench must start its two ranks itself (round 3
     parsed --gpus and never read it: an 8-GPU driver run would have measured one GPU), every rank must see WORLD_SIZE == --gpus,
-    `value` must be the metric as BASELINE.json words it (ONE batch over the whole node: strong scaling) with the weak figure
-    alongside, and rank 0 must also time the product's own multi-GPU path (one process, one act_node handle over both devices).
+    `value` must be weak scaling (independent proofs sharded over the ranks, every rank its own batch: per-GPU work fixed) with the
+    strong figure (ONE batch cut over the whole node) alongside, and rank 0 must also time the product's own multi-GPU path (one process, one act_node handle over both devices).
     Two gloo ranks that both drive device 0 through the bench's --dist-backend / --force-device hooks (RCCL refuses two ranks on
     one device)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -124,11 +124,11 @@ def test_bench_two_ranks_on_one_device():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # ONE line, relayed from rank 0
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["cpu_baseline"] is None
-    assert d["config"]["batch_per_gpu"] == 2048 and d["config"]["batch_total"] == 4096
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["batch_per_gpu"] == 4096 and d["config"]["batch_total"] == 8192
     assert d["config"]["transcript"] == "host BLAKE3 (src/transcript.rs)" and "resident in HBM" in d["config"]["workload"]
-    assert d["value"] == d["strong"]["value"]
-    assert abs(d["value"] - 4096 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]          # whole-job aggregate over both ranks
+    assert d["value"] == d["weak"]["value"]
+    assert abs(d["value"] - 2 * 4096 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]      # whole-job aggregate over both ranks
     s, w = d["strong"], d["weak"]
     assert s["batch_total"] == 4096 and s["batch_per_gpu"] == 2048 and s["scaling"] == "strong"
     assert w["batch_per_gpu"] == 4096 and abs(w["value"] - 2 * 4096 * 2 / (w["ms_per_step"] * 2 / 1e3)) < 1e-6 * w["value"]
@@ -137,14 +137,15 @@ def test_bench_two_ranks_on_one_device():
     nm = d["node_multi"]
     assert "error" not in nm, nm
     assert nm["devices"] == [0, 0] and nm["proofs"] == 4096 and nm["value"] > 0 and nm["host_pool"]["threads_created"] <= nm["host_pool"]["pool_size"]
-    # under a launcher (the other way the driver may start it), --scaling weak swaps which of the two is `value`
+    # under a launcher (the other way the driver may start it), --scaling strong swaps which of the two is `value`
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29671",
-           os.path.join(ROOT, "bench.py")] + args + ["--scaling", "weak", "--no-node-multi"]
+           os.path.join(ROOT, "bench.py")] + args + ["--scaling", "strong", "--no-node-multi"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["batch_per_gpu"] == 4096 and d["strong"]["batch_per_gpu"] == 2048
-    assert d["value"] == d["weak"]["value"] and "node_multi" not in d
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 2048 and d["config"]["batch_total"] == 4096
+    assert d["value"] == d["strong"]["value"] and d["weak"]["batch_per_gpu"] == 4096 and "node_multi" not in d
+    assert abs(d["value"] - 4096 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
     # a launcher whose world size disagrees with --gpus is refused: the line would claim GPUs that were not measured
     bad = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29672",
            os.path.join(ROOT, "bench.py")] + args
