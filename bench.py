@@ -394,15 +394,24 @@ def main():
     torch.cuda.set_device(local)
     use_dist = world > 1 or args.force_dist
     ctl = None
+    rccl = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29677")
+        # The default group is gloo on the CPU: it carries the control plane (ranks that wait while rank 0 measures `node_multi` must not
+        # sit in an RCCL barrier kernel that polls on their GPU).  RCCL, as the launch contract asks, carries the barrier and the one
+        # float of the timed region (the path has no collective) in a group of its own; if it cannot come up on this node -- every rank
+        # then fails the same way on the probe -- the measurement goes on over gloo rather than being lost, and the line says so.
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-        # control-plane group on the CPU: ranks that wait while rank 0 measures `node_multi` must not sit in an RCCL barrier
-        # kernel that polls on their GPU
-        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))
+            try:
+                rccl = dist.new_group(backend="nccl")
+                probe = torch.ones(1, device="cuda"); dist.all_reduce(probe, group=rccl); torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as e:
+                sys.stderr.write("bench.py rank %d: RCCL did not come up (%s); barrier and timing reduction over gloo\n" % (rank, repr(e)[:300]))
+                rccl = None
+                args.dist_backend = "gloo (RCCL failed to initialise)"
+        ctl = dist.group.WORLD
 
     from act_amd import capi
     n = 1 << args.batch_log2
@@ -436,7 +445,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            dist.barrier(group=rccl) if rccl is not None else dist.barrier()
         torch.cuda.synchronize()
 
     def timed_region(m, steps, warmup):
@@ -461,8 +470,8 @@ def main():
                                  "transcripts_over_pcie_GBps": round(hs["bytes"] / elapsed / 1e9, 2), "host_hash_GBps_while_hashing": round(hs["bytes"] / hs["hash_s"] / 1e9, 2) if hs["hash_s"] else None,
                                  "host_threads": eng.lib.act_host_usable_cpus()})
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if rccl is not None else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=rccl)      # (group=None is the default, gloo, group)
             elapsed = float(t.item())
         assert os.environ.get("ACT_BENCH_NO_CHECK") or torch.equal(status[:m], expect[:m]), "verification statuses wrong"
         return elapsed, eng.prof(), loc
@@ -544,6 +553,7 @@ def main():
                        "input_generation_s": round(t_gen, 2), "prove_spend_proofs_per_s": round(distinct / t_prove) if t_prove else None},
         }
         if world > 1:
+            out["config"]["dist_backend"] = args.dist_backend + " (barrier + max of the ranks' times; the data path has no collective)"
             out["per_rank"] = per_rank
         else:
             out["rank_report"] = per_rank[0]

@@ -146,6 +146,13 @@ def test_bench_two_ranks_on_one_device():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["batch_per_gpu"] == 2048 and d["config"]["batch_total"] == 4096
     assert d["value"] == d["strong"]["value"] and d["weak"]["batch_per_gpu"] == 4096 and "node_multi" not in d
     assert abs(d["value"] - 4096 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 1e-6 * d["value"]
+    # RCCL that cannot come up (here: two ranks on ONE device, which it refuses) must not cost the measurement: the barrier and the
+    # reduction of the ranks' times fall back to gloo -- the data path has no collective -- and the line says which carried them
+    args_rccl = [a for a in args if a not in ("--dist-backend", "gloo")] + ["--no-node-multi"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args_rccl, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["dist_backend"].startswith("gloo (RCCL failed to initialise)")
     # a launcher whose world size disagrees with --gpus is refused: the line would claim GPUs that were not measured
     bad = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29672",
            os.path.join(ROOT, "bench.py")] + args
