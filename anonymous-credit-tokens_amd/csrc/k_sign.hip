@@ -231,6 +231,7 @@ __global__ void __launch_bounds__(256) k_request_b(RequestArgs a) {
 // before its verdict is known, which changes nothing observable: a rejected lane's record is zero and its nonces never leave the
 // registers; the engine takes this kernel only when the slice a lane would draw does not depend on other lanes' verdicts
 // (ACT_RNG_PER_LANE, or one lane).  One launch instead of six; the dependent chain is max(check, signature) instead of their sum.
+constexpr uint32_t FUSED_CTR_A = 128, FUSED_CTR_Y = 256;      // k_sign_fused: the A quarters' and the Y_A quarters' own counters, beside the group's (engine.hip: 512 words per slot)
 __device__ __forceinline__ bool group_last_arrival(uint32_t* counter, uint32_t roles) {
   __shared__ uint32_t ticket;
   __threadfence();                                             // this block's global writes are visible before its arrival is
@@ -327,19 +328,28 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
     ge_store(park + (size_t)(role - R_A0) * GE_WORDS, chain_ct_quarter(xa, is_a ? inv : sc_mul(alpha, inv), q));
   }
   ACT_STAMP(3);
+  // The four quarters of A meet in whichever of their blocks arrives last (a counter of their own), which adds them and encodes A
+  // while the Y_A blocks do the same for Y_A: two 0.1 ms encodings side by side instead of one after the other in the final block.
+  uint32_t* const enc_park = park + 8 * GE_WORDS;              // enc(A) for the record, words 288..295 of the lane's set (BUCKET_WORDS = 324)
+  if (role >= R_A0 && role < R_M) {
+    const bool is_a = role < R_Y0;
+    if (group_last_arrival(a.group_counter + (is_a ? FUSED_CTR_A : FUSED_CTR_Y) + blockIdx.x, 4u) && sign) {
+      const uint32_t* q0 = park + (size_t)(is_a ? 0 : 4) * GE_WORDS;
+      ge sum = ge_load(q0);
+      for (int q = 1; q < 4; q++) sum = ge_add(sum, ge_load(q0 + (size_t)q * GE_WORDS));
+      ristretto_encode(enc, sum); tr_put_bytes(el2 + 40 * (is_a ? 1 : 4), enc);
+      if (is_a) store8(reinterpret_cast<uint8_t*>(enc_park), enc);
+    }
+  }
   if (!group_last_arrival(a.group_counter + blockIdx.x, CHECK ? (uint32_t)ROLES : (uint32_t)ROLES - 1u)) return;
   ACT_STAMP(4);
-  // ---- the last block of the group to arrive: A and Y_A from their quarters, the hash, z, the record ------------------------------
+  // ---- the last block of the group to arrive: the hash, z, the record -----------------------------------------------------------------
   if (!in) return;
   const int rec_out = a.label == LABEL_RESPOND ? 160 : 128;
   uint8_t* out = a.out + (size_t)p * rec_out;
   const uint8_t v = spec ? (uint8_t)0 : __atomic_load_n(a.status + p, __ATOMIC_RELAXED);      // (written by another block of this launch)
   if (v == 0) {
-    uint32_t enc_a[8];
-    ge sa = ge_load(park), sy = ge_load(park + 4 * GE_WORDS);
-    for (int q = 1; q < 4; q++) { sa = ge_add(sa, ge_load(park + (size_t)q * GE_WORDS)); sy = ge_add(sy, ge_load(park + (size_t)(4 + q) * GE_WORDS)); }
-    ristretto_encode(enc_a, sa); tr_put_bytes(el2 + 40 * 1, enc_a);
-    ristretto_encode(enc, sy); tr_put_bytes(el2 + 40 * 4, enc);
+    uint32_t enc_a[8]; load8(enc_a, reinterpret_cast<const uint8_t*>(enc_park));      // (A and Y_A are in the transcript already)
     ACT_STAMP(5);
     e = load_wide(rng); alpha = load_wide(rng + 64);
     uint32_t w[16];
@@ -352,7 +362,7 @@ __global__ void __launch_bounds__(64) k_sign_fused(SignFusedArgs a) {
     for (int i = 0; i < rec_out; i += 32) zero8(out + i);
   }
   ACT_STAMP(6);
-  if (sign) for (int i = 0; i < 8 * GE_WORDS; i += 4) *reinterpret_cast<uint4*>(park + i) = make_uint4(0, 0, 0, 0);      // the quarters are functions of the nonces
+  if (sign) for (int i = 0; i < 8 * GE_WORDS + 8; i += 4) *reinterpret_cast<uint4*>(park + i) = make_uint4(0, 0, 0, 0);      // the quarters are functions of the nonces
   if (a.wipe_rng) {                                            // the engine's staged copies (issue_tiny): nothing of the call stays behind
     uint8_t* q = const_cast<uint8_t*>(rng); for (int i = 0; i < 128; i += 32) zero8(q + i);
     if (rec) { q = const_cast<uint8_t*>(rec); for (uint32_t i = 0; i < a.point_stride; i += 32) zero8(q + i); }
