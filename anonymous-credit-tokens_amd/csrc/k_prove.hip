@@ -121,7 +121,7 @@ constexpr uint32_t PROVE_WIDE_MAX = 8192;
 void launch_prove_head(const ProveArgs& a, hipStream_t s) {
   if (!a.n) return;
   static const bool no_wide = getenv("ACT_NO_WIDE_PROVE") != nullptr;     // A/B knob
-  if (a.n <= PROVE_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_prove_head_wide, dim3((a.n + 63) / 64, 14), dim3(64), 0, s, a);
+  if (a.n <= PROVE_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_prove_head_wide, dim3((a.n + 63) / 64, 14), dim3(64), isolate_roles((a.n + 63) / 64 * 14), s, a);
   else hipLaunchKernelGGL(k_prove_head, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }
 void launch_prove_bits(const ProveArgs& a, hipStream_t s) {
@@ -134,7 +134,7 @@ void launch_prove_enc(const ProveArgs& a, hipStream_t s) {
   size_t threads = ((size_t)a.n * a.P.L * 3 + PROVE_ENC_BATCH - 1) / PROVE_ENC_BATCH;
   hipLaunchKernelGGL(k_prove_enc, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
 }
-void launch_prove_tail(const ProveArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_prove_tail, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
+void launch_prove_tail(const ProveArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_prove_tail, dim3((a.n + 63) / 64), dim3(64), isolate_role((a.n + 63) / 64), s, a); }
 void launch_prove_resp(const ProveArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t lanes = (size_t)a.n * a.P.L;

@@ -386,9 +386,10 @@ void launch_sign_commit(const uint8_t* status, uint8_t* held, uint8_t* out, uint
 }
 void launch_sign_fused(const SignFusedArgs& a, bool check, hipStream_t s) {
   if (!a.n) return;
-  if (check && a.check_only) { hipLaunchKernelGGL(k_sign_fused<true>, dim3((a.n + 63) / 64, 1), dim3(64), 0, s, a); return; }
-  if (check) hipLaunchKernelGGL(k_sign_fused<true>, dim3((a.n + 63) / 64, 10), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(k_sign_fused<false>, dim3((a.n + 63) / 64, 9), dim3(64), 0, s, a);
+  const unsigned g = (a.n + 63) / 64;
+  if (check && a.check_only) { hipLaunchKernelGGL(k_sign_fused<true>, dim3(g, 1), dim3(64), isolate_roles(g), s, a); return; }
+  if (check) hipLaunchKernelGGL(k_sign_fused<true>, dim3(g, 10), dim3(64), isolate_roles(g * 10), s, a);
+  else hipLaunchKernelGGL(k_sign_fused<false>, dim3(g, 9), dim3(64), isolate_roles(g * 9), s, a);      // (a tiny refund: beside the verification's kernels)
 }
 
 // ---- PreIssuance::request for TINY calls: the whole method in ONE kernel -------------------------------------------------------

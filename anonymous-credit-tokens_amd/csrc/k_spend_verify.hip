@@ -60,13 +60,14 @@ void launch_spend_prep(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKe
 void launch_spend_prep_role(const SpendArgs& a, int role, hipStream_t s) {
   if (!a.n) return;
   const dim3 grid((a.n + 63) / 64), block(64);
+  const unsigned own = isolate_role(grid.x);
   switch (role) {
-    case 0: hipLaunchKernelGGL(k_spend_prep_a, grid, block, 0, s, a); break;
-    case 1: hipLaunchKernelGGL(k_spend_prep_b, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_spend_prep_c, grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(k_spend_prep_c1, grid, block, 0, s, a); break;
-    case 5: hipLaunchKernelGGL(k_spend_prep_c2, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_spend_prep_join, grid, block, 0, s, a); break;
+    case 0: hipLaunchKernelGGL(k_spend_prep_a, grid, block, own, s, a); break;
+    case 1: hipLaunchKernelGGL(k_spend_prep_b, grid, block, own, s, a); break;
+    case 2: hipLaunchKernelGGL(k_spend_prep_c, grid, block, own, s, a); break;
+    case 4: hipLaunchKernelGGL(k_spend_prep_c1, grid, block, own, s, a); break;
+    case 5: hipLaunchKernelGGL(k_spend_prep_c2, grid, block, own, s, a); break;
+    default: hipLaunchKernelGGL(k_spend_prep_join, grid, block, own, s, a); break;
   }
 }
 void launch_spend_coords(const SpendArgs& a, hipStream_t s) {
@@ -78,8 +79,8 @@ void launch_spend_bits(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
   size_t lanes = (size_t)a.n * a.P.L;
   const dim3 grid((unsigned)((lanes + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK));
-  if (a.P.L % 64 == 0) hipLaunchKernelGGL(k_spend_bits<true>, grid, dim3(ACT_BITS_BLOCK), 0, s, a);
-  else hipLaunchKernelGGL(k_spend_bits<false>, grid, dim3(ACT_BITS_BLOCK), 0, s, a);
+  if (a.P.L % 64 == 0) hipLaunchKernelGGL(k_spend_bits<true>, grid, dim3(ACT_BITS_BLOCK), isolate_bits(grid.x), s, a);
+  else hipLaunchKernelGGL(k_spend_bits<false>, grid, dim3(ACT_BITS_BLOCK), isolate_bits(grid.x), s, a);
 }
 void launch_spend_enc(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
@@ -91,9 +92,9 @@ void launch_spend_enc_small(const SpendArgs& a, hipStream_t s) {
   size_t threads = ((size_t)a.n * a.P.L * 2 + ENC_BATCH_SMALL - 1) / ENC_BATCH_SMALL;
   hipLaunchKernelGGL(k_spend_enc_small, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
 }
-void launch_spend_tail_k(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail_k, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
-void launch_spend_tail_c(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail_c, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
-void launch_spend_tail(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail, dim3((a.n + 63) / 64), dim3(64), 0, s, a); }
+void launch_spend_tail_k(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail_k, dim3((a.n + 63) / 64), dim3(64), isolate_role((a.n + 63) / 64), s, a); }
+void launch_spend_tail_c(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail_c, dim3((a.n + 63) / 64), dim3(64), isolate_role((a.n + 63) / 64), s, a); }
+void launch_spend_tail(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_tail, dim3((a.n + 63) / 64), dim3(64), isolate_role((a.n + 63) / 64), s, a); }
 void launch_spend_finish(const SpendArgs& a, hipStream_t s) { if (a.n) hipLaunchKernelGGL(k_spend_finish, dim3((a.n + 255) / 256), dim3(256), 0, s, a); }
 
 }  // namespace act

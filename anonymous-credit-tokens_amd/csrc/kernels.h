@@ -1,6 +1,7 @@
 // kernels.h — argument blocks and launchers shared by the HIP kernels and the host engine.
 // One lane = one proof (head / tail / sign kernels) or one (proof, bit) pair (range-proof kernels).
 #pragma once
+#include <stdlib.h>
 #include <stddef.h>
 #include <stdint.h>
 #if defined(__HIPCC__)
@@ -244,6 +245,18 @@ void launch_spend_enc_small(const SpendArgs& a, hipStream_t s);
 void launch_spend_coords(const SpendArgs& a, hipStream_t s);
 void launch_spend_bits(const SpendArgs& a, hipStream_t s);
 void launch_spend_enc(const SpendArgs& a, hipStream_t s);
+// Launches that leave most of the chip empty (a call of a few hundred proofs, a one-item call's role blocks beside other kernels)
+// want every wavefront on a SIMD of its own: their lanes are dependent chains, and two workgroups that the dispatcher happens to put
+// on one CU run at half speed each while other CUs idle (measured: the range kernel of a 192-proof call 1.65 ms, of a 224-proof call
+// 1.09 ms -- placement, not size; with it gone a 256-proof call takes 1.87 ms instead of 2.46).  LDS is the one resource a launch can
+// claim without using it: with 40 KB of dynamic LDS beside its 72 KB a range-kernel workgroup owns its CU (two no longer fit the
+// 160 KB), and with 60 KB a one-wavefront workgroup of the per-proof kernels cannot join it there either (and at most two of its own
+// kind share a CU).  Only for grids that fit the chip that way; ACT_NO_LDS_ISOLATION=1 turns it off (A/B).
+inline bool lds_isolation() { static const bool off = getenv("ACT_NO_LDS_ISOLATION") != nullptr; return !off; }
+inline unsigned isolate_bits(unsigned blocks) { return (lds_isolation() && blocks <= 224u) ? 40u * 1024u : 0u; }      // 256-thread workgroups of k_spend_bits
+inline unsigned isolate_role(unsigned blocks) { return (lds_isolation() && blocks <= 7u) ? 60u * 1024u : 0u; }        // 64-thread workgroups, several such kernels at once
+inline unsigned isolate_roles(unsigned blocks) { return (lds_isolation() && blocks <= 32u) ? 60u * 1024u : 0u; }      // a role-block kernel (blockIdx.y = role) of a tiny call
+
 void launch_spend_tail(const SpendArgs& a, hipStream_t s);
 void launch_sign_commit(const uint8_t* status, uint8_t* held, uint8_t* out, uint32_t n, uint32_t rec_bytes, hipStream_t s);      // out[p] = status[p] == 0 ? held[p] : 0; held wiped
 void launch_spend_tail_k(const SpendArgs& a, hipStream_t s);      // the tail in two launches: K', X_A ...
