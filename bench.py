@@ -33,7 +33,7 @@ The one JSON line carries
 and at N = 1
   extra.hbm_device_transcripts     the round-1..3 headline: device BLAKE3, nothing crosses PCIe inside a step
   extra.tiled_4096                 the round-1/2 input (4 096 distinct proofs tiled x256): what tiling flatters
-  extra.call_latency_ms            one call over 1 / 64 / 4 096 proofs (the crate's call shape is one proof per call)
+  extra.call_latency_ms            one call over 1 / 64 / 256 / 1 024 / 4 096 / 16 384 proofs (the crate's call shape is one proof per call)
   extra.concurrent_callers         4 threads with a context each making such calls back to back: whole-GPU rate
   extra.single_item_refunds        16 threads sharing one node handle, each calling the single-item refund; coalescing off / on
   extra.refund                     verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
@@ -730,7 +730,7 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     for mode, key in ((capi.TRANSCRIPT_DEVICE, "device_transcripts"), (capi.TRANSCRIPT_HOST, "host_transcripts")):
         eng.set_transcript_mode(mode)
         row = {}
-        for k in (1, 64, 1024, 4096, 16384):
+        for k in (1, 64, 256, 1024, 4096, 16384):
             if k > nl:
                 continue
             ts = []
