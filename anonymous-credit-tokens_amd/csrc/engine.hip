@@ -1116,240 +1116,7 @@ static int wire_unframe_chunk(act_ctx* c, Slot& sl, const WireSrc& w, int mem, s
 static int copy_chain_wait(act_ctx* c, Slot& sl, bool out);        // (defined with client_batch below)
 static int copy_chain_record(act_ctx* c, Slot& sl, bool out);
 
-// ---- the small-batch schedule (spend_lanes.h) ----------------------------------------------------------------------------------
-// Every kernel of a call goes on the stream of its kind, so that the per-proof kernels run NEXT TO the range kernel instead of in
-// front of and behind it:
-//     aux 3 (copies)        H2D                                                        (host-memory callers; then D2H of transcripts, H2D of challenges)
-//     aux 0                 prep role C1 -> role C2 -> role A                          (C1 first: the range kernel waits for its digits and h2 terms)
-//     aux 1                 prep role B -> (A, C done) A1 / A2
-//     slot 1's stream       Com_j decode -> k_spend_tail
-//     slot 0's stream       k_spend_bits
-//     aux 2                 k_spend_enc (8 points per lane) -> (all done) hash (16 lanes per transcript) -> finish
-// One proof is then the depth of its longest stream: 1.85 ms instead of 5.6 ms (profiles/r04_small_timeline2.txt).  The schedule can
-// cut a call into sub-chunks that follow each other through the six streams (ACT_SMALL_SUB proofs each; copies of sub-chunk k + 1
-// under the kernels of k), but measured (profiles/r04_small_sweep*.txt) one launch per kernel wins at every size: a range-kernel
-// launch of one round (1 024 proofs = two wavefronts on every SIMD) takes 3.1 ms instead of 2.2 ms when per-proof kernels -- 256
-// VGPRs each, i.e. half a SIMD -- hold some of its slots, because the displaced blocks need a second round; longer launches absorb
-// that.  So the default sub-chunk is 2^20 lanes (8 192 proofs at L = 128) = the schedule's size limit, and larger calls keep the
-// two-slot pipeline of 65 536-proof chunks (one lane per proof is the cheaper form once a launch fills the chip: DESIGN.md section 8).
-// Scratch of the roles lives in d_small, wiped like every other key-dependent buffer (finish_call).
-enum { SM_IN = 0, SM_A, SM_C, SM_JOIN, SM_TAIL, SM_BITS, SM_READY, SM_D2H, SM_K, SM_SPEC, SM_EVENTS };
-constexpr size_t SPEC_HELD_OFF = (size_t)TINY_MAX * PREP_BUCKET_SETS * BUCKET_WORDS * 4;        // k_sign_fused parks in set 2 of a lane's three ...
-constexpr size_t SPEC_PARK_BYTES = SPEC_HELD_OFF + (size_t)TINY_MAX * 128;                        // ... and the finished records wait here for their verdicts
-static int small_prepare(act_ctx* c, size_t n, size_t subs) {
-  if (!c->aux[0]) {
-    int least = 0, greatest = 0;
-    HIPCK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    // a priority class of their own: the runtime keeps separate hardware queues per class, so these cannot alias the slots' streams
-    static const bool normal_prio = getenv("ACT_SMALL_NORMAL_PRIO") != nullptr;      // tuning knob: the same class as the slots' streams
-    for (hipStream_t& a : c->aux) HIPCK(c, hipStreamCreateWithPriority(&a, hipStreamNonBlocking, normal_prio ? 0 : greatest));
-  }
-  while (c->sm_ev.size() < subs * SM_EVENTS) { hipEvent_t e; HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->sm_ev.push_back(e); }
-  const size_t per_proof = ((size_t)PREP_BUCKET_SETS * BUCKET_WORDS + (size_t)PART_POINTS * GE_WORDS) * 4;
-  if (n * per_proof + SPEC_PARK_BYTES > c->d_small_cap) {
-    // (+ in front: where a tiny refund's signature, computed beside the verification, parks its partial points: spend_small_locked)
-    const size_t cap = std::min(c->max_batch, std::max<size_t>(c->small_max.load(), n)) * per_proof + SPEC_PARK_BYTES;
-    if (c->d_small) { HIPCK(c, hipMemset(c->d_small, 0, c->d_small_cap)); HIPCK(c, hipFree(c->d_small)); c->d_small = nullptr; c->d_small_cap = 0; }
-    HIPCK(c, hipMalloc(&c->d_small, cap)); c->d_small_cap = cap;
-    // starts clean like the other secret-bearing buffers (the allocator may hand back freed memory).  On a stream of this context and
-    // waited for: a plain hipMemset goes to the null stream, which the context's non-blocking streams do not wait for -- it could land
-    // in the middle of the role kernels that are about to fill this buffer.
-    HIPCK(c, hipMemsetAsync(c->d_small, 0, cap, c->slots[0].stream));
-    HIPCK(c, hipStreamSynchronize(c->slots[0].stream));
-  }
-  c->d_small_dirty = std::max(c->d_small_dirty, n * per_proof + SPEC_PARK_BYTES);
-  return ACT_OK;
-}
-// At most SMALL_IN_FLIGHT small-batch calls run on one device at a time, whatever number of contexts (threads of a server) issue
-// them: a small call keeps six streams busy, and once the streams of four or more contexts are active together the process has more
-// active hardware queues than the GPU schedules side by side -- the queues are then time-sliced and one-proof calls take 20 - 60 ms
-// instead of 2 (profiles/r04_concurrent_small_calls.txt, with GPU_MAX_HW_QUEUES=8; the default of 4 does not get there).  Two calls
-// in flight already use the chip better than one (900 against 585 one-proof calls per second); the rest wait their turn here.
-namespace {
-struct SmallGate {
-  std::mutex m; std::condition_variable cv; int in_flight = 0;
-  static SmallGate& of(int device) {
-    static std::mutex gm; static std::map<int, SmallGate*> gates;
-    std::lock_guard<std::mutex> lk(gm);
-    SmallGate*& g = gates[device];
-    if (!g) g = new SmallGate();
-    return *g;
-  }
-  static int limit() { static const int v = [] { const char* e = getenv("ACT_SMALL_IN_FLIGHT"); const int k = e ? atoi(e) : 2; return k < 1 ? 1 : k; }(); return v; }
-};
-struct SmallTicket {
-  SmallGate& g;
-  explicit SmallTicket(SmallGate& g_) : g(g_) { std::unique_lock<std::mutex> lk(g.m); g.cv.wait(lk, [&] { return g.in_flight < SmallGate::limit(); }); g.in_flight++; }
-  ~SmallTicket() { { std::lock_guard<std::mutex> lk(g.m); g.in_flight--; } g.cv.notify_one(); }
-};
-}  // namespace
-
-// d_ready (nullable): the proofs as records already in device memory, written by work queued on slot 0's stream (a wire-bytes call's
-// unframing kernel); `proof` / the copy in are then not used, everything else (outputs, rng) still follows `mem`
-static int spend_small_locked(act_ctx* c, size_t n, int mem, const uint8_t* proof, bool sign, const uint8_t* rng, int rng_mode, uint8_t* out_refund,
-                              uint8_t* status, uint8_t* out_kprime, const uint8_t* d_ready = nullptr) {
-  SmallTicket ticket(SmallGate::of(c->device));      // held until this call's work has left the GPU (sync_all below)
-  // ACT_SMALL_TRACE=1 (diagnostics): host-side time stamps of this schedule on stderr -- enqueue, wait, outputs
-  static const bool small_trace = getenv("ACT_SMALL_TRACE") != nullptr;
-  const auto t_in = std::chrono::steady_clock::now();
-  auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_in).count(); };
-  const SpendTranscript st{c->L};
-  const size_t pb = ProofLayout{c->L}.bytes(), L = (size_t)c->L;
-  static const size_t sub_env = [] { const char* e = getenv("ACT_SMALL_SUB"); return e ? (size_t)atol(e) : (size_t)0; }();      // tuning knob: proofs per sub-chunk
-  const size_t S = sub_env ? sub_env : std::max<size_t>(64, ((size_t)1 << 20) / L);        // measured (profiles/r04_small_sweep.txt): sub-chunks of one round lose to one launch
-  const size_t K = (n + S - 1) / S;
-  int rc = small_prepare(c, n, K); if (rc) return rc;
-  c->aux_used = true;
-  Slot& sl = c->slots[0];
-  // One sub-chunk (every call unless ACT_SMALL_SUB cuts finer): the range kernel's own line -- digits, range kernel, encodings, hash,
-  // verdict -- runs IN ORDER on one stream; a dependency between streams costs 20 - 50 us of event latency each, and this line is the
-  // call's critical path (tools/small_batch_timeline.py).  Only the per-proof kernels, which run beside it, meet it through events.
-  const bool inorder = K == 1;
-  hipStream_t s_bits = sl.stream, s_tail = c->slots[1].stream, s_a = c->aux[0], s_b = c->aux[1], s_e = inorder ? sl.stream : c->aux[2], s_x = c->aux[3];
-  auto ev = [&](size_t k, int what) { return c->sm_ev[k * SM_EVENTS + what]; };
-  const bool host_tr = c->tr_mode == ACT_TRANSCRIPT_HOST;
-  // device views of the caller's arrays (staged on slot 0 for host memory; the copies themselves go piece by piece below)
-  const uint8_t* d_proofs = proof; uint8_t *d_kprime = out_kprime, *d_out = out_refund;
-  bool copy_in = mem == ACT_MEM_HOST && !d_ready;
-  if (d_ready) {
-    d_proofs = d_ready;
-    if ((rc = copy_chain_record(c, sl, false))) return rc;            // the unframing kernel on slot 0's stream ...
-    HIPCK(c, hipStreamWaitEvent(s_x, sl.cp_in_ev, 0));                // ... precedes everything that hangs on SM_IN
-  } else if (copy_in) {
-    if (const uint8_t* v = mapped_view(c, proof, n * pb)) { d_proofs = v; copy_in = false; }      // pinned host memory: read in place
-    else { if ((rc = stage_reserve(c, sl, 0, n * pb))) return rc; d_proofs = sl.d_stage[0]; }
-  }
-  if (out_kprime && (rc = dev_out_begin(c, sl, 2, mem, out_kprime, n * 32, &d_kprime))) return rc;
-  if (sign && (rc = dev_out_begin(c, sl, 4, mem, out_refund, n * 128, &d_out))) return rc;
-  if (host_tr) {
-    if (n * st.stride() > sl.h_tr_cap) {
-      if (sl.h_tr) HIPCK(c, hipHostFree(sl.h_tr));
-      sl.h_tr = nullptr; sl.h_tr_cap = 0;
-      HIPCK(c, hipHostMalloc(&sl.h_tr, n * st.stride(), hipHostMallocDefault)); sl.h_tr_cap = n * st.stride();
-    }
-    if (n * 64 > sl.h_xof_cap) {
-      if (sl.h_xof) HIPCK(c, hipHostFree(sl.h_xof));
-      sl.h_xof = nullptr; sl.h_xof_cap = 0;
-      HIPCK(c, hipHostMalloc(&sl.h_xof, n * 64, hipHostMallocDefault)); sl.h_xof_cap = n * 64;
-    }
-  }
-  HIPCK(c, hipMemsetAsync(sl.d_flags, 0, n * 4, s_x));               // every kernel ORs its flags in
-  // A tiny refund signs BESIDE its verification: X_A = g + K' exists as soon as k_spend_tail has run (1.3 ms into a 1.9 ms call), and the
-  // WHOLE signature (X_A -> (e+x)^-1 -> the quartered products -> encodings, hash, z: k_sign_fused with before_verdict, 1.0 ms) then runs on the
-  // tail's stream while the range kernel, the encodings and the hash finish; the records wait in a buffer of the context's and a copy
-  // kernel hands out those the verdicts allow (launch_sign_commit), zeroing the rest and the buffer.  A lane's e, alpha are read before its verdict is known, which is observable only if the slice a lane draws depends
-  // on other lanes' verdicts: ACT_RNG_PER_LANE or a single lane (as PrivateKey::issue's tiny path, k_sign.hip).  A rejected lane's
-  // partial points are zeroed by the finish like everybody's; its record is zero.
-  const bool spec_sign = sign && K == 1 && n <= TINY_MAX && tiny_enabled(c) && (rng_mode == ACT_RNG_PER_LANE || (rng_mode == ACT_RNG_SEQUENTIAL && n == 1));
-  SignFusedArgs sf{};
-  if (spec_sign) {
-    const uint8_t* d_rng = rng;
-    if (mem == ACT_MEM_HOST) {
-      if ((rc = stage_reserve(c, sl, 3, n * 128))) return rc;
-      HIPCK(c, hipMemcpyAsync(sl.d_stage[3], rng, n * 128, hipMemcpyHostToDevice, s_tail));
-      d_rng = sl.d_stage[3];
-    }
-    launch_iota(sl.d_slot, (uint32_t)n, 0u, s_tail);
-    sf.P = c->P; sf.K = c->key; sf.n = (uint32_t)n; sf.label = LABEL_REFUND; sf.xa = sl.d_xa; sf.rng_slot = sl.d_slot; sf.rng = d_rng;
-    sf.status_in = sl.d_status; sf.status = sl.d_status; sf.out = reinterpret_cast<uint8_t*>(c->d_small) + SPEC_HELD_OFF; sf.trs = sl.d_trs; sf.pbk = c->d_small;
-    sf.group_counter = group_counters(c, sl); sf.before_verdict = 1;
-  }
-  std::vector<SpendArgs> args(K);
-  for (size_t k = 0; k < K; k++) {
-    const size_t off = k * S, m = std::min(S, n - off);
-    if (copy_in) {
-      hipError_t ce = hipSuccess;
-      if ((rc = prof_launch_on(c, sl, s_x, PK_COPY_H2D, m * pb, [&] { ce = hipMemcpyAsync(sl.d_stage[0] + off * pb, proof + off * pb, m * pb, hipMemcpyHostToDevice, s_x); }))) return rc;
-      HIPCK(c, ce);
-    }
-    HIPCK(c, hipEventRecord(ev(k, SM_IN), s_x));
-    SpendArgs& a = args[k];
-    a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = d_proofs + off * pb; a.n = (uint32_t)m; a.tr = sl.d_tr + off * st.stride(); a.tr_stride = (uint32_t)st.stride();
-    a.coords = sl.d_coords + off * L * NIELS_WORDS; a.d01 = sl.d_d01 + off * 2 * GE_WORDS; a.buckets = sl.d_buckets + off * L * BUCKET_WORDS;
-    a.xa = sl.d_xa + off * GE_WORDS; a.flags = sl.d_flags + off; a.xof = sl.d_xof + off * 16; a.status = sl.d_status + off;
-    a.kprime_enc = d_kprime ? d_kprime + off * 32 : nullptr; a.naf = sl.d_naf + off * NAF_WORDS; a.dig = sl.d_dig + off * L * 8;
-    uint32_t* const small0 = c->d_small + SPEC_PARK_BYTES / 4;
-    a.pbk = small0 + off * PREP_BUCKET_SETS * BUCKET_WORDS; a.part = small0 + n * PREP_BUCKET_SETS * BUCKET_WORDS + off * PART_POINTS * GE_WORDS;
-    for (hipStream_t s : {s_a, s_b, s_tail}) HIPCK(c, hipStreamWaitEvent(s, ev(k, SM_IN), 0));
-    if (inorder) {
-      HIPCK(c, hipStreamWaitEvent(s_bits, ev(k, SM_IN), 0));
-      if ((rc = prof_launch_on(c, sl, s_bits, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 4, s_bits); }))) return rc;      // C1: digits and h2 terms of the range kernel
-    } else {
-      if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 4, s_a); }))) return rc;
-      HIPCK(c, hipEventRecord(ev(k, SM_C), s_a));
-    }
-    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_C, m, [&] { launch_spend_prep_role(a, 5, s_a); }))) return rc;      // C2: the fixed-base part of A2
-    if ((rc = prof_launch_on(c, sl, s_a, PK_SPEND_PREP_A, m, [&] { launch_spend_prep_role(a, 0, s_a); }))) return rc;
-    HIPCK(c, hipEventRecord(ev(k, SM_A), s_a));
-    if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_B, m, [&] { launch_spend_prep_role(a, 1, s_b); }))) return rc;
-    HIPCK(c, hipStreamWaitEvent(s_b, ev(k, SM_A), 0));                 // role C precedes role A on the same stream
-    if ((rc = prof_launch_on(c, sl, s_b, PK_SPEND_PREP_JOIN, m, [&] { launch_spend_prep_role(a, 3, s_b); }))) return rc;
-    HIPCK(c, hipEventRecord(ev(k, SM_JOIN), s_b));
-    if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_COORDS, m * L, [&] { launch_spend_coords(a, s_tail); }))) return rc;
-    if (!spec_sign) {
-      if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, m, [&] { launch_spend_tail(a, s_tail); }))) return rc;
-      HIPCK(c, hipEventRecord(ev(k, SM_TAIL), s_tail));
-    } else {
-      // the tail in two launches: the signature's roles follow K' / X_A on this stream while C is made on the copy stream (idle by now)
-      if ((rc = prof_launch_on(c, sl, s_tail, PK_SPEND_TAIL, m, [&] { launch_spend_tail_k(a, s_tail); }))) return rc;
-      HIPCK(c, hipEventRecord(ev(k, SM_K), s_tail));
-      HIPCK(c, hipStreamWaitEvent(s_x, ev(k, SM_K), 0));
-      if ((rc = prof_launch_on(c, sl, s_x, PK_SPEND_TAIL, m, [&] { launch_spend_tail_c(a, s_x); }))) return rc;
-      HIPCK(c, hipEventRecord(ev(k, SM_TAIL), s_x));
-      if ((rc = prof_launch_on(c, sl, s_tail, PK_SIGN_A, m, [&] { launch_sign_fused(sf, false, s_tail); }))) return rc;
-      HIPCK(c, hipEventRecord(ev(k, SM_SPEC), s_tail));
-    }
-    if (!inorder) HIPCK(c, hipStreamWaitEvent(s_bits, ev(k, SM_C), 0));               // implies SM_IN
-    if ((rc = prof_launch_on(c, sl, s_bits, PK_SPEND_BITS, (uint64_t)m * L, [&] { launch_spend_bits(a, s_bits); }))) return rc;
-    HIPCK(c, hipEventRecord(ev(k, SM_BITS), s_bits));
-    if (!inorder) HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_BITS), 0));
-    if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_ENC, (uint64_t)m * L * 2, [&] { launch_spend_enc_small(a, s_e); }))) return rc;
-    HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_JOIN), 0)); HIPCK(c, hipStreamWaitEvent(s_e, ev(k, SM_TAIL), 0));
-    if (!host_tr) {
-      HashArgs h{a.tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), (uint32_t)m, sl.d_xof + off * 16, nullptr};
-      if ((rc = prof_launch_on(c, sl, s_e, PK_HASH_SPEND, m, [&] { launch_hash_par(h, s_e); }))) return rc;
-      if ((rc = prof_launch_on(c, sl, s_e, PK_SPEND_FINISH, m, [&] { launch_spend_finish(a, s_e); }))) return rc;
-    } else {
-      HIPCK(c, hipEventRecord(ev(k, SM_READY), s_e));
-      HIPCK(c, hipStreamWaitEvent(s_x, ev(k, SM_READY), 0));
-      hipError_t ce = hipSuccess;
-      if ((rc = prof_launch_on(c, sl, s_x, PK_COPY_D2H, m * st.stride(), [&] { ce = hipMemcpyAsync(sl.h_tr + off * st.stride(), a.tr, m * st.stride(), hipMemcpyDeviceToHost, s_x); }))) return rc;
-      HIPCK(c, ce);
-      HIPCK(c, hipEventRecord(ev(k, SM_D2H), s_x));
-    }
-  }
-  if (host_tr)
-    for (size_t k = 0; k < K; k++) {      // hash sub-chunk k on the host while the GPU works on k + 1
-      const size_t off = k * S, m = std::min(S, n - off);
-      HIPCK(c, hipEventSynchronize(ev(k, SM_D2H)));
-      host_hash_many(c, sl.h_tr + off * st.stride(), st.stride(), (uint32_t)st.bytes(), m, sl.h_xof + off * 16);
-      HIPCK(c, hipMemcpyAsync(sl.d_xof + off * 16, sl.h_xof + off * 16, m * 64, hipMemcpyHostToDevice, s_x));
-      if ((rc = prof_launch_on(c, sl, s_x, PK_SPEND_FINISH, m, [&] { launch_spend_finish(args[k], s_x); }))) return rc;
-    }
-  // everything of this call joins slot 0's stream, which carries what is left: outputs, the signatures, the wipe (finish_call)
-  hipStream_t last = host_tr ? s_x : s_e;
-  if (last != s_bits) {
-    HIPCK(c, hipEventRecord(ev(0, SM_IN), last));                      // (the events of sub-chunk 0 have all been consumed)
-    HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_IN), 0));
-  }
-  sl.last_spend_lanes = n; c->last_spend_slot = 0;
-  if (out_kprime && (rc = dev_out_end(c, sl, mem, out_kprime, d_kprime, n * 32))) return rc;
-  if (spec_sign) {
-    HIPCK(c, hipStreamWaitEvent(s_bits, ev(0, SM_SPEC), 0));
-    if ((rc = prof_launch(c, sl, PK_SIGN_B, n, [&] { launch_sign_commit(sl.d_status, sf.out, d_out, (uint32_t)n, 128u, sl.stream); }))) return rc;
-    if ((rc = dev_out_end(c, sl, mem, out_refund, d_out, n * 128))) return rc;
-  } else if (sign) {
-    const uint8_t* d_rng; size_t cursor = 0;
-    if ((rc = prepare_rng_slots(c, sl, (uint32_t)n, 0, mem, rng, rng_mode, &cursor, &d_rng))) return rc;
-    if ((rc = sign_phase(c, sl, (uint32_t)n, LABEL_REFUND, d_rng, nullptr, d_out))) return rc;
-    if ((rc = dev_out_end(c, sl, mem, out_refund, d_out, n * 128))) return rc;
-  }
-  if ((rc = copy_status_out(c, sl, mem, status, (uint32_t)n))) return rc;
-  const double t_enq = small_trace ? since() : 0;
-  rc = sync_all(c);
-  if (small_trace) fprintf(stderr, "small n=%zu sign=%d: enqueued after %.0f us, GPU done after %.0f us\n", n, (int)sign, t_enq, since());
-  return rc;
-}
+#include "small_impl.inc"      // the small-batch schedule: small_prepare, SmallGate, spend_small_locked
 
 // verify (sign == false) or refund (sign == true), two-slot software pipeline: stage 1 of chunk i+1 is enqueued before
 // the host touches chunk i again.  The caller holds the context (Call).

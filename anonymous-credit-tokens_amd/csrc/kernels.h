@@ -138,7 +138,7 @@ struct SignFusedArgs {
   int check_only;                                  // CHECK: only the check role runs (act_issue_check_batch): status out, no signature
   int before_verdict;                              // !CHECK: EVERY lane is signed and `status` is neither read nor written -- the verdicts are not known yet: a tiny
                                                    // refund signs beside its verification, into a buffer of the engine's; launch_sign_commit then hands out
-                                                   // what the verdicts allow (engine.hip spend_small_locked)
+                                                   // what the verdicts allow (small_impl.inc spend_small_locked)
   int wipe_rng;                                    // rng is the engine's staged copy: zero it when done
   unsigned long long* dbg;                         // -DACT_TINY_TIMING builds only: 8 time stamps per role
 };

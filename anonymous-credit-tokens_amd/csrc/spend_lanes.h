@@ -121,7 +121,7 @@ ACT_HD void spend_prep_lane(const SpendArgs& a, uint32_t p) {
   a.flags[p] = flags;     // bits kernel ORs its decode failures in afterwards (same stream)
 }
 
-// ---- the small-batch schedule (engine.hip spend_small): the same pieces as kernels of their own ---------------------------------
+// ---- the small-batch schedule (small_impl.inc): the same pieces as kernels of their own ---------------------------------
 // The crate's call shape is ONE proof per call (/root/reference/src/lib.rs:781-786, benches/benchmark.rs:166-212).  A lane of
 // k_spend_prep is ~8 200 dependent field operations, one of k_spend_tail ~5 300, and below ~2^15 proofs a launch of either leaves
 // most of the chip idle: the serial depth of prep -> bits -> enc -> tail IS the call's latency (5.7 ms for one proof in round 3).
@@ -288,7 +288,7 @@ ACT_HD void spend_tail_lane(const SpendArgs& a, uint32_t p) {
   spend_tail_c(a, p, kp, spend_tail_fixed(a, p));
   spend_tail_xa(a, p, kp);
 }
-// The same in two kernels, for the call that signs beside its verification (engine.hip spend_small_locked): X_A leaves after the
+// The same in two kernels, for the call that signs beside its verification (small_impl.inc spend_small_locked): X_A leaves after the
 // Horner run -- 0.5 ms into a 1.25 ms lane -- and the signature's chain starts there; C follows from K' = X_A - g.
 ACT_HD void spend_tail_k_lane(const SpendArgs& a, uint32_t p) { spend_tail_xa(a, p, spend_tail_horner(a, p, 0, a.P.L, 0)); }
 ACT_HD void spend_tail_c_lane(const SpendArgs& a, uint32_t p) {

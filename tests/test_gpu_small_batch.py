@@ -1,4 +1,4 @@
-"""The small-batch schedule (engine.hip spend_small_locked: calls of at most 8 192 proofs run the per-proof kernels next to the
+"""The small-batch schedule (small_impl.inc spend_small_locked: calls of at most 8 192 proofs run the per-proof kernels next to the
 range kernel on six streams -- the crate's own call shape is ONE proof per call, /root/reference/src/lib.rs:781-786) against the
 pipelined schedule and the C oracle: statuses, enc(K'), refunds under both rng modes and the complete transcripts must be the same
 bytes whichever schedule runs them.  Every rejection kind, ragged widths, single-proof calls."""

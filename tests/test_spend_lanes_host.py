@@ -14,7 +14,7 @@ hx = bytes.fromhex
 
 def host_verify(hc, h, L, sk, proofs):
     """Runs the lane bodies in the order of the pipelined schedule AND in the small-batch schedule's (the roles of k_spend_prep as
-    kernels of their own, k_spend_tail in front of k_spend_bits, engine.hip spend_small_locked): the two must agree on every byte
+    kernels of their own, k_spend_tail in front of k_spend_bits, small_impl.inc spend_small_locked): the two must agree on every byte
     and on the operation counts; returns the former."""
     pb = 32 * (14 + 4 * L)
     n = len(proofs) // pb

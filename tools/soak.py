@@ -14,7 +14,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 r = random.Random(seed)
 for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
     o = Oracle(); h = o.params_new("soak-org", "svc", "env", "v%d" % seed); octx = o.ctx(h, L)
-    # ACT_SOAK_MAX_BATCH >= n: one chunk = the small-batch schedule (engine.hip spend_small_locked); the default, 600, pipelines chunks
+    # ACT_SOAK_MAX_BATCH >= n: one chunk = the small-batch schedule (small_impl.inc spend_small_locked); the default, 600, pipelines chunks
     eng = capi.Engine(h, L, max_batch=int(os.environ.get("ACT_SOAK_MAX_BATCH", "600")), transcript=capi.TRANSCRIPT_DEVICE)
     sk = eng.private_key_random(sh("sk%d" % seed, 64))
     pre = eng.pre_issuance_random(sh("pre%d" % seed, 128 * n)); req = eng.request(pre, sh("rq%d" % seed, 128 * n))
@@ -93,7 +93,7 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
         if errs:
             raise errs[0]
     # ACT_SOAK_TINY=1: the same proofs once more as refunds of 1 - 64 proofs -- the calls whose signature is computed beside the
-    # verification (engine.hip spend_small_locked) -- per-lane rng from pageable memory, from pinned memory read in place, and one-proof
+    # verification (small_impl.inc spend_small_locked) -- per-lane rng from pageable memory, from pinned memory read in place, and one-proof
     # calls with the sequential convention; every answer against the batch answers above and, for one-proof calls, the oracle
     tiny_note = ""
     if os.environ.get("ACT_SOAK_TINY"):
