@@ -221,8 +221,9 @@ __global__ void __launch_bounds__(256) k_request_b(RequestArgs a) {
 //                   (msm.h chain_ct_quarter: 64 i doublings + 33 chain steps each instead of 127 steps in one wavefront)
 //     role M        X_g = e g + w,  Y_g = alpha g,  X_A (encode only), and the head of the transcript
 // the partial points parked in the lane's bucket area, the encodings written into its "respond" / "refund" transcript (global
-// memory, as k_sign_a_wide does); the block of a group that ARRIVES LAST (a counter per group) adds the quarters, encodes A and
-// Y_A, hashes the transcript -- one BLAKE3 chunk, the routine of k_hash_xof -- and finishes z = gamma (x + e) + alpha (:660 / :861).  X_A = g + c h1 + K (:644) or g + K' (:848) is cheap (one table product)
+// memory, as k_sign_a_wide does).  The A quarters meet in whichever of their four blocks arrives last (a counter of their own), which
+// adds them and encodes A while the Y_A blocks do the same for Y_A; the block of the group that ARRIVES LAST of all (a counter per
+// group) hashes the transcript -- one BLAKE3 chunk, the routine of k_hash_xof -- and finishes z = gamma (x + e) + alpha (:660 / :861).  X_A = g + c h1 + K (:644) or g + K' (:848) is cheap (one table product)
 // and every role that needs it makes its own.
 // Why blocks and not the wavefronts of one block: where the wavefronts of a workgroup land is the dispatcher's business, and roles
 // that land on one SIMD run at half speed each -- the same kernel took 0.9 or 2.0 ms from call to call (profiles/r05_tiny_ab.txt:
@@ -231,6 +232,8 @@ __global__ void __launch_bounds__(256) k_request_b(RequestArgs a) {
 // before its verdict is known, which changes nothing observable: a rejected lane's record is zero and its nonces never leave the
 // registers; the engine takes this kernel only when the slice a lane would draw does not depend on other lanes' verdicts
 // (ACT_RNG_PER_LANE, or one lane).  One launch instead of six; the dependent chain is max(check, signature) instead of their sum.
+// Without CHECK and with `before_verdict` the same holds for a tiny refund, whose check is the whole spend-proof verification on other
+// streams: every lane is signed into a buffer of the engine's and k_sign_commit hands out what the verdicts allow (small_impl.inc).
 constexpr uint32_t FUSED_CTR_A = 128, FUSED_CTR_Y = 256;      // k_sign_fused: the A quarters' and the Y_A quarters' own counters, beside the group's (engine.hip: 512 words per slot)
 __device__ __forceinline__ bool group_last_arrival(uint32_t* counter, uint32_t roles) {
   __shared__ uint32_t ticket;
