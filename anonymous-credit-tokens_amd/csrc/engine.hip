@@ -264,6 +264,9 @@ void host_hash_many(const act_ctx* c, const uint8_t* msgs, size_t stride, uint32
 // transcript hashing step, split so that callers can overlap the host part with other slots' GPU work:
 //   hash_begin : device mode -> launch k_hash_xof;  host mode -> enqueue the D2H copy of the pre-images
 //   hash_end   : device mode -> nothing;            host mode -> wait for the copy, hash on host threads, enqueue H2D of the XOF words
+// pieces a batch of n pre-images comes back in: a piece must be worth waking the worker pool for (~60 us a time), so short batches
+// come back whole
+inline int hash_pieces(uint32_t n) { const uint32_t k = n / 512u; return k < 1u ? 1 : (k > (uint32_t)HASH_PIECES ? HASH_PIECES : (int)k); }
 int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_t stride, uint32_t len, uint32_t n) {
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) {
     HashArgs h{d_msgs, stride, len, n, sl.d_xof, nullptr};
@@ -286,8 +289,9 @@ int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_
   }
   // the pre-images come back in HASH_PIECES pieces, each followed by an event, so that hash_end can hash piece k while
   // piece k+1 is still crossing PCIe
-  for (int k = 0; k < HASH_PIECES; k++) {
-    size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
+  const int pieces = hash_pieces(n);
+  for (int k = 0; k < pieces; k++) {
+    size_t i0 = (size_t)n * k / pieces, i1 = (size_t)n * (k + 1) / pieces;
     if (!sl.h_ev[k]) HIPCK(c, hipEventCreateWithFlags(&sl.h_ev[k], hipEventDisableTiming));
     if (i1 > i0) {
       hipError_t ce = hipSuccess;
@@ -304,8 +308,9 @@ int hash_end(act_ctx* c, Slot& sl, uint32_t stride, uint32_t len, uint32_t n) {
   static const bool trace = getenv("ACT_TRACE") != nullptr;      // where the host side of the host-transcript mode spends its time
   double& t_wait = c->trace_wait_s; double& t_hash = c->trace_hash_s; size_t& n_msgs = c->trace_msgs;      // per context: contexts run on their own threads
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  for (int k = 0; k < HASH_PIECES; k++) {
-    size_t i0 = (size_t)n * k / HASH_PIECES, i1 = (size_t)n * (k + 1) / HASH_PIECES;
+  const int pieces = hash_pieces(n);
+  for (int k = 0; k < pieces; k++) {
+    size_t i0 = (size_t)n * k / pieces, i1 = (size_t)n * (k + 1) / pieces;
     const double t0 = now();
     HIPCK(c, hipEventSynchronize(sl.h_ev[k]));
     const double t1 = now();
