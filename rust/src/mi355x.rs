@@ -636,6 +636,20 @@ impl PrivateKey {
         });
         refund_messages(&out, &status[..n])
     }
+    /// ONE message, the 128 bytes of e and alpha drawn BEFORE the verdict (see `refund_eager`): unframing, verification and the
+    /// signature beside it as one library call, 2.1 ms instead of 3.1.  The message returned is the one `refund_cbor_batch` returns
+    /// for the same generator; a rejected message has then consumed 128 bytes of it where the crate consumes none.
+    pub fn refund_cbor_eager(&self, params: &Params, msg: &[u8], mut rng: impl CryptoRngCore) -> Result<Vec<u8>, WireError> {
+        let offsets = [0u64, msg.len() as u64];
+        let rng_bytes = draw(&mut rng, 2);
+        let (sk, gpu) = (self.record(), params.gpu());
+        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES + 1], vec![0u8; 2]);
+        gpu.check(unsafe {
+            act_node_refund_cbor_batch(gpu.0, 1, sk.as_ptr(), msg.as_ptr(), offsets.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL,
+                                       out.as_mut_ptr(), status.as_mut_ptr())
+        });
+        refund_messages(&out, &status[..1]).pop().unwrap()
+    }
     /// Verdicts only (`refund` up to the challenge check, src/lib.rs:787-844) for CBOR `SpendProof` messages.
     pub fn verify_spend_cbor_batch(&self, params: &Params, msgs: &[&[u8]]) -> Vec<Result<(), WireError>> {
         let (blob, offsets) = gather(msgs);
