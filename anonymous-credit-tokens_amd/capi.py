@@ -33,7 +33,7 @@ EXPORTS = [
     "act_node_issue_check_batch", "act_node_issue_sign_batch", "act_node_refund_sign_batch",
     "act_node_nullifier_set_create", "act_node_nullifier_set_destroy", "act_node_nullifier_set_len", "act_node_nullifier_set_last_error",
     "act_node_nullifier_check_and_insert_batch",
-    "act_verify_spend_cbor_keys_batch", "act_node_verify_spend_cbor_keys_batch", "act_refund_sign_cbor_batch", "act_refund_cbor_batch",
+    "act_verify_spend_cbor_keys_batch", "act_node_verify_spend_cbor_keys_batch", "act_refund_sign_cbor_batch", "act_refund_cbor_batch", "act_refund_cbor_keys_batch",
     "act_node_refund_sign_cbor_batch", "act_node_refund_cbor_batch", "act_redeem_cbor_batch", "act_node_redeem_cbor_batch",
     "act_ctx_host_hash_stats", "act_ctx_set_tiny_calls", "act_node_set_balance", "act_node_device_stats", "act_node_balance_state", "act_debug_set_slowdown", "act_debug_fail_next_signs",
 ]
@@ -174,6 +174,7 @@ def load() -> C.CDLL:
     lib.act_node_verify_spend_cbor_keys_batch.argtypes = [vp, sz, u8p, u8p, vp, u8p, u8p, u8p]
     lib.act_refund_sign_cbor_batch.argtypes = [vp, sz, i32, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_refund_cbor_batch.argtypes = [vp, sz, i32, u8p, u8p, vp, u8p, i32, u8p, u8p]
+    lib.act_refund_cbor_keys_batch.argtypes = [vp, sz, i32, u8p, u8p, vp, u8p, i32, u8p, u8p, u8p]
     lib.act_node_refund_sign_cbor_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_node_refund_cbor_batch.argtypes = [vp, sz, u8p, u8p, vp, u8p, i32, u8p, u8p]
     lib.act_redeem_cbor_batch.argtypes = [vp, vp, sz, i32, u8p, u8p, vp, u8p, i32, u8p, u8p]

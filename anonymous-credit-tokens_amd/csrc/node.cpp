@@ -658,6 +658,24 @@ static int node_redeem(act_node* nd, act_node_nullifier_set* set, size_t n, cons
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL && rng_mode != ACT_RNG_CALLBACK) return ACT_ERR_ARG;
   if (n == 0) return ACT_OK;
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]), out_rec = wire ? act_cbor_size(nd->ctx[0], ACT_CBOR_REFUND) : 128;
+  // A few items whose rng slices do not depend on the verdicts (per-lane bytes, or one item with its 128 bytes): ONE context computes
+  // the refunds in one call, the signature beside the verification (2.1 ms for one item instead of 3.1 through verify -> store ->
+  // sign); then the store decides, and a lane whose nullifier was not fresh gets its status and loses its refund.  The same answers
+  // and the same store as the general path below; nothing is signed behind a recorded nullifier here, so nothing can fail there.
+  if (n <= 64 && (rng_mode == ACT_RNG_PER_LANE || (rng_mode == ACT_RNG_SEQUENTIAL && n == 1))) {
+    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    std::vector<uint8_t> st(n), sp(n), nl(wire ? n * 32 : 0);
+    int rc = wire ? act_refund_cbor_keys_batch(c, n, ACT_MEM_HOST, sk, cbor, offsets, rng, rng_mode, out, st.data(), nl.data())
+                  : act_refund_batch(c, n, ACT_MEM_HOST, sk, proof, rng, rng_mode, out, st.data());
+    if (rc) { small_call_err(nd, c); return rc; }
+    const int rc_null = act_node_nullifier_check_and_insert_batch(set, n, wire ? nl.data() : proof, wire ? 32 : pb, st.data(), sp.data());
+    for (size_t i = 0; i < n; i++) {
+      if (st[i] == 0 && sp[i]) { st[i] = sp[i] == 1 ? ACT_STATUS_DOUBLE_SPEND : ACT_STATUS_NULLIFIER_UNDETERMINED; memset(out + i * out_rec, 0, out_rec); }
+      status[i] = st[i];
+    }
+    if (rc_null) { std::lock_guard<std::mutex> node_lock(nd->mu); set_node_err(nd, std::string("nullifier set: ") + act_node_nullifier_set_last_error(set)); }
+    return rc_null;
+  }
   std::vector<uint8_t> kprime(n * 32), verdict(n), spent(n), nul(wire ? n * 32 : 0);
   int rc = wire ? act_node_verify_spend_cbor_keys_batch(nd, n, sk, cbor, offsets, verdict.data(), kprime.data(), nul.data())
                 : act_node_verify_spend_batch(nd, n, sk, proof, verdict.data(), kprime.data());

@@ -381,6 +381,11 @@ int act_refund_sign_cbor_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk
                                const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
 int act_refund_cbor_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
                           const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
+/* ... and the nullifier `k` of every message as it stood on the wire (n*32; zero for a message that did not parse), as
+ * act_verify_spend_cbor_keys_batch returns it: for a caller that keeps the double-spend store itself and decides AFTER the refund was
+ * computed whether to hand it out (what act_node_redeem_cbor_batch does with a few messages: refund in one call, then the store). */
+int act_refund_cbor_keys_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
+                               const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status, uint8_t *out_nullifier);
 int act_node_refund_sign_cbor_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *kprime, const uint8_t *status_in,
                                     const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
 int act_node_refund_cbor_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
@@ -444,7 +449,11 @@ int act_node_nullifier_check_and_insert_batch(act_node_nullifier_set *set, size_
  *   the signature step failed           nullifiers ARE recorded; the lanes that were to be signed (node form: those of the failing GPU's
  *                                       shard) get ACT_STATUS_RECORDED_UNSIGNED and a zero record.  Their refund is owed: call
  *                                       act_verify_spend_batch(out_kprime) and act_refund_sign_batch on exactly those lanes.  Redeeming them
- *                                       again would report DoubleSpendError and the client would lose its credits. */
+ *                                       again would report DoubleSpendError and the client would lose its credits.
+ * A few items at a time (host memory, at most 64, rng slices that do not depend on the verdicts: ACT_RNG_PER_LANE bytes, or ONE item
+ * with its 128 bytes): the refunds are computed FIRST -- one call, the signature beside the verification -- and the store then decides
+ * which of them are handed out (2.1 ms for one item instead of 3.2).  Same statuses, refunds and store; the third failure above cannot
+ * occur on this road (nothing is signed behind a recorded nullifier). */
 int act_redeem_batch(act_ctx *ctx, act_nullifier_set *set, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof,
                      const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
 int act_node_redeem_batch(act_node *node, act_node_nullifier_set *set, size_t n, const uint8_t sk[64], const uint8_t *proof,

@@ -722,6 +722,22 @@ impl PrivateKey {
         let engine_failure = if rc != 0 { Some(unsafe { CStr::from_ptr(act_node_last_error(gpu.0)) }.to_string_lossy().into_owned()) } else { None };
         Redeemed { lanes: refund_messages(&out, &status[..n]), engine_failure }
     }
+    /// ONE message, the way a server that answers requests one at a time calls it: the 128 bytes of e and alpha are drawn BEFORE the
+    /// verdict (see `refund_eager`), the refund is computed in one library call with the signature beside the verification, THEN the
+    /// store decides -- 2.1 ms instead of 3.2.  Same message and same store as `redeem_cbor_batch` over that one message; a message
+    /// that is rejected (or a double spend) has consumed 128 bytes of the generator where the loop consumes none.
+    pub fn redeem_cbor_eager(&self, params: &Params, store: &GpuNullifierStore, msg: &[u8], mut rng: impl CryptoRngCore) -> Redeemed<Vec<u8>> {
+        let offsets = [0u64, msg.len() as u64];
+        let rng_bytes = draw(&mut rng, 2);
+        let (sk, gpu) = (self.record(), params.gpu());
+        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES + 1], vec![0u8; 2]);
+        let rc = unsafe {
+            act_node_redeem_cbor_batch(gpu.0, store.0, 1, sk.as_ptr(), msg.as_ptr(), offsets.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL,
+                                       out.as_mut_ptr(), status.as_mut_ptr())
+        };
+        let engine_failure = if rc != 0 { Some(unsafe { CStr::from_ptr(act_node_last_error(gpu.0)) }.to_string_lossy().into_owned()) } else { None };
+        Redeemed { lanes: refund_messages(&out, &status[..1]), engine_failure }
+    }
     /// The same over `SpendProof`s (marshalled on all cores: 130 `compress()` per proof).
     pub fn redeem_batch(&self, params: &Params, store: &GpuNullifierStore, proofs: &[SpendProof], mut rng: impl CryptoRngCore) -> Redeemed<Refund> {
         let n = proofs.len();

@@ -116,10 +116,13 @@ int act_refund_sign_cbor_batch(act_ctx* c, size_t n, int mem, const uint8_t* sk,
   for (size_t i = 0; i < n; i++) { memset(out + 129 * i, 0, 129); if (!status[i]) { out[129 * i] = 0xa4; memcpy(out + 129 * i + 1, rec.data() + 128 * i, 128); } }
   return ACT_OK;
 }
-int act_refund_cbor_batch(act_ctx* c, size_t n, int mem, const uint8_t* sk, const uint8_t* cbor, const uint64_t* offsets, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status) {
+int act_refund_cbor_keys_batch(act_ctx* c, size_t n, int mem, const uint8_t* sk, const uint8_t* cbor, const uint64_t* offsets, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status, uint8_t* nul) {
   std::vector<uint8_t> kp(32 * n + 1), st(n + 1);
-  int rc = act_verify_spend_cbor_keys_batch(c, n, mem, sk, cbor, offsets, st.data(), kp.data(), nullptr);
+  int rc = act_verify_spend_cbor_keys_batch(c, n, mem, sk, cbor, offsets, st.data(), kp.data(), nul);
   return rc ? rc : act_refund_sign_cbor_batch(c, n, mem, sk, kp.data(), st.data(), rng, mode, out, status);
+}
+int act_refund_cbor_batch(act_ctx* c, size_t n, int mem, const uint8_t* sk, const uint8_t* cbor, const uint64_t* offsets, const uint8_t* rng, int mode, uint8_t* out, uint8_t* status) {
+  return act_refund_cbor_keys_batch(c, n, mem, sk, cbor, offsets, rng, mode, out, status, nullptr);
 }
 int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int, const uint8_t* prer, const uint8_t* proof, const uint8_t* refund, const uint8_t*, uint8_t* out, uint8_t* status) {
   c->lanes += n; for (size_t i = 0; i < n; i++) { emit(out + 160 * i, 160, prer + 96 * i, refund + 128 * i); out[159 + 160 * i] = proof[kPB * i]; status[i] = 0; } return ACT_OK;

@@ -89,7 +89,32 @@ def test_redeem_equals_the_sequential_loop(engine_factory, oracle, bench_params,
     for i, p in enumerate(first):
         if st[i] == 0:
             assert octx.refund(sk, p, rng[128 * i:128 * i + 128]) == (0, rf[128 * i:128 * i + 128])
+    ns.close()
+    # one item per call (the server's own rhythm: examples/act.rs:62-73), its 128 bytes handed over with it: the refund is computed as
+    # one call with the signature beside the verification, THEN the nullifier decides (nullifier_impl.inc) -- the same answers and the
+    # same database as the loop, item by item
+    ns = capi.NullifierSet(1000)
+    cur = 0
+    for i, p in enumerate(first + second):
+        want = (want1 if i < len(first) else want2)
+        j = i if i < len(first) else i - len(first)
+        st, rf = eng.redeem(ns, sk, p, rng[128 * cur:128 * cur + 128], capi.RNG_SEQUENTIAL)
+        assert (st, rf) == (want[0][j:j + 1], want[1][128 * j:128 * j + 128]), i
+        cur += st == b"\0"
+    assert len(ns) == 13 and cur == want1[2] + want2[2]
+    ns.close()
+    # ... and a few items with per-lane slices (the same path, n <= max_batch here)
+    ns = capi.NullifierSet(1000)
+    st, rf = eng.redeem(ns, sk, b"".join(first[:5]), rng, capi.RNG_PER_LANE)
+    assert st == want1[0][:5]
+    for i, p in enumerate(first[:5]):
+        assert rf[128 * i:128 * i + 128] == (octx.refund(sk, p, rng[128 * i:128 * i + 128])[1] if st[i] == 0 else bytes(128))
+    assert eng.redeem(ns, sk, b"".join(first[:5]), rng, capi.RNG_PER_LANE)[0] == bytes(3 if v == 0 else v for v in want1[0][:5])      # everything again: double spends
     # empty batch; a set on a context's own device only
+    assert eng.redeem(ns, sk, b"", b"") == (b"", b"")
+    ns.close()
+    ns = capi.NullifierSet(1000)
+    eng.redeem(ns, sk, b"".join(first), rng, capi.RNG_PER_LANE)
     assert eng.redeem(ns, sk, b"", b"") == (b"", b"") and len(ns) == 9
     ns.close()
     assert eng.secret_residue() == 0

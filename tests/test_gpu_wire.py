@@ -117,6 +117,16 @@ def test_refund_and_redeem_on_wire_bytes_equal_the_server_loop(engine_factory, o
         st2, out2 = eng.redeem_cbor(ns, sk, msgs, g, capi.RNG_CALLBACK)
         assert st2 == bytes(3 if s == 0 else s for s in want_st) and not any(out2) and g.pos == 0
         ns.close()
+        # one message per call with its 128 bytes (the refund in one call, the signature beside the verification, THEN the nullifier
+        # store: nullifier_impl.inc): message by message what the loop with the store answers, the same store at the end
+        ns = capi.NullifierSet(4 * N)
+        cur = 0
+        for i, msg in enumerate(msgs):
+            st1, out1 = eng.redeem_cbor(ns, sk, [msg], stream[128 * cur:128 * cur + 128], capi.RNG_SEQUENTIAL)
+            assert (st1, out1) == (r_st[i:i + 1], r_out[i:i + 1]), i
+            cur += st1 == b"\0"
+        assert len(ns) == len(db) and 128 * cur == r_drawn
+        ns.close()
     # device memory (offsets stay on the host): refund with pre-drawn sequential bytes, redeem through the callback
     blob = b"".join(msgs)
     offs = np.zeros(N + 1, np.uint64); offs[1:] = np.cumsum([len(x) for x in msgs], dtype=np.uint64)

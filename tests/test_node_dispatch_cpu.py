@@ -375,6 +375,26 @@ def test_wire_level_calls_and_the_generator_callback(lib, ndev):
     for i in range(n):
         assert out6.raw[128 * i:128 * (i + 1)] == (bytes(128) if want[i] else check_rec(recs, rrng, want, i))
     lib.act_node_nullifier_set_destroy(ns); lib.act_node_nullifier_set_destroy(ns2)
+    # a few items with per-lane rng bytes (n <= 64): one context computes the refunds in one call, THEN the store decides -- the same
+    # statuses, refunds and store as the general path; a second submission is all double spends; wire bytes and records
+    for wire_form in (True, False):
+        ns3 = C.c_void_p()
+        assert lib.act_node_nullifier_set_create(devs, 2, C.c_size_t(1000), None, C.byref(ns3)) == 0
+        rl = RL if wire_form else 128
+        out7 = C.create_string_buffer(rl * n); st7 = C.create_string_buffer(n)
+        call = (lambda: lib.act_node_redeem_cbor_batch(nd, ns3, C.c_size_t(n), bytes(64), msgs, offs, rrng, 0, out7, st7)) if wire_form else \
+               (lambda: lib.act_node_redeem_batch(nd, ns3, C.c_size_t(n), bytes(64), recs, rrng, 0, out7, st7))
+        assert call() == 0 and st7.raw == bytes(want)
+        for i in range(n):
+            slot = out7.raw[rl * i:rl * (i + 1)]
+            if want[i]:
+                assert slot == bytes(rl), i
+            else:
+                body = slot[1:] if wire_form else slot
+                assert (not wire_form or slot[0] == 0xa4) and body[:8] == recs[PB * i:PB * i + 8] and body[8:16] == rrng[128 * i:128 * i + 8], i
+        assert lib.act_node_nullifier_set_len(ns3) == signed
+        assert call() == 0 and st7.raw == bytes(3 if v == 0 else v for v in verdict) and out7.raw == bytes(rl * n)
+        lib.act_node_nullifier_set_destroy(ns3)
     lib.act_node_destroy(nd)
 
 
@@ -458,7 +478,7 @@ def test_node_last_error_is_the_calling_threads_own(lib):
     whichever thread failed last.  A thread that never failed on the handle sees the handle's most recent text."""
     import threading
     lib.act_node_last_error.restype = C.c_char_p
-    n, ndev = 64, 2
+    n, ndev = 200, 2          # (more than 64 items: the general path, whose signature step can fail behind a recorded nullifier)
     recs = records(n, PB, 91); rrng = records(n, 128, 92)
     nd = make_node(lib, ndev)
     devs = (C.c_int * ndev)(*range(ndev))
