@@ -1311,7 +1311,8 @@ int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const 
                      uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  if (mem == ACT_MEM_HOST && rng_mode == ACT_RNG_PER_LANE && n && n <= c->co_req_max.load()) { CoReq r{CO_REFUND, sk, proof, n, nullptr, nullptr, rng, false, out_refund, status, nullptr}; return spend_coalesced(c, r); }
+  // (one lane under ACT_RNG_SEQUENTIAL owns slice 0 whatever its verdict: the same thing as ACT_RNG_PER_LANE, and as mergeable)
+  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) { CoReq r{CO_REFUND, sk, proof, n, nullptr, nullptr, rng, false, out_refund, status, nullptr}; return spend_coalesced(c, r); }
   return spend_batch(c, n, mem, sk, proof, true, rng, rng_mode, out_refund, status, nullptr);
 }
 

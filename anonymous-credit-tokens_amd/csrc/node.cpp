@@ -425,6 +425,12 @@ int act_node_refund_batch(act_node* nd, size_t n, const uint8_t sk[64], const ui
                           uint8_t* out_refund, uint8_t* status) {
   if (!nd || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {      // small enough to merge with other threads' calls: one context, no node lock
+    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    const int rc = act_refund_batch(c, n, ACT_MEM_HOST, sk, proof, rng, rng_mode, out_refund, status);
+    if (rc) small_call_err(nd, c);
+    return rc;
+  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)

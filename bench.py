@@ -804,6 +804,25 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
                 x.join()
             dt = time.perf_counter() - t0
             single["coalescing_off" if not co else "coalescing_64"] = {"refunds_per_s": round(T * calls / dt), "ms_per_refund": round(1e3 * dt / calls, 2)}
+        # the same 16 threads making ONE library call per refund (act_node_refund_batch over one proof with its 128 bytes: the binding's
+        # refund_eager), merged the same way: the merged call signs beside its verification
+        node.set_coalescing(64)
+        calls = 48
+        def work1(t):
+            s2, rf = np.zeros(1, np.uint8), np.zeros(128, np.uint8)
+            for c in range(calls):
+                i = valid[(t + c) % len(valid)]
+                assert lib.act_node_refund_batch(nd, 1, skb, items[i].ctypes.data, rbytes[i].ctypes.data, capi.RNG_SEQUENTIAL, rf.ctypes.data, s2.ctypes.data) == 0 and s2[0] == 0
+        work1(0)
+        th = [threading.Thread(target=work1, args=(t,)) for t in range(T)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        single["one_call_coalescing_64"] = {"refunds_per_s": round(T * calls / dt), "ms_per_refund": round(1e3 * dt / calls, 2),
+                                            "what": "act_node_refund_batch(1 proof, its 128 rng bytes) per refund instead of the two calls"}
         node.close()
         ex["single_item_refunds"] = dict(single, threads=T, what="16 threads sharing one node handle, each: act_node_verify_spend_batch(1 proof) then "
                                                                  "act_node_refund_sign_batch(1 lane, ACT_RNG_SEQUENTIAL); device transcripts")
