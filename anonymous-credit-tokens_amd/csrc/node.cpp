@@ -456,7 +456,7 @@ int act_node_refund_cbor_batch(act_node* nd, size_t n, const uint8_t sk[64], con
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL && rng_mode != ACT_RNG_CALLBACK) return ACT_ERR_ARG;
   if (n == 0) return ACT_OK;
   // A few messages whose rng slices do not depend on the verdicts (per-lane bytes, or one message with its 128 bytes): one context does
-  // all of it in ONE call -- unframing, verification, the signature beside it (cbor_impl.inc refund_cbor_tiny: 2.1 ms for one message
+  // all of it in ONE call -- unframing, verification, the signature beside it (cbor_impl.inc refund_cbor_tiny_records: 2.1 ms for one message
   // instead of 3.1).  The context's own lock serialises it with whatever else that context is doing.
   if (n <= 64 && (rng_mode == ACT_RNG_PER_LANE || (rng_mode == ACT_RNG_SEQUENTIAL && n == 1))) {
     act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];

@@ -90,7 +90,7 @@ def test_refund_and_redeem_on_wire_bytes_equal_the_server_loop(engine_factory, o
         for i in (0, 2, 4, n + 3, N - 1):
             assert eng.refund_cbor(sk, [msgs[i]], stream[:128], capi.RNG_SEQUENTIAL) == _loop(octx, sk, L, [msgs[i]], stream)[:2]
         # a few canonical messages with per-lane slices: unframing, verification and the signature beside it in one call (cbor_impl.inc
-        # refund_cbor_tiny); with a non-canonical message among them the same call falls back to the general path
+        # refund_cbor_tiny_records); with a non-canonical message among them the same call falls back to the general path
         k = min(6, max_batch)
         assert eng.refund_cbor(sk, msgs[:k], stream[:128 * k], capi.RNG_PER_LANE) == _loop(octx, sk, L, msgs[:k], stream, per_lane=True)[:2]
         mixed = [msgs[1], msgs[n + 3], msgs[0]][:max_batch]
