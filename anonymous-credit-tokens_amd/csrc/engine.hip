@@ -970,10 +970,33 @@ static int issue_tiny(act_ctx* c, size_t n, int mem, const uint8_t* req, const u
   return prof_collect(c, sl);
 }
 
+// (requests of concurrent callers that merge into one call: spend_coalesced, further down)
+enum { CO_VERIFY = 0, CO_REFUND, CO_SIGN, CO_ISSUE_CHECK, CO_ISSUE_SIGN, CO_ISSUE };   // act_verify_spend / act_refund / act_refund_sign / act_issue_check / act_issue_sign / act_issue _batch
+struct CoReq {
+  int kind; const uint8_t* sk;            // sk: null for the key-less check
+  const uint8_t* in; size_t n;            // proofs (verify, refund), enc(K') (refund sign), IssuanceRequests (issue check / sign)
+  const uint8_t* camt; const uint8_t* status_in; const uint8_t* rng; bool rng_if_accepted;
+  uint8_t* out; uint8_t* status; uint8_t* out_kprime;
+  int rc = ACT_OK; bool done = false;
+  std::string err;                        // rc != 0: the merged call's error text, for this caller's act_last_error
+};
+static int spend_coalesced(act_ctx* c, CoReq& r);
+static int issue_batch_impl(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
+                            int rng_mode, uint8_t* out_resp, uint8_t* status);
 int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
                     int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!c || !sk || (n && (!req || !camt || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  // small calls of threads that share the context merge (act_ctx_set_coalescing), as verify / refund calls do: lane i of a request draws
+  // from its own 128 bytes (per-lane rng; one lane under the sequential convention is the same thing)
+  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) {
+    CoReq r{CO_ISSUE, sk, req, n, camt, nullptr, rng, false, out_resp, status, nullptr};
+    return spend_coalesced(c, r);
+  }
+  return issue_batch_impl(c, n, mem, sk, req, camt, rng, rng_mode, out_resp, status);
+}
+static int issue_batch_impl(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
+                            int rng_mode, uint8_t* out_resp, uint8_t* status) {
   Call call(c, n);
   HIPCK(c, hipSetDevice(c->device));
   int rc = set_key(c, sk); if (rc) return rc;
@@ -1008,17 +1031,6 @@ int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const u
 // The two halves of issue / refund as separate calls, for callers that must see every verdict before any rng is assigned:
 // the node dispatcher (node.cpp) makes ACT_RNG_SEQUENTIAL exact across the GPUs of a node by checking on all shards,
 // counting the accepted lanes of the shards in front, and only then signing.
-// (requests of concurrent callers that merge into one call: spend_coalesced, further down)
-enum { CO_VERIFY = 0, CO_REFUND, CO_SIGN, CO_ISSUE_CHECK, CO_ISSUE_SIGN };   // act_verify_spend / act_refund / act_refund_sign / act_issue_check / act_issue_sign _batch
-struct CoReq {
-  int kind; const uint8_t* sk;            // sk: null for the key-less check
-  const uint8_t* in; size_t n;            // proofs (verify, refund), enc(K') (refund sign), IssuanceRequests (issue check / sign)
-  const uint8_t* camt; const uint8_t* status_in; const uint8_t* rng; bool rng_if_accepted;
-  uint8_t* out; uint8_t* status; uint8_t* out_kprime;
-  int rc = ACT_OK; bool done = false;
-  std::string err;                        // rc != 0: the merged call's error text, for this caller's act_last_error
-};
-static int spend_coalesced(act_ctx* c, CoReq& r);
 
 static int tiny_buffers(act_ctx* c);
 static void wipe_host(uint8_t* p, size_t n);
@@ -1233,9 +1245,9 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
 static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
   const int kind = batch[0]->kind;
   const size_t pbytes = ProofLayout{c->L}.bytes();
-  const size_t in_b = kind == CO_SIGN ? 32 : (kind == CO_ISSUE_CHECK || kind == CO_ISSUE_SIGN) ? 128 : pbytes;
-  const size_t out_b = kind == CO_ISSUE_SIGN ? 160 : 128;
-  const bool sign = kind == CO_REFUND || kind == CO_SIGN || kind == CO_ISSUE_SIGN, has_sin = kind == CO_SIGN || kind == CO_ISSUE_SIGN;
+  const size_t in_b = kind == CO_SIGN ? 32 : (kind == CO_ISSUE_CHECK || kind == CO_ISSUE_SIGN || kind == CO_ISSUE) ? 128 : pbytes;
+  const size_t out_b = (kind == CO_ISSUE_SIGN || kind == CO_ISSUE) ? 160 : 128;
+  const bool sign = kind == CO_REFUND || kind == CO_SIGN || kind == CO_ISSUE_SIGN || kind == CO_ISSUE, has_sin = kind == CO_SIGN || kind == CO_ISSUE_SIGN;
   bool want_kp = false;
   for (CoReq* q : batch) want_kp = want_kp || q->out_kprime;
   if (total > c->h_co_cap) {                              // only the leader is here: no other thread touches these buffers
@@ -1254,7 +1266,7 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
   for (CoReq* q : batch) {
     memcpy(c->h_co_proofs + off * in_b, q->in, q->n * in_b);
     if (has_sin) memcpy(h_sin + off, q->status_in, q->n);
-    if (kind == CO_ISSUE_SIGN) memcpy(h_camt + off * 32, q->camt, q->n * 32);
+    if (kind == CO_ISSUE_SIGN || kind == CO_ISSUE) memcpy(h_camt + off * 32, q->camt, q->n * 32);
     if (sign) {
       // a one-lane ACT_RNG_SEQUENTIAL request owns 128 bytes only if its lane is to be signed (the reference draws after the checks)
       if (q->rng_if_accepted && q->status_in[0] != 0) memset(c->h_co_rng + off * 128, 0, 128);
@@ -1264,6 +1276,7 @@ static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
   }
   int rc;
   if (kind == CO_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_REFUND, batch[0]->sk, c->h_co_proofs, 32, nullptr, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
+  else if (kind == CO_ISSUE) rc = issue_batch_impl(c, total, ACT_MEM_HOST, batch[0]->sk, c->h_co_proofs, h_camt, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
   else if (kind == CO_ISSUE_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_RESPOND, batch[0]->sk, c->h_co_proofs, 128, h_camt, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
   else if (kind == CO_ISSUE_CHECK) rc = issue_check_impl(c, total, ACT_MEM_HOST, c->h_co_proofs, h_st);
   else rc = spend_batch(c, total, ACT_MEM_HOST, batch[0]->sk, c->h_co_proofs, sign, sign ? c->h_co_rng : nullptr, ACT_RNG_PER_LANE,

@@ -267,6 +267,12 @@ int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uin
                          int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!nd || !sk || (n && (!req || !c || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
+  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {      // small enough to merge with other threads' calls: one context, no node lock
+    act_ctx* cx = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    const int rc = act_issue_batch(cx, n, ACT_MEM_HOST, sk, req, c, rng, rng_mode, out_resp, status);
+    if (rc) small_call_err(nd, cx);
+    return rc;
+  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
     return run(nd, n, [&](size_t k, size_t off, size_t m) {

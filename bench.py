@@ -823,6 +823,32 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
         dt = time.perf_counter() - t0
         single["one_call_coalescing_64"] = {"refunds_per_s": round(T * calls / dt), "ms_per_refund": round(1e3 * dt / calls, 2),
                                             "what": "act_node_refund_batch(1 proof, its 128 rng bytes) per refund instead of the two calls"}
+        # ... and the issuance endpoint: the same 16 threads, one PrivateKey::issue per call (act_node_issue_batch over one request with
+        # its 128 bytes), queued on the handle against merged
+        try:
+            pre_i = eng.pre_issuance_random(shake("bench-si-pre", 128 * 64)); req_i = np.frombuffer(eng.request(pre_i, shake("bench-si-rq", 128 * 64)), np.uint8).reshape(64, 128).copy()
+            cam_i = np.frombuffer(b"".join(scb(100 + i) for i in range(64)), np.uint8).reshape(64, 32).copy()
+            issues = {}
+            for co in (0, 64):
+                node.set_coalescing(co)
+                calls = 24 if not co else 96
+                def work2(t):
+                    s2, rs = np.zeros(1, np.uint8), np.zeros(160, np.uint8)
+                    for c in range(calls):
+                        i = (t + c) % 64
+                        assert lib.act_node_issue_batch(nd, 1, skb, req_i[i].ctypes.data, cam_i[i].ctypes.data, rbytes[i].ctypes.data, capi.RNG_SEQUENTIAL, rs.ctypes.data, s2.ctypes.data) == 0 and s2[0] == 0
+                work2(0)
+                th = [threading.Thread(target=work2, args=(t,)) for t in range(T)]
+                t0 = time.perf_counter()
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                dt = time.perf_counter() - t0
+                issues["coalescing_off" if not co else "coalescing_64"] = {"issues_per_s": round(T * calls / dt), "ms_per_issue": round(1e3 * dt / calls, 2)}
+            ex["single_item_issues"] = dict(issues, threads=T, what="16 threads sharing one node handle, each: act_node_issue_batch(1 request, its 128 rng bytes); device transcripts")
+        except Exception as e:
+            ex["single_item_issues"] = {"error": repr(e)}
         node.close()
         ex["single_item_refunds"] = dict(single, threads=T, what="16 threads sharing one node handle, each: act_node_verify_spend_batch(1 proof) then "
                                                                  "act_node_refund_sign_batch(1 lane, ACT_RNG_SEQUENTIAL); device transcripts")

@@ -171,16 +171,16 @@ int act_ctx_set_small_batch_max(act_ctx *ctx, size_t n);
  * separate workgroups (a signature's two variable-base products cut into quarters), the block that arrives last assembling the
  * transcript, hashing it -- these transcripts are a single BLAKE3 chunk; the routine is the one ACT_TRANSCRIPT_DEVICE runs, so the
  * bytes are those of either transcript mode -- and finishing the record; inputs cross PCIe in one copy from a pinned buffer, which
- * the kernel zeroes itself.  One item, MI355X: request 0.28 ms (was 0.58), issue 1.2 (2.7), PreIssuance::to_credit_token 1.2 (2.3),
- * PreRefund::to_credit_token 1.6 (3.0), refund 3.3 (3.7), prove_spend 2.5 (3.2): profiles/r05_single_item_latency.txt.
+ * the kernel zeroes itself.  One item, MI355X: request 0.27 ms (was 0.58), issue 1.15 (2.7), PreIssuance::to_credit_token 1.1 (2.3),
+ * PreRefund::to_credit_token 1.5 (3.0), refund 2.0 (3.7), prove_spend 2.0 (3.2): profiles/r05_single_item_latency.txt.
  * act_ctx_set_tiny_calls(ctx, 0) (or ACT_NO_FUSED_TINY=1 in the environment) keeps the multi-launch paths, whose transcripts follow
  * the context's transcript mode -- a deployment that wants every hash on the host, whatever the call size (same bytes either way;
  * tests/test_gpu_tiny.py compares). */
 int act_ctx_set_tiny_calls(act_ctx *ctx, int on);           /* default 1 */
 /* Several threads, ONE context, one proof per call -- what a server built on the crate's single-item API does with the context the
  * Rust binding keeps inside `Params`.  Such callers queue on the context (a call is ~1.7 ms whatever its size: ~600 calls/s between
- * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch, act_refund_batch, act_refund_sign_batch, act_issue_check_batch and
- * act_issue_sign_batch calls of at most k lanes from host memory (rng: ACT_RNG_PER_LANE, or one lane in either mode) MERGE instead: the caller that finds no merged call running takes every request queued so far with the same
+ * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch, act_refund_batch, act_refund_sign_batch, act_issue_batch,
+ * act_issue_check_batch and act_issue_sign_batch calls of at most k lanes from host memory (rng: ACT_RNG_PER_LANE, or one lane in either mode) MERGE instead: the caller that finds no merged call running takes every request queued so far with the same
  * key, runs them as one call and hands each caller its own statuses / K' / refunds; requests pile up only while a call runs, nobody
  * waits for company.  Per lane the result is the one the caller's own call would have produced.  0 (default) = off. */
 int act_ctx_set_coalescing(act_ctx *ctx, size_t max_proofs_per_call);
@@ -291,7 +291,7 @@ int act_node_set_host_threads(act_node *node, int per_gpu);    /* host BLAKE3 wo
 int act_node_set_balance(act_node *node, int weighted, int tail_64ths);
 int act_node_device_stats(act_node *node, int k, double *weight, uint64_t *last_lanes, double *last_seconds, uint64_t *last_calls);
 int act_node_balance_state(act_node *node, double *spread, double *tail_fraction);
-/* act_ctx_set_coalescing on every context, and: act_node_verify_spend_batch / _refund_sign_batch / _issue_check_batch / _issue_sign_batch calls of at most
+/* act_ctx_set_coalescing on every context, and: act_node_verify_spend_batch / _refund_batch / _refund_sign_batch / _issue_batch / _issue_check_batch / _issue_sign_batch calls of at most
  * max_proofs_per_call proofs are no longer cut over the GPUs under the handle's lock -- each goes to one context (round robin) and
  * merges there with the small calls other threads make on the same handle at the same time.  What the Rust binding's single-item
  * `refund` turns into when a server's threads share one `Params`.  0 (default) = off. */

@@ -251,3 +251,57 @@ def test_coalesced_callers_get_their_own_answers(engine_factory, bench_params, o
     so, rf = oracle.ctx(bench_params, L).refund(sks[j], blob[:pb], rng[:128])
     st, out = alone[0][jobs[0].index((j, blob, sign, rng))]
     assert st[0] == so and out[:128] == rf
+
+
+def test_coalesced_issues_get_their_own_answers(engine_factory, bench_params, oracle):
+    """PrivateKey::issue from twelve threads that share one context (a server's issuance endpoint): with act_ctx_set_coalescing the calls of
+    1 - 3 requests each merge into launches of the fused issue kernel; every caller gets exactly what its own call returns alone --
+    statuses (a tampered request is rejected on its own lane only) and IssuanceResponse records byte for byte, for both keys in play,
+    per-lane rng and one-lane sequential rng."""
+    import random
+    import threading
+    from act_amd import capi
+    L, D = 8, 40
+    eng = engine_factory(bench_params, L, max_batch=256, transcript=1)
+    octx = oracle.ctx(bench_params, L)
+    sks = [eng.private_key_random(shake("ci-sk%d" % j, 64)) for j in range(2)]
+    pre = eng.pre_issuance_random(shake("ci-pre", 128 * D)); req = eng.request(pre, shake("ci-rq", 128 * D))
+    r = random.Random(4)
+    jobs = []
+    for t in range(12):
+        mine = []
+        for c in range(10):
+            k = r.randrange(1, 4)
+            lanes = [r.randrange(D) for _ in range(k)]
+            blob = bytearray(b"".join(req[128 * i:128 * i + 128] for i in lanes))
+            if r.randrange(3) == 0:
+                blob[128 * r.randrange(k) + 40] ^= 1                # gamma: InvalidIssuanceRequestProof on that lane only
+            mode = capi.RNG_SEQUENTIAL if (k == 1 and r.randrange(2)) else capi.RNG_PER_LANE
+            mine.append((r.randrange(2), bytes(blob), b"".join(scb(r.randrange(1, 200)) for _ in range(k)), shake("ci-r%d-%d" % (t, c), 128 * k), mode))
+        jobs.append(mine)
+    try:
+        eng.set_coalescing(0)
+        alone = [[eng.issue(sks[j], blob, cam, rng, mode) for j, blob, cam, rng, mode in jobs[t]] for t in range(12)]
+        j, blob, cam, rng, mode = jobs[0][0]                        # (and the oracle on one of them)
+        so, ro = octx.issue(sks[j], blob[:128], cam[:32], rng[:128])
+        assert (alone[0][0][0][:1], alone[0][0][1][:160]) == (bytes([so]), ro)
+        eng.set_coalescing(16)
+        merged = [None] * 12
+
+        def work(t):
+            try:
+                merged[t] = [eng.issue(sks[j], blob, cam, rng, mode) for j, blob, cam, rng, mode in jobs[t]]
+            except BaseException as e:
+                merged[t] = e
+        th = [threading.Thread(target=work, args=(t,)) for t in range(12)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    finally:
+        eng.set_coalescing(0)
+    for t in range(12):
+        assert not isinstance(merged[t], BaseException), merged[t]
+        assert merged[t] == alone[t], t
+    assert any(1 in st for res in alone for st, _ in res) and any(0 in st for res in alone for st, _ in res)
+    assert eng.secret_residue() == 0
