@@ -149,6 +149,28 @@ int main(int argc, char** argv) {
     expect("act_node_redeem_cbor_batch (second submission: double spends)", st, spent); expect("  no refunds", o_msgs, bytes(n * rl, 0));
     if (gen.pos != 0) { fprintf(stderr, "a rejected batch drew %zu bytes\n", gen.pos); g_fail++; }
     act_node_nullifier_set_destroy(nset);
+    // one message per call with its 128 bytes, a server's own rhythm: the refund is one call (signature beside the verification), then
+    // the store decides -- message by message the same bytes as the batch above, and the same store
+    rc = act_node_nullifier_set_create(ndev, 2, 1024, nullptr, &nset);
+    if (rc) { fprintf(stderr, "act_node_nullifier_set_create -> %d\n", rc); return 3; }
+    bytes one_by_one(n * rl, 7), st1(n, 9);
+    size_t cur = 0;
+    for (size_t i = 0; i < n; i++) {
+      rc = act_node_redeem_cbor_batch(node, nset, 1, sk.data(), msgs.data() + i * ml, nullptr, refund_rng.data() + 128 * cur, ACT_RNG_SEQUENTIAL, one_by_one.data() + i * rl, st1.data() + i);
+      if (rc) { fprintf(stderr, "act_node_redeem_cbor_batch (message %zu) -> %d (%s)\n", i, rc, act_node_last_error(node)); return 3; }
+      cur += st1[i] == 0;
+    }
+    expect("act_node_redeem_cbor_batch, one message per call", one_by_one, want); expect("  status", st1, status);
+    if (act_node_nullifier_set_len(nset) != accepted) { fprintf(stderr, "nullifier set holds %zu, want %zu\n", act_node_nullifier_set_len(nset), accepted); g_fail++; }
+    act_node_nullifier_set_destroy(nset);
+    // refund + nullifiers in one call (a caller with a store of its own): the nullifier is the first field of the record
+    bytes nul(n * 32, 7), keyed(n * rl, 7);
+    rc = act_refund_cbor_keys_batch(ctx, n, ACT_MEM_HOST, sk.data(), msgs.data(), nullptr, refund_rng.data(), ACT_RNG_SEQUENTIAL, keyed.data(), st.data(), nul.data());
+    if (rc) { fprintf(stderr, "act_refund_cbor_keys_batch -> %d (%s)\n", rc, act_last_error(ctx)); return 3; }
+    expect("act_refund_cbor_keys_batch", keyed, want); expect("  status", st, status);
+    bytes first_fields(n * 32);
+    for (size_t i = 0; i < n; i++) memcpy(first_fields.data() + 32 * i, proof_in.data() + i * (proof_in.size() / n), 32);
+    expect("  nullifiers", nul, first_fields);
   }
   act_node_destroy(node);
 
