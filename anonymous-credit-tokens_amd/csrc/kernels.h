@@ -253,9 +253,22 @@ void launch_spend_enc(const SpendArgs& a, hipStream_t s);
 // 160 KB), and with 60 KB a one-wavefront workgroup of the per-proof kernels cannot join it there either (and at most two of its own
 // kind share a CU).  Only for grids that fit the chip that way; ACT_NO_LDS_ISOLATION=1 turns it off (A/B).
 inline bool lds_isolation() { static const bool off = getenv("ACT_NO_LDS_ISOLATION") != nullptr; return !off; }
-inline unsigned isolate_bits(unsigned blocks) { return (lds_isolation() && blocks <= 224u) ? 40u * 1024u : 0u; }      // 256-thread workgroups of k_spend_bits
-inline unsigned isolate_role(unsigned blocks) { return (lds_isolation() && blocks <= 7u) ? 60u * 1024u : 0u; }        // 64-thread workgroups, several such kernels at once
-inline unsigned isolate_roles(unsigned blocks) { return (lds_isolation() && blocks <= 32u) ? 60u * 1024u : 0u; }      // a role-block kernel (blockIdx.y = role) of a tiny call
+// The sizes at which a launch "fits the chip that way" follow the CU count of the device the calling thread has current (256 on an
+// unpartitioned MI355X; a CPX partition has 32): 7/8 of the CUs for the range kernel's workgroups, the rest for the per-proof kernels.
+#if defined(__HIPCC__)
+inline unsigned device_cus() {
+  static unsigned cus[16] = {0};      // per device ordinal; a benign race writes the same value twice
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256u;
+  if (!cus[dev]) { int n = 0; cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? (unsigned)n : 256u; }
+  return cus[dev];
+}
+#else
+inline unsigned device_cus() { return 256u; }
+#endif
+inline unsigned isolate_bits(unsigned blocks) { return (lds_isolation() && blocks <= device_cus() * 7u / 8u) ? 40u * 1024u : 0u; }      // 256-thread workgroups of k_spend_bits
+inline unsigned isolate_role(unsigned blocks) { return (lds_isolation() && blocks <= device_cus() / 36u) ? 60u * 1024u : 0u; }        // 64-thread workgroups, several such kernels at once
+inline unsigned isolate_roles(unsigned blocks) { return (lds_isolation() && blocks <= device_cus() / 8u) ? 60u * 1024u : 0u; }        // a role-block kernel (blockIdx.y = role) of a tiny call
 
 void launch_spend_tail(const SpendArgs& a, hipStream_t s);
 void launch_sign_commit(const uint8_t* status, uint8_t* held, uint8_t* out, uint32_t n, uint32_t rec_bytes, hipStream_t s);      // out[p] = status[p] == 0 ? held[p] : 0; held wiped
