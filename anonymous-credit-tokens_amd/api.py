@@ -106,10 +106,7 @@ def _draw_signed(rng, n_lanes: int, run):
     every verdict is known.  `rng.fill_bytes(k)` is called with exactly that many bytes."""
     import ctypes as C
 
-    def draw(_ctx, dst, n):
-        if n:
-            C.memmove(dst, rng.fill_bytes(n), n)
-    cb = capi.RNG_DRAW_FN(draw)
+    cb = capi.rng_trampoline(rng.fill_bytes)          # an exception in fill_bytes, or a short read, fails the call: nothing is signed
     src = capi.RngSource(cb, None)
     holder = type("Src", (), {"ptr": C.addressof(src), "keep": (cb, src)})()
     return run(_CallbackRng(holder), capi.RNG_CALLBACK)

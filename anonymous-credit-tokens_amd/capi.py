@@ -13,11 +13,11 @@ LIB_PATH = os.environ.get("ACT_LIB_PATH") or os.path.join(_HERE, "libact_mi355x.
 MEM_HOST, MEM_DEVICE = 0, 1
 RNG_PER_LANE, RNG_SEQUENTIAL, RNG_CALLBACK = 0, 1, 2
 TRANSCRIPT_HOST, TRANSCRIPT_DEVICE = 0, 1
-_ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO_DEVICE"}
+_ERRS = {1: "ACT_ERR_ARG", 2: "ACT_ERR_HIP", 3: "ACT_ERR_PARAMS", 4: "ACT_ERR_NO_DEVICE", 5: "ACT_ERR_RNG"}
 
 EXPORTS = [
     "act_params_new", "act_params_random", "act_ctx_create", "act_ctx_destroy", "act_ctx_set_transcript_mode",
-    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_parallel_for", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_ctx_set_coalescing", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
+    "act_ctx_set_host_threads", "act_host_usable_cpus", "act_host_hash_many", "act_host_parallel_for", "act_host_pool_stats", "act_ctx_streams_overlap", "act_ctx_set_pipeline_depth", "act_ctx_set_small_batch_max", "act_ctx_set_fixed_base_bits", "act_node_set_fixed_base_bits", "act_tuning_set", "act_build_has_ct_secret_tables", "act_ctx_fixed_base_bits", "act_last_error", "act_spend_proof_bytes", "act_prove_rng_bytes",
     "act_spend_transcript_bytes", "act_private_key_random", "act_pre_issuance_random_batch", "act_request_batch",
     "act_issue_batch", "act_issuance_to_credit_token_batch", "act_prove_spend_batch", "act_prove_spend_seeded_batch", "act_node_prove_spend_seeded_batch", "act_verify_spend_batch",
     "act_refund_batch", "act_refund_to_credit_token_batch", "act_debug_last_spend_transcripts", "act_debug_scalarmult_batch", "act_debug_secret_residue", "act_prof_enable",
@@ -28,7 +28,7 @@ EXPORTS = [
     "act_nullifier_check_and_insert_batch",
     "act_issue_check_batch", "act_issue_sign_batch", "act_refund_sign_batch",
     "act_node_create", "act_node_destroy", "act_node_device_count", "act_node_ctx", "act_node_last_error", "act_node_set_transcript_mode",
-    "act_node_set_host_threads", "act_node_set_coalescing", "act_node_request_batch", "act_node_issue_batch", "act_node_issuance_to_credit_token_batch",
+    "act_node_set_host_threads", "act_node_request_batch", "act_node_issue_batch", "act_node_issuance_to_credit_token_batch",
     "act_node_prove_spend_batch", "act_node_verify_spend_batch", "act_node_refund_batch", "act_node_refund_to_credit_token_batch",
     "act_node_issue_check_batch", "act_node_issue_sign_batch", "act_node_refund_sign_batch",
     "act_node_nullifier_set_create", "act_node_nullifier_set_destroy", "act_node_nullifier_set_len", "act_node_nullifier_set_last_error",
@@ -81,7 +81,9 @@ def load() -> C.CDLL:
     lib.act_ctx_set_host_threads.argtypes = [vp, i32]
     lib.act_ctx_set_pipeline_depth.argtypes = [vp, i32]
     lib.act_ctx_set_small_batch_max.argtypes = [vp, sz]
-    lib.act_ctx_set_coalescing.argtypes = [vp, sz]
+    lib.act_ctx_set_fixed_base_bits.argtypes = [vp, i32, i32]
+    lib.act_node_set_fixed_base_bits.argtypes = [vp, i32, i32]
+    lib.act_tuning_set.argtypes = [C.c_char_p, C.c_int64]
     lib.act_host_usable_cpus.argtypes = []
     lib.act_host_hash_many.argtypes = [u8p, sz, C.c_uint32, sz, i32, u8p]
     lib.act_host_hash_many.restype = None
@@ -151,7 +153,6 @@ def load() -> C.CDLL:
     lib.act_node_last_error.restype = C.c_char_p
     lib.act_node_set_transcript_mode.argtypes = [vp, i32]
     lib.act_node_set_host_threads.argtypes = [vp, i32]
-    lib.act_node_set_coalescing.argtypes = [vp, sz]
     lib.act_node_request_batch.argtypes = [vp, sz, u8p, u8p, u8p]
     lib.act_node_issue_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, i32, u8p, u8p]
     lib.act_node_issuance_to_credit_token_batch.argtypes = [vp, sz, u8p, u8p, u8p, u8p, u8p, u8p]
@@ -187,10 +188,51 @@ def load() -> C.CDLL:
     lib.act_debug_set_slowdown.argtypes = [vp, C.c_uint32]
     lib.act_debug_fail_next_signs.argtypes = [vp, i32]
     _lib = lib
+    forward_tuning_env(lib)
     return lib
 
 
-RNG_DRAW_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+# The library reads no ACT_* tuning variable itself (act_tuning_set is the only way in): tools/, tests/ and bench.py keep their
+# environment-variable interface HERE, in the binding they all go through.  ACT_<NAME>=v -> act_tuning_set("<name>", v).
+TUNING_ENV = ("NO_MAPPED_READS", "NO_STREAM_PROBE", "NO_FUSED_TINY", "NO_TAPER", "NO_WIDE_CLIENT", "NO_WIDE_PROVE", "NO_WIDE_SIGN", "NO_LDS_ISOLATION",
+              "SMALL_NORMAL_PRIO", "SMALL_TRACE", "SMALL_IN_FLIGHT", "SMALL_SUB", "STAGGER", "HOST_CHUNK", "CBOR_CHUNK_MSGS", "UBENCH_ITERS")
+
+
+def forward_tuning_env(lib=None):
+    """(also callable later: a test that changes ACT_CBOR_CHUNK_MSGS between calls re-forwards)"""
+    lib = lib or load()
+    defaults = {"STAGGER": -1, "SMALL_IN_FLIGHT": 2}
+    for name in TUNING_ENV:
+        v = os.environ.get("ACT_" + name)
+        try:
+            val = defaults.get(name, 0) if v is None else (int(v) if v.strip() else 1)
+        except ValueError:
+            val = 1
+        lib.act_tuning_set(name.lower().encode(), val)
+
+
+RNG_DRAW_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def rng_trampoline(fill):
+    """act_rng_draw_fn around `fill(n) -> n bytes`.  ctypes swallows an exception raised inside a callback (it prints it and returns
+    garbage), so the trampoline catches everything itself, checks the length, and reports failure as the ABI says: non-zero -- the
+    library then signs nothing (ACT_ERR_RNG).  The exception is kept in `.error` of the returned callback's holder list."""
+    err = []
+
+    def draw(_ctx, dst, n):
+        try:
+            data = fill(n)
+            if len(data) != n:
+                raise ValueError("generator returned %d bytes, %d asked" % (len(data), n))
+            C.memmove(dst, bytes(data), n)
+            return 0
+        except BaseException as e:      # noqa: BLE001 -- nothing may propagate into C
+            err.append(e)
+            return 1
+    cb = RNG_DRAW_FN(draw)
+    cb.errors = err
+    return cb
 
 
 class RngSource(C.Structure):
@@ -204,12 +246,14 @@ class ReplayRng:
     def __init__(self, data: bytes):
         self.data, self.pos, self.draws = bytes(data), 0, []
 
-        def draw(_ctx, dst, n):
-            assert self.pos + n <= len(self.data), "generator exhausted"
-            C.memmove(dst, self.data[self.pos:self.pos + n], n)
+        def fill(n):
+            if self.pos + n > len(self.data):
+                raise ValueError("generator exhausted")
+            out = self.data[self.pos:self.pos + n]
             self.pos += n
             self.draws.append(n)
-        self._cb = RNG_DRAW_FN(draw)
+            return out
+        self._cb = rng_trampoline(fill)
         self.source = RngSource(self._cb, None)
 
     @property
@@ -312,6 +356,11 @@ class Engine:
                 self.lib.act_ctx_destroy(ctx)
             raise ActError(f"act_ctx_create failed: {_ERRS.get(rc, rc)} {msg}")
         self.ctx = ctx
+        forward_tuning_env(self.lib)       # ACT_* measurement knobs as they stand now (tests change them between engines)
+        wide = os.environ.get("ACT_FB_WIDE_BITS")          # tools' A/B interface of rounds 3-5; the library itself no longer looks
+        if wide and wide.isdigit() and int(wide) != 16:
+            for b in ((0, 1, 2, 3) if os.environ.get("ACT_FB_ALL_WIDE") else (1, 3)):
+                self.lib.act_ctx_set_fixed_base_bits(ctx, b, int(wide))
         self.proof_bytes = self.lib.act_spend_proof_bytes(ctx)
         self.prove_rng_bytes = self.lib.act_prove_rng_bytes(ctx)
         self.transcript_bytes = self.lib.act_spend_transcript_bytes(ctx)
@@ -353,9 +402,21 @@ class Engine:
         self._ck(self.lib.act_ubench_table_read(self.ctx, base, waves_per_simd, in_flight, C.byref(r), C.byref(ms)))
         return r.value, ms.value
 
-    def set_coalescing(self, max_proofs_per_call: int):
-        """calls of at most this many proofs from host memory merge with other threads' calls on this context (0 = off)"""
-        self._ck(self.lib.act_ctx_set_coalescing(self.ctx, max_proofs_per_call))
+    def set_fixed_base_bits(self, base: int, bits: int):
+        """Window width of the table of base 0..3 (g, h1, h2, h3); act_ctx_create leaves all four at 16 bits."""
+        self._ck(self.lib.act_ctx_set_fixed_base_bits(self.ctx, base, bits))
+
+    def set_wide_range_tables(self, bits: int = 24) -> bool:
+        """24-bit windows for h1 and h3, the range kernel's bases (+47 GB, +3 % verifies/s): what a GPU that serves nothing else asks
+        for.  Returns False (tables unchanged) when the device has not the room."""
+        try:
+            self.set_fixed_base_bits(1, bits); self.set_fixed_base_bits(3, bits)
+            return True
+        except ActError:
+            for b in (1, 3):
+                if self.lib.act_ctx_fixed_base_bits(self.ctx, b) != 16:
+                    self.lib.act_ctx_set_fixed_base_bits(self.ctx, b, 16)
+            return False
 
     def set_small_batch_max(self, n: int):
         """Calls of at most n proofs take the small-batch (latency) schedule; 0 = never."""
@@ -635,8 +696,8 @@ class Node:
     def set_host_threads(self, per_gpu: int):
         self._ck(self.lib.act_node_set_host_threads(self.nd, per_gpu))
 
-    def set_coalescing(self, max_proofs_per_call: int):
-        self._ck(self.lib.act_node_set_coalescing(self.nd, max_proofs_per_call))
+    def set_fixed_base_bits(self, base: int, bits: int):
+        self._ck(self.lib.act_node_set_fixed_base_bits(self.nd, base, bits))
 
     def streams_overlap(self) -> list:
         return [self.lib.act_ctx_streams_overlap(self.lib.act_node_ctx(self.nd, k)) for k in range(self.device_count())]

@@ -18,11 +18,38 @@
 #include <thread>
 #include <vector>
 #include "kernels.h"
-#include "coalesce.h"
 #include "rng_source.h"
 #include "../../include/act_mi355x.h"
 
+// ROCTX ranges (the tracing subsystem), compiled in with -DACT_ROCTX (tools/profile_round.sh builds that variant
+// and runs it under `rocprofv3 --kernel-trace --marker-trace`): the pipeline the design describes -- phase A of chunk i+1 enqueued
+// while chunk i's transcripts cross PCIe and are hashed on the host, then phase B -- as named host-side intervals on the same
+// timeline as the kernels.  The product build carries none of it (no dependency on the profiler's library).
+#if defined(ACT_ROCTX)
+#include <rocprofiler-sdk-roctx/roctx.h>
+namespace {
+struct RoctxRange {
+  explicit RoctxRange(const char* fmt, size_t a = 0, size_t b = 0) { char t[96]; snprintf(t, sizeof t, fmt, a, b); roctxRangePushA(t); }
+  ~RoctxRange() { roctxRangePop(); }
+};
+}
+#define ACT_RANGE_CAT2(a, b) a##b
+#define ACT_RANGE_CAT(a, b) ACT_RANGE_CAT2(a, b)
+#define ACT_RANGE(...) RoctxRange ACT_RANGE_CAT(act_roctx_range_, __LINE__)(__VA_ARGS__)
+#else
+#define ACT_RANGE(...) do { } while (0)
+#endif
+
 using namespace act;
+
+// the measurement knobs (kernels.h TuneKey): defaults, and the one way to change them (act_tuning_set)
+namespace act {
+std::atomic<long> g_tune[T_COUNT] = {};
+namespace {
+struct TuneInit { TuneInit() { g_tune[T_STAGGER].store(-1); g_tune[T_SMALL_IN_FLIGHT].store(2); } } g_tune_init;
+}
+}  // namespace act
+
 
 extern "C" void act_host_hash_many(const uint8_t* msgs, size_t stride, uint32_t len, size_t n, int max_threads, uint32_t* xof);   // host_pool.cpp
 
@@ -61,6 +88,7 @@ struct Slot {
   uint8_t* d_stage[N_STAGE] = {};   // staging for host-memory callers (grow-only); 5 = key decoding scratch, 6 = records unframed from wire bytes, 7 = their offsets, 8 = CBOR layout tables
   size_t d_stage_cap[N_STAGE] = {};
   size_t d_stage_dirty[N_STAGE] = {};     // bytes written since the last wipe (finish_call)
+  size_t d_trs_dirty = 0;                 // lanes of d_trs that a sign-beside-the-check kernel wrote (k_sign_fused<CHECK> / before_verdict): wiped by finish_call
   std::vector<uint64_t> h_rel;            // message offsets of the chunk in flight, relative to its first byte (act_verify_spend_cbor_batch)
   uint8_t* h_tr = nullptr; size_t h_tr_cap = 0;        // pinned host buffers of the host-transcript mode
   uint32_t* h_xof = nullptr; size_t h_xof_cap = 0;
@@ -76,7 +104,7 @@ struct Slot {
 // for seconds, and a failing call on one thread must not tear the string another thread is copying.
 // The text of a handle's last failure.  A handle is shared between threads, and "last" must mean the calling thread's own last
 // failing call, not whichever thread failed most recently: every assignment is also kept in a slot of the assigning thread, which
-// act_last_error prefers; a caller whose request was merged into another thread's call is handed the leader's text (CoReq::err).
+// act_last_error prefers.
 struct ErrText {
   mutable std::mutex m; std::string s;
   struct Mine { const ErrText* of = nullptr; std::string text; };
@@ -92,7 +120,6 @@ struct ErrText {
   void forget_mine() const { Mine& t = mine(); if (t.of == this) t.text.clear(); }      // a new call of this thread on this handle begins
   operator std::string() const { return get(); }
 };
-struct CoReq;       // a small call waiting to be merged with others (defined with the entry points that merge)
 struct act_ctx {
   int device = 0, L = 128;
   size_t max_batch = 0;
@@ -125,18 +152,14 @@ struct act_ctx {
   bool aux_used = false;               // the running call has put work on the aux streams: finish_call waits for them before it wipes
   std::vector<hipEvent_t> sm_ev;       // SM_EVENTS per sub-chunk, created on first use, kept
   uint32_t* d_small = nullptr; size_t d_small_cap = 0, d_small_dirty = 0;      // bytes
-  std::atomic<size_t> small_max{8192}; // (atomic: merged callers read it without the context's lock)  calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
+  std::atomic<size_t> small_max{8192}; // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
   double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
   double host_wait_s = 0, host_hash_s = 0; uint64_t host_hash_bytes = 0; // act_ctx_host_hash_stats: the calling thread's time in hash_end since the last reset
-  // coalescing of concurrent callers' small verify / refund calls (act_ctx_set_coalescing; spend_coalesced below)
-  std::atomic<size_t> co_req_max{0};   // 0 = off; else: calls of at most this many proofs from host memory may be merged
-  act::Combiner<struct CoReq>* co = nullptr;     // the queue of requests waiting to be merged (coalesce.h); created with the context
-  uint8_t *h_co_proofs = nullptr, *h_co_rng = nullptr, *h_co_out = nullptr;   // pinned gather / scatter buffers of the leader (grow-only)
-  size_t h_co_cap = 0;                 // lanes
   // tiny calls (at most TINY_MAX lanes: the crate's one-item call shape): one pinned + one device buffer, one copy each way, one kernel
   uint8_t *d_tiny = nullptr, *h_tiny = nullptr;
+  bool tiny_dirty = false;             // a tiny call staged inputs (secrets among them) there: finish_call wipes both on EVERY exit
   std::atomic<bool> tiny_on{true};     // act_ctx_set_tiny_calls
   uint32_t* d_group_ctr = nullptr;     // one word per group of 64 lanes (k_sign_fused ...: which role block arrives last), zero between launches
   uint8_t* d_tiny_tr = nullptr;        // TINY_MAX "request" transcripts of the fused issue kernel
@@ -207,8 +230,7 @@ int stage_reserve(act_ctx* c, Slot& sl, int slot, size_t bytes) {
 // RECORDS (public, read in 2 KiB-contiguous wavefront loads): wire bytes and secrets keep their staged (secrets: wiped) copies.  Returns the device address of p, or null (pageable memory,
 // a range that leaves its allocation, memory pinned under another device, or ACT_NO_MAPPED_READS set).
 const uint8_t* mapped_view(const act_ctx* c, const uint8_t* p, size_t bytes) {
-  static const bool off = getenv("ACT_NO_MAPPED_READS") != nullptr;
-  if (off || !p || !bytes) return nullptr;
+  if (tune(T_NO_MAPPED_READS) || !p || !bytes) return nullptr;
   hipPointerAttribute_t a0{}, a1{};
   if (hipPointerGetAttributes(&a0, p) != hipSuccess || hipPointerGetAttributes(&a1, p + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   if (a0.type != hipMemoryTypeHost || a1.type != hipMemoryTypeHost || !a0.devicePointer || !a1.devicePointer) return nullptr;
@@ -268,6 +290,7 @@ void host_hash_many(const act_ctx* c, const uint8_t* msgs, size_t stride, uint32
 // come back whole
 inline int hash_pieces(uint32_t n) { const uint32_t k = n / 512u; return k < 1u ? 1 : (k > (uint32_t)HASH_PIECES ? HASH_PIECES : (int)k); }
 int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_t stride, uint32_t len, uint32_t n) {
+  ACT_RANGE("transcript.hash_begin n=%zu (device: k_hash_xof; host: D2H of the pre-images queued)", (size_t)n);
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) {
     HashArgs h{d_msgs, stride, len, n, sl.d_xof, nullptr};
     // few long messages (a small prove_spend / verify call's "spend" transcripts): sixteen lanes per message (k_hash_xof_par)
@@ -305,6 +328,7 @@ int hash_begin(act_ctx* c, Slot& sl, int prof_id, const uint8_t* d_msgs, uint32_
 }
 int hash_end(act_ctx* c, Slot& sl, uint32_t stride, uint32_t len, uint32_t n) {
   if (c->tr_mode == ACT_TRANSCRIPT_DEVICE) return ACT_OK;
+  ACT_RANGE("transcript.hash_end n=%zu (wait for D2H pieces, BLAKE3 on the host pool, H2D of the XOF words)", (size_t)n);
   static const bool trace = getenv("ACT_TRACE") != nullptr;      // where the host side of the host-transcript mode spends its time
   double& t_wait = c->trace_wait_s; double& t_hash = c->trace_hash_s; size_t& n_msgs = c->trace_msgs;      // per context: contexts run on their own threads
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -481,8 +505,7 @@ int streams_overlap_probe3(act_ctx* c, int* overlap) {
 // per priority, so the two cannot alias whatever else the process has created.  What is left is reported by
 // act_ctx_streams_overlap() and documented for the embedding process (GPU_MAX_HW_QUEUES).
 int streams_settle(act_ctx* c) {
-  static const bool skip = getenv("ACT_NO_STREAM_PROBE") != nullptr;
-  if (skip) { c->streams_overlap = -1; return ACT_OK; }
+  if (tune(T_NO_STREAM_PROBE)) { c->streams_overlap = -1; return ACT_OK; }
   int ov = 0, rc = streams_overlap_probe3(c, &ov); if (rc) return rc;
   if (!ov) {
     int least = 0, greatest = 0;
@@ -522,6 +545,18 @@ int finish_call(act_ctx* c, size_t n) {
       if (sl.d_stage_dirty[i]) { HIPCK(c, hipMemsetAsync(sl.d_stage[i], 0, sl.d_stage_dirty[i], sl.stream)); sl.d_stage_dirty[i] = 0; }
     if (&sl == &c->slots[0] && c->d_small_dirty) {          // the small-batch schedule's partial sums ((e_bar - x gamma) A' among them) and buckets
       HIPCK(c, hipMemsetAsync(c->d_small, 0, c->d_small_dirty, sl.stream)); c->d_small_dirty = 0;
+    }
+    // A kernel that signs BESIDE the check (k_sign.hip k_sign_fused<CHECK>, or before_verdict) has written e, enc(A), X_A, X_g, Y_A,
+    // Y_g of EVERY lane into its small transcript, the rejected ones included: a complete signature over a K (or K') that nothing has
+    // verified.  The reference draws e only after its checks (src/lib.rs:638-643, 842-846); here such a lane's transcript dies with
+    // the call.  (Accepted lanes' transcripts hold only what their response publishes; they go too.)
+    if (sl.d_trs_dirty) { HIPCK(c, hipMemsetAsync(sl.d_trs, 0, std::min(sl.d_trs_dirty, c->max_batch) * SMALL_TR_STRIDE, sl.stream)); sl.d_trs_dirty = 0; }
+    // the tiny calls' staging pair: the kernels zero their inputs and the paths wipe the pinned side when they succeed, but an early
+    // return between the copy in and that wipe skipped both
+    if (&sl == &c->slots[0] && c->tiny_dirty && c->d_tiny) {
+      HIPCK(c, hipMemsetAsync(c->d_tiny, 0, TINY_BYTES, sl.stream));
+      volatile uint8_t* q = c->h_tiny; for (size_t i = 0; i < TINY_BYTES; i++) q[i] = 0;
+      c->tiny_dirty = false;
     }
     if (lanes) {
       HIPCK(c, hipMemsetAsync(sl.d_state, 0, lanes * 24 * 4, sl.stream));
@@ -602,8 +637,10 @@ int prepare_rng_slots(act_ctx* c, Slot& sl, uint32_t m, size_t off, int mem, con
 // counters of the role-block kernels (which block of a group arrives last): a set per slot, because the two slots' launches overlap
 uint32_t* group_counters(act_ctx* c, const Slot& sl) { return c->d_group_ctr + (size_t)(&sl - c->slots) * (GROUP_CTR_WORDS / 2); }
 // (tiny calls: see request_tiny further down)  ACT_NO_FUSED_TINY=1 keeps the multi-launch paths (A/B; the tests compare the two)
-bool tiny_enabled(const act_ctx* c) { static const bool off = getenv("ACT_NO_FUSED_TINY") != nullptr; return !off && c->tiny_on.load(); }
+bool tiny_enabled(const act_ctx* c) { return !tune(T_NO_FUSED_TINY) && c->tiny_on.load(); }
 int sign_phase(act_ctx* c, Slot& sl, uint32_t m, int label, const uint8_t* d_rng, const uint8_t* d_camount, uint8_t* d_out) {
+  ACT_RANGE("sign.phaseA+hash+phaseB m=%zu label=%zu", (size_t)m, (size_t)label);
+  sl.d_trs_dirty = std::max(sl.d_trs_dirty, (size_t)m);
   if (m <= TINY_MAX && tiny_enabled(c)) {
     // tiny calls: phase A, the transcript's BLAKE3 (one chunk, in the kernel: same bytes as either transcript mode) and phase B in
     // ONE launch, the five transcript points on three wavefronts (k_sign.hip k_sign_fused); nothing secret reaches global memory
@@ -625,6 +662,7 @@ struct SpendChunk { uint32_t m = 0; size_t off = 0; const uint8_t* d_proofs = nu
 
 // stage 1: everything up to (and including the start of) the transcript hash
 int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
+  ACT_RANGE("spend.phaseA off=%zu m=%zu (prep, bits, enc, tail enqueued; transcripts on their way)", ch.off, (size_t)ch.m);
   const SpendTranscript st{c->L};
   SpendArgs& a = ch.a;
   a = SpendArgs{}; a.P = c->P; a.K = c->key; a.proofs = ch.d_proofs; a.n = ch.m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride();
@@ -652,6 +690,7 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
 }
 // stage 2: finish the hash (host mode blocks on this slot only) and set the statuses
 int spend_stage2(act_ctx* c, Slot& sl, SpendChunk& ch) {
+  ACT_RANGE("spend.phaseB off=%zu m=%zu (hash_end, then k_spend_finish)", ch.off, (size_t)ch.m);
   const SpendTranscript st{c->L};
   int rc;
   if ((rc = hash_end(c, sl, (uint32_t)st.stride(), (uint32_t)st.bytes(), ch.m))) return rc;
@@ -687,7 +726,6 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev) return ACT_ERR_ARG;
   act_ctx* c = new act_ctx();
-  c->co = new act::Combiner<CoReq>();
   *out = c;   // returned even on failure so that act_last_error() can be read; the caller destroys it
   // lanes per launch = max_batch * L must stay below 2^31 (kernels index lanes with 32-bit integers)
   if (max_batch > ((size_t)1 << 22)) { c->err = "max_batch above 2^22: lanes per launch (max_batch * L) must stay below 2^31"; return ACT_ERR_ARG; }
@@ -707,36 +745,12 @@ int act_ctx_create(const uint8_t h[96], int L, int device, size_t max_batch, act
   HIPCK(c, hipMemcpyAsync(ok, d_ok, 16, hipMemcpyDeviceToHost, s0));
   HIPCK(c, hipStreamSynchronize(s0));
   if (!(ok[0] && ok[1] && ok[2] && ok[3])) { c->err = "h1/h2/h3 is not a canonical Ristretto encoding"; return ACT_ERR_PARAMS; }
-  // Window widths: 16 bits everywhere (128 MiB per base) unless the device is plainly being used for nothing but this.  The two bases
-  // the range kernel multiplies (h1, h3: 48 of its table additions per proof-bit) gain +3 % verifies/s from 24-bit windows, which cost
-  // 23.6 GB each -- 47 GB for 3 %.  A context therefore takes them only when it is sized for throughput (max_batch >= 65536) AND at
-  // least 128 GB of the device are still free after its own workspace (a 288 GB MI355X running one or two such contexts; never a GPU
-  // shared with other tenants), or when asked: ACT_FB_WIDE_BITS=24 (any width 4..24; needs the tables' size + 16 GB free),
-  // ACT_FB_WIDE_BITS=16 = never, ACT_FB_ALL_WIDE=1 widens g and h2 as well (prover-heavy deployments).  Tables of one width on one
-  // device are shared by all contexts of the process, so the second context pays nothing either way.
-  {
-    static const int wide_env = [] { const char* e = getenv("ACT_FB_WIDE_BITS"); return e ? atoi(e) : 0; }();
-    static const bool all_wide = getenv("ACT_FB_ALL_WIDE") != nullptr;
-    int wide = wide_env ? wide_env : (c->max_batch >= 65536 ? 24 : FB_WBITS);
-    if (wide < 4 || wide > 24) wide = FB_WBITS;
-    for (int b = 0; b < 4; b++) c->fb_bits[b] = (b == BASE_H1 || b == BASE_H3 || all_wide) ? wide : FB_WBITS;
-    if (wide > FB_WBITS) {
-      size_t need = 0, free_b = 0, total_b = 0;
-      for (int b = 0; b < 4; b++)
-        if (c->fb_bits[b] > FB_WBITS && !table_cached(device, enc + 32 * b, c->fb_bits[b])) need += fb_table_words((uint32_t)c->fb_bits[b]) * 4;
-      const size_t floor_free = wide_env ? need + ((size_t)16 << 30) : std::max(need + ((size_t)16 << 30), (size_t)128 << 30);
-      if (need && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < floor_free)) {
-        (void)hipGetLastError();
-        for (int b = 0; b < 4; b++) c->fb_bits[b] = FB_WBITS;
-      }
-    }
-  }
+  // Window widths: 16 bits for every base (128 MiB each) -- ONE fixed footprint, whatever the device has free.  Wider windows are the
+  // caller's decision: act_ctx_set_fixed_base_bits (below; bench.py asks for 24 bits on h1 and h3, the range kernel's bases: +47 GB,
+  // +3 % verifies/s).  Tables of one width on one device are shared by all contexts of the process.
+  for (int b = 0; b < 4; b++) c->fb_bits[b] = FB_WBITS;
   for (int b = 0; b < 4; b++) {
     c->d_tables[b] = table_acquire(device, enc + 32 * b, c->fb_bits[b], d_ext + b * GE_WORDS, s0, nullptr);
-    if (!c->d_tables[b] && c->fb_bits[b] > FB_WBITS) {           // no room after all (another process took it meanwhile): the default width
-      c->fb_bits[b] = FB_WBITS;
-      c->d_tables[b] = table_acquire(device, enc + 32 * b, FB_WBITS, d_ext + b * GE_WORDS, s0, nullptr);
-    }
     if (!c->d_tables[b]) { c->err = "fixed-base table allocation failed"; return ACT_ERR_HIP; }
     c->P.tab[b] = FbTab{c->d_tables[b], (uint32_t)c->fb_bits[b], (uint32_t)b};
   }
@@ -799,14 +813,12 @@ void act_ctx_destroy(act_ctx* c) {
   if (c->d_group_ctr) (void)hipFree(c->d_group_ctr);
   if (c->d_tiny_tr) (void)hipFree(c->d_tiny_tr);
   if (c->h_tiny) { memset(c->h_tiny, 0, TINY_BYTES); (void)hipHostFree(c->h_tiny); }
-  for (uint8_t* p : {c->h_co_proofs, c->h_co_rng, c->h_co_out}) if (p) (void)hipHostFree(p);
   for (uint32_t* t : c->d_tables) table_release(c->device, t);
   if (c->d_half_h1) (void)hipFree(c->d_half_h1);
   if (c->d_tables_ct) (void)hipFree(c->d_tables_ct);
   if (c->d_tables_mf) (void)hipFree(c->d_tables_mf);
   if (c->d_wire_flags) (void)hipFree(c->d_wire_flags);
   memset(&c->key, 0, sizeof(c->key)); memset(c->sk_cached, 0, 64);
-  delete c->co;
   delete c;
 }
 int act_ctx_set_transcript_mode(act_ctx* c, int mode) {
@@ -815,6 +827,54 @@ int act_ctx_set_transcript_mode(act_ctx* c, int mode) {
 }
 int act_ctx_streams_overlap(const act_ctx* c) { return c ? c->streams_overlap : -1; }
 int act_ctx_fixed_base_bits(const act_ctx* c, int base) { return (c && base >= 0 && base < 4) ? c->fb_bits[base] : 0; }
+// The table of base `base` at another window width, built (or shared with the process's other contexts on the device) now; the
+// old one is released.  Refused -- width unchanged -- when the table is not there yet and the device has not its size + 16 GB free.
+int act_ctx_set_fixed_base_bits(act_ctx* c, int base, int bits) {
+  if (!c || base < 0 || base > 3 || bits < 4 || bits > 24) return ACT_ERR_ARG;
+  Call call(c, 0);
+  HIPCK(c, hipSetDevice(c->device));
+  if (bits == c->fb_bits[base]) return call.finish();
+  uint8_t enc[32];
+  memcpy(enc, base == 0 ? kGeneratorEnc : c->henc + 32 * (base - 1), 32);
+  if (!table_cached(c->device, enc, bits)) {
+    size_t free_b = 0, total_b = 0;
+    const size_t need = fb_table_words((uint32_t)bits) * 4 + ((size_t)16 << 30);
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need) {
+      (void)hipGetLastError();
+      c->err = "act_ctx_set_fixed_base_bits: not enough free device memory for a table of that width (its size + 16 GB)";
+      return ACT_ERR_HIP;
+    }
+  }
+  hipStream_t s0 = c->slots[0].stream;
+  uint8_t* d_enc = nullptr; uint32_t *d_ext = nullptr, *d_ok = nullptr;
+  HIPCK(c, hipMalloc(&d_enc, 32)); HIPCK(c, hipMalloc(&d_ext, GE_WORDS * 4)); HIPCK(c, hipMalloc(&d_ok, 4));
+  HIPCK(c, hipMemcpyAsync(d_enc, enc, 32, hipMemcpyHostToDevice, s0));
+  launch_decode_points(d_enc, 1, d_ext, d_ok, s0);
+  uint32_t* t = table_acquire(c->device, enc, bits, d_ext, s0, nullptr);
+  const hipError_t se = hipStreamSynchronize(s0);
+  (void)hipFree(d_enc); (void)hipFree(d_ext); (void)hipFree(d_ok);
+  if (!t || se != hipSuccess) {
+    (void)hipGetLastError();
+    if (t) table_release(c->device, t);
+    c->err = "act_ctx_set_fixed_base_bits: table allocation failed";
+    return ACT_ERR_HIP;
+  }
+  table_release(c->device, c->d_tables[base]);
+  c->d_tables[base] = t; c->fb_bits[base] = bits;
+  c->P.tab[base] = FbTab{t, (uint32_t)bits, (uint32_t)base};
+  return call.finish();
+}
+// measurement knobs (kernels.h): name = the ACT_* variable of rounds 1-5 without the prefix, lower case
+int act_tuning_set(const char* name, int64_t value) {
+  static const struct { const char* name; TuneKey key; } names[] = {
+    {"no_mapped_reads", T_NO_MAPPED_READS}, {"no_stream_probe", T_NO_STREAM_PROBE}, {"no_fused_tiny", T_NO_FUSED_TINY}, {"no_taper", T_NO_TAPER},
+    {"no_wide_client", T_NO_WIDE_CLIENT}, {"no_wide_prove", T_NO_WIDE_PROVE}, {"no_wide_sign", T_NO_WIDE_SIGN}, {"no_lds_isolation", T_NO_LDS_ISOLATION},
+    {"small_normal_prio", T_SMALL_NORMAL_PRIO}, {"small_trace", T_SMALL_TRACE}, {"small_in_flight", T_SMALL_IN_FLIGHT}, {"small_sub", T_SMALL_SUB},
+    {"stagger", T_STAGGER}, {"host_chunk", T_HOST_CHUNK}, {"cbor_chunk_msgs", T_CBOR_CHUNK_MSGS}, {"ubench_iters", T_UBENCH_ITERS}};
+  if (!name) return ACT_ERR_ARG;
+  for (const auto& e : names) if (!strcmp(name, e.name)) { g_tune[e.key].store((long)value); return ACT_OK; }
+  return ACT_ERR_ARG;
+}
 int act_build_has_ct_secret_tables(void) {
 #if defined(ACT_CT_SECRET_TABLES)
   return 1;
@@ -883,6 +943,7 @@ int act_pre_issuance_random_batch(act_ctx* c, size_t n, int mem, const uint8_t* 
 // itself -- the device BLAKE3 of blake3_hd.h whatever the context's transcript mode: same bytes -- and zeroes its staged inputs when
 // done.  ACT_NO_FUSED_TINY=1 keeps the two-phase path (A/B, and the tests compare the two).
 static int tiny_buffers(act_ctx* c) {
+  c->tiny_dirty = true;                 // whoever asks for the buffers is about to stage inputs in them
   if (c->d_tiny) return ACT_OK;
   HIPCK(c, hipMalloc(&c->d_tiny, TINY_BYTES));
   HIPCK(c, hipHostMalloc(&c->h_tiny, TINY_BYTES, hipHostMallocDefault));
@@ -923,6 +984,7 @@ int act_request_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const u
   Slot& sl = c->slots[0];
   for (size_t off = 0; off < n; off += c->max_batch) {
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    sl.d_trs_dirty = std::max(sl.d_trs_dirty, (size_t)m);
     RequestArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xof = sl.d_xof; int rc;
     if ((rc = dev_in(c, sl, 0, mem, pre + off * 64, (size_t)m * 64, &a.pre))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, rng + off * 128, (size_t)m * 128, &a.rng))) return rc;
@@ -942,6 +1004,7 @@ static int issue_tiny(act_ctx* c, size_t n, int mem, const uint8_t* req, const u
   Slot& sl = c->slots[0];
   SignFusedArgs f{}; f.P = c->P; f.K = c->key; f.n = (uint32_t)n; f.label = LABEL_RESPOND; f.point_stride = 128;
   f.pbk = sl.d_buckets; f.trs = sl.d_trs; f.trs_req = c->d_tiny_tr; f.group_counter = group_counters(c, sl);
+  sl.d_trs_dirty = std::max(sl.d_trs_dirty, n);       // signatures of rejected lanes land in their transcripts: finish_call wipes them
 #if defined(ACT_TINY_TIMING)
   static unsigned long long* d_dbg = nullptr;
   if (!d_dbg) { HIPCK(c, hipMalloc(&d_dbg, 16 * 8 * 8)); }
@@ -970,29 +1033,12 @@ static int issue_tiny(act_ctx* c, size_t n, int mem, const uint8_t* req, const u
   return prof_collect(c, sl);
 }
 
-// (requests of concurrent callers that merge into one call: spend_coalesced, further down)
-enum { CO_VERIFY = 0, CO_REFUND, CO_SIGN, CO_ISSUE_CHECK, CO_ISSUE_SIGN, CO_ISSUE };   // act_verify_spend / act_refund / act_refund_sign / act_issue_check / act_issue_sign / act_issue _batch
-struct CoReq {
-  int kind; const uint8_t* sk;            // sk: null for the key-less check
-  const uint8_t* in; size_t n;            // proofs (verify, refund), enc(K') (refund sign), IssuanceRequests (issue check / sign)
-  const uint8_t* camt; const uint8_t* status_in; const uint8_t* rng; bool rng_if_accepted;
-  uint8_t* out; uint8_t* status; uint8_t* out_kprime;
-  int rc = ACT_OK; bool done = false;
-  std::string err;                        // rc != 0: the merged call's error text, for this caller's act_last_error
-};
-static int spend_coalesced(act_ctx* c, CoReq& r);
 static int issue_batch_impl(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
                             int rng_mode, uint8_t* out_resp, uint8_t* status);
 int act_issue_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
                     int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!c || !sk || (n && (!req || !camt || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  // small calls of threads that share the context merge (act_ctx_set_coalescing), as verify / refund calls do: lane i of a request draws
-  // from its own 128 bytes (per-lane rng; one lane under the sequential convention is the same thing)
-  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) {
-    CoReq r{CO_ISSUE, sk, req, n, camt, nullptr, rng, false, out_resp, status, nullptr};
-    return spend_coalesced(c, r);
-  }
   return issue_batch_impl(c, n, mem, sk, req, camt, rng, rng_mode, out_resp, status);
 }
 static int issue_batch_impl(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* req, const uint8_t* camt, const uint8_t* rng,
@@ -1011,6 +1057,7 @@ static int issue_batch_impl(act_ctx* c, size_t n, int mem, const uint8_t sk[64],
     Slot& sl = c->slots[chunk % c->depth];
     if (chunk >= (size_t)c->depth) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    sl.d_trs_dirty = std::max(sl.d_trs_dirty, (size_t)m);
     IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.pbk = sl.d_buckets;
     if ((rc = dev_in(c, sl, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
     if ((rc = dev_in(c, sl, 1, mem, camt + off * 32, (size_t)m * 32, &a.c_amount))) return rc;
@@ -1041,6 +1088,7 @@ static int issue_check_impl(act_ctx* c, size_t n, int mem, const uint8_t* req, u
   if (n && n <= TINY_MAX && n <= c->max_batch && tiny_enabled(c)) {
     // the PoK check of a tiny call as ONE kernel (k_sign_fused's check role on its own): K1, the 266-byte transcript, its BLAKE3, the verdict
     Slot& sl = c->slots[0];
+    sl.d_trs_dirty = std::max(sl.d_trs_dirty, n);
     SignFusedArgs f{}; f.P = c->P; f.n = (uint32_t)n; f.label = LABEL_RESPOND; f.point_stride = 128; f.check_only = 1;
     f.pbk = sl.d_buckets; f.trs = sl.d_trs; f.trs_req = c->d_tiny_tr; f.group_counter = group_counters(c, sl);
     if (mem == ACT_MEM_DEVICE) { f.point = req; f.status = status; }
@@ -1063,6 +1111,7 @@ static int issue_check_impl(act_ctx* c, size_t n, int mem, const uint8_t* req, u
     Slot& sl = c->slots[chunk % c->depth];
     if (chunk >= (size_t)c->depth) { HIPCK(c, hipStreamSynchronize(sl.stream)); if ((rc = prof_collect(c, sl))) return rc; }
     uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
+    sl.d_trs_dirty = std::max(sl.d_trs_dirty, (size_t)m);
     IssueArgs a{}; a.P = c->P; a.n = m; a.trs = sl.d_trs; a.xa = sl.d_xa; a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.pbk = sl.d_buckets;
     if ((rc = dev_in(c, sl, 0, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc;
     if ((rc = prof_launch(c, sl, PK_ISSUE_A, m, [&] { launch_issue_a(a, sl.stream); }))) return rc;
@@ -1074,7 +1123,6 @@ static int issue_check_impl(act_ctx* c, size_t n, int mem, const uint8_t* req, u
 }
 int act_issue_check_batch(act_ctx* c, size_t n, int mem, const uint8_t* req, uint8_t* status) {
   if (!c || (n && (!req || !status))) return ACT_ERR_ARG;
-  if (mem == ACT_MEM_HOST && n && n <= c->co_req_max.load()) { CoReq r{CO_ISSUE_CHECK, nullptr, req, n, nullptr, nullptr, nullptr, false, nullptr, status, nullptr}; return spend_coalesced(c, r); }
   return issue_check_impl(c, n, mem, req, status);
 }
 // signs the lanes whose status_in is 0; `point` = IssuanceRequest records (label RESPOND, with amounts) or enc(K') (label REFUND)
@@ -1108,21 +1156,12 @@ int act_issue_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], co
                          const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!c || !sk || (n && (!req || !camt || !status_in || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) {
-    CoReq r{CO_ISSUE_SIGN, sk, req, n, camt, status_in, rng, rng_mode == ACT_RNG_SEQUENTIAL, out_resp, status, nullptr};
-    return spend_coalesced(c, r);
-  }
   return sign_only_batch(c, n, mem, LABEL_RESPOND, sk, req, 128, camt, status_in, rng, rng_mode, out_resp, status);
 }
 int act_refund_sign_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* kprime, const uint8_t* status_in,
                           const uint8_t* rng, int rng_mode, uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!kprime || !status_in || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  // (a one-lane ACT_RNG_SEQUENTIAL call draws its 128 bytes if and only if the lane is signed: per-lane in all but name)
-  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) {
-    CoReq r{CO_SIGN, sk, kprime, n, nullptr, status_in, rng, rng_mode == ACT_RNG_SEQUENTIAL, out_refund, status, nullptr};
-    return spend_coalesced(c, r);
-  }
   return sign_only_batch(c, n, mem, LABEL_REFUND, sk, kprime, 32, nullptr, status_in, rng, rng_mode, out_refund, status);
 }
 
@@ -1150,13 +1189,13 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
   const size_t pb = ProofLayout{c->L}.bytes();
   const uint8_t* proof_view = (mem == ACT_MEM_HOST && !wire) ? mapped_view(c, proof, n * pb) : nullptr;      // pinned: the kernels read the proofs in place
   const bool in_host = mem == ACT_MEM_HOST && !proof_view;       // the proofs travel through the staging buffers
-  static const size_t host_chunk_env = [] { const char* e = getenv("ACT_HOST_CHUNK"); return e ? (size_t)atol(e) : (size_t)0; }();   // tuning knob
+  const size_t host_chunk_env = (size_t)tune(T_HOST_CHUNK);   // measurement knob (act_tuning_set)
   // host-transcript mode: a chunk's transcripts go to the host, are hashed there and come back before its status kernel, all
   // of which only overlaps with compute if there are other chunks to compute: long batches use full-size chunks (the
   // kernels' best size), short ones are cut finer so that there is something to pipeline
   const size_t host_chunk = host_chunk_env ? host_chunk_env : (n >= 8 * c->max_batch ? c->max_batch : (size_t)16384);
   const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
-  static const int stagger_env = [] { const char* e = getenv("ACT_STAGGER"); return e ? atoi(e) : -1; }();      // tuning knob: force on / off
+  const int stagger_env = (int)tune(T_STAGGER);      // measurement knob: force on / off (-1 = decide)
   const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (in_host || c->tr_mode == ACT_TRANSCRIPT_HOST);
   // Chunk schedule.  Full-size chunks are the kernels' best size, but whenever a call moves data over PCIe the pipeline has a
   // head (nothing computes until the first chunk's proofs have arrived and its per-proof kernel has run) and a tail (the
@@ -1164,7 +1203,7 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
   // ~60 ms of a 2.2 s call with 65 536-proof chunks.  Such calls therefore open and close with quarter- and half-size chunks.
   std::vector<std::pair<size_t, size_t>> sched;          // (offset, lanes)
   {
-    static const bool taper_off = getenv("ACT_NO_TAPER") != nullptr;
+    const bool taper_off = tune(T_NO_TAPER) != 0;
     std::vector<size_t> head, tail;
     size_t left = n;
     if (stagger && !taper_off && chunk_len >= 4096 && n >= 4 * chunk_len) {
@@ -1232,100 +1271,14 @@ static int spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], cons
   return rc ? rc : call.finish();
 }
 
-// ---- several threads, one context, one proof per call ------------------------------------------------------------------------
-// The crate's entry points take ONE proof (src/lib.rs:781-786) and the Rust binding keeps one context inside `Params`, which the
-// threads of a server share.  A call over one proof is ~1.7 ms of latency whatever happens (the range kernel's dependent chain), so
-// callers that queue on the context's lock get ~600 verifies per second between them -- while the same 1.7 ms would verify a
-// thousand proofs.  With act_ctx_set_coalescing(ctx, k) the callers of one context merge instead of queueing: whoever arrives
-// while no merged call runs becomes the leader, takes every request that has queued (same key, same kind), runs them as ONE call
-// through the ordinary path from a pinned gather buffer, hands every caller its own statuses / K' / refunds and passes the
-// leadership on.  Nobody waits for company: a lone caller's request runs at once; requests pile up only while a call is running.
-// Per lane the result is what the caller's own call would have produced (lanes are independent; refunds: ACT_RNG_PER_LANE only,
-// lane i of a request draws from its own 128 bytes).  Off by default.
-static int co_run(act_ctx* c, const std::vector<CoReq*>& batch, size_t total) {
-  const int kind = batch[0]->kind;
-  const size_t pbytes = ProofLayout{c->L}.bytes();
-  const size_t in_b = kind == CO_SIGN ? 32 : (kind == CO_ISSUE_CHECK || kind == CO_ISSUE_SIGN || kind == CO_ISSUE) ? 128 : pbytes;
-  const size_t out_b = (kind == CO_ISSUE_SIGN || kind == CO_ISSUE) ? 160 : 128;
-  const bool sign = kind == CO_REFUND || kind == CO_SIGN || kind == CO_ISSUE_SIGN || kind == CO_ISSUE, has_sin = kind == CO_SIGN || kind == CO_ISSUE_SIGN;
-  bool want_kp = false;
-  for (CoReq* q : batch) want_kp = want_kp || q->out_kprime;
-  if (total > c->h_co_cap) {                              // only the leader is here: no other thread touches these buffers
-    if (hipSetDevice(c->device) != hipSuccess) return ACT_ERR_HIP;
-    const size_t cap = std::max<size_t>(total, 256);
-    for (uint8_t** p : {&c->h_co_proofs, &c->h_co_rng, &c->h_co_out}) if (*p) { (void)hipHostFree(*p); *p = nullptr; }
-    c->h_co_cap = 0;
-    if (hipHostMalloc(&c->h_co_proofs, cap * std::max<size_t>(pbytes, 128), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(&c->h_co_rng, cap * (128 + 32 + 1), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(&c->h_co_out, cap * (160 + 32 + 1), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
-    c->h_co_cap = cap;
-  }
-  uint8_t *h_out = c->h_co_out, *h_kp = c->h_co_out + c->h_co_cap * 160, *h_st = c->h_co_out + c->h_co_cap * 192;
-  uint8_t *h_camt = c->h_co_rng + c->h_co_cap * 128, *h_sin = c->h_co_rng + c->h_co_cap * 160;
-  size_t off = 0;
-  for (CoReq* q : batch) {
-    memcpy(c->h_co_proofs + off * in_b, q->in, q->n * in_b);
-    if (has_sin) memcpy(h_sin + off, q->status_in, q->n);
-    if (kind == CO_ISSUE_SIGN || kind == CO_ISSUE) memcpy(h_camt + off * 32, q->camt, q->n * 32);
-    if (sign) {
-      // a one-lane ACT_RNG_SEQUENTIAL request owns 128 bytes only if its lane is to be signed (the reference draws after the checks)
-      if (q->rng_if_accepted && q->status_in[0] != 0) memset(c->h_co_rng + off * 128, 0, 128);
-      else memcpy(c->h_co_rng + off * 128, q->rng, q->n * 128);
-    }
-    off += q->n;
-  }
-  int rc;
-  if (kind == CO_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_REFUND, batch[0]->sk, c->h_co_proofs, 32, nullptr, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
-  else if (kind == CO_ISSUE) rc = issue_batch_impl(c, total, ACT_MEM_HOST, batch[0]->sk, c->h_co_proofs, h_camt, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
-  else if (kind == CO_ISSUE_SIGN) rc = sign_only_batch(c, total, ACT_MEM_HOST, LABEL_RESPOND, batch[0]->sk, c->h_co_proofs, 128, h_camt, h_sin, c->h_co_rng, ACT_RNG_PER_LANE, h_out, h_st);
-  else if (kind == CO_ISSUE_CHECK) rc = issue_check_impl(c, total, ACT_MEM_HOST, c->h_co_proofs, h_st);
-  else rc = spend_batch(c, total, ACT_MEM_HOST, batch[0]->sk, c->h_co_proofs, sign, sign ? c->h_co_rng : nullptr, ACT_RNG_PER_LANE,
-                        sign ? h_out : nullptr, h_st, want_kp ? h_kp : nullptr);
-  if (sign) memset(c->h_co_rng, 0, total * 128);        // signing nonces' seeds: not left in a long-lived buffer
-  off = 0;
-  const std::string why = rc ? c->err.get() : std::string();
-  for (CoReq* q : batch) {
-    q->rc = rc;
-    if (rc) q->err = why;
-    if (!rc) {
-      memcpy(q->status, h_st + off, q->n);
-      if (q->out_kprime) memcpy(q->out_kprime, h_kp + off * 32, q->n * 32);
-      if (sign) memcpy(q->out, h_out + off * out_b, q->n * out_b);
-    }
-    off += q->n;
-  }
-  return rc;
-}
-
-static int spend_coalesced(act_ctx* c, CoReq& r) {
-  const size_t sm = c->small_max.load();
-  const size_t cap = std::max<size_t>(c->co_req_max.load(), std::min<size_t>(c->max_batch, sm ? sm : c->max_batch));   // lanes per merged call
-  // the oldest request decides key and kind; every queued request of the same key and kind joins (coalesce.h)
-  c->err.forget_mine();
-  const int rc = c->co->submit(r, cap,
-                               [](const CoReq& a, const CoReq& b) { return a.kind == b.kind && (!a.sk || ct_equal(a.sk, b.sk, 64)); },
-                               [c](const std::vector<CoReq*>& batch, size_t total) { return co_run(c, batch, total); });
-  if (rc && !r.err.empty()) c->err.keep(r.err);        // the merged call ran on another thread: its text, for THIS thread's act_last_error
-  return rc;
-}
-
-int act_ctx_set_coalescing(act_ctx* c, size_t max_proofs_per_call) {
-  if (!c) return ACT_ERR_ARG;
-  c->co_req_max.store(max_proofs_per_call);
-  return ACT_OK;
-}
-
 int act_verify_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!c || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
-  if (mem == ACT_MEM_HOST && n && n <= c->co_req_max.load()) { CoReq r{CO_VERIFY, sk, proof, n, nullptr, nullptr, nullptr, false, nullptr, status, out_kprime}; return spend_coalesced(c, r); }
   return spend_batch(c, n, mem, sk, proof, false, nullptr, ACT_RNG_PER_LANE, nullptr, status, out_kprime);
 }
 int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, const uint8_t* rng, int rng_mode,
                      uint8_t* out_refund, uint8_t* status) {
   if (!c || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  // (one lane under ACT_RNG_SEQUENTIAL owns slice 0 whatever its verdict: the same thing as ACT_RNG_PER_LANE, and as mergeable)
-  if (mem == ACT_MEM_HOST && (rng_mode == ACT_RNG_PER_LANE || n == 1) && n && n <= c->co_req_max.load()) { CoReq r{CO_REFUND, sk, proof, n, nullptr, nullptr, rng, false, out_refund, status, nullptr}; return spend_coalesced(c, r); }
   return spend_batch(c, n, mem, sk, proof, true, rng, rng_mode, out_refund, status, nullptr);
 }
 
@@ -1342,7 +1295,7 @@ static int prove_spend_impl(act_ctx* c, size_t n, int mem, const uint8_t* token,
   // part's kernels (a proof takes ~0.3 us to leave, ~0.9 us to make)
   std::vector<std::pair<size_t, size_t>> sched;          // (offset, lanes)
   for (size_t off = 0; off < n; off += c->max_batch) sched.emplace_back(off, std::min(c->max_batch, n - off));
-  static const bool taper_off = getenv("ACT_NO_TAPER") != nullptr;      // A/B knob, read once
+  const bool taper_off = tune(T_NO_TAPER) != 0;
   if (mem == ACT_MEM_HOST && !sched.empty() && sched.back().second >= 8192 && !taper_off) {
     const size_t off = sched.back().first, l = sched.back().second, t = (l * 5 / 16 + 1023) / 1024 * 1024;
     sched.back() = {off, l - t}; sched.emplace_back(off + l - t, t);
@@ -1447,7 +1400,7 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
   // Device-memory callers: one slot, full-size chunks.
   size_t chunk = std::min(c->max_batch, std::max<size_t>(16384, (n / 4 + 1023) / 1024 * 1024));      // (below 16 384 lanes the kernels no longer fill the chip)
   // (issuance: 352 B per lane, nothing to hide)
-  static const bool taper_off = getenv("ACT_NO_TAPER") != nullptr;      // A/B knob, read once
+  const bool taper_off = tune(T_NO_TAPER) != 0;
   const uint8_t* proofs_view = (!issuance && mem == ACT_MEM_HOST) ? mapped_view(c, proofs, n * pb) : nullptr;      // pinned: the SpendProofs (public, 16.8 KB each) are read in place
   const bool two_slots = mem == ACT_MEM_HOST && !issuance && !proofs_view && c->depth > 1 && n > chunk && !taper_off;
   if (!two_slots) chunk = c->max_batch;
@@ -1456,6 +1409,7 @@ static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t*
     Slot& sl = c->slots[two_slots ? (k & 1) : 0];
     if (two_slots) HIPCK(c, hipStreamSynchronize(sl.stream));      // the chunk before last has left this slot's staging areas
     uint32_t m = (uint32_t)std::min(chunk, n - off);
+    sl.d_trs_dirty = std::max(sl.d_trs_dirty, (size_t)m);
     ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = sl.d_coords; a.trs = sl.d_trs; a.flags = sl.d_flags; a.pbk = sl.d_buckets;
     a.xof = sl.d_xof; a.status = sl.d_status;
     if (two_slots && (rc = copy_chain_wait(c, sl, false))) return rc;
@@ -1518,7 +1472,7 @@ int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
   if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
-  static const int iters_env = [] { const char* e = getenv("ACT_UBENCH_ITERS"); return e ? atoi(e) : 0; }();        // tuning knob: probe length
+  const int iters_env = (int)tune(T_UBENCH_ITERS);        // measurement knob: probe length
   // 8 blocks x 4 waves per CU: 8 waves per SIMD.  Long enough (~0.3 s) for the clock to settle where a sustained ALU load
   // leaves it (the measured rate rises from 2.8e13 over 6 ms to 3.49e13 over 0.3 s and stays there)
   const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = iters_env > 0 ? (uint32_t)iters_env : 262144u;
@@ -1616,9 +1570,9 @@ int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
     regions.emplace_back(sl.d_d01, c->max_batch * 3 * GE_WORDS * 4);
     regions.emplace_back(sl.d_buckets, c->max_batch * PREP_BUCKET_SETS * BUCKET_WORDS * 4);
   }
+  for (Slot& sl : c->slots) regions.emplace_back(sl.d_trs, std::min<size_t>(4096, c->max_batch) * SMALL_TR_STRIDE);      // the small transcripts (first lanes): a rejected lane's signature (sign-beside-the-check kernels) must not survive the call
   if (c->d_tiny) { regions.emplace_back(c->d_tiny, TINY_OUT); for (size_t i = 0; i < TINY_OUT; i++) nz += c->h_tiny[i] != 0; }      // staged inputs of the tiny calls (device + pinned)
   if (c->d_small) regions.emplace_back(c->d_small, c->d_small_cap);      // the small-batch schedule's partial sums and bucket sets (what single-item calls use)
-  if (c->h_co_rng) for (size_t i = 0; i < c->h_co_cap * 128; i++) nz += c->h_co_rng[i] != 0;      // the merged calls' pinned rng gather buffer (host memory)
   for (auto& r : regions) total += r.second;
   if (total > ((size_t)1 << 30)) { c->err = "act_debug_secret_residue: context too large to read back (use a small max_batch)"; return ACT_ERR_ARG; }
   std::vector<uint8_t> buf;

@@ -115,19 +115,16 @@ ACT_HD ge_ded ge_ded_cneg(const ge_ded& c, bool neg) {
   return r;
 }
 ACT_HD ge ge_add_ded(const ge& p, const ge_ded& q) {
-  fe A = fe_mul(fe_sub(p.Y, p.X), q.YpX);        // 3 * 2
-  fe B = fe_mul(fe_add(p.Y, p.X), q.YmX);        // 2 * 3
-  fe C = fe_mul(fe_dbl(p.Z), q.T);               // 2 * 2
-  fe D = fe_mul(fe_dbl(p.T), q.Z);
+  fe A, B, C, D;                                 // (fe_mul2: two independent products; one interleaved statement under -DACT_FE_PAIR_ASM)
+  fe_mul2(A, B, fe_sub(p.Y, p.X), q.YpX, fe_add(p.Y, p.X), q.YmX);      // 3 * 2, 2 * 3
+  fe_mul2(C, D, fe_dbl(p.Z), q.T, fe_dbl(p.T), q.Z);                    // 2 * 2
   fe E = fe_add(D, C);                           // {2}
   fe F = fe_sub(B, A);                           // {3}
   fe G = fe_add(B, A);                           // {2}
   fe H = fe_sub(D, C);                           // {3}
   ge r;                                          // every product 2 * 3
-  r.X = fe_mul(E, F);
-  r.Y = fe_mul(G, H);
-  r.Z = fe_mul(G, F);
-  r.T = fe_mul(E, H);
+  fe_mul2(r.X, r.Y, E, F, G, H);
+  fe_mul2(r.Z, r.T, G, F, E, H);
   return r;
 }
 ACT_HD ge ge_add(const ge& p, const ge& q) { return ge_add_cached(p, ge_to_cached(q)); }
@@ -135,19 +132,18 @@ ACT_HD ge ge_sub(const ge& p, const ge& q) { return ge_add_cached(p, ge_cached_c
 
 // 2p with the T coordinate computed only when `with_t` (a wave-uniform flag): 4S + 3M or 4S + 4M
 ACT_HD ge ge_double_opt(const ge& p, bool with_t) {
-  fe xx = fe_sq(p.X), yy = fe_sq(p.Y);
-  fe zz2 = fe_dbl(fe_sq(p.Z));
-  fe xpy2 = fe_sq(fe_add(p.X, p.Y));
+  fe xx, yy, zz, xpy2;
+  fe_sq2(xx, yy, p.X, p.Y);
+  fe_sq2(zz, xpy2, p.Z, fe_add(p.X, p.Y));
+  fe zz2 = fe_dbl(zz);
   fe yypxx = fe_add(yy, xx);
   fe yymxx = fe_sub(yy, xx);
   fe cx = fe_sub4(xpy2, yypxx);
   fe ct = fe_carry(fe_sub4(zz2, yymxx));      // operand sizes: ge_double below
   ge r;
-  r.X = fe_mul(ct, cx);
-  r.Y = fe_mul(yypxx, yymxx);
-  r.Z = fe_mul(ct, yymxx);
+  fe_mul2(r.X, r.Y, ct, cx, yypxx, yymxx);
   r.T = fe_zero();
-  if (with_t) r.T = fe_mul(yypxx, cx);
+  if (with_t) fe_mul2(r.Z, r.T, ct, yymxx, yypxx, cx); else r.Z = fe_mul(ct, yymxx);
   return r;
 }
 // 2p.  4S + 4M (3M without T).  Input T unused.

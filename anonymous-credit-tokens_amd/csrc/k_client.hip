@@ -192,7 +192,7 @@ constexpr uint32_t CLIENT_WIDE_MAX = 8192;
 // (the wide form ORs into the flags word: client_batch clears it for both labels)
 void launch_client_a(const ClientArgs& a, hipStream_t s) {
   if (!a.n) return;
-  static const bool no_wide = getenv("ACT_NO_WIDE_CLIENT") != nullptr;     // A/B knob
+  const bool no_wide = tune(T_NO_WIDE_CLIENT) != 0;     // A/B knob (act_tuning_set)
   if (a.n <= CLIENT_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_client_a_wide, dim3((a.n + 63) / 64, 4), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_client_a, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }

@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_prove_resp(ProveArgs a) {
 constexpr uint32_t PROVE_WIDE_MAX = 8192;
 void launch_prove_head(const ProveArgs& a, hipStream_t s) {
   if (!a.n) return;
-  static const bool no_wide = getenv("ACT_NO_WIDE_PROVE") != nullptr;     // A/B knob
+  const bool no_wide = tune(T_NO_WIDE_PROVE) != 0;     // A/B knob (act_tuning_set)
   if (a.n <= PROVE_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_prove_head_wide, dim3((a.n + 63) / 64, 14), dim3(64), isolate_roles((a.n + 63) / 64 * 14), s, a);
   else hipLaunchKernelGGL(k_prove_head, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(64) k_sign_a_wide(SignArgs a) {
 constexpr uint32_t SIGN_WIDE_MAX = 8192;
 void launch_sign_a(const SignArgs& a, hipStream_t s) {
   if (!a.n) return;
-  static const bool no_wide = getenv("ACT_NO_WIDE_SIGN") != nullptr;     // A/B knob
+  const bool no_wide = tune(T_NO_WIDE_SIGN) != 0;     // A/B knob (act_tuning_set)
   if (a.n <= SIGN_WIDE_MAX && !no_wide) hipLaunchKernelGGL(k_sign_a_wide, dim3((a.n + 63) / 64, 4), dim3(64), 0, s, a);
   else hipLaunchKernelGGL(k_sign_a, dim3((a.n + 63) / 64), dim3(64), 0, s, a);
 }
@@ -229,8 +229,10 @@ __global__ void __launch_bounds__(256) k_request_b(RequestArgs a) {
 // that land on one SIMD run at half speed each -- the same kernel took 0.9 or 2.0 ms from call to call (profiles/r05_tiny_ab.txt:
 // min / median of 30 calls); separate workgroups go to separate CUs.
 // With CHECK the signature is computed NEXT TO the check instead of behind it -- a lane's e, alpha are then read from its rng slice
-// before its verdict is known, which changes nothing observable: a rejected lane's record is zero and its nonces never leave the
-// registers; the engine takes this kernel only when the slice a lane would draw does not depend on other lanes' verdicts
+// before its verdict is known, which changes nothing observable: a rejected lane's record is zero, its nonces never leave the
+// registers, and the transcript the roles assemble for it in `trs` -- which does hold e and enc(A), a signature over a K nobody has
+// verified -- is wiped with the call (engine.hip finish_call, Slot::d_trs_dirty; act_debug_secret_residue reads it back).  The engine
+// takes this kernel only when the slice a lane would draw does not depend on other lanes' verdicts
 // (ACT_RNG_PER_LANE, or one lane).  One launch instead of six; the dependent chain is max(check, signature) instead of their sum.
 // Without CHECK and with `before_verdict` the same holds for a tiny refund, whose check is the whole spend-proof verification on other
 // streams: every lane is signed into a buffer of the engine's and k_sign_commit hands out what the verdicts allow (small_impl.inc).

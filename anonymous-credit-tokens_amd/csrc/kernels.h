@@ -11,6 +11,22 @@
 #endif
 #include "msm.h"
 #include "blake3_hd.h"
+#include <atomic>
+
+// ---- measurement knobs ----------------------------------------------------------------------------------------------------
+// A/B switches and size overrides that tools/ and tests/ use (same-box comparisons; tests that want many chunks out of a small
+// batch).  The library does not read the process environment for any of them: act_tuning_set(name, value) (include/act_mi355x.h,
+// debug section) is the only way in, the Python binding forwards the ACT_* variables of the same names (capi.py), and a deployment
+// that never calls it runs the defaults.  (engine.hip holds the table; the environment is read only for ACT_TRACE /
+// ACT_TIMELINE_FILE diagnostics and ACT_NUMA.)
+namespace act {
+enum TuneKey {
+  T_NO_MAPPED_READS, T_NO_STREAM_PROBE, T_NO_FUSED_TINY, T_NO_TAPER, T_NO_WIDE_CLIENT, T_NO_WIDE_PROVE, T_NO_WIDE_SIGN, T_NO_LDS_ISOLATION,
+  T_SMALL_NORMAL_PRIO, T_SMALL_TRACE, T_SMALL_IN_FLIGHT, T_SMALL_SUB, T_STAGGER, T_HOST_CHUNK, T_CBOR_CHUNK_MSGS, T_UBENCH_ITERS, T_COUNT
+};
+extern std::atomic<long> g_tune[T_COUNT];
+inline long tune(TuneKey k) { return g_tune[k].load(std::memory_order_relaxed); }
+}  // namespace act
 
 #if defined(__HIPCC__)
 #define ACT_HDC __host__ __device__
@@ -252,7 +268,7 @@ void launch_spend_enc(const SpendArgs& a, hipStream_t s);
 // claim without using it: with 40 KB of dynamic LDS beside its 72 KB a range-kernel workgroup owns its CU (two no longer fit the
 // 160 KB), and with 60 KB a one-wavefront workgroup of the per-proof kernels cannot join it there either (and at most two of its own
 // kind share a CU).  Only for grids that fit the chip that way; ACT_NO_LDS_ISOLATION=1 turns it off (A/B).
-inline bool lds_isolation() { static const bool off = getenv("ACT_NO_LDS_ISOLATION") != nullptr; return !off; }
+inline bool lds_isolation() { return !tune(T_NO_LDS_ISOLATION); }
 // The sizes at which a launch "fits the chip that way" follow the CU count of the device the calling thread has current (256 on an
 // unpartitioned MI355X; a CPX partition has 32): 7/8 of the CUs for the range kernel's workgroups, the rest for the per-proof kernels.
 #if defined(__HIPCC__)

@@ -24,10 +24,6 @@ struct act_node {
   int L = 0;
   std::string err;
   std::mutex mu;      // every act_node_*_batch call holds it: a handle shared between host threads is used by one at a time
-  // ... except calls small enough to merge (act_node_set_coalescing): those go to ONE context, round robin, without the node's lock,
-  // and merge there with the calls of other threads (engine.hip spend_coalesced)
-  std::atomic<size_t> co_max{0};
-  std::atomic<unsigned> co_next{0};
   // Load balance (all under mu).  The GPUs of a node are not equally fast -- clocks differ by several percent between devices and
   // move with temperature -- and a call ends when its slowest GPU does.  Two mechanisms, both invisible in the output bytes:
   //   weights   every throughput-sized call measures what each context did with its head piece; the next call cuts the heads in
@@ -45,8 +41,8 @@ struct act_node {
   std::vector<DevStats> last;    // what each context did in the most recent cut call
 };
 
-// A node handle's last error is the CALLING THREAD's last failure on it where there is one (threads share the handle; small calls do
-// not even take its lock): every write also lands in a slot of the writing thread, which act_node_last_error prefers.
+// A node handle's last error is the CALLING THREAD's last failure on it where there is one (threads share the handle): every write
+// also lands in a slot of the writing thread, which act_node_last_error prefers.
 namespace {
 struct NodeErrMine { const void* of = nullptr; std::string text; };
 NodeErrMine& node_err_mine() { thread_local NodeErrMine t; return t; }
@@ -222,6 +218,12 @@ int act_node_set_host_threads(act_node* nd, int per_gpu) {
   for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_host_threads(c, per_gpu); if (rc) return rc; }
   return ACT_OK;
 }
+int act_node_set_fixed_base_bits(act_node* nd, int base, int bits) {
+  if (!nd) return ACT_ERR_ARG;
+  std::lock_guard<std::mutex> node_lock(nd->mu);
+  for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_fixed_base_bits(c, base, bits); if (rc) { set_node_err(nd, act_last_error(c)); return rc; } }
+  return ACT_OK;
+}
 int act_node_set_balance(act_node* nd, int weighted, int tail_64ths) {
   if (!nd || tail_64ths < -1 || tail_64ths > 32) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
@@ -245,16 +247,6 @@ int act_node_device_stats(act_node* nd, int k, double* weight, uint64_t* last_la
   if (last_calls) *last_calls = nd->last[k].calls;
   return ACT_OK;
 }
-// verify / refund-sign calls of at most `max_proofs_per_call` proofs are not cut over the GPUs (a one-proof call has nothing to cut):
-// each goes to one context -- the next one, round robin -- and merges there with the small calls other threads make at the same time
-int act_node_set_coalescing(act_node* nd, size_t max_proofs_per_call) {
-  if (!nd) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> node_lock(nd->mu);
-  for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_coalescing(c, max_proofs_per_call); if (rc) return rc; }
-  nd->co_max.store(max_proofs_per_call);
-  return ACT_OK;
-}
-
 int act_node_request_batch(act_node* nd, size_t n, const uint8_t* pre, const uint8_t* rng, uint8_t* out_req) {
   if (!nd || (n && (!pre || !rng || !out_req))) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
@@ -267,12 +259,6 @@ int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uin
                          int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!nd || !sk || (n && (!req || !c || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {      // small enough to merge with other threads' calls: one context, no node lock
-    act_ctx* cx = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    const int rc = act_issue_batch(cx, n, ACT_MEM_HOST, sk, req, c, rng, rng_mode, out_resp, status);
-    if (rc) small_call_err(nd, cx);
-    return rc;
-  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
     return run(nd, n, [&](size_t k, size_t off, size_t m) {
@@ -293,12 +279,6 @@ int act_node_issue_batch(act_node* nd, size_t n, const uint8_t sk[64], const uin
 // by exactly 128 bytes per accepted lane, as the sequential loop would: INTEGRATION.md).
 int act_node_issue_check_batch(act_node* nd, size_t n, const uint8_t* req, uint8_t* status) {
   if (!nd || (n && (!req || !status))) return ACT_ERR_ARG;
-  if (n && n <= nd->co_max.load()) {          // small enough to merge with other threads' calls: one context, no node lock
-    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    const int rc = act_issue_check_batch(c, n, ACT_MEM_HOST, req, status);
-    if (rc) small_call_err(nd, c);
-    return rc;
-  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   return run(nd, n, [&](size_t k, size_t off, size_t m) { return act_issue_check_batch(nd->ctx[k], m, ACT_MEM_HOST, at(req, off, 128), status + off); });
 }
@@ -306,12 +286,6 @@ int act_node_issue_sign_batch(act_node* nd, size_t n, const uint8_t sk[64], cons
                               const uint8_t* rng, int rng_mode, uint8_t* out_resp, uint8_t* status) {
   if (!nd || !sk || (n && (!req || !c || !status_in || !rng || !out_resp || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {
-    act_ctx* cx = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    const int rc = act_issue_sign_batch(cx, n, ACT_MEM_HOST, sk, req, c, status_in, rng, rng_mode, out_resp, status);
-    if (rc) small_call_err(nd, cx);
-    return rc;
-  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const std::vector<uint8_t> checked(status_in, status_in + n);
   const AcceptedBefore before(checked.data(), n);
@@ -339,13 +313,6 @@ static int refund_sign_any(act_node* nd, size_t n, const uint8_t sk[64], const u
   act::DrawnRng drawn;
   if (!cbor && rng_mode == ACT_RNG_CALLBACK) return ACT_ERR_ARG;      // (the record-level halves take bytes: include/act_mi355x.h)
   int rc = drawn.resolve(rng, rng_mode, rng_mode == ACT_RNG_CALLBACK ? count_zero(status_in, n) : 0); if (rc) return rc;
-  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {
-    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    rc = cbor ? act_refund_sign_cbor_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out, status)
-              : act_refund_sign_batch(c, n, ACT_MEM_HOST, sk, kprime, status_in, rng, rng_mode, out, status);
-    if (rc) small_call_err(nd, c);
-    return rc;
-  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   return refund_sign_locked(nd, n, sk, kprime, status_in, rng, rng_mode, cbor, out, status, nullptr);
 }
@@ -392,12 +359,6 @@ int act_node_prove_spend_seeded_batch(act_node* nd, size_t n, const uint8_t* tok
 
 int act_node_verify_spend_batch(act_node* nd, size_t n, const uint8_t sk[64], const uint8_t* proof, uint8_t* status, uint8_t* out_kprime) {
   if (!nd || !sk || (n && (!proof || !status))) return ACT_ERR_ARG;
-  if (n && n <= nd->co_max.load()) {
-    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    const int rc = act_verify_spend_batch(c, n, ACT_MEM_HOST, sk, proof, status, out_kprime);
-    if (rc) small_call_err(nd, c);
-    return rc;
-  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   return run(nd, n, [&](size_t k, size_t off, size_t m) {
@@ -410,12 +371,6 @@ int act_node_verify_spend_cbor_keys_batch(act_node* nd, size_t n, const uint8_t 
                                           uint8_t* out_kprime, uint8_t* out_nullifier) {
   if (!nd || !sk || (n && (!cbor || !status))) return ACT_ERR_ARG;
   const size_t ml = act_cbor_size(nd->ctx[0], ACT_CBOR_SPEND_PROOF);
-  if (n && n <= nd->co_max.load()) {          // a call this small has nothing to cut: one context, round robin, no node lock
-    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    const int rc = act_verify_spend_cbor_keys_batch(c, n, ACT_MEM_HOST, sk, cbor, offsets, status, out_kprime, out_nullifier);
-    if (rc) small_call_err(nd, c);
-    return rc;
-  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   return run(nd, n, [&](size_t k, size_t off, size_t m) {
     return act_verify_spend_cbor_keys_batch(nd->ctx[k], m, ACT_MEM_HOST, sk, offsets ? cbor : cbor + off * ml, offsets ? offsets + off : nullptr,
@@ -431,12 +386,6 @@ int act_node_refund_batch(act_node* nd, size_t n, const uint8_t sk[64], const ui
                           uint8_t* out_refund, uint8_t* status) {
   if (!nd || !sk || (n && (!proof || !rng || !out_refund || !status))) return ACT_ERR_ARG;
   if (rng_mode != ACT_RNG_PER_LANE && rng_mode != ACT_RNG_SEQUENTIAL) return ACT_ERR_ARG;
-  if (n && n <= nd->co_max.load() && (rng_mode == ACT_RNG_PER_LANE || n == 1)) {      // small enough to merge with other threads' calls: one context, no node lock
-    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    const int rc = act_refund_batch(c, n, ACT_MEM_HOST, sk, proof, rng, rng_mode, out_refund, status);
-    if (rc) small_call_err(nd, c);
-    return rc;
-  }
   std::lock_guard<std::mutex> node_lock(nd->mu);
   const size_t pb = act_spend_proof_bytes(nd->ctx[0]);
   if (rng_mode == ACT_RNG_PER_LANE || nd->ctx.size() == 1)
@@ -465,7 +414,7 @@ int act_node_refund_cbor_batch(act_node* nd, size_t n, const uint8_t sk[64], con
   // all of it in ONE call -- unframing, verification, the signature beside it (cbor_impl.inc refund_cbor_tiny_records: 2.1 ms for one message
   // instead of 3.1).  The context's own lock serialises it with whatever else that context is doing.
   if (n <= 64 && (rng_mode == ACT_RNG_PER_LANE || (rng_mode == ACT_RNG_SEQUENTIAL && n == 1))) {
-    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
+    act_ctx* c = nd->ctx[0];          // nothing to cut: the node's first context
     const int rc = act_refund_cbor_batch(c, n, ACT_MEM_HOST, sk, cbor, offsets, rng, rng_mode, out_refund_cbor, status);
     if (rc) small_call_err(nd, c);
     return rc;
@@ -675,14 +624,18 @@ static int node_redeem(act_node* nd, act_node_nullifier_set* set, size_t n, cons
   // sign); then the store decides, and a lane whose nullifier was not fresh gets its status and loses its refund.  The same answers
   // and the same store as the general path below; nothing is signed behind a recorded nullifier here, so nothing can fail there.
   if (n <= 64 && (rng_mode == ACT_RNG_PER_LANE || (rng_mode == ACT_RNG_SEQUENTIAL && n == 1))) {
-    act_ctx* c = nd->ctx[nd->co_next.fetch_add(1) % nd->ctx.size()];
-    std::vector<uint8_t> st(n), sp(n), nl(wire ? n * 32 : 0);
-    int rc = wire ? act_refund_cbor_keys_batch(c, n, ACT_MEM_HOST, sk, cbor, offsets, rng, rng_mode, out, st.data(), nl.data())
-                  : act_refund_batch(c, n, ACT_MEM_HOST, sk, proof, rng, rng_mode, out, st.data());
+    act_ctx* c = nd->ctx[0];          // nothing to cut: the node's first context
+    // the refunds are computed into a buffer of this function's: a refund for a token that turns out to be spent must never be visible
+    // in the caller's memory, not even until the store has answered (the engine-level twin, nullifier_impl.inc redeem_impl, does the same)
+    std::vector<uint8_t> st(n), sp(n), nl(wire ? n * 32 : 0), rec(n * out_rec);
+    struct Wipe { std::vector<uint8_t>& v; ~Wipe() { volatile uint8_t* q = v.data(); for (size_t i = 0; i < v.size(); i++) q[i] = 0; } } wipe_rec{rec};
+    int rc = wire ? act_refund_cbor_keys_batch(c, n, ACT_MEM_HOST, sk, cbor, offsets, rng, rng_mode, rec.data(), st.data(), nl.data())
+                  : act_refund_batch(c, n, ACT_MEM_HOST, sk, proof, rng, rng_mode, rec.data(), st.data());
     if (rc) { small_call_err(nd, c); return rc; }
     const int rc_null = act_node_nullifier_check_and_insert_batch(set, n, wire ? nl.data() : proof, wire ? 32 : pb, st.data(), sp.data());
     for (size_t i = 0; i < n; i++) {
-      if (st[i] == 0 && sp[i]) { st[i] = sp[i] == 1 ? ACT_STATUS_DOUBLE_SPEND : ACT_STATUS_NULLIFIER_UNDETERMINED; memset(out + i * out_rec, 0, out_rec); }
+      if (st[i] == 0 && sp[i]) st[i] = sp[i] == 1 ? ACT_STATUS_DOUBLE_SPEND : ACT_STATUS_NULLIFIER_UNDETERMINED;
+      if (st[i] == 0) memcpy(out + i * out_rec, rec.data() + i * out_rec, out_rec); else memset(out + i * out_rec, 0, out_rec);
       status[i] = st[i];
     }
     if (rc_null) { std::lock_guard<std::mutex> node_lock(nd->mu); set_node_err(nd, std::string("nullifier set: ") + act_node_nullifier_set_last_error(set)); }

@@ -24,7 +24,8 @@ struct DrawnRng {
     const act_rng_source* src = reinterpret_cast<const act_rng_source*>(rng);
     if (!src || !src->draw) return ACT_ERR_ARG;
     buf.assign(signed_lanes * 128 + 16, 0);        // never empty: the signing calls want a non-null pointer
-    if (signed_lanes) src->draw(src->rng_ctx, buf.data(), signed_lanes * 128);
+    // a draw that failed must never turn into a signature over zero nonces (e = alpha = 0 makes z = gamma * x: the key): fail the call
+    if (signed_lanes && src->draw(src->rng_ctx, buf.data(), signed_lanes * 128) != 0) { wipe(); return ACT_ERR_RNG; }
     rng = buf.data(); mode = ACT_RNG_SEQUENTIAL;
     return ACT_OK;
   }

@@ -32,10 +32,7 @@ The one JSON line carries
                        memory, host transcripts: the path the Rust binding takes (PCIe-inclusive, never `value`)
 and at N = 1
   extra.hbm_device_transcripts     the round-1..3 headline: device BLAKE3, nothing crosses PCIe inside a step
-  extra.tiled_4096                 the round-1/2 input (4 096 distinct proofs tiled x256): what tiling flatters
   extra.call_latency_ms            one call over 1 / 64 / 256 / 1 024 / 4 096 / 16 384 proofs (the crate's call shape is one proof per call)
-  extra.concurrent_callers         4 threads with a context each making such calls back to back: whole-GPU rate
-  extra.single_item_refunds        16 threads sharing one node handle, each calling the single-item refund; coalescing off / on
   extra.refund                     verify + BBS re-sign (src/lib.rs:787-868), device transcripts, HBM-resident
   extra.verify_L64                 BASELINE config 2: 2^16 verifies at L = 64
 
@@ -323,6 +320,9 @@ def parse_args(argv=None):
     ap.add_argument("--transcript", choices=("host", "device"), default="host",
                     help="where the timed region hashes its transcripts: host = the library default / north-star contract (src/transcript.rs on the host)")
     ap.add_argument("--max-batch", type=int, default=65536)
+    ap.add_argument("--range-table-bits", type=int, default=24,
+                    help="window width asked for on h1 and h3, the range kernel's fixed bases (act_ctx_set_fixed_base_bits): 24 = +47 GB of HBM, +3 %% verifies/s -- "
+                         "this benchmark owns its GPU; 16 = what act_ctx_create leaves (the library never widens on its own)")
     ap.add_argument("--extra-log2", type=int, default=18, help="proofs per extra measurement (refund, host-memory variants)")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="chunks in flight; 1 for profiling runs (rocprofv3 per-kernel durations then do not overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -422,6 +422,8 @@ def main():
     h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01", device=local)    # benches/benchmark.rs:9-16
     eng = capi.Engine(h, L, device=local, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
     eng.set_pipeline_depth(args.pipeline_depth)
+    if args.range_table_bits > 16:
+        eng.set_wide_range_tables(args.range_table_bits)      # falls back to 16 bits (reported in config) if the device has not the room
     if world > 1:
         eng.set_host_threads(host_threads)
     sk = eng.private_key_random(shake("bench-sk", 64))
@@ -688,21 +690,10 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
     # (0) the round-1..3 headline: the same batch with the transcripts hashed by the device BLAKE3 kernel (nothing crosses PCIe)
     eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
     sync()
-    dt = timed(lambda: eng.verify_spend_dev(sk, n, dev.data_ptr(), stf.data_ptr()), sync)
+    dt = timed(lambda: eng.verify_spend_dev(sk, n, dev.data_ptr(), stf.data_ptr()), sync, reps=1)      # one warm-up + one timed pass over 2^20: 4 s
     assert torch.equal(stf, expect)
     ex["hbm_device_transcripts"] = {"value": n / dt, "unit": "verifies/s", "proofs": n,
                                     "what": "ACT_TRANSCRIPT_DEVICE over the whole 2^%d batch, proofs in HBM: byte-identical transcripts hashed on the GPU" % args.batch_log2}
-    # (0b) what tiling flatters: the round-1/2 input, 4 096 distinct proofs x256 (every 65 536-proof launch holds each proof 16
-    #      times, so the scalar-addressed reads of the 24-bit tables hit in L2 / Infinity Cache)
-    if distinct == n and n >= 8192:
-        clean = torch.nonzero(expect[:8192] == 0).flatten()[:4096]          # untampered lanes only: tamper() is applied to the tiled copy afresh
-        tiled = dev[clean].repeat(n // 4096, 1).contiguous()
-        t_exp, _ = tamper(torch, tiled, n)
-        sync()
-        dt = timed(lambda: eng.verify_spend_dev(sk, n, tiled.data_ptr(), stf.data_ptr()), sync)
-        assert torch.equal(stf, t_exp)
-        ex["tiled_4096"] = {"value": n / dt, "unit": "verifies/s", "proofs": n, "what": "device transcripts, 4 096 distinct proofs tiled x%d" % (n // 4096)}
-        del tiled
     del stf
     # (1) host transcripts on a quarter-size batch: pipeline fill and drain are a larger share
     eng.set_transcript_mode(capi.TRANSCRIPT_HOST)
@@ -742,118 +733,6 @@ def extras(args, eng, capi, torch, np, sk, dev, expect, h, local, L, PB, distinc
         lat[key] = row
     eng.set_transcript_mode(capi.TRANSCRIPT_DEVICE)
     ex["call_latency_ms"] = {"proofs_per_call": lat, "what": "median wall time of one act_verify_spend_batch call over k proofs in pinned host memory"}
-    # (2c) a server has several callers: 4 threads, a context each (the tables are shared), calls of k proofs back to back.  The library
-    #      lets two small calls run on a device at a time (engine.hip SmallGate: more, and the process has more active hardware queues
-    #      than the GPU runs side by side)
-    try:
-        import threading
-        kmax = min(nl, 4096); T = 4
-        engs = [capi.Engine(h, L, device=local, max_batch=8192, transcript=capi.TRANSCRIPT_DEVICE) for _ in range(T)]
-        hst = [torch.zeros(kmax, dtype=torch.uint8, pin_memory=True) for _ in range(T)]
-        conc = {}
-        for k in (1, kmax):
-            calls = 60 if k == 1 else 12
-            def work(t):
-                for _ in range(calls):
-                    engs[t].verify_spend_ptr(sk, k, capi.MEM_HOST, hp1.data_ptr(), hst[t].data_ptr())
-            for t in range(T):
-                engs[t].verify_spend_ptr(sk, k, capi.MEM_HOST, hp1.data_ptr(), hst[t].data_ptr())
-            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-            t0 = time.perf_counter()
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            dt = time.perf_counter() - t0
-            assert all(torch.equal(hst[t][:k], expect[:k].cpu()) for t in range(T))
-            conc["%d" % k] = {"verifies_per_s": round(T * calls * k / dt), "ms_per_call": round(1e3 * dt / calls, 3)}
-        ex["concurrent_callers"] = {"threads": T, "proofs_per_call": conc,
-                                    "what": "4 threads, one context each, calls back to back from pinned host memory, device transcripts: whole-GPU rate"}
-        for e in engs:
-            e.close()
-    except Exception as e:          # an accessory measurement must never cost the line
-        ex["concurrent_callers"] = {"error": repr(e)}
-    # (2d) the crate's API under a server's load: 16 threads share ONE node handle (what the Rust binding keeps inside `Params`) and
-    #      call the single-item refund -- verify over one proof, then refund-sign with 128 rng bytes -- in a loop; without and with
-    #      act_node_set_coalescing (rust/src/mi355x.rs turns it on)
-    try:
-        import ctypes as C
-        import threading
-        T = 16
-        node = capi.Node(h, L, devices=(local,), max_batch=8192, transcript=capi.TRANSCRIPT_DEVICE)
-        lib, nd = node.lib, node.nd
-        skb = (C.c_uint8 * 64).from_buffer_copy(sk)
-        valid = [i for i in range(64) if int(expect[i]) == 0]
-        items = hp1[:64].numpy().copy(); rbytes = np.frombuffer(shake("bench-single-item", 128 * 64), np.uint8).reshape(64, 128).copy()
-        single = {}
-        for co in (0, 64):
-            node.set_coalescing(co)
-            calls = 12 if not co else 48
-            def work(t):
-                s1, kp, s2, rf = np.zeros(1, np.uint8), np.zeros(32, np.uint8), np.zeros(1, np.uint8), np.zeros(128, np.uint8)
-                for c in range(calls):
-                    i = valid[(t + c) % len(valid)]
-                    assert lib.act_node_verify_spend_batch(nd, 1, skb, items[i].ctypes.data, s1.ctypes.data, kp.ctypes.data) == 0 and s1[0] == 0
-                    assert lib.act_node_refund_sign_batch(nd, 1, skb, kp.ctypes.data, s1.ctypes.data, rbytes[i].ctypes.data, capi.RNG_SEQUENTIAL, rf.ctypes.data, s2.ctypes.data) == 0 and s2[0] == 0
-            work(0)
-            th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-            t0 = time.perf_counter()
-            for x in th:
-                x.start()
-            for x in th:
-                x.join()
-            dt = time.perf_counter() - t0
-            single["coalescing_off" if not co else "coalescing_64"] = {"refunds_per_s": round(T * calls / dt), "ms_per_refund": round(1e3 * dt / calls, 2)}
-        # the same 16 threads making ONE library call per refund (act_node_refund_batch over one proof with its 128 bytes: the binding's
-        # refund_eager), merged the same way: the merged call signs beside its verification
-        node.set_coalescing(64)
-        calls = 48
-        def work1(t):
-            s2, rf = np.zeros(1, np.uint8), np.zeros(128, np.uint8)
-            for c in range(calls):
-                i = valid[(t + c) % len(valid)]
-                assert lib.act_node_refund_batch(nd, 1, skb, items[i].ctypes.data, rbytes[i].ctypes.data, capi.RNG_SEQUENTIAL, rf.ctypes.data, s2.ctypes.data) == 0 and s2[0] == 0
-        work1(0)
-        th = [threading.Thread(target=work1, args=(t,)) for t in range(T)]
-        t0 = time.perf_counter()
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        dt = time.perf_counter() - t0
-        single["one_call_coalescing_64"] = {"refunds_per_s": round(T * calls / dt), "ms_per_refund": round(1e3 * dt / calls, 2),
-                                            "what": "act_node_refund_batch(1 proof, its 128 rng bytes) per refund instead of the two calls"}
-        # ... and the issuance endpoint: the same 16 threads, one PrivateKey::issue per call (act_node_issue_batch over one request with
-        # its 128 bytes), queued on the handle against merged
-        try:
-            pre_i = eng.pre_issuance_random(shake("bench-si-pre", 128 * 64)); req_i = np.frombuffer(eng.request(pre_i, shake("bench-si-rq", 128 * 64)), np.uint8).reshape(64, 128).copy()
-            cam_i = np.frombuffer(b"".join(scb(100 + i) for i in range(64)), np.uint8).reshape(64, 32).copy()
-            issues = {}
-            for co in (0, 64):
-                node.set_coalescing(co)
-                calls = 24 if not co else 96
-                def work2(t):
-                    s2, rs = np.zeros(1, np.uint8), np.zeros(160, np.uint8)
-                    for c in range(calls):
-                        i = (t + c) % 64
-                        assert lib.act_node_issue_batch(nd, 1, skb, req_i[i].ctypes.data, cam_i[i].ctypes.data, rbytes[i].ctypes.data, capi.RNG_SEQUENTIAL, rs.ctypes.data, s2.ctypes.data) == 0 and s2[0] == 0
-                work2(0)
-                th = [threading.Thread(target=work2, args=(t,)) for t in range(T)]
-                t0 = time.perf_counter()
-                for x in th:
-                    x.start()
-                for x in th:
-                    x.join()
-                dt = time.perf_counter() - t0
-                issues["coalescing_off" if not co else "coalescing_64"] = {"issues_per_s": round(T * calls / dt), "ms_per_issue": round(1e3 * dt / calls, 2)}
-            ex["single_item_issues"] = dict(issues, threads=T, what="16 threads sharing one node handle, each: act_node_issue_batch(1 request, its 128 rng bytes); device transcripts")
-        except Exception as e:
-            ex["single_item_issues"] = {"error": repr(e)}
-        node.close()
-        ex["single_item_refunds"] = dict(single, threads=T, what="16 threads sharing one node handle, each: act_node_verify_spend_batch(1 proof) then "
-                                                                 "act_node_refund_sign_batch(1 lane, ACT_RNG_SEQUENTIAL); device transcripts")
-    except Exception as e:
-        ex["single_item_refunds"] = {"error": repr(e)}
     del hp1
     # (4) refund = verify + sign (src/lib.rs:787-868), per-lane rng resident in HBM
     g = torch.Generator(device="cuda"); g.manual_seed(7)
@@ -926,6 +805,12 @@ def node_host_path(args, capi, torch, np, sk, dev, expect, h, devices, L, PB):
         res["note"] = "batch scaled down from 2^%d: %.0f GB of host memory needed" % (args.batch_log2, need_gb)
     node = capi.Node(h, L, devices=devices, max_batch=args.max_batch, transcript=capi.TRANSCRIPT_HOST)
     try:
+        if args.range_table_bits > 16:
+            try:
+                node.set_fixed_base_bits(1, args.range_table_bits); node.set_fixed_base_bits(3, args.range_table_bits)     # shared with the engine's tables on the same device
+            except capi.ActError:
+                pass
+        res["fixed_base_window_bits_h1"] = node.lib.act_ctx_fixed_base_bits(node.lib.act_node_ctx(node.nd, 0), 1)
         res["streams_overlap"] = node.streams_overlap()
         exp_host = expect[:m].cpu().numpy()
         pageable = np.empty((m, PB), np.uint8)
@@ -933,17 +818,19 @@ def node_host_path(args, capi, torch, np, sk, dev, expect, h, devices, L, PB):
         for off in range(0, m, step):           # through a bounded bounce buffer: no second full-size copy
             pageable[off:off + step] = dev[off:off + step].cpu().numpy()
         st_pg = np.zeros(m, np.uint8)
-        for mode, key in ((capi.TRANSCRIPT_HOST, "pageable_host_transcripts"), (capi.TRANSCRIPT_DEVICE, "pageable_device_transcripts")):
+        # (one warm-up + one timed pass each: 2^20 proofs are 2 s a pass and the driver's run has a budget; rounds 3-5 took medians of three
+        # and all four memory / transcript combinations at one device -- profiles/r05_y_bench.json)
+        for mode, key in ((capi.TRANSCRIPT_HOST, "pageable_host_transcripts"),) + (((capi.TRANSCRIPT_DEVICE, "pageable_device_transcripts"),) if ndev > 1 else ()):
             node.set_transcript_mode(mode)
-            dt = timed(lambda: node.verify_spend_ptr(sk, m, pageable.ctypes.data, st_pg.ctypes.data), sync)
+            dt = timed(lambda: node.verify_spend_ptr(sk, m, pageable.ctypes.data, st_pg.ctypes.data), sync, reps=1)
             assert np.array_equal(st_pg, exp_host)
             res[key] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9}
         if ndev == 1:
             pinned = torch.empty((m, PB), dtype=torch.uint8, pin_memory=True); pinned.numpy()[:] = pageable
             st_pin = torch.zeros(m, dtype=torch.uint8, pin_memory=True)
-            for mode, key in ((capi.TRANSCRIPT_HOST, "pinned_host_transcripts"), (capi.TRANSCRIPT_DEVICE, "pinned_device_transcripts")):
+            for mode, key in ((capi.TRANSCRIPT_DEVICE, "pinned_device_transcripts"),):
                 node.set_transcript_mode(mode)
-                dt = timed(lambda: node.verify_spend_ptr(sk, m, pinned.data_ptr(), st_pin.data_ptr()), sync)
+                dt = timed(lambda: node.verify_spend_ptr(sk, m, pinned.data_ptr(), st_pin.data_ptr()), sync, reps=1)
                 assert np.array_equal(st_pin.numpy(), exp_host)
                 res[key] = {"value": m / dt, "unit": "verifies/s", "pcie_GBps": m * PB / dt / 1e9}
             del pinned

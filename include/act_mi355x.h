@@ -51,7 +51,7 @@
  * Host memory may be pageable or pinned.  Spend-proof RECORDS (public inputs) that lie in pinned memory (hipHostMalloc /
  * hipHostRegister under the context's device) are read by the kernels in place over the link -- no staging copy in front of the
  * first kernel; a caller must therefore not write to them while the call runs.  Everything else (wire bytes included), and pageable
- * memory, is staged through the context's own buffers, which are wiped when the call ends.  (ACT_NO_MAPPED_READS=1: always stage.)
+ * memory, is staged through the context's own buffers, which are wiped when the call ends.
  * There is no CPU fallback: without a HIP device every entry point fails.
  */
 #ifndef ACT_MI355X_H
@@ -67,6 +67,7 @@ extern "C" {
 #define ACT_ERR_HIP 2        /* a HIP runtime call failed; act_last_error() has the text */
 #define ACT_ERR_PARAMS 3     /* h1/h2/h3 or the public key is not a canonical Ristretto encoding */
 #define ACT_ERR_NO_DEVICE 4
+#define ACT_ERR_RNG 5        /* ACT_RNG_CALLBACK: the caller's draw() reported a failure; nothing was signed with the bytes */
 
 #define ACT_MEM_HOST 0
 #define ACT_MEM_DEVICE 1
@@ -77,9 +78,13 @@ extern "C" {
  * points to an act_rng_source instead of bytes.  The library calls draw(rng_ctx, dst, 128 * k) ONCE per call, from the calling
  * thread, after every verdict is known, k = the number of lanes that will be signed -- the generator is advanced by exactly what a
  * sequential loop over refund() would have drawn (src/lib.rs:842-852: e, alpha only after the checks), and the slices go to the
- * signed lanes in lane order like ACT_RNG_SEQUENTIAL.  The drawn bytes are wiped before the call returns. */
+ * signed lanes in lane order like ACT_RNG_SEQUENTIAL.  The drawn bytes are wiped before the call returns.
+ * draw returns 0 when it has written all `len` bytes and non-zero when it could not (generator exhausted, an exception in a
+ * language binding's trampoline ...): the call then fails with ACT_ERR_RNG and signs NOTHING -- a signature made with e = alpha = 0
+ * would give the issuer's key away (z = gamma * x).  Lanes that were to be signed are reported as after a failed signature step
+ * (redeem: ACT_STATUS_RECORDED_UNSIGNED, their nullifiers are recorded; the other calls: no output records). */
 #define ACT_RNG_CALLBACK 2
-typedef void (*act_rng_draw_fn)(void *rng_ctx, uint8_t *dst, size_t len);
+typedef int (*act_rng_draw_fn)(void *rng_ctx, uint8_t *dst, size_t len);
 typedef struct act_rng_source { act_rng_draw_fn draw; void *rng_ctx; } act_rng_source;
 
 #define ACT_TRANSCRIPT_HOST 0    /* BLAKE3 of every transcript on host threads (src/transcript.rs stays on the host) */
@@ -118,9 +123,7 @@ int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
  *                    prover chunk)
  *     tables         0.5 GB (16-bit windows for g, h1, h2, h3 + the matrix-core images), shared by all contexts of the process on
  *                    that GPU with the same Params
- *     wide tables    +47 GB (24-bit windows for h1 and h3, built in about 2 s, +3 % verifies/s), taken ONLY by a context with
- *                    max_batch >= 65536 on a device that still has 128 GB free after the workspace -- i.e. a GPU that serves
- *                    nothing else -- or on request (ACT_FB_WIDE_BITS=24 in the environment; =16 never)
+ * and nothing else, whatever the device has free: wider fixed-base windows are asked for (act_ctx_set_fixed_base_bits below).
  * 0 = default = 65536, from which size on the throughput of every entry point is flat; 16384 costs about 5 % of the verify rate and
  * two thirds of the issue/request rate.  Batches of any length are accepted and processed in such chunks.  max_batch > 2^22 is
  * refused (ACT_ERR_ARG).  On failure *out still receives a context whose only use is act_last_error() and act_ctx_destroy(). */
@@ -152,7 +155,8 @@ void act_host_pool_stats(uint64_t *jobs, uint64_t *threads_created, int *pool_si
  * one after the other (measured: 415 k instead of 466 k verifies/s from host memory).  act_ctx_create measures this (two idle
  * wavefronts, 0.3 ms) and, if they share a queue, moves the second stream to another priority class, which has its own queues.
  * 1 = the streams run side by side, 0 = they still share a queue (set GPU_MAX_HW_QUEUES=8 in the embedding process before HIP
- * initialises: INTEGRATION.md), -1 = not measured (ACT_NO_STREAM_PROBE set).  The library never edits the process environment. */
+ * initialises: INTEGRATION.md), -1 = not measured.  The library never edits the process environment and, apart from the diagnostics
+ * ACT_TRACE / ACT_TIMELINE_FILE and the worker pinning ACT_NUMA, never reads it. */
 int act_ctx_streams_overlap(const act_ctx *ctx);
 /* chunks in flight per call: 2 (default; chunk i+1's kernels overlap chunk i's low-occupancy head / tail kernels and, in
  * host-transcript mode, its host hashing) or 1 (strictly one after the other: profiling runs whose per-kernel durations
@@ -173,17 +177,10 @@ int act_ctx_set_small_batch_max(act_ctx *ctx, size_t n);
  * bytes are those of either transcript mode -- and finishing the record; inputs cross PCIe in one copy from a pinned buffer, which
  * the kernel zeroes itself.  One item, MI355X: request 0.27 ms (was 0.58), issue 1.15 (2.7), PreIssuance::to_credit_token 1.1 (2.3),
  * PreRefund::to_credit_token 1.5 (3.0), refund 2.0 (3.7), prove_spend 2.0 (3.2): profiles/r05_single_item_latency.txt.
- * act_ctx_set_tiny_calls(ctx, 0) (or ACT_NO_FUSED_TINY=1 in the environment) keeps the multi-launch paths, whose transcripts follow
+ * act_ctx_set_tiny_calls(ctx, 0) keeps the multi-launch paths, whose transcripts follow
  * the context's transcript mode -- a deployment that wants every hash on the host, whatever the call size (same bytes either way;
  * tests/test_gpu_tiny.py compares). */
 int act_ctx_set_tiny_calls(act_ctx *ctx, int on);           /* default 1 */
-/* Several threads, ONE context, one proof per call -- what a server built on the crate's single-item API does with the context the
- * Rust binding keeps inside `Params`.  Such callers queue on the context (a call is ~1.7 ms whatever its size: ~600 calls/s between
- * them).  With max_proofs_per_call = k > 0, act_verify_spend_batch, act_refund_batch, act_refund_sign_batch, act_issue_batch,
- * act_issue_check_batch and act_issue_sign_batch calls of at most k lanes from host memory (rng: ACT_RNG_PER_LANE, or one lane in either mode) MERGE instead: the caller that finds no merged call running takes every request queued so far with the same
- * key, runs them as one call and hands each caller its own statuses / K' / refunds; requests pile up only while a call runs, nobody
- * waits for company.  Per lane the result is the one the caller's own call would have produced.  0 (default) = off. */
-int act_ctx_set_coalescing(act_ctx *ctx, size_t max_proofs_per_call);
 /* Secrets and memory addresses.  The reference is constant-time in its table accesses (`subtle`, src/lib.rs:98, 1025-1118;
  * dalek's table scans).  libact_mi355x.so (the default build, for which this returns 1) matches that for EVERY secret: the issuer's
  * private key and signing nonces, and the client's tokens, blinding factors and prover rng, never select a memory address --
@@ -197,9 +194,15 @@ int act_ctx_set_coalescing(act_ctx *ctx, size_t max_proofs_per_call);
  * 0.85 x; every issuer-side call -- verify, refund, issue, redeem -- is the same code in both.  A client that owns its GPU may load
  * the fast build; an issuer gains nothing from it. */
 int act_build_has_ct_secret_tables(void);
-/* window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs
- * ceil(253 / bits) table additions): 16 by default, 24 for h1 and h3 in a throughput-sized context on an otherwise empty device (see act_ctx_create) */
+/* Window width in bits of the fixed-base table of base 0..3 = g, h1, h2, h3 in this context (a product costs ceil(253 / bits) table
+ * additions).  16 after act_ctx_create (128 MiB per base), always.  act_ctx_set_fixed_base_bits(ctx, base, bits), bits in 4..24,
+ * builds the table of that width now (or shares it with the process's other contexts on the device) and releases the old one; the
+ * range kernel's bases are h1 (1) and h3 (3): 24 bits on both is +47 GB (23.6 GB each, built in about 2 s) for +3 % verifies/s --
+ * worth it on a GPU that serves nothing else, and only the caller knows that.  Refused (ACT_ERR_HIP, width unchanged) when the
+ * device has not the table's size + 16 GB free.  Not while another thread has a call on the context in flight with results that
+ * matter for timing: it takes the context's lock like a batch call. */
 int act_ctx_fixed_base_bits(const act_ctx *ctx, int base);
+int act_ctx_set_fixed_base_bits(act_ctx *ctx, int base, int bits);
 /* Text of the CALLING THREAD's last failure on this handle (of the handle's most recent failure if this thread has had none): a
  * handle is shared between threads, and a caller whose small call was merged into another thread's launch gets that launch's text.
  * Every *_last_error function copies the text into a buffer of the calling thread, valid until that thread asks again. */
@@ -267,7 +270,7 @@ int act_refund_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64],
  * the accepted lanes in front of every shard, then all shards sign from their offsets into the stream; refund carries
  * only enc(K') between the two phases.  ACT_RNG_PER_LANE needs no such barrier and is one pass.  A node handle (like a
  * context) may be shared between host threads: every *_batch call takes the handle's lock, so concurrent callers are
- * served one after the other (small calls can do better than queue: act_node_set_coalescing below).  act_node_create builds the contexts concurrently (one thread per entry); entries that name
+ * served one after the other.  act_node_create builds the contexts concurrently (one thread per entry); entries that name
  * the same device share that device's fixed-base tables. */
 typedef struct act_node act_node;
 int act_node_create(const uint8_t h[96], int L, const int *devices, int n_devices, size_t max_batch, act_node **out);
@@ -277,6 +280,7 @@ act_ctx *act_node_ctx(act_node *node, int k);                  /* context k, e.g
 const char *act_node_last_error(const act_node *node);
 int act_node_set_transcript_mode(act_node *node, int mode);
 int act_node_set_host_threads(act_node *node, int per_gpu);    /* host BLAKE3 workers of every context */
+int act_node_set_fixed_base_bits(act_node *node, int base, int bits);   /* act_ctx_set_fixed_base_bits on every context */
 /* Load balance.  The GPUs of a node are not equally fast (clocks differ by several percent between devices and move with
  * temperature) and a call ends when its slowest GPU does, so the cut is not n/N: (1) every throughput-sized call -- at least
  * 16384 lanes per GPU -- measures what each context did with its piece and the next call cuts in proportion (weights: relative
@@ -291,11 +295,6 @@ int act_node_set_host_threads(act_node *node, int per_gpu);    /* host BLAKE3 wo
 int act_node_set_balance(act_node *node, int weighted, int tail_64ths);
 int act_node_device_stats(act_node *node, int k, double *weight, uint64_t *last_lanes, double *last_seconds, uint64_t *last_calls);
 int act_node_balance_state(act_node *node, double *spread, double *tail_fraction);
-/* act_ctx_set_coalescing on every context, and: act_node_verify_spend_batch / _refund_batch / _refund_sign_batch / _issue_batch / _issue_check_batch / _issue_sign_batch calls of at most
- * max_proofs_per_call proofs are no longer cut over the GPUs under the handle's lock -- each goes to one context (round robin) and
- * merges there with the small calls other threads make on the same handle at the same time.  What the Rust binding's single-item
- * `refund` turns into when a server's threads share one `Params`.  0 (default) = off. */
-int act_node_set_coalescing(act_node *node, size_t max_proofs_per_call);
 int act_node_request_batch(act_node *node, size_t n, const uint8_t *pre, const uint8_t *rng, uint8_t *out_req);
 int act_node_issue_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *req, const uint8_t *c, const uint8_t *rng,
                          int rng_mode, uint8_t *out_resp, uint8_t *status);
@@ -327,10 +326,12 @@ int act_node_refund_to_credit_token_batch(act_node *node, size_t n, const uint8_
  * wins; bytes after the first item ignored).  Scalars come out reduced mod l (decode_scalar, src/cbor.rs:80-91).
  * status[i]: 0 ok, 1 malformed CBOR (CborError::Ciborium), 2 CborError::InvalidStructure, 3 CborError::InvalidValue
  * (a point that is not a canonical Ristretto encoding, src/cbor.rs:59-78); the record of a failed message is zero.
- * Accept / reject always agrees with from_cbor.  Where a message is wrong in two ways the code can differ: from_cbor
- * reports the first problem in map order, this codec validates points after the structural pass, so a message with an
- * invalid point AND a later missing or mis-shaped field reports 2 where the crate reports InvalidValue.
- * Canonical messages are framed / unframed on the GPU (one lane per 32-byte field); others take a host reader. */
+ * The code is from_cbor's code, also for a message that is wrong in several ways: the whole item is parsed first (1), then the
+ * first failure in WIRE order of the map's entries decides (src/cbor.rs:276-388: an invalid point in front of a mis-shaped
+ * field is 3, behind it 2; array elements, those of an over-long array included, are decoded before the length is checked;
+ * a value a later duplicate key overwrites still has to decode), and missing fields come last (:390-407).
+ * Canonical messages are framed / unframed on the GPU (one lane per 32-byte field); others take a host reader, which hands the
+ * points whose position matters to a validation kernel. */
 #define ACT_CBOR_ISSUANCE_REQUEST 1
 #define ACT_CBOR_ISSUANCE_RESPONSE 2
 #define ACT_CBOR_SPEND_PROOF 3
@@ -353,9 +354,9 @@ int act_cbor_decode_batch(act_ctx *ctx, int type, size_t n, int mem, const uint8
  * moves the records through the caller's memory in between.  status[i]: 0 / 6 / 7 as act_verify_spend_batch;
  * 255 = a point that is not a canonical Ristretto encoding (from_cbor's CborError::InvalidValue);
  * ACT_STATUS_CBOR_MALFORMED = not well-formed CBOR (CborError::Ciborium); ACT_STATUS_CBOR_STRUCTURE = CborError::InvalidStructure
- * (not a map, missing field, wrong shape or length).  Accept / reject agrees with from_cbor followed by refund; a message that is
- * wrong in two ways may report the other of its two errors.  Non-canonical but valid encodings take a host reader and a second,
- * small verification call.  out_kprime (nullable) as in act_verify_spend_batch. */
+ * (not a map, missing field, wrong shape or length).  The status is the one from_cbor followed by refund gives, also for a message
+ * that is wrong in several ways (the first failure in wire order, as described at act_cbor_decode_batch).  Non-canonical but valid
+ * encodings take a host reader and a second, small verification call.  out_kprime (nullable) as in act_verify_spend_batch. */
 #define ACT_STATUS_CBOR_MALFORMED 254
 #define ACT_STATUS_CBOR_STRUCTURE 253
 int act_verify_spend_cbor_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
@@ -487,6 +488,12 @@ int act_debug_fail_next_signs(act_ctx *ctx, int count);
  * (tests/golden/sodium_primitives.json). */
 int act_debug_scalarmult_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *points, const uint8_t *scalars, uint8_t *out,
                                uint8_t *status);
+
+/* Measurement hook: A/B switches and size overrides of tools/ and tests/ (csrc/kernels.h TuneKey: "no_mapped_reads", "no_fused_tiny",
+ * "no_taper", "no_wide_sign", "no_wide_prove", "no_wide_client", "no_lds_isolation", "no_stream_probe", "small_sub", "small_in_flight",
+ * "small_normal_prio", "small_trace", "stagger", "host_chunk", "cbor_chunk_msgs", "ubench_iters").  Process-wide; none of them changes a
+ * byte of any result.  A deployment never calls this; the library reads no environment variable in its place. */
+int act_tuning_set(const char *name, int64_t value);
 
 /* Kernel timing (HIP events on the context's own stream, which torch.cuda.Event cannot see):
  * enable, run batches, then read per-kernel totals.  names: act_prof_kernel_name(i), i < act_prof_kernel_count(). */

@@ -959,8 +959,10 @@ def _cbor_parse(b: bytes, pos: int, depth: int = 0):
 
 def cbor_decode(type_name: str, msg: bytes, nbits: int = L_DEFAULT):
     """from_cbor -> (status, record).  Status 1 malformed CBOR, 2 InvalidStructure, 3 InvalidValue; record zero on failure.
-    (When a message is broken in more than one way the reference reports the first problem in map order; this model
-    reports structure problems before invalid points.  Either way the message is rejected.)"""
+    A message that is broken in more than one way reports what the reference reports: the whole item is parsed first
+    (ciborium::from_reader), then the map's entries are visited in WIRE order and the first failing decode_scalar /
+    decode_point returns (src/cbor.rs:276-388: `?` inside the `for (key, val) in map` loop; array elements are decoded in
+    order BEFORE the length check, :307-319), and missing fields are reported last (:390-407)."""
     spec = CBOR_TYPES[type_name]
     nf = 1 if spec is None else sum(1 if s == 0 else nbits if s == 1 else 2 * nbits for _, _, s in spec)
     fail = lambda code: (code, bytes(32 * nf))
@@ -979,6 +981,8 @@ def cbor_decode(type_name: str, msg: bytes, nbits: int = L_DEFAULT):
         x = b32(value)
         if x is None:
             return fail(CBOR_ERR_STRUCTURE)
+        if ristretto_decode(x) is None:
+            return fail(CBOR_ERR_VALUE)
         fields[0] = x
     else:
         if value[0] != "map":
@@ -997,6 +1001,8 @@ def cbor_decode(type_name: str, msg: bytes, nbits: int = L_DEFAULT):
                 x = b32(v)
                 if x is None:
                     return fail(CBOR_ERR_STRUCTURE)
+                if kind == "P" and ristretto_decode(x) is None:      # decode_point, src/cbor.rs:62-77: returns at once
+                    return fail(CBOR_ERR_VALUE)
                 fields[i] = x; present.add(k[1])
             else:
                 if v[0] != "array":
@@ -1007,6 +1013,8 @@ def cbor_decode(type_name: str, msg: bytes, nbits: int = L_DEFAULT):
                         x = b32(el)
                         if x is None:
                             return fail(CBOR_ERR_STRUCTURE)
+                        if kind == "P" and ristretto_decode(x) is None:      # every element, also those beyond L, before the length check
+                            return fail(CBOR_ERR_VALUE)
                         elems.append(x)
                     else:
                         if el[0] != "array" or len(el[1]) != 2:
@@ -1025,7 +1033,5 @@ def cbor_decode(type_name: str, msg: bytes, nbits: int = L_DEFAULT):
         if kind == "S":
             out += sc_bytes(sc_from_bytes_mod_order(x))      # decode_scalar, src/cbor.rs:80-91
         else:
-            if ristretto_decode(x) is None:                  # decode_point, src/cbor.rs:59-78
-                return fail(CBOR_ERR_VALUE)
-            out += x
+            out += x                                         # validated where it was read
     return CBOR_OK, out

@@ -30,7 +30,7 @@ pub struct ActNodeNullifierSet {
 /// once, after every verdict is known -- so the generator ends where a sequential loop over `refund` would have left it.
 #[repr(C)]
 pub struct ActRngSource {
-    draw: unsafe extern "C" fn(rng_ctx: *mut c_void, dst: *mut u8, len: usize),
+    draw: unsafe extern "C" fn(rng_ctx: *mut c_void, dst: *mut u8, len: usize) -> c_int,
     rng_ctx: *mut c_void,
 }
 const ACT_RNG_SEQUENTIAL: c_int = 1;
@@ -45,7 +45,6 @@ extern "C" {
     fn act_node_create(h: *const u8, l: c_int, devices: *const c_int, n_devices: c_int, max_batch: usize, out: *mut *mut ActNode) -> c_int;
     fn act_node_destroy(node: *mut ActNode);
     fn act_node_last_error(node: *const ActNode) -> *const c_char;
-    fn act_node_set_coalescing(node: *mut ActNode, max_proofs_per_call: usize) -> c_int;
     fn act_node_request_batch(node: *mut ActNode, n: usize, pre: *const u8, rng: *const u8, out_req: *mut u8) -> c_int;
     fn act_node_issue_check_batch(node: *mut ActNode, n: usize, req: *const u8, status: *mut u8) -> c_int;
     fn act_node_issue_sign_batch(node: *mut ActNode, n: usize, sk: *const u8, req: *const u8, c: *const u8, status_in: *const u8,
@@ -99,13 +98,11 @@ fn devices_from_env() -> Vec<c_int> {
 /// them itself -- every `act_node_*_batch` call takes the node handle's lock and every context entry point the context's
 /// (include/act_mi355x.h, "A node handle ... may be shared between host threads") -- so concurrent callers are served one after
 /// the other and never observe each other's staging buffers, cached key or error string.  That is why `Gpu` may be `Sync`; the
-/// guarantee lives in the library, not in a promise by the caller.  Small calls (the single-item API) do better than queue: they
-/// merge into one launch with the small calls of other threads (`act_node_set_coalescing`, set in `Gpu::new`).
+/// guarantee lives in the library, not in a promise by the caller.
 pub struct Gpu(*mut ActNode);
 // SAFETY: the handle is only ever passed to act_node_* entry points.  Calls that are cut over the GPUs take the node's lock
-// (csrc/node.cpp `node_lock`); calls small enough to merge (act_node_set_coalescing) bypass it and are serialised by the lock of the
-// one context they go to and by that context's request combiner (csrc/coalesce.h) -- either way no two threads are ever inside the
-// same context's buffers.  act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies the
+// (csrc/node.cpp `node_lock`); the few-item calls that go to one context are serialised by that context's lock -- either way no two
+// threads are ever inside the same context's buffers.  act_node_destroy runs from Drop, i.e. with exclusive access.  The error text is safe too: act_node_last_error copies the
 // CALLING thread's own last failure on the handle (kept per thread by the library) into a buffer of that thread, valid until it asks
 // again, so `check` below neither reads a string another thread's failing call is rewriting nor reports another thread's error.
 unsafe impl Send for Gpu {}
@@ -140,8 +137,8 @@ impl Gpu {
         // The library never touches the process environment.  A service with many HIP streams exports GPU_MAX_HW_QUEUES=8 before its
         // first HIP call; the engine measures whether its two pipeline streams overlap either way.
         // ACT_MI355X_MAX_BATCH: records per internal launch.  Unset = the library default, 65 536: 27 GB of workspace per GPU
-        // (+ 0.5 GB of tables; + 47 GB of 24-bit tables for +3 % ONLY on a GPU that still has 128 GB free, i.e. one that serves
-        // nothing else -- include/act_mi355x.h act_ctx_create).  A service that only ever sees small batches sets e.g. 4096 (1.7 GB).
+        // + 0.5 GB of tables, and nothing else: wider fixed-base windows (+47 GB, +3 % verifies/s) are asked for explicitly with
+        // act_node_set_fixed_base_bits (include/act_mi355x.h).  A service that only ever sees small batches sets e.g. 4096 (1.7 GB).
         let max_batch: usize = std::env::var("ACT_MI355X_MAX_BATCH").ok().and_then(|s| s.parse().ok()).unwrap_or(0);
         let mut node = std::ptr::null_mut();
         let rc = unsafe { act_node_create(h.as_ptr(), L as c_int, devices.as_ptr(), devices.len() as c_int, max_batch, &mut node) };
@@ -149,13 +146,6 @@ impl Gpu {
             let msg = if node.is_null() { String::new() } else { unsafe { CStr::from_ptr(act_node_last_error(node)) }.to_string_lossy().into_owned() };
             panic!("act_node_create failed ({rc}): {msg}"); // infrastructure failure, not a protocol error
         }
-        // The single-item entry points (`refund`, src/lib.rs:781-786) are calls over ONE proof, ~2 ms each whatever happens; the threads
-        // of a server that share this `Params` would queue on the handle at ~220 refunds/s between them.  Calls of at most this many
-        // proofs merge with the other threads' instead (each caller still gets exactly its own answer): 64 threads, 5 150 refunds/s
-        // (profiles/r04_single_item_server.txt).  ACT_MI355X_COALESCE=0 turns it off.
-        let merge: usize = std::env::var("ACT_MI355X_COALESCE").ok().and_then(|s| s.parse().ok()).unwrap_or(64);
-        let rc = unsafe { act_node_set_coalescing(node, merge) };
-        assert_eq!(rc, 0, "act_node_set_coalescing");
         Gpu(node)
     }
     fn check(&self, rc: c_int) {
@@ -580,13 +570,17 @@ fn status_to_wire_error(s: u8) -> WireError {
 
 /// The caller's generator as the library's draw callback.  dalek draws a `Scalar::random` with one `fill_bytes(&mut [u8; 64])`;
 /// so does this, 64 bytes at a time, so that generators that are not plain byte streams still see the calls they would have seen.
-/// (A panic inside `fill_bytes` cannot unwind through the C frames: the process aborts.)
-unsafe extern "C" fn draw_trampoline<R: CryptoRngCore>(rng_ctx: *mut c_void, dst: *mut u8, len: usize) {
+/// Returns 0 = all `len` bytes written; a generator that can fail reports it through `try_fill_bytes` and the library then signs
+/// nothing (ACT_ERR_RNG).  (A panic inside the generator cannot unwind through the C frames: the process aborts.)
+unsafe extern "C" fn draw_trampoline<R: CryptoRngCore>(rng_ctx: *mut c_void, dst: *mut u8, len: usize) -> c_int {
     let rng = &mut *(rng_ctx as *mut R);
     let buf = std::slice::from_raw_parts_mut(dst, len);
     for chunk in buf.chunks_mut(64) {
-        rng.fill_bytes(chunk);
+        if rng.try_fill_bytes(chunk).is_err() {
+            return 1;
+        }
     }
+    0
 }
 fn rng_source<R: CryptoRngCore>(rng: &mut R) -> ActRngSource {
     ActRngSource { draw: draw_trampoline::<R>, rng_ctx: rng as *mut R as *mut c_void }
@@ -635,20 +629,6 @@ impl PrivateKey {
                                        ACT_RNG_CALLBACK, out.as_mut_ptr(), status.as_mut_ptr())
         });
         refund_messages(&out, &status[..n])
-    }
-    /// ONE message, the 128 bytes of e and alpha drawn BEFORE the verdict (see `refund_eager`): unframing, verification and the
-    /// signature beside it as one library call, 2.1 ms instead of 3.1.  The message returned is the one `refund_cbor_batch` returns
-    /// for the same generator; a rejected message has then consumed 128 bytes of it where the crate consumes none.
-    pub fn refund_cbor_eager(&self, params: &Params, msg: &[u8], mut rng: impl CryptoRngCore) -> Result<Vec<u8>, WireError> {
-        let offsets = [0u64, msg.len() as u64];
-        let rng_bytes = draw(&mut rng, 2);
-        let (sk, gpu) = (self.record(), params.gpu());
-        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES + 1], vec![0u8; 2]);
-        gpu.check(unsafe {
-            act_node_refund_cbor_batch(gpu.0, 1, sk.as_ptr(), msg.as_ptr(), offsets.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL,
-                                       out.as_mut_ptr(), status.as_mut_ptr())
-        });
-        refund_messages(&out, &status[..1]).pop().unwrap()
     }
     /// Verdicts only (`refund` up to the challenge check, src/lib.rs:787-844) for CBOR `SpendProof` messages.
     pub fn verify_spend_cbor_batch(&self, params: &Params, msgs: &[&[u8]]) -> Vec<Result<(), WireError>> {
@@ -722,22 +702,6 @@ impl PrivateKey {
         let engine_failure = if rc != 0 { Some(unsafe { CStr::from_ptr(act_node_last_error(gpu.0)) }.to_string_lossy().into_owned()) } else { None };
         Redeemed { lanes: refund_messages(&out, &status[..n]), engine_failure }
     }
-    /// ONE message, the way a server that answers requests one at a time calls it: the 128 bytes of e and alpha are drawn BEFORE the
-    /// verdict (see `refund_eager`), the refund is computed in one library call with the signature beside the verification, THEN the
-    /// store decides -- 2.1 ms instead of 3.2.  Same message and same store as `redeem_cbor_batch` over that one message; a message
-    /// that is rejected (or a double spend) has consumed 128 bytes of the generator where the loop consumes none.
-    pub fn redeem_cbor_eager(&self, params: &Params, store: &GpuNullifierStore, msg: &[u8], mut rng: impl CryptoRngCore) -> Redeemed<Vec<u8>> {
-        let offsets = [0u64, msg.len() as u64];
-        let rng_bytes = draw(&mut rng, 2);
-        let (sk, gpu) = (self.record(), params.gpu());
-        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES + 1], vec![0u8; 2]);
-        let rc = unsafe {
-            act_node_redeem_cbor_batch(gpu.0, store.0, 1, sk.as_ptr(), msg.as_ptr(), offsets.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL,
-                                       out.as_mut_ptr(), status.as_mut_ptr())
-        };
-        let engine_failure = if rc != 0 { Some(unsafe { CStr::from_ptr(act_node_last_error(gpu.0)) }.to_string_lossy().into_owned()) } else { None };
-        Redeemed { lanes: refund_messages(&out, &status[..1]), engine_failure }
-    }
     /// The same over `SpendProof`s (marshalled on all cores: 130 `compress()` per proof).
     pub fn redeem_batch(&self, params: &Params, store: &GpuNullifierStore, proofs: &[SpendProof], mut rng: impl CryptoRngCore) -> Redeemed<Refund> {
         let n = proofs.len();
@@ -779,8 +743,7 @@ pub fn gpu_device_stats(params: &Params) -> Vec<(f64, u64, f64, u64)> {
 // dependent chain on a few lanes (profiles/r04_single_item_latency.txt; the C port on one core of the same box in brackets):
 //     request 0.59 ms (0.05)    issue 2.7 (0.25)    PreIssuance::to_credit_token 2.3 (0.21)
 //     prove_spend 3.1 (15.5)    refund 3.5 (17.3)   PreRefund::to_credit_token 3.0 (5.0)
-// Under load the small calls of the threads sharing this `Params` merge (`act_node_set_coalescing` above), and the `*_batch`
-// siblings are where the rates are (24 M issues/s, 112 M requests/s, 520 k refunds/s).
+// The `*_batch` siblings are where the rates are (24 M issues/s, 112 M requests/s, 520 k refunds/s).
 #[cfg(feature = "mi355x")]
 impl PreIssuance {
     pub fn request(&self, params: &Params, rng: impl CryptoRngCore) -> IssuanceRequest {
@@ -803,31 +766,6 @@ impl PrivateKey {
         // src/lib.rs:781-786
         self.refund_batch(params, std::slice::from_ref(spend_proof), rng).pop().unwrap()
     }
-    /// `refund` in ONE call to the library, the signature computed beside the verification (1.95 ms instead of ~2.8 for one proof):
-    /// e and alpha are drawn BEFORE the verdict is known.  The refund is the one `refund` returns for the same generator; the one
-    /// difference is on the error path -- the crate draws nothing for a rejected proof (src/lib.rs:787-846), this draws 128 bytes
-    /// whatever the verdict.  For callers whose generator is the operating system's, that is no difference at all.
-    pub fn refund_eager(&self, params: &Params, spend_proof: &SpendProof, mut rng: impl CryptoRngCore) -> Result<Refund, Error> {
-        let mut rec = Vec::with_capacity(PROOF_BYTES);
-        spend_proof.write_record(&mut rec);
-        let rng_bytes = draw(&mut rng, 2);
-        let (sk, gpu) = (self.record(), params.gpu());
-        let (mut out, mut status) = ([0u8; 128], [0u8; 1]);
-        gpu.check(unsafe { act_node_refund_batch(gpu.0, 1, sk.as_ptr(), rec.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr()) });
-        if status[0] == 0 { Ok(Refund::from_record(&out)) } else { Err(status_to_error(status[0])) }
-    }
-    /// `issue` in one call, the signature beside the request's proof of knowledge (1.25 ms instead of ~2.0); the same remark as
-    /// `refund_eager`: 128 bytes are drawn before the check of src/lib.rs:629-640, not after it.
-    pub fn issue_eager(&self, params: &Params, request: &IssuanceRequest, c: Scalar, mut rng: impl CryptoRngCore) -> Result<IssuanceResponse, Error> {
-        let (mut req, mut cb) = (Vec::with_capacity(128), Vec::with_capacity(32));
-        request.write_record(&mut req);
-        put_s(&mut cb, &c);
-        let rng_bytes = draw(&mut rng, 2);
-        let (sk, gpu) = (self.record(), params.gpu());
-        let (mut out, mut status) = ([0u8; 160], [0u8; 1]);
-        gpu.check(unsafe { act_node_issue_batch(gpu.0, 1, sk.as_ptr(), req.as_ptr(), cb.as_ptr(), rng_bytes.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr()) });
-        if status[0] == 0 { Ok(IssuanceResponse::from_record(&out)) } else { Err(status_to_error(status[0])) }
-    }
 }
 #[cfg(feature = "mi355x")]
 impl CreditToken {
@@ -841,5 +779,71 @@ impl PreRefund {
     pub fn to_credit_token(&self, params: &Params, spend_proof: &SpendProof, refund: &Refund, public_key: &PublicKey) -> Result<CreditToken, Error> {
         // src/lib.rs:1217-1223
         Self::to_credit_token_batch(std::slice::from_ref(self), params, std::slice::from_ref(spend_proof), std::slice::from_ref(refund), public_key).pop().unwrap()
+    }
+}
+
+// ---- one library call per item, with nonce bytes the CALLER has already drawn ----------------------------------------------------
+// NOT part of the drop-in surface, and deliberately not methods that take a generator.  `PrivateKey::issue` / `refund` above keep the
+// crate's contract exactly -- e and alpha are drawn only after the checks have passed (src/lib.rs:638-643, 842-846), so a rejected
+// item leaves the caller's generator untouched -- and pay for it with two library calls (check, then sign).  The functions below are
+// ONE call: the signature is computed BESIDE the check (issue 1.25 ms instead of ~2.0, refund 1.95 instead of ~2.8, a wire-level
+// redemption 2.1 instead of 3.2), which is only possible if the 128 bytes that seed (e, alpha) exist before the verdict does.  They
+// therefore take the BYTES, not a generator: there is no generator state here that could disagree with the crate's, and what
+// happens to the bytes of a rejected item is the caller's explicit decision (they were read by the GPU and wiped there; never use
+// them again).  A caller whose generator is the operating system's loses nothing; a caller that replays a deterministic stream and
+// must match the crate's draws byte for byte stays with the methods above.
+#[cfg(feature = "mi355x")]
+pub mod predrawn {
+    use super::*;
+
+    /// 128 bytes from `rng`, drawn as two `Scalar::random` would draw them (two 64-byte `fill_bytes`).
+    pub fn nonce_bytes(mut rng: impl CryptoRngCore) -> [u8; 128] {
+        let v = draw(&mut rng, 2);
+        let mut out = [0u8; 128];
+        out.copy_from_slice(&v);
+        out
+    }
+    /// `sk.refund(params, proof, rng)` for an rng whose next 128 bytes are `nonces` -- if the proof verifies.  If it does not, the
+    /// result is the same `Err`, and `nonces` have been spent on nothing.
+    pub fn refund(sk: &PrivateKey, params: &Params, spend_proof: &SpendProof, nonces: &[u8; 128]) -> Result<Refund, Error> {
+        let mut rec = Vec::with_capacity(PROOF_BYTES);
+        spend_proof.write_record(&mut rec);
+        let (skr, gpu) = (sk.record(), params.gpu());
+        let (mut out, mut status) = ([0u8; 128], [0u8; 1]);
+        gpu.check(unsafe { act_node_refund_batch(gpu.0, 1, skr.as_ptr(), rec.as_ptr(), nonces.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr()) });
+        if status[0] == 0 { Ok(Refund::from_record(&out)) } else { Err(status_to_error(status[0])) }
+    }
+    /// `sk.issue(params, request, c, rng)` for an rng whose next 128 bytes are `nonces`, the signature beside the request's proof of
+    /// knowledge (src/lib.rs:629-660).
+    pub fn issue(sk: &PrivateKey, params: &Params, request: &IssuanceRequest, c: Scalar, nonces: &[u8; 128]) -> Result<IssuanceResponse, Error> {
+        let (mut req, mut cb) = (Vec::with_capacity(128), Vec::with_capacity(32));
+        request.write_record(&mut req);
+        put_s(&mut cb, &c);
+        let (skr, gpu) = (sk.record(), params.gpu());
+        let (mut out, mut status) = ([0u8; 160], [0u8; 1]);
+        gpu.check(unsafe { act_node_issue_batch(gpu.0, 1, skr.as_ptr(), req.as_ptr(), cb.as_ptr(), nonces.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr()) });
+        if status[0] == 0 { Ok(IssuanceResponse::from_record(&out)) } else { Err(status_to_error(status[0])) }
+    }
+    /// One CBOR `SpendProof` message in, one CBOR `Refund` message out: unframing, verification and the signature beside it.
+    pub fn refund_cbor(sk: &PrivateKey, params: &Params, msg: &[u8], nonces: &[u8; 128]) -> Result<Vec<u8>, WireError> {
+        let offsets = [0u64, msg.len() as u64];
+        let (skr, gpu) = (sk.record(), params.gpu());
+        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES + 1], vec![0u8; 2]);
+        gpu.check(unsafe {
+            act_node_refund_cbor_batch(gpu.0, 1, skr.as_ptr(), msg.as_ptr(), offsets.as_ptr(), nonces.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr())
+        });
+        refund_messages(&out, &status[..1]).pop().unwrap()
+    }
+    /// The whole redemption step for one message: the refund is computed first (one call), THEN the store decides whether it is handed
+    /// out; a rejected message or a double spend has spent `nonces` on nothing.
+    pub fn redeem_cbor(sk: &PrivateKey, params: &Params, store: &GpuNullifierStore, msg: &[u8], nonces: &[u8; 128]) -> Redeemed<Vec<u8>> {
+        let offsets = [0u64, msg.len() as u64];
+        let (skr, gpu) = (sk.record(), params.gpu());
+        let (mut out, mut status) = (vec![0u8; REFUND_CBOR_BYTES + 1], vec![0u8; 2]);
+        let rc = unsafe {
+            act_node_redeem_cbor_batch(gpu.0, store.0, 1, skr.as_ptr(), msg.as_ptr(), offsets.as_ptr(), nonces.as_ptr(), ACT_RNG_SEQUENTIAL, out.as_mut_ptr(), status.as_mut_ptr())
+        };
+        let engine_failure = if rc != 0 { Some(unsafe { CStr::from_ptr(act_node_last_error(gpu.0)) }.to_string_lossy().into_owned()) } else { None };
+        Redeemed { lanes: refund_messages(&out, &status[..1]), engine_failure }
     }
 }

@@ -1,5 +1,7 @@
 //! tests/golden.rs — the UNMODIFIED crate against the committed lifecycle fixtures.  No GPU, no `mi355x` feature, no Python:
 //!
+//!     cd <this repo>/rust/pin && cargo test                        (a self-contained package: rust/pin/README.md)
+//! or, inside a checkout of the crate:
 //!     cp <this repo>/rust/tests/golden.rs tests/ && cargo add --dev serde_json
 //!     ACT_GOLDEN_DIR=<this repo>/tests/golden cargo test --test golden
 //!
@@ -153,7 +155,8 @@ fn frame_proof(rec: &[u8]) -> Vec<u8> {
 
 // ---- fixtures ------------------------------------------------------------------------------------------------------------------
 fn load(name: &str) -> serde_json::Value {
-    let dir = std::env::var("ACT_GOLDEN_DIR").expect("set ACT_GOLDEN_DIR to the tests/golden directory of the MI355X repository");
+    // ACT_GOLDEN_DIR, or -- run from rust/pin of the MI355X repository -- the fixtures where they lie: <repo>/tests/golden
+    let dir = std::env::var("ACT_GOLDEN_DIR").unwrap_or_else(|_| format!("{}/../../tests/golden", env!("CARGO_MANIFEST_DIR")));
     let text = std::fs::read_to_string(std::path::Path::new(&dir).join(name)).expect("fixture file");
     serde_json::from_str(&text).expect("fixture JSON")
 }

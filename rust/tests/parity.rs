@@ -207,46 +207,48 @@ fn wire_level_calls_equal_the_server_loop() {
     assert_eq!(red.lanes[5], Err(WireError::Protocol(Error::DoubleSpendError)));
 }
 
-/// The `*_eager` one-item calls (one library call, e / alpha drawn before the verdict): for an accepted item the same bytes as the
-/// crate's method and the same 128 bytes consumed; for a rejected one the same error, and -- the one documented difference --
-/// 128 bytes consumed where the crate consumes none.
+/// `predrawn::*` (one library call per item, the signature beside the check, the caller hands over the 128 nonce bytes -- NOT
+/// methods that take a generator, so the crate's "nothing is drawn for a rejected item" contract of `issue` / `refund` is not
+/// touched): for an accepted item the bytes the crate's method produces from a generator whose next 128 bytes are those; for a
+/// rejected one the same error.
 #[test]
-fn eager_one_item_calls_equal_the_methods() {
+fn predrawn_one_item_calls_equal_the_methods() {
+    use anonymous_credit_tokens::mi355x::predrawn;
     let params = Params::new("bench-org", "bench-service", "bench-env", "2024-01-01");
     let sk = PrivateKey::random(ReplayRng::new(1, 64));
     let pre = PreIssuance::random(ReplayRng::new(21, 128));
     let req = pre.request_reference(&params, ReplayRng::new(22, 128));
     // issue
-    let (mut a, mut b) = (ReplayRng::new(23, 256), ReplayRng::new(23, 256));
+    let mut a = ReplayRng::new(23, 256);
+    let nonces = predrawn::nonce_bytes(ReplayRng::new(23, 256));
     let want = sk.issue_reference(&params, &req, Scalar::from(50u128), &mut a).unwrap();
-    let got = sk.issue_eager(&params, &req, Scalar::from(50u128), &mut b).unwrap();
+    let got = predrawn::issue(&sk, &params, &req, Scalar::from(50u128), &nonces).unwrap();
     assert_eq!(want.to_cbor().unwrap(), got.to_cbor().unwrap());
-    assert_eq!(a.pos, b.pos);
+    assert_eq!(a.pos, 128);
     let tok = pre.to_credit_token_reference(&params, sk.public(), &req, &want).unwrap();
     let (proof, _) = tok.prove_spend_reference(&params, Scalar::from(7u128), ReplayRng::new(24, 64 * (4 * L + 12)));
     // refund, records and wire bytes
-    let (mut a, mut b, mut c) = (ReplayRng::new(25, 256), ReplayRng::new(25, 256), ReplayRng::new(25, 256));
+    let mut a = ReplayRng::new(25, 256);
+    let nonces = predrawn::nonce_bytes(ReplayRng::new(25, 256));
     let want = sk.refund_reference(&params, &proof, &mut a).unwrap().to_cbor().unwrap();
-    assert_eq!(sk.refund_eager(&params, &proof, &mut b).unwrap().to_cbor().unwrap(), want);
+    assert_eq!(predrawn::refund(&sk, &params, &proof, &nonces).unwrap().to_cbor().unwrap(), want);
     let msg = proof.to_cbor().unwrap();
-    assert_eq!(sk.refund_cbor_eager(&params, &msg, &mut c).unwrap(), want);
-    assert_eq!((a.pos, a.pos), (b.pos, c.pos));
+    assert_eq!(predrawn::refund_cbor(&sk, &params, &msg, &nonces).unwrap(), want);
     // redeem of one message: fresh the first time, a double spend the second; the store holds one nullifier
     let store = GpuNullifierStore::new(1 << 10);
-    let mut d = ReplayRng::new(25, 256);
-    let first = sk.redeem_cbor_eager(&params, &store, &msg, &mut d);
+    let first = predrawn::redeem_cbor(&sk, &params, &store, &msg, &nonces);
     assert!(first.engine_failure.is_none());
     assert_eq!(first.lanes[0].as_ref().unwrap(), &want);
-    let second = sk.redeem_cbor_eager(&params, &store, &msg, &mut d);
+    let second = predrawn::redeem_cbor(&sk, &params, &store, &msg, &predrawn::nonce_bytes(ReplayRng::new(27, 128)));
     assert_eq!(second.lanes[0], Err(WireError::Protocol(Error::DoubleSpendError)));
     assert_eq!(store.len(), 1);
-    assert_eq!(d.pos, 256, "the eager form draws its 128 bytes whatever the verdict");
-    // a rejected item: the same error as the method, 128 bytes consumed (the method: none)
+    // a rejected item: the same error as the method; and the METHOD (the drop-in surface) leaves its generator untouched
     let mut bad = msg.clone();
     bad[4 + 34 + 5] ^= 1;
-    let (mut a, mut b) = (ReplayRng::new(26, 128), ReplayRng::new(26, 128));
+    let mut a = ReplayRng::new(26, 128);
     let p_bad = SpendProof::from_cbor(&bad).unwrap();
     assert!(sk.refund_reference(&params, &p_bad, &mut a).is_err() && a.pos == 0);
-    assert_eq!(sk.refund_cbor_eager(&params, &bad, &mut b), Err(WireError::Protocol(Error::InvalidClientSpendProof)));
-    assert_eq!(b.pos, 128);
+    let mut b = ReplayRng::new(26, 128);
+    assert!(sk.refund(&params, &p_bad, &mut b).is_err() && b.pos == 0);
+    assert_eq!(predrawn::refund_cbor(&sk, &params, &bad, &nonces), Err(WireError::Protocol(Error::InvalidClientSpendProof)));
 }

@@ -124,7 +124,7 @@ int main(int argc, char** argv) {
     if (rc) { fprintf(stderr, "act_node_refund_cbor_batch -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }
     expect("act_node_refund_cbor_batch (sequential rng)", o_msgs, want); expect("  status", st, status);
     struct Gen { const bytes* stream; size_t pos; int draws; } gen{&refund_rng, 0, 0};
-    act_rng_source src{[](void* g_, uint8_t* dst, size_t len) { Gen* g = static_cast<Gen*>(g_); memcpy(dst, g->stream->data() + g->pos, len); g->pos += len; g->draws++; }, &gen};
+    act_rng_source src{[](void* g_, uint8_t* dst, size_t len) -> int { Gen* g = static_cast<Gen*>(g_); if (g->pos + len > g->stream->size()) return 1; memcpy(dst, g->stream->data() + g->pos, len); g->pos += len; g->draws++; return 0; }, &gen};
     std::fill(o_msgs.begin(), o_msgs.end(), 7);
     rc = act_node_refund_cbor_batch(node, n, sk.data(), msgs.data(), nullptr, reinterpret_cast<const uint8_t*>(&src), ACT_RNG_CALLBACK, o_msgs.data(), st.data());
     if (rc) { fprintf(stderr, "act_node_refund_cbor_batch (callback) -> %d (%s)\n", rc, act_node_last_error(node)); return 3; }

@@ -73,6 +73,7 @@ def engine_factory():
         if key not in _engines:
             _engines[key] = capi.Engine(h, L, max_batch=max_batch)
         e = _engines[key]
+        capi.forward_tuning_env()          # the ACT_* measurement knobs as the test has set them (the library reads no environment itself)
         e.set_transcript_mode(capi.TRANSCRIPT_HOST if transcript is None else transcript)
         return e
     return make

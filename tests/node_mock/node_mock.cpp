@@ -142,7 +142,7 @@ void act_host_parallel_for(size_t n, size_t grain, int, void (*fn)(void*, size_t
 }
 #endif
 
-int act_ctx_set_coalescing(act_ctx*, size_t) { return ACT_OK; }
+int act_ctx_set_fixed_base_bits(act_ctx*, int, int) { return ACT_OK; }
 int act_nullifier_set_create(int device, size_t, const uint8_t*, act_nullifier_set** out) { *out = new act_nullifier_set(); (*out)->device = device; return ACT_OK; }
 void act_nullifier_set_destroy(act_nullifier_set* s) { delete s; }
 size_t act_nullifier_set_len(const act_nullifier_set* s) { return s->keys.size(); }

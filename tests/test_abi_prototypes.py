@@ -34,10 +34,10 @@ def kind(param: str) -> str:
     t = p.rsplit(" ", 1)[0].replace("const ", "")
     if t == "act_host_range_fn":
         return "fnptr"
-    return {"int": "int", "size_t": "size_t", "uint64_t": "u64", "uint32_t": "u32", "double": "double"}[t]
+    return {"int": "int", "size_t": "size_t", "uint64_t": "u64", "uint32_t": "u32", "double": "double", "int64_t": "i64"}[t]
 
 
-CT = {"int": C.c_int, "size_t": C.c_size_t, "u64": C.c_uint64, "u32": C.c_uint32, "double": C.c_double, "void_p": C.c_void_p, "char_p": C.c_char_p}
+CT = {"int": C.c_int, "size_t": C.c_size_t, "u64": C.c_uint64, "u32": C.c_uint32, "double": C.c_double, "void_p": C.c_void_p, "char_p": C.c_char_p, "i64": C.c_int64}
 
 
 def test_every_prototype_matches_the_binding():
@@ -128,6 +128,7 @@ def test_rust_extern_block_matches_the_header():
     rs = open(os.path.join(ROOT, "rust", "src", "mi355x.rs")).read()
     hd = open(os.path.join(ROOT, "include", "act_mi355x.h")).read()
     assert re.search(r"typedef struct act_rng_source \{ act_rng_draw_fn draw; void \*rng_ctx; \} act_rng_source;", hd)
-    assert re.search(r"pub struct ActRngSource \{\s*draw: unsafe extern \"C\" fn\(rng_ctx: \*mut c_void, dst: \*mut u8, len: usize\),\s*rng_ctx: \*mut c_void,\s*\}", rs)
+    assert "typedef int (*act_rng_draw_fn)(void *rng_ctx, uint8_t *dst, size_t len);" in hd      # 0 = drawn; anything else fails the call (ACT_ERR_RNG)
+    assert re.search(r"pub struct ActRngSource \{\s*draw: unsafe extern \"C\" fn\(rng_ctx: \*mut c_void, dst: \*mut u8, len: usize\) -> c_int,\s*rng_ctx: \*mut c_void,\s*\}", rs)
     assert "const ACT_RNG_CALLBACK: c_int = 2;" in rs and "#define ACT_RNG_CALLBACK 2" in hd
     assert "const ACT_RNG_SEQUENTIAL: c_int = 1;" in rs and "#define ACT_RNG_SEQUENTIAL 1" in hd

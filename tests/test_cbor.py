@@ -69,8 +69,31 @@ def _variants(t, rec, L):
     for idx, (key, kind, shape) in enumerate(spec):
         if kind == "P" and shape == 0:
             out.append((hd(n) + body(ents[:idx] + [(key, bstr(b"\x01" + bytes(31)))] + ents[idx + 1:]), None)); break
+    # broken in TWO ways: from_cbor reports the first failure in wire order (src/cbor.rs:276-388), and so must the codec -- an invalid
+    # point (InvalidValue) against a mis-shaped or missing field (InvalidStructure), in both orders, and through a duplicate key
+    bad_pt, short = bstr(b"\x01" + bytes(31)), b"\x58\x1f" + bytes(31)
+    p_idx = next((i for i, (_, kind, shape) in enumerate(spec) if kind == "P" and shape == 0), None)
+    s_idx = next((i for i, (_, kind, shape) in enumerate(spec) if kind == "S" and shape == 0), None)
+    if p_idx is not None and s_idx is not None:
+        both = list(ents); both[p_idx] = (ents[p_idx][0], bad_pt); both[s_idx] = (ents[s_idx][0], short)
+        out.append((hd(n) + body(both), None)); out.append((hd(n) + body(both[::-1]), None))          # whichever comes first on the wire
+        only_pt = list(ents); only_pt[p_idx] = (ents[p_idx][0], bad_pt)
+        rest = [e for i, e in enumerate(only_pt) if i != s_idx]
+        out.append((hd(n - 1) + body(rest), None))                                                    # invalid point + a missing field: the point is met first
+        out.append((hd(n + 1) + kb(ents[p_idx][0]) + bad_pt + body(ents), None))                      # invalid point under a key that a later duplicate overwrites
+        out.append((hd(n + 1) + body(ents) + kb(ents[p_idx][0]) + bad_pt, None))                      # ... and the other way round
     if t == "SpendProof":
         com = dict(ents)[5]
+        ch = len(m._cbor_head(4, L))
+        bad_com = com[:ch] + com[ch:ch + 34 * (L - 1)] + bad_pt                                       # last element invalid
+        sub = lambda k2, v2, es=ents: [(k, v) if k != k2 else (k2, v2) for k, v in es]
+        out.append((hd(n) + body(sub(5, m._cbor_head(4, L - 1) + bad_com[ch + 34:])), None))          # Com too short AND its last element invalid: the element is met first
+        out.append((hd(n) + body(sub(5, m._cbor_head(4, L + 1) + com[ch:] + bad_pt)), None))          # over-long Com whose extra element is invalid: InvalidValue, not "wrong size"
+        out.append((hd(n) + body(sub(5, m._cbor_head(4, L + 1) + com[ch:] + com[ch:ch + 34])), None)) # over-long Com, all valid: wrong size
+        out.append((hd(n) + body(sub(5, bstr(bytes(32)), sub(4, bad_pt))), None))                      # B_bar invalid, Com not an array (= missing, reported last)
+        z3 = dict(ents)[15]; z3 = z3[:ch] + b"\x83" + z3[ch + 1:ch + 69] + bstr(bytes(32)) + z3[ch + 69:]
+        out.append((hd(n) + body(sub(15, z3, sub(5, bad_com))), None))                                 # invalid Com element in front of a 3-element z pair
+        out.append((hd(n) + body(sub(15, z3, sub(5, bad_com))[::-1]), None))                           # ... and behind it
         out.append((hd(n) + body([(k, v) if k != 5 else (5, m._cbor_head(4, L - 1) + com[len(m._cbor_head(4, L)):-34]) for k, v in ents]), None))   # Com too short
         out.append((hd(n) + body([(k, v) if k != 5 else (5, b"\x9f" + com[len(m._cbor_head(4, L)):] + b"\xff") for k, v in ents]), None))          # indefinite array
         out.append((hd(n) + body([(k, v) if k != 5 else (5, bstr(bytes(32))) for k, v in ents]), None))                                                # not an array -> missing

@@ -33,16 +33,23 @@ def test_no_secret_residue_after_any_call(bench_params, mode):
     assert st == bytes(N)
     st, out = eng.debug_scalarmult(proofs[64:96] * 3, sk[:32] * 3); assert eng.secret_residue() == 0
     # calls that fit one launch take the small-batch schedule (what every single-item call of the Rust binding is): its scratch --
-    # (e_bar - x gamma) A' partial sums, role B's bucket sets -- is part of what is read back; so is the merged calls' rng gather buffer
+    # (e_bar - x gamma) A' partial sums, role B's bucket sets -- is part of what is read back
     pb = eng.proof_bytes
     for k in (1, 4):
         assert eng.verify_spend(sk, proofs[:pb * k]) == bytes(k) and eng.secret_residue() == 0
         st, rf1 = eng.refund(sk, proofs[:pb * k], shake("hy-rr", 128 * k)); assert rf1 == rf[:128 * k] and eng.secret_residue() == 0
-    eng.set_coalescing(4)
-    st, rf1 = eng.refund(sk, proofs[:pb * 2], shake("hy-rr", 128 * 2)); assert rf1 == rf[:128 * 2] and eng.secret_residue() == 0
     msgs = eng.cbor_encode("SpendProof", proofs[:pb * 3])
     st, out = eng.refund_cbor(sk, msgs, shake("hy-rr", 128 * 3), capi.RNG_SEQUENTIAL); assert st == bytes(3) and eng.secret_residue() == 0
-    eng.set_coalescing(0)
+    # Kernels that sign BESIDE the check (tiny issue with per-lane rng, tiny refund) compute a complete signature for lanes that are then
+    # rejected; it lands in the lane's small transcript, which must die with the call: rejected lanes, nothing left behind
+    bad_req = bytearray(req[:128 * 3]); bad_req[70] ^= 1; bad_req[128 + 70] ^= 1
+    st1, resp1 = eng.issue(sk, bytes(bad_req), scb(40) * 3, shake("hy-ir", 128 * 3), capi.RNG_PER_LANE)
+    assert st1 == bytes([1, 1, 0]) and resp1[:320] == bytes(320) and eng.secret_residue() == 0
+    bad_pr = bytearray(proofs[:pb * 2]); bad_pr[40] ^= 1
+    st1, rf1 = eng.refund(sk, bytes(bad_pr), shake("hy-rr", 128 * 2), capi.RNG_PER_LANE)
+    assert st1 == bytes([7, 0]) and rf1[:128] == bytes(128) and rf1[128:] == rf[128:256] and eng.secret_residue() == 0
+    st1, out1 = eng.refund_cbor(sk, eng.cbor_encode("SpendProof", bytes(bad_pr[:pb])), shake("hy-rr", 128), capi.RNG_SEQUENTIAL)
+    assert st1 == bytes([7]) and eng.secret_residue() == 0
     # staging that has to grow (a larger batch than any before) frees the old buffers only after clearing them, and the
     # results are still right
     pre2 = eng.pre_issuance_random(shake("hy-pre2", 128 * 40)); req2 = eng.request(pre2, shake("hy-rq2", 128 * 40))

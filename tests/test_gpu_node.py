@@ -222,11 +222,10 @@ def test_bench_rccl_path_with_one_rank():
     assert d["n_gpus"] == 1 and d["config"]["distinct_proofs_per_gpu"] == 4096 and d["value"] > 0
 
 
-def test_single_item_refunds_from_many_threads_merge_on_a_node_handle(engine_factory, bench_params):
+def test_single_item_refunds_from_many_threads_on_a_node_handle(engine_factory, bench_params):
     """The Rust binding's `PrivateKey::refund` (rust/src/mi355x.rs): act_node_verify_spend_batch over ONE proof, then -- with 128
     bytes drawn only if it verified -- act_node_refund_sign_batch (ACT_RNG_SEQUENTIAL), on the one node handle every thread of a
-    server shares.  With act_node_set_coalescing such calls merge instead of queueing on the handle; every thread must get exactly
-    the refund (or the rejection) it gets alone."""
+    server shares.  Such calls queue on the handle; every thread must get exactly the refund (or the rejection) it gets alone."""
     import threading
     from act_amd import capi
     L, D = 8, 40
@@ -253,7 +252,6 @@ def test_single_item_refunds_from_many_threads_merge_on_a_node_handle(engine_fac
         return stv, st2, rf
     try:
         alone = [refund_one(i) for i in range(D)]
-        node.set_coalescing(4)
         merged = [None] * D
 
         def work(t):
@@ -275,9 +273,9 @@ def test_single_item_refunds_from_many_threads_merge_on_a_node_handle(engine_fac
         assert alone[i][0][0] == (7 if i % 5 == 0 else 0) and (alone[i][2] == bytes(128)) == (i % 5 == 0)
 
 
-def test_single_item_issues_from_many_threads_merge_on_a_node_handle(engine_factory, bench_params, oracle):
+def test_single_item_issues_from_many_threads_on_a_node_handle(engine_factory, bench_params, oracle):
     """The Rust binding's `PrivateKey::issue`: act_node_issue_check_batch over ONE request, then act_node_issue_sign_batch
-    (ACT_RNG_SEQUENTIAL, 128 bytes drawn only if the request verified), from eight threads that share a node handle, merging."""
+    (ACT_RNG_SEQUENTIAL, 128 bytes drawn only if the request verified), from eight threads that share a node handle."""
     import threading
     from act_amd import capi
     L, D = 8, 32
@@ -299,7 +297,6 @@ def test_single_item_issues_from_many_threads_merge_on_a_node_handle(engine_fact
         return stc, st2, resp
     try:
         alone = [issue_one(i) for i in range(D)]
-        node.set_coalescing(4)
         merged = [None] * D
 
         def work(t):

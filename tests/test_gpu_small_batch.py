@@ -183,10 +183,11 @@ def test_four_concurrent_callers_do_not_collapse():
 
 
 @pytest.mark.parametrize("mode", MODES)
-def test_coalesced_callers_get_their_own_answers(engine_factory, bench_params, oracle, mode):
-    """act_ctx_set_coalescing: sixteen threads share ONE context and make calls of 1 - 3 proofs each (verify with K', refund with
-    per-lane rng, two different keys, some proofs tampered).  Whatever merges with whatever, every call must return exactly what the
-    same call returns alone: statuses, enc(K'), refunds byte for byte -- checked against a sequential pass with coalescing off."""
+def test_threads_sharing_a_context_get_their_own_answers(engine_factory, bench_params, oracle, mode):
+    """Sixteen threads share ONE context (the Rust binding keeps the handle inside `Params`, which safe code may share) and make
+    calls of 1 - 3 proofs each (verify with K', refund with per-lane rng, two different keys, some proofs tampered).  The context
+    serves them one at a time; every call must return exactly what the same call returns alone: statuses, enc(K'), refunds byte for
+    byte -- checked against a sequential pass."""
     import random
     import threading
     L, D = 8, 48
@@ -232,15 +233,13 @@ def test_coalesced_callers_get_their_own_answers(engine_factory, bench_params, o
             x.join()
 
     try:
-        eng.set_coalescing(0)
         alone = [None] * 16
-        for t in range(16):                      # one thread after the other, nothing to merge with
+        for t in range(16):                      # one thread after the other
             alone[t] = [eng.refund(sks[j], blob, rng) if sign else eng.verify_spend(sks[j], blob, True) for j, blob, sign, rng in jobs[t]]
-        eng.set_coalescing(8)
         merged = [None] * 16
         run_all(merged)
     finally:
-        eng.set_coalescing(0)
+        pass
     for t in range(16):
         assert not isinstance(merged[t], BaseException), merged[t]
         assert merged[t] == alone[t], t
@@ -253,9 +252,9 @@ def test_coalesced_callers_get_their_own_answers(engine_factory, bench_params, o
     assert st[0] == so and out[:128] == rf
 
 
-def test_coalesced_issues_get_their_own_answers(engine_factory, bench_params, oracle):
-    """PrivateKey::issue from twelve threads that share one context (a server's issuance endpoint): with act_ctx_set_coalescing the calls of
-    1 - 3 requests each merge into launches of the fused issue kernel; every caller gets exactly what its own call returns alone --
+def test_threads_sharing_a_context_issue_their_own_answers(engine_factory, bench_params, oracle):
+    """PrivateKey::issue from twelve threads that share one context (a server's issuance endpoint), calls of 1 - 3 requests each,
+    served one at a time under the context's lock; every caller gets exactly what its own call returns alone --
     statuses (a tampered request is rejected on its own lane only) and IssuanceResponse records byte for byte, for both keys in play,
     per-lane rng and one-lane sequential rng."""
     import random
@@ -280,12 +279,10 @@ def test_coalesced_issues_get_their_own_answers(engine_factory, bench_params, or
             mine.append((r.randrange(2), bytes(blob), b"".join(scb(r.randrange(1, 200)) for _ in range(k)), shake("ci-r%d-%d" % (t, c), 128 * k), mode))
         jobs.append(mine)
     try:
-        eng.set_coalescing(0)
         alone = [[eng.issue(sks[j], blob, cam, rng, mode) for j, blob, cam, rng, mode in jobs[t]] for t in range(12)]
         j, blob, cam, rng, mode = jobs[0][0]                        # (and the oracle on one of them)
         so, ro = octx.issue(sks[j], blob[:128], cam[:32], rng[:128])
         assert (alone[0][0][0][:1], alone[0][0][1][:160]) == (bytes([so]), ro)
-        eng.set_coalescing(16)
         merged = [None] * 12
 
         def work(t):
@@ -299,7 +296,7 @@ def test_coalesced_issues_get_their_own_answers(engine_factory, bench_params, or
         for x in th:
             x.join()
     finally:
-        eng.set_coalescing(0)
+        pass
     for t in range(12):
         assert not isinstance(merged[t], BaseException), merged[t]
         assert merged[t] == alone[t], t

@@ -177,8 +177,7 @@ def test_wire_calls_through_the_node(engine_factory, oracle, bench_params):
             assert stv == want_st and node.refund_sign_cbor(sk, kp, stv, stream) == (want_st, want_out)
         g = capi.ReplayRng(stream)
         assert node.redeem_cbor(ns, sk, msgs, g, capi.RNG_CALLBACK) == (r_st, r_out) and g.pos == r_drawn and len(ns) == len(db)
-        # small calls on a coalescing node: one context each, same bytes
-        node.set_coalescing(8)
+        # small calls on a node: one context each, same bytes
         for i in (0, 1, 2, N - 1):
             assert node.refund_cbor(sk, [msgs[i]], stream[:128], capi.RNG_SEQUENTIAL) == _loop(octx, sk, L, [msgs[i]], stream)[:2]
     finally:

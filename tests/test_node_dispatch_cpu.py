@@ -280,12 +280,15 @@ class _Replay:
 
     def __init__(self, data):
         self.data, self.pos, self.draws = data, 0, []
-        FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t)
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 
         def draw(_ctx, dst, n):
+            if self.pos + n > len(self.data):
+                return 1
             C.memmove(dst, self.data[self.pos:self.pos + n], n)
             self.pos += n
             self.draws.append(n)
+            return 0
 
         class Src(C.Structure):
             _fields_ = [("draw", FN), ("ctx", C.c_void_p)]

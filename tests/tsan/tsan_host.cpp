@@ -1,7 +1,5 @@
 // ThreadSanitizer driver for the library's host-side concurrency (tests/test_sanitizers.py builds it with -fsanitize=thread):
 //   * csrc/host_pool.cpp   the process-wide worker pool: act_host_hash_many and act_host_parallel_for from several threads at once
-//   * csrc/coalesce.h      the queueing protocol of merged small calls (engine.hip runs GPU calls through it; here the merged
-//                          "call" is a stand-in that sleeps and answers every request from its own input)
 //   * csrc/node.cpp        the node-level nullifier set's routing on those workers (real host_pool.cpp here, not the mock's
 //                          two-thread stand-in) and a node handle used from several threads
 // linked against tests/node_mock/node_mock.cpp for the single-GPU entry points.  Any report makes the process exit non-zero.
@@ -13,7 +11,6 @@
 #include <thread>
 #include <vector>
 #include "../../include/act_mi355x.h"
-#include "../../anonymous-credit-tokens_amd/csrc/coalesce.h"
 #include <chrono>
 
 static std::atomic<uint64_t> g_sum{0};
@@ -61,11 +58,10 @@ int main() {
   });
   for (auto& x : th) x.join();
   th.clear();
-  // ---- one node handle, four threads, small calls that bypass the handle's lock (act_node_set_coalescing) beside large ones ----
+  // ---- one node handle, four threads, small calls beside large ones (all under the handle's lock) ----
   act_node* nd = nullptr; uint8_t h[96] = {0};
   int two[2] = {0, 1};
   if (act_node_create(h, 128, two, 2, 0, &nd)) { printf("node create failed\n"); return 7; }
-  act_node_set_coalescing(nd, 4);
   for (int t = 0; t < 4; t++) th.emplace_back([t, nd] {
     uint8_t sk[64] = {0};
     for (int rep = 0; rep < 50; rep++) {
@@ -79,36 +75,6 @@ int main() {
   for (auto& x : th) x.join();
   th.clear();
   act_node_destroy(nd);
-  // ---- the combiner: 24 threads, requests of 1 - 3 lanes in two groups; every request must get ITS answer, merged calls must
-  //      only ever hold requests of one group and stay within the cap, and nobody may be lost or served twice
-  {
-    struct Req { size_t n; int rc = 0; bool done = false; int group; uint64_t in[3]; uint64_t out[3] = {0, 0, 0}; int served = 0; };
-    act::Combiner<Req> co;
-    std::atomic<int> calls{0}, merged_lanes{0}, bad{0};
-    auto run = [&](const std::vector<Req*>& batch, size_t total) {
-      calls.fetch_add(1); merged_lanes.fetch_add((int)total);
-      size_t sum = 0;
-      for (Req* q : batch) { if (q->group != batch[0]->group) bad.fetch_add(1); sum += q->n; }
-      if (sum != total || (batch.size() > 1 && total > 16)) bad.fetch_add(1);
-      std::this_thread::sleep_for(std::chrono::microseconds(300));          // a call takes a while: requests pile up behind it
-      for (Req* q : batch) { for (size_t i = 0; i < q->n; i++) q->out[i] = q->in[i] * 3 + 1; q->served++; }
-      return 0;
-    };
-    for (int t = 0; t < 24; t++) th.emplace_back([t, &co, &run, &bad] {
-      for (int rep = 0; rep < 60; rep++) {
-        Req r; r.n = 1 + (size_t)((t + rep) % 3); r.group = (t * 7 + rep) % 2;
-        for (size_t i = 0; i < r.n; i++) r.in[i] = (uint64_t)t * 1000003u + (uint64_t)rep * 17u + i;
-        const int rc = co.submit(r, 16, [](const Req& a, const Req& b) { return a.group == b.group; }, run);
-        if (rc || !r.done || r.served != 1) bad.fetch_add(1);
-        for (size_t i = 0; i < r.n; i++) if (r.out[i] != r.in[i] * 3 + 1) bad.fetch_add(1);
-      }
-    });
-    for (auto& x : th) x.join();
-    th.clear();
-    if (bad.load() || !co.q.empty() || co.leader) { printf("combiner: %d bad\n", bad.load()); return 10; }
-    if (calls.load() >= 24 * 60) { printf("combiner never merged anything (%d calls)\n", calls.load()); return 11; }
-    printf("combiner: %d requests in %d merged calls\n", 24 * 60, calls.load());
-  }
   printf("TSAN DRIVER DONE\n");
   return 0;
 }

@@ -29,15 +29,12 @@ PB = eng0.proof_bytes
 KMAX = int(os.environ.get("KMAX", "4096"))
 hp = torch.empty((KMAX, PB), dtype=torch.uint8, pin_memory=True)
 hp.numpy()[:] = np.tile(np.frombuffer(proofs, np.uint8).reshape(D, PB), (KMAX // D, 1))
-SHARED = int(os.environ.get("COALESCE", "0"))          # k > 0: ALL threads share context 0 with act_ctx_set_coalescing(k) (the Rust binding's shape)
 TMAX = max(int(x) for x in os.environ.get("TS", "1,2,4,8").split(","))
-engines = [eng0] * TMAX if SHARED else [eng0] + [capi.Engine(h, L, max_batch=8192, transcript=mode) for _ in range(TMAX - 1)]
-if SHARED:
-    eng0.set_coalescing(SHARED)
-elif os.environ.get("SHARE_CTX"):
-    engines = [eng0] * TMAX                             # one context, callers queue on its lock (no merging)
+engines = [eng0] + [capi.Engine(h, L, max_batch=8192, transcript=mode) for _ in range(TMAX - 1)]
+if os.environ.get("SHARE_CTX"):
+    engines = [eng0] * TMAX                             # one context, callers queue on its lock
 stat = [torch.zeros(KMAX, dtype=torch.uint8, pin_memory=True) for _ in range(TMAX)]
-print("transcripts: %s%s" % ("host" if mode == capi.TRANSCRIPT_HOST else "device", ", ONE shared context, coalescing %d" % SHARED if SHARED else (", ONE shared context, no coalescing" if os.environ.get("SHARE_CTX") else "")))
+print("transcripts: %s%s" % ("host" if mode == capi.TRANSCRIPT_HOST else "device", ", ONE shared context" if os.environ.get("SHARE_CTX") else ""))
 KS = [int(x) for x in os.environ.get("KS", "1,64,1024,4096").split(",")]; TS = [int(x) for x in os.environ.get("TS", "1,2,4,8").split(",")]
 for k in KS:
     row = []

@@ -90,6 +90,101 @@ used = sorted({int(a[1]) for k in range(17) for a, b in sq_terms(k) if a.endswit
 sq_prep = ("  const uint32_t " + ", ".join(f"f{i} = f.v[{i}]" for i in range(9)) + "; \\\n"
            "  const uint32_t " + ", ".join(f"f{i}_2 = 2u * f{i}" for i in used) + ";")
 mb, sb = body(mul_terms, mul_prep), body(sq_terms, sq_prep)
+
+# ---- the whole product as ONE asm statement (-DACT_FE_ONE_ASM; device only) -------------------------------------------------
+# Same instructions as the per-column form above, scheduled here instead of by the compiler: no wait state is inserted between
+# the pieces (the compiler puts an `s_nop 0` after every asm statement whose result the next instruction reads -- ~1 950 of them
+# in k_spend_bits -- which the hardware does not need between VALU instructions) and no value is moved between statements.
+# The sub-registers of a 64-bit operand cannot be named in an asm template, so the column accumulators live in FIXED registers
+# listed as clobbers (TB .. TB+10; the k_spend_* kernels have a 256-register budget): two rotating pairs for the high columns, two
+# for the low columns, the pair Q = (l0 residue, 19 * top carry's high bits), one scratch.
+# Schedule: h9; then seven phases (h_{j+10} || l_j), two independent chains of 10 multiply-accumulates interleaved instruction by
+# instruction; then l7, l8 and the wrap-around.
+TB = 244
+def pr(p): return f"v[{p[0]}:{p[1]}]"
+def one_asm_lines(terms_of, TB=TB, tag=""):
+    """the instruction list of one product: temporaries from register TB on, operands %[<name><tag>] (tag: the second product of a pair)"""
+    HP = [(TB, TB + 1), (TB + 2, TB + 3)]
+    LP = [(TB + 4, TB + 5), (TB + 6, TB + 7)]
+    Q = (TB + 8, TB + 9)
+    SC = TB + 10
+    # the doubled limbs are operands, computed outside the statement: operands shared by several products (ge_from_completed)
+    # then share their preparation, as they do in the per-column form
+    def R(x): return f"%[{x}{tag}]"
+    out = []
+    def mads(dst, terms, first_addend):
+        r, add = [], first_addend
+        for x, y in terms:
+            r.append(f"v_mad_u64_u32 {pr(dst)}, vcc, {x}, {y}, {add}"); add = pr(dst)
+        return r
+    def prod(k): return [(R(a), R(b)) for a, b in terms_of(k)]
+    h = HP[0]
+    out += mads(h, prod(9), "0")
+    for j in range(7):                                        # phase: h_{j+10} || l_j
+        hn, hp = HP[(j + 1) & 1], HP[j & 1]
+        ln, lp = LP[j & 1], LP[(j + 1) & 1]
+        hc = mads(hn, [(f"v{hp[1]}", str(1 << (32 - W[j])))] + prod(j + 10), "0")
+        lc = []
+        if j == 0:
+            lc += mads(ln, [(f"v{hp[0]}", "19")] + prod(0), "0")
+        else:
+            lc.append(f"v_lshrrev_b64 {pr(ln)}, {W[j-1]}, {pr(lp)}")
+            lc += mads(ln, [(f"v{hp[0]}", "19")] + prod(j), pr(ln))
+            if j == 1: lc.append(f"v_and_b32 v{Q[0]}, 0x{(1 << W[0]) - 1:x}, v{lp[0]}")
+            else: lc.append(f"v_and_b32 %[o{j-1}{tag}], 0x{(1 << W[j-1]) - 1:x}, v{lp[0]}")
+        # interleave, high chain first; the longer tail runs on alone
+        for i in range(max(len(hc), len(lc))):
+            if i < len(hc): out.append(hc[i])
+            if i < len(lc): out.append(lc[i])
+    h16 = HP[1]                                               # h16 was written in phase j = 6 -> HP[(6 + 1) & 1]
+    for j in (7, 8):
+        ln, lp = LP[j & 1], LP[(j + 1) & 1]
+        out.append(f"v_lshrrev_b64 {pr(ln)}, {W[j-1]}, {pr(lp)}")
+        first = (f"v{h16[0]}", "19") if j == 7 else (f"v{h16[1]}", "%[c304]")
+        lc = mads(ln, [first] + prod(j), pr(ln))
+        lc.insert(2, f"v_and_b32 %[o{j-1}{tag}], 0x{(1 << W[j-1]) - 1:x}, v{lp[0]}")
+        out += lc
+    l8, t0 = LP[0], LP[1]                                     # l8 in LP[8 & 1]; the other pair is free for t0
+    out += [f"v_lshrrev_b32 v{Q[1]}, 28, v{l8[1]}",
+            f"v_alignbit_b32 v{SC}, v{l8[1]}, v{l8[0]}, 28",
+            f"v_mul_u32_u24 v{Q[1]}, 19, v{Q[1]}",
+            f"v_and_b32 %[o8{tag}], 0x{(1 << W[8]) - 1:x}, v{l8[0]}",
+            f"v_mad_u64_u32 {pr(t0)}, vcc, v{SC}, 19, {pr(Q)}",
+            f"v_alignbit_b32 v{SC}, v{t0[1]}, v{t0[0]}, 29",
+            f"v_and_b32 %[o0{tag}], 0x{(1 << W[0]) - 1:x}, v{t0[0]}",
+            f"v_add_u32 %[o1{tag}], %[o1{tag}], v{SC}"]
+    return out
+
+def asm_stmt(lines, outs, ins, temps):
+    clob = ", ".join(f'"v{r}"' for r in temps) + ', "vcc"'
+    text = " \\\n      ".join('"' + l + '\\n\\t"' for l in lines)
+    return f"asm({text} \\\n      : {outs} \\\n      : {ins} \\\n      : {clob});"
+
+def one_asm(terms_of, doubled, inputs):
+    """doubled: names like 'f1_2' (the limb they double is the name without _2); inputs: operand names"""
+    out = one_asm_lines(terms_of)
+    outs = ", ".join(f'[o{i}] "=&v"(h.v[{i}])' for i in range(9))
+    ins = ", ".join(f'[{n}] "v"({n[0]}.v[{n[1]}])' for n in inputs) + ", " + ", ".join(f'[{n}] "v"({n})' for n in doubled) + ', [c304] "s"(304u)'
+    return asm_stmt(out, outs, ins, range(TB, TB + 11)), len(out)
+
+# ---- TWO independent products in one statement, interleaved instruction by instruction (-DACT_FE_PAIR_ASM; measurement variant) ------
+# ge_double squares X, Y, Z and X + Y; the d-free addition multiplies four independent pairs twice.  Two products side by side give
+# every dependent multiply-accumulate -> shift -> multiply-accumulate step of one an independent instruction of the other to issue
+# behind, which is what two wavefronts per SIMD cannot always provide (profiles/r03_ubench_dep.txt).  Second product: operands
+# <name>b, results `hb`, temporaries TB2 .. TB2 + 10.
+TB2 = 232
+def pair_asm(terms_of, doubled, inputs, second):
+    """second: (struct names of the second product's inputs) e.g. {'f': 'fb', 'g': 'gb'}"""
+    a, b = one_asm_lines(terms_of, TB, ""), one_asm_lines(terms_of, TB2, "b")
+    lines = [x for pair in zip(a, b) for x in pair]
+    outs = ", ".join(f'[o{i}] "=&v"(h.v[{i}])' for i in range(9)) + ", " + ", ".join(f'[o{i}b] "=&v"(hb.v[{i}])' for i in range(9))
+    ins = (", ".join(f'[{n}] "v"({n[0]}.v[{n[1]}])' for n in inputs) + ", " + ", ".join(f'[{n}] "v"({n})' for n in doubled) + ", " +
+           ", ".join(f'[{n}b] "v"({second[n[0]]}.v[{n[1]}])' for n in inputs) + ", " + ", ".join(f'[{n}b] "v"({n}b)' for n in doubled) + ', [c304] "s"(304u)')
+    return asm_stmt(lines, outs, ins, list(range(TB2, TB2 + 11)) + list(range(TB, TB + 11)))
+
+mul_one, n_mul = one_asm(mul_terms, [f"f{i}_2" for i in (1, 4, 7)] + [f"g{i}_2" for i in (1, 4, 7)], [f"f{i}" for i in range(9)] + [f"g{i}" for i in range(9)])
+sq_one, n_sq = one_asm(sq_terms, [f"f{i}_2" for i in used], [f"f{i}" for i in range(9)])
+
 print("// GENERATED by tools/gen_fe_mul.py -- do not edit")
 print("#if defined(__HIP_DEVICE_COMPILE__)")
 for n, (d, h) in helpers.items(): print(d)
@@ -98,5 +193,20 @@ for n, (d, h) in helpers.items(): print(h)
 print("#endif")
 print("#define ACT_FE_MUL_BODY \\\n" + mb + "\n")
 print("#define ACT_FE_SQ_BODY \\\n" + sb)
+print()
+print("// one statement per product (fe25519.h: ACT_FE_ONE_ASM); result in `fe h`, operands `f`, `g`")
+print("#define ACT_FE_MUL_ONE_ASM \\\n  const uint32_t " + ", ".join(f"f{i}_2 = 2u * f.v[{i}]" for i in (1, 4, 7)) + ", " + ", ".join(f"g{i}_2 = 2u * g.v[{i}]" for i in (1, 4, 7)) + "; \\\n  " + mul_one)
+print()
+print("#define ACT_FE_SQ_ONE_ASM \\\n  const uint32_t " + ", ".join(f"f{i}_2 = 2u * f.v[{i}]" for i in used) + "; \\\n  " + sq_one)
+print()
+print("// two products per statement (fe25519.h: ACT_FE_PAIR_ASM): h = f * g, hb = fb * gb;  h = f^2, hb = fb^2")
+mul_d = [f"f{i}_2" for i in (1, 4, 7)] + [f"g{i}_2" for i in (1, 4, 7)]
+print("#define ACT_FE_MUL2_ONE_ASM \\\n  const uint32_t " + ", ".join(f"f{i}_2 = 2u * f.v[{i}]" for i in (1, 4, 7)) + ", " + ", ".join(f"g{i}_2 = 2u * g.v[{i}]" for i in (1, 4, 7)) + ", " +
+      ", ".join(f"f{i}_2b = 2u * fb.v[{i}]" for i in (1, 4, 7)) + ", " + ", ".join(f"g{i}_2b = 2u * gb.v[{i}]" for i in (1, 4, 7)) + "; \\\n  " +
+      pair_asm(mul_terms, mul_d, [f"f{i}" for i in range(9)] + [f"g{i}" for i in range(9)], {"f": "fb", "g": "gb"}))
+print()
+print("#define ACT_FE_SQ2_ONE_ASM \\\n  const uint32_t " + ", ".join(f"f{i}_2 = 2u * f.v[{i}]" for i in used) + ", " + ", ".join(f"f{i}_2b = 2u * fb.v[{i}]" for i in used) + "; \\\n  " +
+      pair_asm(sq_terms, [f"f{i}_2" for i in used], [f"f{i}" for i in range(9)], {"f": "fb"}))
 import sys
+print(f"// one-statement forms: {n_mul} / {n_sq} instructions", file=sys.stderr)
 print(f"// multiply-accumulates: mul {sum(len(mul_terms(k)) for k in range(17)) + 16}, sq {sum(len(sq_terms(k)) for k in range(17)) + 16}; widths {W}", file=sys.stderr)

@@ -49,8 +49,8 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
         for k, i in enumerate(range(0, n, max(1, n // 256))):
             so, ro = ref_o[k]
             assert so == st2[i] and ro == rf[128 * i:128 * i + 128], ("refund mismatch", L, mode, i)
-    # ACT_SOAK_THREADS=T: the same proofs once more as calls of 1 - 5 proofs from T threads that share the context, merging
-    # (act_ctx_set_coalescing): verify with K', refund with per-lane rng, the two-call refund of the Rust binding -- every call's
+    # ACT_SOAK_THREADS=T: the same proofs once more as calls of 1 - 5 proofs from T threads that share the context (served one at a
+    # time under its lock): verify with K', refund with per-lane rng, the two-call refund of the Rust binding -- every call's
     # answer against the batch answers above
     T = int(os.environ.get("ACT_SOAK_THREADS", "0"))
     if T:
@@ -62,7 +62,6 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
         while i < n:
             k = min(n - i, r.randrange(1, 6)); cuts.append((i, k)); i += k
         errs = []
-        eng.set_coalescing(8)
         def work(tid):
             try:
                 for j, (a, k) in enumerate(cuts):
@@ -89,7 +88,6 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
         th = [threading.Thread(target=work, args=(x,)) for x in range(T)]
         for x in th: x.start()
         for x in th: x.join()
-        eng.set_coalescing(0)
         if errs:
             raise errs[0]
     # ACT_SOAK_TINY=1: the same proofs once more as refunds of 1 - 64 proofs -- the calls whose signature is computed beside the
