@@ -1193,7 +1193,10 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
   // host-transcript mode: a chunk's transcripts go to the host, are hashed there and come back before its status kernel, all
   // of which only overlaps with compute if there are other chunks to compute: long batches use full-size chunks (the
   // kernels' best size), short ones are cut finer so that there is something to pipeline
-  const size_t host_chunk = host_chunk_env ? host_chunk_env : (n >= 8 * c->max_batch ? c->max_batch : (size_t)16384);
+  // (measured per share of a 2^20 batch, profiles/r06_strong_share.txt: 2^19 and 2^18 proofs are fastest in full-size chunks -- 525 k
+  // and 517 k/s against 501 k in 16 384s at 2^18 --, 2^17 in half-size ones -- 501 k against 493 k --, below that 16 384)
+  const size_t host_chunk = host_chunk_env ? host_chunk_env
+                                           : (n >= 4 * c->max_batch ? c->max_batch : n >= 2 * c->max_batch ? std::max<size_t>(c->max_batch / 2, 16384) : (size_t)16384);
   const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
   const int stagger_env = (int)tune(T_STAGGER);      // measurement knob: force on / off (-1 = decide)
   const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (in_host || c->tr_mode == ACT_TRANSCRIPT_HOST);
@@ -1372,7 +1375,7 @@ int act_prove_spend_seeded_batch(act_ctx* c, size_t n, int mem, const uint8_t* t
 }
 
 // Two slots that each copy in, compute, copy out fall into step when left alone: both copy in at once (sharing the link), then both
-// compute, then both copy out, and nothing overlaps (profiles/r04_codec_trace.txt).  Chaining the copies of one direction across
+// compute, then both copy out, and nothing overlaps (docs/history/profiles/r04_codec_trace.txt).  Chaining the copies of one direction across
 // the two streams keeps them in anti-phase: chunk k + 1 copies in while chunk k computes.
 // the chunk on `sl` is about to copy in (out = false) or out (out = true): after the other slot's copy of the same direction
 static int copy_chain_wait(act_ctx* c, Slot& sl, bool out) {

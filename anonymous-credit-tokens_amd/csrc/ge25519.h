@@ -54,11 +54,9 @@ template <bool WITH_T = true>
 ACT_HD ge ge_from_completed(const fe& cx, const fe& cy, const fe& cz, const fe& ct) {
   ge r;
   // operand order: fe_mul doubles limbs 1, 4, 7 of both operands; each operand appears twice on the same side, so the
-  // compiler shares those preparations
-  r.X = fe_mul(ct, cx);
-  r.Y = fe_mul(cy, cz);
-  r.Z = fe_mul(ct, cz);
-  if (WITH_T) r.T = fe_mul(cy, cx); else r.T = fe_zero();
+  // compiler shares those preparations.  (fe_mul2: two independent products -- one interleaved statement in the range kernel's build)
+  fe_mul2(r.X, r.Y, ct, cx, cy, cz);
+  if (WITH_T) fe_mul2(r.Z, r.T, ct, cz, cy, cx); else { r.Z = fe_mul(ct, cz); r.T = fe_zero(); }
   return r;
 }
 
@@ -67,10 +65,10 @@ template <bool WITH_T = true>
 ACT_HD ge ge_add_cached(const ge& p, const ge_cached& q) {
   fe ypx = fe_add(p.Y, p.X);                 // {2}
   fe ymx = fe_sub(p.Y, p.X);                 // {3}
-  fe pp = fe_mul(ypx, q.YpX);                // 2 * 2
-  fe mm = fe_mul(ymx, q.YmX);                // 3 * 3
-  fe tt2d = fe_mul(p.T, q.T2d);              // 1 * 2
-  fe zz2 = fe_dbl(fe_mul(p.Z, q.Z));         // {2}
+  fe pp, mm, tt2d, zz;
+  fe_mul2(pp, mm, ypx, q.YpX, ymx, q.YmX);   // 2 * 2, 3 * 3
+  fe_mul2(tt2d, zz, p.T, q.T2d, p.Z, q.Z);   // 1 * 2
+  fe zz2 = fe_dbl(zz);                       // {2}
   fe cx = fe_sub(pp, mm);                    // {3}
   fe cy = fe_add(pp, mm);                    // {2}
   fe cz = fe_add(zz2, tt2d);                 // {3}
@@ -82,8 +80,8 @@ template <bool WITH_T = true>
 ACT_HD ge ge_madd(const ge& p, const ge_niels& q) {
   fe ypx = fe_add(p.Y, p.X);
   fe ymx = fe_sub(p.Y, p.X);
-  fe pp = fe_mul(ypx, q.ypx);
-  fe mm = fe_mul(ymx, q.ymx);
+  fe pp, mm;
+  fe_mul2(pp, mm, ypx, q.ypx, ymx, q.ymx);
   fe tt2d = fe_mul(p.T, q.xy2d);
   fe zz2 = fe_dbl(p.Z);
   fe cx = fe_sub(pp, mm);

@@ -24,15 +24,7 @@ __global__ void __launch_bounds__(256, 2) k_spend_enc_small(SpendArgs a) {
 __global__ void __launch_bounds__(64, 2) k_spend_prep_join(SpendArgs a) { uint32_t p = blockIdx.x * 64 + threadIdx.x; if (p < a.n) spend_prep_join_lane(a, p); }
 __global__ void __launch_bounds__(64, 2) k_spend_coords(SpendArgs a) { spend_coords_lane(a, blockIdx.x * 64 + threadIdx.x); }
 
-#ifndef ACT_BITS_BLOCK
-#define ACT_BITS_BLOCK 256
-#endif
-// UNIFORM: L is a multiple of 64, so a wavefront holds bits of ONE proof and reads that proof's challenge digits into SGPRs
-template <bool UNIFORM>
-__global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
-  __shared__ uint32_t u_lds[(ACT_BITS_BLOCK / 64) * 2 * GE_LDS_WORDS_PER_WAVE];            // 18 KiB per wavefront
-  spend_bits_lane<UNIFORM>(a, blockIdx.x * ACT_BITS_BLOCK + threadIdx.x, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
-}
+// (the range kernel k_spend_bits lives in k_spend_bits.hip: a translation unit of its own, built with its own field-product form)
 
 __global__ void __launch_bounds__(256, 2) k_spend_enc(SpendArgs a) {
   spend_enc_lane(a, ((uint64_t)blockIdx.x * 256 + threadIdx.x) * ENC_BATCH);
@@ -74,13 +66,6 @@ void launch_spend_coords(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
   const size_t lanes = (size_t)a.n * a.P.L;
   hipLaunchKernelGGL(k_spend_coords, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, a);
-}
-void launch_spend_bits(const SpendArgs& a, hipStream_t s) {
-  if (!a.n) return;
-  size_t lanes = (size_t)a.n * a.P.L;
-  const dim3 grid((unsigned)((lanes + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK));
-  if (a.P.L % 64 == 0) hipLaunchKernelGGL(k_spend_bits<true>, grid, dim3(ACT_BITS_BLOCK), isolate_bits(grid.x), s, a);
-  else hipLaunchKernelGGL(k_spend_bits<false>, grid, dim3(ACT_BITS_BLOCK), isolate_bits(grid.x), s, a);
 }
 void launch_spend_enc(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;

@@ -61,7 +61,7 @@ ELL = 2**252 + 27742317777372353535851937790883648493
 CSRC = os.path.join(ROOT, "anonymous-credit-tokens_amd", "csrc")
 # sources that determine k_spend_bits: PMC summaries under profiles/ are only cited when they were taken from these bytes
 KERNEL_SOURCES = ["fe25519.h", "fe25519_gen.inc", "fe25519_consts.inc", "sc25519.h", "ge25519.h", "msm.h", "kernels.h", "spend_lanes.h",
-                  "k_spend_verify.hip", "prove_lanes.h", "k_prove.hip"]
+                  "k_spend_verify.hip", "k_spend_bits.hip", "prove_lanes.h", "k_prove.hip"]
 MAD_PER_MUL, MAD_PER_SQ = 97, 61          # fe25519.h / tools/gen_fe_mul.py: 81 (45) limb products + 7 carries of the high half + 9 folds by 19, all v_mad_u64_u32
 LIMB_PRODUCTS_PER_MUL, LIMB_PRODUCTS_PER_SQ = 81, 45   # the part of those no 9-limb representation can avoid
 
@@ -881,7 +881,7 @@ def prover_roofline(hc_path, prof, peak_mad, h, L, eng, n_proofs, t_prove, max_b
     pm = newest_matching_pmc("pmc_prover", max_batch, kernel_source_sha16(), L)
     out = {"kernel": "k_prove_bits", "avg_launch_ms": 1e3 * launch_s, "proofs_per_launch": proofs_per_launch,
            "build": ("default: address-free for the client's secrets too (matrix-core table look-ups, 37 additions per fixed-base product); "
-                     "libact_mi355x_fast.so: 2.1 x this rate with scalar-addressed tables (profiles/r04_*_other_configs_1gpu*.json)") if ct else
+                     "libact_mi355x_fast.so: 2.1 x this rate with scalar-addressed tables (docs/history/profiles/r04_*_other_configs_1gpu*.json)") if ct else
                     "fast: scalar-addressed 16- / 24-bit tables for the client's secrets",
            "valu": {"achieved": rate, "peak": peak_mad, "frac": rate / peak_mad, "unit": "lane multiply-accumulates (v_mad_u64_u32) per second",
                     "algorithmic_mad_per_proof_in_this_kernel": mad_bits, "mad_per_proof_whole_path": mad_all},

@@ -1,5 +1,5 @@
 """C-ABI-only timing of the batch CBOR codec and of the fused wire-to-verdict call (SpendProof, L = 128), no Python copies in
-the timed regions; prints one JSON object (profiles/r03_cbor_c_abi.json).
+the timed regions; prints one JSON object (docs/history/profiles/r03_cbor_c_abi.json).
   encode / decode          act_cbor_encode_batch / act_cbor_decode_batch, host memory and device memory
   records_from_host        act_verify_spend_batch over raw records in pinned host memory (the reference point)
   wire_to_status           act_verify_spend_cbor_batch over the same proofs as CBOR messages in pinned host memory

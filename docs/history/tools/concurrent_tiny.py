@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """T threads, a context each (or one shared node handle), one-proof verify calls back to back: the whole-GPU rate of tiny calls from
 several callers, against the hardware-queue count HIP maps a process's streams onto (GPU_MAX_HW_QUEUES, default 4).
-    python tools/concurrent_tiny.py                  # sweeps queues x threads in child processes
-    python tools/concurrent_tiny.py child T calls    # one measurement in this process"""
+    python docs/history/tools/concurrent_tiny.py                  # sweeps queues x threads in child processes
+    python docs/history/tools/concurrent_tiny.py child T calls    # one measurement in this process"""
 import hashlib
 import os
 import subprocess

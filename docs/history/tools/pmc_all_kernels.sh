@@ -1,7 +1,7 @@
 #!/bin/bash
 # VALU instructions of EVERY kernel of one verify chunk (NB proofs, L = 128; tools/pmc_run.py), one rocprofv3 --pmc pass:
 # the evidence behind "the path is work-bound" (DESIGN.md section 6): sum over kernels of instructions x cycles per instruction
-# against the chunk's time.   usage (GPU box): tools/pmc_all_kernels.sh <tag>  -> gpurun_out/<tag>_pmc_all_kernels.json
+# against the chunk's time.   usage (GPU box): docs/history/tools/pmc_all_kernels.sh <tag>  -> gpurun_out/<tag>_pmc_all_kernels.json
 tag=${1:-r02_f}
 export NB=${NB:-65536}
 root=${GRAFT_REPO_ROOT:-$PWD}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small-batch schedule sweep (small_impl.inc spend_small_locked): wall time of one act_verify_spend_batch call over n proofs in pinned
 host memory, for sub-chunk sizes ACT_SMALL_SUB (read once per process: this script re-runs itself per setting) and with the
-schedule switched off (the two-slot pipeline).  Usage: python tools/small_batch_sweep.py [--child]"""
+schedule switched off (the two-slot pipeline).  Usage: python docs/history/tools/small_batch_sweep.py [--child]"""
 import json
 import os
 import subprocess

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel timeline (HIP events on the engine's streams, ACT_TIMELINE_FILE) of ONE small-batch call: where the latency of
-act_verify_spend_batch over n proofs goes.  Usage: python tools/small_batch_timeline.py n [host|dev] [hbm]   (hbm: proofs resident
+act_verify_spend_batch over n proofs goes.  Usage: python docs/history/tools/small_batch_timeline.py n [host|dev] [hbm]   (hbm: proofs resident
 in device memory instead of pinned host memory; long timelines print their head, tail and the gaps between range kernels)"""
 import hashlib
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ACT_SMALL_TRACE=1 python tools/small_trace.py: host-side stamps of one-proof verify / refund calls (small_impl.inc spend_small_locked)
+"""ACT_SMALL_TRACE=1 python docs/history/tools/small_trace.py: host-side stamps of one-proof verify / refund calls (small_impl.inc spend_small_locked)
 beside the call's wall time: how much of a small call is enqueueing, how much GPU, how much the wipe and the return."""
 import hashlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -189,7 +189,7 @@ int act_ctx_set_tiny_calls(act_ctx *ctx, int on);           /* default 1 */
  * so a window holds 64 entries (37 per product) with no entry ever addressed by a digit (csrc/msm.h fixed_base_acc_mf).
  * libact_mi355x_fast.so (make fast; returns 0) differs only for the CLIENT's secrets (act_prove_spend_*, act_request_batch): they go
  * through scalar-addressed 16- / 24-bit tables and Pippenger buckets -- the instruction stream still does not depend on them, the
- * memory-access pattern does.  Same bytes either way.  Measured on one MI355X (profiles/r04_*_other_configs_1gpu*.json): default
+ * memory-access pattern does.  Same bytes either way.  Measured on one MI355X (docs/history/profiles/r04_*_other_configs_1gpu*.json): default
  * vs fast build prove_spend 0.48 x (1.16 M/s vs 2.40 M/s; round 3's masked scan: 0.26 x), request 0.55 x, a whole lifecycle
  * 0.85 x; every issuer-side call -- verify, refund, issue, redeem -- is the same code in both.  A client that owns its GPU may load
  * the fast build; an issuer gains nothing from it. */

@@ -922,10 +922,11 @@ def _cbor_parse(b: bytes, pos: int, depth: int = 0):
                 raise _CborParseError
             if b[pos] == 0xFF:
                 return (("bytes" if major == 2 else "text"), acc), pos + 1
-            (kind, chunk), pos = _cbor_parse(b, pos, depth + 1)
-            if kind != ("bytes" if major == 2 else "text"):
+            # a chunk is a DEFINITE-length string of the same major type (RFC 8949 3.2.3); anything else is not well-formed
+            if b[pos] >> 5 != major or (b[pos] & 31) == 31:
                 raise _CborParseError
-            acc += chunk
+            v, pos = _cbor_parse(b, pos, depth + 1)
+            acc += v[1]
     if major in (4, 5):
         items = []
         per = 2 if major == 5 else 1

@@ -740,7 +740,7 @@ pub fn gpu_device_stats(params: &Params) -> Vec<(f64, u64, f64, u64)> {
 // ---- the kept single-call signatures: batches of one ------------------------------------------------------------------
 // In src/lib.rs the six existing method bodies become `#[cfg(not(feature = "mi355x"))]`; these take their place otherwise: with the
 // feature on, nothing of the protocol runs on the CPU.  One item per call is latency, not throughput, and a GPU's latency is a
-// dependent chain on a few lanes (profiles/r04_single_item_latency.txt; the C port on one core of the same box in brackets):
+// dependent chain on a few lanes (docs/history/profiles/r04_single_item_latency.txt; the C port on one core of the same box in brackets):
 //     request 0.59 ms (0.05)    issue 2.7 (0.25)    PreIssuance::to_credit_token 2.3 (0.21)
 //     prove_spend 3.1 (15.5)    refund 3.5 (17.3)   PreRefund::to_credit_token 3.0 (5.0)
 // The `*_batch` siblings are where the rates are (24 M issues/s, 112 M requests/s, 520 k refunds/s).

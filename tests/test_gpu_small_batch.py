@@ -166,7 +166,7 @@ def test_four_concurrent_callers_do_not_collapse():
     """Four threads with a context each making one-proof calls at the same time, in a process that allows HIP eight hardware queues
     per priority class (what INTEGRATION.md recommends): without the library's limit of two small calls in flight per device the
     process has more active queues than the GPU runs side by side and a call takes 20 - 60 ms instead of ~2
-    (profiles/r04_concurrent_small_calls.txt).  With it, four callers wait their turn: a few times one caller's latency."""
+    (docs/history/profiles/r04_concurrent_small_calls.txt).  With it, four callers wait their turn: a few times one caller's latency."""
     import os
     import re
     import subprocess

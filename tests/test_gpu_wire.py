@@ -219,3 +219,52 @@ def test_settle_windows_and_sparse_non_canonical_messages(engine_factory, bench_
     msgs2[4500] = bytes(bad)
     st2, kp2 = eng.verify_spend_cbor(sk, msgs2, True)
     assert st2[4500] == 7 and sum(st2) == 7 and kp2[32 * 4499:32 * 4500] == kp_ref[32 * (4499 % 8):32 * (4499 % 8) + 32]
+
+
+def test_a_failing_generator_fails_the_call_and_signs_nothing(engine_factory, bench_params):
+    """ACT_RNG_CALLBACK could not report a failed draw -- act_rng_draw_fn returned void, the library zero-filled its
+    buffer and signed with e = alpha = 0 (z = gamma * x: the issuer's key falls out of one published refund), and ctypes swallows an
+    exception raised inside a callback, so a Python generator that ran dry looked exactly like that.  Now draw() returns int: a
+    generator that raises (the binding's trampoline catches it and reports 1), one that returns too few bytes, and one that is
+    exhausted all fail the CALL with ACT_ERR_RNG, and not one Refund message is emitted."""
+    from act_amd import api, capi
+    L = 8
+    eng = engine_factory(bench_params, L, max_batch=6)
+    sk = eng.private_key_random(shake("rf-sk", 64))
+    msgs = eng.cbor_encode("SpendProof", _proofs(eng, sk, 5, "rf"))
+    lib, ml = eng.lib, eng.cbor_size("Refund")
+
+    def call(source_ptr, keep):
+        n = len(msgs); p0, k0, offs = capi._msgs(msgs); ps, ks = capi._in(sk, 64)
+        st = np.zeros(n, np.uint8); out = np.full(ml * n, 0x55, np.uint8)
+        rc = lib.act_refund_cbor_batch(eng.ctx, n, capi.MEM_HOST, ps, p0, offs.ctypes.data, source_ptr, capi.RNG_CALLBACK, out.ctypes.data, st.ctypes.data)
+        return rc, out.tobytes()
+
+    class Raises:
+        def fill_bytes(self, n):
+            raise RuntimeError("entropy source unavailable")
+
+    class Short:
+        def fill_bytes(self, n):
+            return bytes(n - 1)
+
+    for gen in (Raises(), Short()):
+        cb = capi.rng_trampoline(gen.fill_bytes)
+        src = capi.RngSource(cb, None)
+        import ctypes as C
+        rc, out = call(C.addressof(src), (cb, src))
+        assert rc == 5 and len(cb.errors) == 1, (rc, cb.errors)              # ACT_ERR_RNG; the exception is kept for the caller
+        assert b"\xa4" not in out[::ml], "a Refund message was framed with nonces nobody drew"
+    dry = capi.ReplayRng(shake("rf-rng", 128 * 5 - 1))                         # one byte short of what five signatures need
+    with pytest.raises(capi.ActError, match="ACT_ERR_RNG"):
+        eng.refund_cbor(sk, msgs, dry, capi.RNG_CALLBACK)
+    assert dry.pos == 0 and eng.secret_residue() == 0
+    # the same generator with enough bytes: five refunds, 640 bytes drawn
+    ok = capi.ReplayRng(shake("rf-rng", 128 * 5))
+    st, outm = eng.refund_cbor(sk, msgs, ok, capi.RNG_CALLBACK)
+    assert st == bytes(5) and all(len(x) == ml for x in outm) and ok.pos == 640
+    # redeem: the nullifiers are recorded by the time the generator is asked; the lanes say that their refund is owed
+    ns = capi.NullifierSet(64)
+    rc, st, outb = eng.redeem_cbor(ns, sk, msgs, capi.ReplayRng(b""), capi.RNG_CALLBACK, raw=True)
+    assert rc == 5 and st == bytes([251] * 5) and outb == bytes(ml * 5) and len(ns) == 5
+    ns.close()

@@ -401,6 +401,40 @@ def test_wire_level_calls_and_the_generator_callback(lib, ndev):
     lib.act_node_destroy(nd)
 
 
+def test_a_generator_that_fails_signs_nothing(lib):
+    """ACT_RNG_CALLBACK whose draw() reports failure (an exhausted generator, an exception in a binding's trampoline -- ADVICE r5: with a
+    void callback the library went on and signed with e = alpha = 0, which gives the issuer's key away): the call fails with
+    ACT_ERR_RNG (5), no lane is signed, no output slot is written; a redemption has recorded its nullifiers by then and says so lane by
+    lane (ACT_STATUS_RECORDED_UNSIGNED: the refund is owed), exactly as when the signature step itself fails."""
+    n = 23
+    nd = make_node(lib, 3)
+    recs = records(n, PB, 77)
+    ML, RL = PB + 3, 129
+    msgs = b"".join(b"\xa1\x01\x58" + recs[PB * i:PB * (i + 1)] for i in range(n))
+    offs = (C.c_uint64 * (n + 1))(*[ML * i for i in range(n + 1)])
+    verdict = [7 if recs[PB * i] & 1 else 0 for i in range(n)]
+    acc = sum(1 for v in verdict if v == 0)
+    assert 0 < acc < n
+    short = _Replay(records(n, 128, 5)[:128 * acc - 1])            # one byte too few: draw() returns 1 and writes nothing
+    out = C.create_string_buffer(b"\x55" * (RL * n), RL * n); st = C.create_string_buffer(n)
+    assert lib.act_node_refund_cbor_batch(nd, C.c_size_t(n), bytes(64), msgs, offs, short.ptr, 2, out, st) == 5
+    assert short.draws == [] and b"\xa4" not in out.raw[::RL]       # no Refund message was framed
+    out2 = C.create_string_buffer(128 * n); st2 = C.create_string_buffer(n)
+    stv = C.create_string_buffer(n); kp = C.create_string_buffer(32 * n)
+    assert lib.act_node_verify_spend_batch(nd, C.c_size_t(n), bytes(64), recs, stv, kp) == 0
+    assert lib.act_node_refund_sign_batch(nd, C.c_size_t(n), bytes(64), kp.raw, stv.raw, short.ptr, 2, out2, st2) in (1, 5)   # (the record-level sign call takes bytes only: ACT_ERR_ARG)
+    assert out2.raw == bytes(128 * n)
+    # redeem: verification and the nullifier step have happened when the generator is asked
+    ns = C.c_void_p(); devs = (C.c_int * 2)(0, 1)
+    assert lib.act_node_nullifier_set_create(devs, 2, C.c_size_t(1000), None, C.byref(ns)) == 0
+    out3 = C.create_string_buffer(RL * n); st3 = C.create_string_buffer(n)
+    assert lib.act_node_redeem_cbor_batch(nd, ns, C.c_size_t(n), bytes(64), msgs, offs, short.ptr, 2, out3, st3) == 5
+    assert st3.raw == bytes(251 if v == 0 else v for v in verdict) and out3.raw == bytes(RL * n)
+    assert lib.act_node_nullifier_set_len(ns) == acc and short.draws == []
+    lib.act_node_nullifier_set_destroy(ns)
+    lib.act_node_destroy(nd)
+
+
 def check_rec(recs, stream, want, i):
     """the mock's Refund record of signed lane i under a sequential stream"""
     cur = sum(1 for j in range(i) if want[j] == 0)

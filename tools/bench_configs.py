@@ -40,6 +40,7 @@ def main():
     D = 4096
     for L in (64, 128):
         eng = capi.Engine(h, L, max_batch=a.max_batch, transcript=capi.TRANSCRIPT_DEVICE)
+        eng.set_wide_range_tables(24)      # as bench.py: 24-bit windows on h1 / h3 where the device has the room (act_ctx_create itself never widens)
         sk = eng.private_key_random(shake("sk", 64))
         pre = eng.pre_issuance_random(shake("pre", 128 * D)); req = eng.request(pre, shake("rq", 128 * D))
         cs = [(i * 2654435761) % (2**min(L, 64)) for i in range(D)]

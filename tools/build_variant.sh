@@ -10,9 +10,11 @@ mkdir -p "$out"
 make -C "$src" host_hash.o host_pool.o node.o >/dev/null
 pids=()
 # FILES="k_spend_verify ..." restricts the extra flags to those translation units (default: all)
-for f in engine k_misc k_spend_verify k_sign k_prove k_client; do
+for f in engine k_misc k_spend_verify k_spend_bits k_sign k_prove k_client; do
   extra=("$@")
   if [ -n "$FILES" ] && ! [[ " $FILES " == *" $f "* ]]; then extra=(); fi
+  # the range kernel's unit is built pair-interleaved in the product (csrc/Makefile BITSFLAGS); BITS= overrides that for A/B ("BITS=" = per-column form)
+  if [ "$f" = k_spend_bits ]; then extra+=(${BITS--DACT_FE_PAIR_ASM}); fi
   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed -Wno-unused-value -DACT_CT_SECRET_TABLES "${extra[@]}" -c "$src/$f.hip" -o "$out/$f.o" &
   pids+=($!)
 done

@@ -10,6 +10,7 @@ from act_amd import capi
 L = 128; NB = int(os.environ.get("NB", "65536"))
 h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
 eng = capi.Engine(h, L, max_batch=NB, transcript=capi.TRANSCRIPT_DEVICE)
+eng.set_wide_range_tables(24)      # as bench.py: 24-bit windows on h1 / h3 where the device has the room (act_ctx_create itself never widens)
 eng.set_pipeline_depth(1)
 sk = eng.private_key_random(bench.shake("bench-sk", 64))
 dev, _ = bench.make_distinct_proofs_on_device(eng, capi, torch, np, sk, NB, L, 0, NB)

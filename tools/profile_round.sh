@@ -14,6 +14,17 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/${tag}_
 cd $root
 f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f gpurun_out/${tag}_kernel_stats_depth1.csv
+# the pipeline as named ranges (tracing): the -DACT_ROCTX build (tools/build_variant.sh roctx -DACT_ROCTX, built in
+# the authoring container) under --marker-trace, one chunk sequence of a 2^18 batch, summarised as a timeline
+if [ -f anonymous-credit-tokens_amd/libact_roctx.so ]; then
+  export ACT_LIB_PATH=$root/anonymous-credit-tokens_amd/libact_roctx.so
+  cd /tmp
+  rocprofv3 --kernel-trace --marker-trace --output-format csv -d $root/gpurun_out/${tag}_roctx -- python3 $root/bench.py --steps 1 --warmup 1 --batch-log2 18 --no-extras --no-cpu-baseline --no-node-multi > $root/gpurun_out/${tag}_roctx_bench.json 2> $root/gpurun_out/${tag}_roctx.err
+  cd $root
+  unset ACT_LIB_PATH
+  python3 tools/roctx_summarize.py gpurun_out/${tag}_roctx 160 > gpurun_out/${tag}_roctx_timeline.txt 2>&1
+  rm -rf gpurun_out/${tag}_roctx
+fi
 bash tools/pmc_profile.sh $tag > gpurun_out/${tag}_pmc.log 2>&1
 # the suite (incl. the full-size BASELINE configurations, whose rates land in <tag>_configs_from_tests.json) and the other configs
 ACT_WRITE_RATES=${tag}_configs_from_tests.json python3 -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" > gpurun_out/${tag}_gpu_tests.log

@@ -52,7 +52,29 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "8,128").split(",")]:
         else:                                          # another spelling of the same record (non-canonical but acceptable, or broken)
             vs = _variants("SpendProof", proofs[pb * b:pb * b + pb], L)
             msg = bytearray(vs[r.randrange(len(vs))][0])
+        if len(msg) and r.random() < 0.3:              # ... and damaged a SECOND time: the status must still be from_cbor's (the first
+            k = r.randrange(len(msg)); msg[k] ^= 1 << r.randrange(8)     # failure in wire order), not merely "rejected"
         msgs.append(bytes(msg))
+    # the codec alone, all nine types, every spelling of tests/test_cbor.py damaged once more at random: code equality with from_cbor
+    recs9 = {"IssuanceRequest": req[:128], "IssuanceResponse": resp[:160], "SpendProof": proofs[:pb], "PrivateKey": sk, "PublicKey": sk[32:],
+             "PreIssuance": pre[:64], "CreditToken": tok[:160], "PreRefund": prer[:96]}
+    st0, rf0 = eng.refund(sk, proofs[:pb], sh("wr0%d" % seed, 128)); recs9["Refund"] = rf0
+    for t, rec in recs9.items():
+        vs = [bytearray(v) for v, _ in _variants(t, rec, L)]
+        more = []
+        for v in vs:
+            for _ in range(3):
+                w = bytearray(v)
+                if len(w):
+                    k = r.randrange(len(w)); w[k] ^= 1 << r.randrange(8)
+                more.append(w)
+        batch = [bytes(v) for v in vs + more]
+        st9, out9 = eng.cbor_decode(t, batch)
+        rb9 = len(rec)
+        for i, msg9 in enumerate(batch):
+            es, er = m.cbor_decode(t, msg9, L)
+            assert st9[i] == es and out9[rb9 * i:rb9 * i + rb9] == er, ("codec", t, L, i, st9[i], es, msg9[:40].hex())
+        total += len(batch)
     stream = sh("wrr%d" % seed, 128 * n)
     want = _loop(octx, sk, L, msgs, stream)
     db = set()

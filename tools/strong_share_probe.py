@@ -21,6 +21,7 @@ def child():
     L = 128
     h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
     eng = capi.Engine(h, L, max_batch=65536, transcript=capi.TRANSCRIPT_DEVICE)
+    eng.set_wide_range_tables(24)      # as bench.py: 24-bit windows on h1 / h3 where the device has the room (act_ctx_create itself never widens)
     sk = eng.private_key_random(bench.shake("bench-sk", 64))
     n = 1 << 19
     dev, _ = bench.make_distinct_proofs_on_device(eng, capi, torch, np, sk, n, L, 0, 65536)
