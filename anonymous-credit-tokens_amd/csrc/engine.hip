@@ -864,17 +864,6 @@ int act_ctx_set_fixed_base_bits(act_ctx* c, int base, int bits) {
   c->P.tab[base] = FbTab{t, (uint32_t)bits, (uint32_t)base};
   return call.finish();
 }
-// measurement knobs (kernels.h): name = the ACT_* variable of rounds 1-5 without the prefix, lower case
-int act_tuning_set(const char* name, int64_t value) {
-  static const struct { const char* name; TuneKey key; } names[] = {
-    {"no_mapped_reads", T_NO_MAPPED_READS}, {"no_stream_probe", T_NO_STREAM_PROBE}, {"no_fused_tiny", T_NO_FUSED_TINY}, {"no_taper", T_NO_TAPER},
-    {"no_wide_client", T_NO_WIDE_CLIENT}, {"no_wide_prove", T_NO_WIDE_PROVE}, {"no_wide_sign", T_NO_WIDE_SIGN}, {"no_lds_isolation", T_NO_LDS_ISOLATION},
-    {"small_normal_prio", T_SMALL_NORMAL_PRIO}, {"small_trace", T_SMALL_TRACE}, {"small_in_flight", T_SMALL_IN_FLIGHT}, {"small_sub", T_SMALL_SUB},
-    {"stagger", T_STAGGER}, {"host_chunk", T_HOST_CHUNK}, {"cbor_chunk_msgs", T_CBOR_CHUNK_MSGS}, {"ubench_iters", T_UBENCH_ITERS}};
-  if (!name) return ACT_ERR_ARG;
-  for (const auto& e : names) if (!strcmp(name, e.name)) { g_tune[e.key].store((long)value); return ACT_OK; }
-  return ACT_ERR_ARG;
-}
 int act_build_has_ct_secret_tables(void) {
 #if defined(ACT_CT_SECRET_TABLES)
   return 1;
@@ -1010,7 +999,20 @@ static int issue_tiny(act_ctx* c, size_t n, int mem, const uint8_t* req, const u
   if (!d_dbg) { HIPCK(c, hipMalloc(&d_dbg, 16 * 8 * 8)); }
   HIPCK(c, hipMemsetAsync(d_dbg, 0, 16 * 8 * 8, sl.stream));
   f.dbg = d_dbg;
-  struct Dump { act_ctx* c; Slot& sl; ~Dump() { unsigned long long h[128]; if (hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) { unsigned long long t0 = ~0ull; for (int i = 0; i < 128; i++) if (h[i] && h[i] < t0) t0 = h[i]; for (int r = 0; r < 10; r++) { fprintf(stderr, "[tiny timing] role %d:", r); for (int k = 0; k < 8; k++) fprintf(stderr, " %8.1f", h[r * 8 + k] ? (double)(h[r * 8 + k] - t0) / 100.0 : -1.0); fprintf(stderr, "  us\n"); } } } } dump{c, sl};
+  struct Dump {      // per role: its time stamps in microseconds from the earliest one
+    act_ctx* c; Slot& sl;
+    ~Dump() {
+      unsigned long long h[128];
+      if (hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return;
+      unsigned long long t0 = ~0ull;
+      for (int i = 0; i < 128; i++) if (h[i] && h[i] < t0) t0 = h[i];
+      for (int r = 0; r < 10; r++) {
+        fprintf(stderr, "[tiny timing] role %d:", r);
+        for (int k = 0; k < 8; k++) fprintf(stderr, " %8.1f", h[r * 8 + k] ? (double)(h[r * 8 + k] - t0) / 100.0 : -1.0);
+        fprintf(stderr, "  us\n");
+      }
+    }
+  } dump{c, sl};
 #endif
   int rc;
   if (mem == ACT_MEM_DEVICE) {
@@ -1285,351 +1287,9 @@ int act_refund_batch(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const 
   return spend_batch(c, n, mem, sk, proof, true, rng, rng_mode, out_refund, status, nullptr);
 }
 
-// rng: the caller's bytes, or (seed != nullptr) expanded on the device from a 32-byte seed: lane i draws from the BLAKE3 XOF of
-// seed | u64_le(first_lane + i) (k_misc.hip k_xof_expand) -- 33 536 bytes per proof that then never cross PCIe
-static int prove_spend_impl(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng, const uint8_t* seed,
-                            uint64_t first_lane, uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
-  Call call(c, n);
-  HIPCK(c, hipSetDevice(c->device));
-  const size_t pb = ProofLayout{c->L}.bytes(), rb = act_prove_rng_bytes(c);
-  const SpendTranscript st{c->L};
-  // Chunk schedule: full-size chunks; a host-memory caller's LAST chunk is cut in two (11/16 + 5/16) -- its 16.8 KB per proof leave
-  // after everything is computed (19 ms of a 76 ms call over 65 536 proofs), and the first part's copy out fits under the second
-  // part's kernels (a proof takes ~0.3 us to leave, ~0.9 us to make)
-  std::vector<std::pair<size_t, size_t>> sched;          // (offset, lanes)
-  for (size_t off = 0; off < n; off += c->max_batch) sched.emplace_back(off, std::min(c->max_batch, n - off));
-  const bool taper_off = tune(T_NO_TAPER) != 0;
-  if (mem == ACT_MEM_HOST && !sched.empty() && sched.back().second >= 8192 && !taper_off) {
-    const size_t off = sched.back().first, l = sched.back().second, t = (l * 5 / 16 + 1023) / 1024 * 1024;
-    sched.back() = {off, l - t}; sched.emplace_back(off + l - t, t);
-  }
-  const size_t nchunks = sched.size();
-  ProveArgs args[2]; uint32_t ms[2] = {0, 0}; size_t offs[2] = {0, 0};
-  // two-slot pipeline like spend_batch: head/bits/tail + hash start of chunk i+1 are enqueued before chunk i is finished
-  const size_t depth = (size_t)c->depth;
-  auto stage1 = [&](size_t i) -> int {
-    Slot& sl = c->slots[i % depth]; ProveArgs& a = args[i % depth];
-    size_t off = sched[i].first; uint32_t m = (uint32_t)sched[i].second;
-    ms[i % depth] = m; offs[i % depth] = off;
-    a = ProveArgs{}; a.P = c->P; a.n = m; a.tr = sl.d_tr; a.tr_stride = (uint32_t)st.stride(); a.d3 = sl.d_d01; a.half = sl.d_buckets; a.state = sl.d_state;
-    a.flags = sl.d_flags; a.xof = sl.d_xof; a.status = sl.d_status; a.group_counter = group_counters(c, sl);
-    int rc;
-    if ((rc = dev_in(c, sl, 0, mem, token + off * 160, (size_t)m * 160, &a.tok))) return rc;
-    if ((rc = dev_in(c, sl, 1, mem, s + off * 32, (size_t)m * 32, &a.s))) return rc;
-    if (!seed) { if ((rc = dev_in(c, sl, 3, mem, rng + off * rb, (size_t)m * rb, &a.rng))) return rc; }
-    else {
-      // 48 bytes past the lanes' bytes hold the seed (read by the expansion kernel on this stream)
-      if ((rc = stage_reserve(c, sl, 3, (size_t)m * rb + 48))) return rc;
-      uint8_t* d_seed = sl.d_stage[3] + (size_t)m * rb;
-      HIPCK(c, hipMemcpyAsync(d_seed, seed, 32, hipMemcpyHostToDevice, sl.stream));
-      launch_xof_expand(reinterpret_cast<const uint32_t*>(d_seed), first_lane + off, m, (uint32_t)(rb / 64), sl.d_stage[3], sl.stream);
-      a.rng = sl.d_stage[3];
-    }
-    if ((rc = dev_out_begin(c, sl, 2, mem, out_proof + off * pb, (size_t)m * pb, &a.proof))) return rc;
-    if ((rc = dev_out_begin(c, sl, 4, mem, out_prerefund + off * 96, (size_t)m * 96, &a.prerefund))) return rc;
-    // A call of one short chunk is latency: k_prove_tail (C and r*: functions of the generator bytes alone) then runs on the OTHER
-    // slot's stream beside head / bits / enc instead of behind them (0.5 ms of a 3.6 ms single-item prove_spend)
-    const bool side = nchunks == 1 && depth > 1 && m <= 8192;
-    Slot& other = c->slots[(i + 1) % depth];
-    if (side) {
-      if ((rc = copy_chain_record(c, sl, false))) return rc;                       // inputs and generator bytes are in place
-      HIPCK(c, hipStreamWaitEvent(other.stream, sl.cp_in_ev, 0));
-      if ((rc = prof_launch_on(c, sl, other.stream, PK_PROVE_TAIL, m, [&] { launch_prove_tail(a, other.stream); }))) return rc;
-      if ((rc = copy_chain_record(c, other, true))) return rc;
-    }
-    if ((rc = prof_launch(c, sl, PK_PROVE_HEAD, m, [&] { launch_prove_head(a, sl.stream); }))) return rc;
-    if ((rc = prof_launch(c, sl, PK_PROVE_BITS, (uint64_t)m * c->L, [&] { launch_prove_bits(a, sl.stream); }))) return rc;
-    if ((rc = prof_launch(c, sl, PK_PROVE_ENC, (uint64_t)m * c->L * 3, [&] { launch_prove_enc(a, sl.stream); }))) return rc;
-    if (side) HIPCK(c, hipStreamWaitEvent(sl.stream, other.cp_out_ev, 0));
-    else if ((rc = prof_launch(c, sl, PK_PROVE_TAIL, m, [&] { launch_prove_tail(a, sl.stream); }))) return rc;
-    return hash_begin(c, sl, PK_HASH_SPEND, sl.d_tr, (uint32_t)st.stride(), (uint32_t)st.bytes(), m);
-  };
-  auto stage2 = [&](size_t i) -> int {
-    Slot& sl = c->slots[i % depth]; ProveArgs& a = args[i % depth];
-    uint32_t m = ms[i % depth]; size_t off = offs[i % depth];
-    int rc;
-    if ((rc = hash_end(c, sl, (uint32_t)st.stride(), (uint32_t)st.bytes(), m))) return rc;
-    if ((rc = prof_launch(c, sl, PK_PROVE_RESP, (uint64_t)m * c->L, [&] { launch_prove_resp(a, sl.stream); }))) return rc;
-    if ((rc = dev_out_end(c, sl, mem, out_proof + off * pb, a.proof, (size_t)m * pb))) return rc;
-    if ((rc = dev_out_end(c, sl, mem, out_prerefund + off * 96, a.prerefund, (size_t)m * 96))) return rc;
-    return copy_status_out(c, sl, mem, status + off, m);
-  };
-  int rc;
-  for (size_t i = 0; i < nchunks; i++) {
-    if (i >= depth) { HIPCK(c, hipStreamSynchronize(c->slots[i % depth].stream)); }
-    if ((rc = stage1(i))) return rc;
-    if (i + 1 >= depth && (rc = stage2(i + 1 - depth))) return rc;
-  }
-  for (size_t i = nchunks >= depth ? nchunks - depth + 1 : 0; i < nchunks; i++) if ((rc = stage2(i))) return rc;
-  return call.finish();
-}
-int act_prove_spend_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t* rng,
-                          uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
-  if (!c || (n && (!token || !s || !rng || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
-  return prove_spend_impl(c, n, mem, token, s, rng, nullptr, 0, out_proof, out_prerefund, status);
-}
-int act_prove_spend_seeded_batch(act_ctx* c, size_t n, int mem, const uint8_t* token, const uint8_t* s, const uint8_t seed[32], uint64_t first_lane,
-                                 uint8_t* out_proof, uint8_t* out_prerefund, uint8_t* status) {
-  if (!c || !seed || (n && (!token || !s || !out_proof || !out_prerefund || !status))) return ACT_ERR_ARG;
-  return prove_spend_impl(c, n, mem, token, s, nullptr, seed, first_lane, out_proof, out_prerefund, status);
-}
+#include "client_impl.inc"      // prove_spend and the two to_credit_token calls
 
-// Two slots that each copy in, compute, copy out fall into step when left alone: both copy in at once (sharing the link), then both
-// compute, then both copy out, and nothing overlaps (docs/history/profiles/r04_codec_trace.txt).  Chaining the copies of one direction across
-// the two streams keeps them in anti-phase: chunk k + 1 copies in while chunk k computes.
-// the chunk on `sl` is about to copy in (out = false) or out (out = true): after the other slot's copy of the same direction
-static int copy_chain_wait(act_ctx* c, Slot& sl, bool out) {
-  Slot& other = c->slots[&sl == &c->slots[0] ? 1 : 0];
-  hipEvent_t ev = out ? other.cp_out_ev : other.cp_in_ev;
-  if (ev) HIPCK(c, hipStreamWaitEvent(sl.stream, ev, 0));
-  return ACT_OK;
-}
-static int copy_chain_record(act_ctx* c, Slot& sl, bool out) {
-  hipEvent_t& ev = out ? sl.cp_out_ev : sl.cp_in_ev;
-  if (!ev) HIPCK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  HIPCK(c, hipEventRecord(ev, sl.stream));
-  return ACT_OK;
-}
-
-static int client_batch(act_ctx* c, size_t n, int mem, int label, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
-                        const uint8_t* resp, const uint8_t* proofs, uint8_t* out_token, uint8_t* status) {
-  Call call(c, n);
-  HIPCK(c, hipSetDevice(c->device));
-  int rc = set_pubkey(c, w); if (rc) return rc;
-  const bool issuance = label == LABEL_RESPOND;
-  const size_t pre_b = issuance ? 64 : 96, resp_b = issuance ? 160 : 128, pb = ProofLayout{c->L}.bytes();
-  // Host-memory callers: the refund check reads every proof (16.8 KB per lane over PCIe against ~0.2 us of kernels), so the call is
-  // cut into quarters that alternate between the two slots -- a chunk's kernels and copy out run under the next chunk's copy in.
-  // Device-memory callers: one slot, full-size chunks.
-  size_t chunk = std::min(c->max_batch, std::max<size_t>(16384, (n / 4 + 1023) / 1024 * 1024));      // (below 16 384 lanes the kernels no longer fill the chip)
-  // (issuance: 352 B per lane, nothing to hide)
-  const bool taper_off = tune(T_NO_TAPER) != 0;
-  const uint8_t* proofs_view = (!issuance && mem == ACT_MEM_HOST) ? mapped_view(c, proofs, n * pb) : nullptr;      // pinned: the SpendProofs (public, 16.8 KB each) are read in place
-  const bool two_slots = mem == ACT_MEM_HOST && !issuance && !proofs_view && c->depth > 1 && n > chunk && !taper_off;
-  if (!two_slots) chunk = c->max_batch;
-  size_t k = 0;
-  for (size_t off = 0; off < n; off += chunk, k++) {
-    Slot& sl = c->slots[two_slots ? (k & 1) : 0];
-    if (two_slots) HIPCK(c, hipStreamSynchronize(sl.stream));      // the chunk before last has left this slot's staging areas
-    uint32_t m = (uint32_t)std::min(chunk, n - off);
-    sl.d_trs_dirty = std::max(sl.d_trs_dirty, (size_t)m);
-    ClientArgs a{}; a.P = c->P; a.w = c->w_pub; a.n = m; a.label = label; a.coords = sl.d_coords; a.trs = sl.d_trs; a.flags = sl.d_flags; a.pbk = sl.d_buckets;
-    a.xof = sl.d_xof; a.status = sl.d_status;
-    if (two_slots && (rc = copy_chain_wait(c, sl, false))) return rc;
-    if ((rc = dev_in(c, sl, 0, mem, pre + off * pre_b, (size_t)m * pre_b, &a.pre))) return rc;
-    if ((rc = dev_in(c, sl, 1, mem, resp + off * resp_b, (size_t)m * resp_b, &a.resp))) return rc;
-    if (issuance) { if ((rc = dev_in(c, sl, 3, mem, req + off * 128, (size_t)m * 128, &a.req))) return rc; }
-    else if (proofs_view) a.proofs = proofs_view + off * pb;
-    else { if ((rc = dev_in(c, sl, 3, mem, proofs + off * pb, (size_t)m * pb, &a.proofs))) return rc; }
-    if (two_slots && (rc = copy_chain_record(c, sl, false))) return rc;
-    if ((rc = dev_out_begin(c, sl, 2, mem, out_token + off * 160, (size_t)m * 160, &a.out_token))) return rc;
-    HIPCK(c, hipMemsetAsync(sl.d_flags, 0, (size_t)m * 4, sl.stream));      // the kernels OR their flags in
-    if (!issuance) {
-      if ((rc = prof_launch(c, sl, PK_CLIENT, (uint64_t)m * c->L, [&] { launch_client_decode_com(a, sl.stream); }))) return rc;
-    }
-    a.group_counter = group_counters(c, sl);
-    a.fused = (m <= TINY_MAX && tiny_enabled(c)) ? 1 : 0;          // tiny calls: phase A, the hash and phase B in one launch (k_client.hip)
-    if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_a(a, sl.stream); }))) return rc;
-    if (!a.fused) {
-      uint32_t len = c->P.prefix_len[label] + 40u * (issuance ? 7u : 6u);
-      if ((rc = hash_step(c, sl, PK_HASH_SMALL, sl.d_trs, SMALL_TR_STRIDE, len, m))) return rc;
-      if ((rc = prof_launch(c, sl, PK_CLIENT, m, [&] { launch_client_b(a, sl.stream); }))) return rc;
-    }
-    if ((rc = dev_out_end(c, sl, mem, out_token + off * 160, a.out_token, (size_t)m * 160))) return rc;
-    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
-    if (!two_slots && (rc = sync_all(c))) return rc;
-  }
-  return call.finish();      // waits for both streams
-}
-int act_issuance_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_t* pre, const uint8_t w[32], const uint8_t* req,
-                                       const uint8_t* resp, uint8_t* out_token, uint8_t* status) {
-  if (!c || !w || (n && (!pre || !req || !resp || !out_token || !status))) return ACT_ERR_ARG;
-  return client_batch(c, n, mem, LABEL_RESPOND, pre, w, req, resp, nullptr, out_token, status);
-}
-int act_refund_to_credit_token_batch(act_ctx* c, size_t n, int mem, const uint8_t* prerefund, const uint8_t* proof, const uint8_t* refund,
-                                     const uint8_t w[32], uint8_t* out_token, uint8_t* status) {
-  if (!c || !w || (n && (!prerefund || !proof || !refund || !out_token || !status))) return ACT_ERR_ARG;
-  return client_batch(c, n, mem, LABEL_REFUND, prerefund, w, nullptr, refund, proof, out_token, status);
-}
-
-int act_debug_last_spend_transcripts(act_ctx* c, size_t max_lanes, uint8_t* out, size_t* n_copied) {
-  if (!c || !out || !n_copied) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(c, hipSetDevice(c->device));
-  const SpendTranscript st{c->L};
-  Slot& sl = c->slots[c->last_spend_slot];
-  size_t m = std::min(max_lanes, sl.last_spend_lanes);
-  std::vector<uint8_t> tmp(m * st.stride());
-  HIPCK(c, hipMemcpy(tmp.data(), sl.d_tr, tmp.size(), hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < m; i++) memcpy(out + i * st.bytes(), tmp.data() + i * st.stride(), st.bytes());
-  *n_copied = m;
-  return ACT_OK;
-}
-
-// v_mad_u64_u32 issue-rate micro-benchmark (k_misc.hip k_ubench_mad): the ALU roofline of this arithmetic, measured on the
-// GPU and in the process that runs the workload.  lane_mads_per_s = 64-bit multiply-accumulates per second summed over lanes.
-int act_ubench_mad_u64_u32(int device, double* lane_mads_per_s, double* ms) {
-  if (!lane_mads_per_s) return ACT_ERR_ARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
-  if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
-  const int iters_env = (int)tune(T_UBENCH_ITERS);        // measurement knob: probe length
-  // 8 blocks x 4 waves per CU: 8 waves per SIMD.  Long enough (~0.3 s) for the clock to settle where a sustained ALU load
-  // leaves it (the measured rate rises from 2.8e13 over 6 ms to 3.49e13 over 0.3 s and stays there)
-  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, iters = iters_env > 0 ? (uint32_t)iters_env : 262144u;
-  uint32_t* d = nullptr; hipEvent_t e0, e1; hipStream_t st;
-  int rc = ACT_OK; float t = 0;
-  if (hipMalloc(&d, (size_t)blocks * 256 * 4) != hipSuccess) return ACT_ERR_HIP;
-  if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(d); return ACT_ERR_HIP; }
-  launch_ubench_mad(d, blocks, iters / 16, st);                               // warm-up (clocks, code load)
-  (void)hipEventRecord(e0, st);
-  launch_ubench_mad(d, blocks, iters, st);
-  (void)hipEventRecord(e1, st);
-  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = ACT_ERR_HIP;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); (void)hipFree(d);
-  if (rc) { (void)hipGetLastError(); return rc; }
-  *lane_mads_per_s = (double)blocks * 256.0 * iters * UBENCH_MADS_PER_ITER / (t * 1e-3);
-  if (ms) *ms = t;
-  return ACT_OK;
-}
-
-// 128-byte random-read micro-benchmark (k_misc.hip k_ubench_random_read): the memory-side roofline of the scalar-addressed
-// fixed-base tables.  `gib` GiB of device memory are allocated for the probe and freed again (0 = 16); waves_per_simd (0 = 2) and
-// in_flight (1, 2 or 4; 0 = 2) set how many lines a CU has outstanding.
-static int ubench_random_read_impl(int device, const uint32_t* table, size_t table_bytes, size_t gib, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
-  if (!gbytes_per_s) return ACT_ERR_ARG;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ACT_ERR_NO_DEVICE;
-  if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return ACT_ERR_ARG;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ACT_ERR_HIP;
-  size_t bytes;
-  if (table) { bytes = (size_t)1 << 20; while (bytes * 2 <= table_bytes) bytes *= 2; }      // the largest power-of-two prefix of the table
-  else { size_t g2 = 1; while (g2 * 2 <= (gib ? gib : 16)) g2 *= 2; bytes = g2 << 30; }     // a power of two: the kernel masks its line numbers
-  const uint64_t lines = bytes / 128;
-  if (waves_per_simd <= 0) waves_per_simd = 2;
-  if (waves_per_simd > 8) waves_per_simd = 8;
-  if (in_flight <= 0) in_flight = 2;
-  const uint32_t blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)waves_per_simd, iters = 4096u * 8u / (uint32_t)waves_per_simd;
-  uint32_t *buf = const_cast<uint32_t*>(table), *out = nullptr; hipEvent_t e0, e1; hipStream_t st;
-  if (!table && hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); return ACT_ERR_HIP; }
-  if (hipMalloc(&out, (size_t)blocks * 256 * 4) != hipSuccess) { (void)hipGetLastError(); if (!table) (void)hipFree(buf); return ACT_ERR_HIP; }
-  int rc = ACT_OK; float t = 0;
-  if (hipStreamCreate(&st) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (!table) (void)hipFree(buf); (void)hipFree(out); return ACT_ERR_HIP; }
-  if (!table) (void)hipMemsetAsync(buf, 0x5a, bytes, st);                      // touch every page
-  launch_ubench_random_read(buf, lines, blocks, 64, in_flight, out, st);       // warm-up
-  (void)hipEventRecord(e0, st);
-  launch_ubench_random_read(buf, lines, blocks, iters, in_flight, out, st);
-  (void)hipEventRecord(e1, st);
-  if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = ACT_ERR_HIP;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(st); if (!table) (void)hipFree(buf); (void)hipFree(out);
-  if (rc) { (void)hipGetLastError(); return rc; }
-  *gbytes_per_s = (double)blocks * 256.0 * iters * 128.0 / (t * 1e-3) / 1e9;     // a 128-byte line per read (112 bytes of it used, as the tables' entries)
-  if (ms) *ms = t;
-  return ACT_OK;
-}
-int act_ubench_random_read(int device, size_t gib, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
-  return ubench_random_read_impl(device, nullptr, 0, gib, waves_per_simd, in_flight, gbytes_per_s, ms);
-}
-// the same probe on the context's OWN table of `base` (0..3 = g, h1, h2, h3): the product's entries in the product's memory, read
-// in the product's pattern with nothing else going on -- the ceiling of fixed_base_acc's look-ups as this context has them
-int act_ubench_table_read(act_ctx* c, int base, int waves_per_simd, int in_flight, double* gbytes_per_s, double* ms) {
-  if (!c || base < 0 || base > 3) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
-  return ubench_random_read_impl(c->device, c->d_tables[base], fb_table_words((uint32_t)c->fb_bits[base]) * 4, 0, waves_per_simd, in_flight, gbytes_per_s, ms);
-}
-
-int act_debug_scalarmult_batch(act_ctx* c, size_t n, int mem, const uint8_t* points, const uint8_t* scalars, uint8_t* out, uint8_t* status) {
-  if (!c || (n && (!points || !scalars || !out || !status))) return ACT_ERR_ARG;
-  Call call(c, n);
-  HIPCK(c, hipSetDevice(c->device));
-  Slot& sl = c->slots[0];
-  for (size_t off = 0; off < n; off += c->max_batch) {
-    uint32_t m = (uint32_t)std::min(c->max_batch, n - off);
-    const uint8_t *d_p, *d_s; uint8_t* d_o; int rc;
-    if ((rc = dev_in(c, sl, 0, mem, points + off * 32, (size_t)m * 32, &d_p))) return rc;
-    if ((rc = dev_in(c, sl, 1, mem, scalars + off * 32, (size_t)m * 32, &d_s))) return rc;
-    if ((rc = dev_out_begin(c, sl, 2, mem, out + off * 32, (size_t)m * 32, &d_o))) return rc;
-    launch_debug_scalarmult(d_p, d_s, m, sl.d_buckets, d_o, sl.d_status, sl.stream);
-    if ((rc = dev_out_end(c, sl, mem, out + off * 32, d_o, (size_t)m * 32))) return rc;
-    if ((rc = copy_status_out(c, sl, mem, status + off, m))) return rc;
-    HIPCK(c, hipStreamSynchronize(sl.stream));
-  }
-  return call.finish();
-}
-
-// Test hook: bytes that are not zero in the context's secret-bearing buffers (what finish_call wipes), read back to the host.
-int act_debug_secret_residue(act_ctx* c, size_t* nonzero_bytes) {
-  if (!c || !nonzero_bytes) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
-  HIPCK(c, hipSetDevice(c->device));
-  size_t total = 0, nz = 0;
-  std::vector<std::pair<const void*, size_t>> regions;
-  for (Slot& sl : c->slots) {
-    for (int i = 0; i < Slot::N_STAGE; i++) if (sl.d_stage[i]) regions.emplace_back(sl.d_stage[i], sl.d_stage_cap[i]);
-    regions.emplace_back(sl.d_state, c->max_batch * 24 * 4);
-    regions.emplace_back(sl.d_d01, c->max_batch * 3 * GE_WORDS * 4);
-    regions.emplace_back(sl.d_buckets, c->max_batch * PREP_BUCKET_SETS * BUCKET_WORDS * 4);
-  }
-  for (Slot& sl : c->slots) regions.emplace_back(sl.d_trs, std::min<size_t>(4096, c->max_batch) * SMALL_TR_STRIDE);      // the small transcripts (first lanes): a rejected lane's signature (sign-beside-the-check kernels) must not survive the call
-  if (c->d_tiny) { regions.emplace_back(c->d_tiny, TINY_OUT); for (size_t i = 0; i < TINY_OUT; i++) nz += c->h_tiny[i] != 0; }      // staged inputs of the tiny calls (device + pinned)
-  if (c->d_small) regions.emplace_back(c->d_small, c->d_small_cap);      // the small-batch schedule's partial sums and bucket sets (what single-item calls use)
-  for (auto& r : regions) total += r.second;
-  if (total > ((size_t)1 << 30)) { c->err = "act_debug_secret_residue: context too large to read back (use a small max_batch)"; return ACT_ERR_ARG; }
-  std::vector<uint8_t> buf;
-  for (auto& r : regions) {
-    buf.resize(r.second);
-    HIPCK(c, hipMemcpy(buf.data(), r.first, r.second, hipMemcpyDeviceToHost));
-    for (uint8_t b : buf) nz += b != 0;
-  }
-  *nonzero_bytes = nz;
-  return ACT_OK;
-}
-
-int act_prof_enable(act_ctx* c, int on) {
-  if (!c) return ACT_ERR_ARG;
-  std::lock_guard<std::mutex> lk(c->mu);
-  c->prof_on = on != 0;
-  if (c->prof_on && !c->prof_base) {
-    HIPCK(c, hipSetDevice(c->device));
-    HIPCK(c, hipEventCreate(&c->prof_base));
-    HIPCK(c, hipEventRecord(c->prof_base, c->slots[0].stream));
-    HIPCK(c, hipEventSynchronize(c->prof_base));
-  }
-  return ACT_OK;
-}
-int act_prof_reset(act_ctx* c) {
-  if (!c) return ACT_ERR_ARG;
-  for (int i = 0; i < PK_COUNT; i++) { c->prof_ms[i] = 0; c->prof_launches[i] = 0; c->prof_lanes[i] = 0; c->prof_iv[i].clear(); }
-  return ACT_OK;
-}
-// time during which at least one launch of kernel i was executing (the union of its launch intervals): with two chunks in
-// flight on two streams the launches of a kernel overlap, and the sum of their durations exceeds the wall time
-int act_prof_get_busy(act_ctx* c, int i, double* ms_busy) {
-  if (!c || i < 0 || i >= PK_COUNT || !ms_busy) return ACT_ERR_ARG;
-  std::vector<std::pair<float, float>> iv = c->prof_iv[i];
-  std::sort(iv.begin(), iv.end());
-  double busy = 0; float lo = 0, hi = -1;
-  for (auto& v : iv) {
-    if (hi < lo || v.first > hi) { if (hi >= lo) busy += hi - lo; lo = v.first; hi = v.second; }
-    else if (v.second > hi) hi = v.second;
-  }
-  if (hi >= lo) busy += hi - lo;
-  *ms_busy = busy;
-  return ACT_OK;
-}
-int act_prof_kernel_count(const act_ctx*) { return PK_COUNT; }
-const char* act_prof_kernel_name(const act_ctx*, int i) { return (i >= 0 && i < PK_COUNT) ? kProfNames[i] : ""; }
-int act_prof_get(act_ctx* c, int i, double* ms_total, uint64_t* launches, uint64_t* lanes) {
-  if (!c || i < 0 || i >= PK_COUNT) return ACT_ERR_ARG;
-  if (ms_total) *ms_total = c->prof_ms[i];
-  if (launches) *launches = c->prof_launches[i];
-  if (lanes) *lanes = c->prof_lanes[i];
-  return ACT_OK;
-}
-
+#include "debug_impl.inc"       // act_debug_*, act_ubench_*, act_prof_*
 }  // extern "C"
 
 #include "cbor_impl.inc"

@@ -208,7 +208,7 @@ def prebuild_cpu_side(want_cpu_baseline):
     return paths
 
 
-def cpu_baseline(paths, proofs_host, expect_host, extra_lanes_host, extra_expect, h, sk, L, seconds_target=12.0):
+def cpu_baseline(paths, proofs_host, expect_host, extra_lanes_host, extra_expect, h, sk, L, seconds_target=9.0):
     """The C oracle (a restatement of the reference algorithm with the reference's operation structure — NOT the
     Rust crate, which cannot be built here) timed on this box's host cores on a bounded sample of the bench's own proofs
     (lanes 0 .. n-1 of the batch, tampered lanes included).  Its statuses must equal the GPU's (`expect`), which also makes

@@ -62,6 +62,7 @@
 extern "C" {
 #endif
 
+/* ======== SURVEY.md 8 rows a7 + b: result codes, memory kinds, rng conventions, per-lane statuses (records: the comment above) ==== */
 #define ACT_OK 0
 #define ACT_ERR_ARG 1        /* null pointer, bad L, bad mode */
 #define ACT_ERR_HIP 2        /* a HIP runtime call failed; act_last_error() has the text */
@@ -106,6 +107,7 @@ typedef struct act_rng_source { act_rng_draw_fn draw; void *rng_ctx; } act_rng_s
 #define ACT_STATUS_NULLIFIER_UNDETERMINED 252   /* verified; the nullifier step could not answer: NOT recorded, NOT signed -- resubmit */
 #define ACT_STATUS_RECORDED_UNSIGNED 251        /* verified, nullifier recorded, the signature step failed: the refund is owed -- sign, never redeem again */
 
+/* ======== row a6: Params::new / Params::random ================================================================================== */
 typedef struct act_ctx act_ctx;
 
 /* Params::new (src/lib.rs:291-315): out_h = enc(h1) | enc(h2) | enc(h3).  Runs on `device`. */
@@ -114,6 +116,7 @@ int act_params_new(int device, const char *organization, const char *service, co
 /* Params::random (src/lib.rs:259-265): rng = 192 bytes (three RistrettoPoint::random draws). */
 int act_params_random(int device, const uint8_t rng[192], uint8_t out_h[96]);
 
+/* ======== row b: the context (one GPU), row a5: where the transcript is hashed, and the context's knobs ========================= */
 /* A context = Params (h1,h2,h3 with their device-resident fixed-base tables, cf. the three
  * RistrettoBasepointTables of src/lib.rs:222-229) + the range-proof width L (src/lib.rs:116; 128 is the
  * crate's value, 1..128 accepted) + one GPU.  max_batch bounds the records per internal launch and thereby the workspace.
@@ -211,15 +214,19 @@ size_t act_spend_proof_bytes(const act_ctx *ctx);           /* 32*(14+4L) */
 size_t act_prove_rng_bytes(const act_ctx *ctx);             /* 64*(4L+12) */
 size_t act_spend_transcript_bytes(const act_ctx *ctx);      /* pre-image of the "spend" challenge */
 
+/* ======== rows a1 - a4 and f1: request, issue, prove_spend, refund (and its verification half), the two client verifiers -- lane i = one call of the method ==== */
 /* PrivateKey::random (src/lib.rs:188-194): rng 64 B -> x | w.  PreIssuance::random (:432-437): rng 128 B -> r | k. */
 int act_private_key_random(act_ctx *ctx, const uint8_t rng[64], uint8_t out_sk[64]);
 int act_pre_issuance_random_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *rng, uint8_t *out_pre);
 
 /* PreIssuance::request: pre n*64, rng n*128 -> req n*128 */
 int act_request_batch(act_ctx *ctx, size_t n, int mem, const uint8_t *pre, const uint8_t *rng, uint8_t *out_req);
-/* PrivateKey::issue: req n*128, c n*32, rng (n or #accepted)*128 -> resp n*160, status n.  ACT_RNG_SEQUENTIAL with n == 1: the buffer
- * must hold its 128 bytes WHATEVER the verdict -- a one-lane call computes the signature beside the check and reads the slice first
- * (the bytes of a rejected lane go nowhere).  A caller that must not even hold bytes for a rejected item uses the two halves below. */
+/* PrivateKey::issue: req n*128, c n*32, rng (n or #accepted)*128 -> resp n*160, status n.  The rng argument is BYTES: this call
+ * never touches a generator, so it cannot advance one for a rejected item.  ACT_RNG_SEQUENTIAL with n == 1: the buffer must hold its
+ * 128 bytes WHATEVER the verdict -- a one-lane call computes the signature beside the check and reads the slice first (the bytes of
+ * a rejected lane are wiped with the call and go nowhere).  A caller that draws from a generator and must leave it where the crate
+ * leaves it (src/lib.rs:638-643: e, alpha only after the check) uses the two halves below, as the Rust binding's `issue` does; the
+ * binding offers the one-call form only as a free function over explicit bytes (rust/src/mi355x.rs `predrawn::issue`). */
 int act_issue_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *req, const uint8_t *c,
                     const uint8_t *rng, int rng_mode, uint8_t *out_resp, uint8_t *status);
 /* PreIssuance::to_credit_token: pre n*64, w 32 (host), req n*128, resp n*160 -> token n*160, status n */
@@ -239,7 +246,8 @@ int act_prove_spend_seeded_batch(act_ctx *ctx, size_t n, int mem, const uint8_t 
 int act_verify_spend_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof,
                            uint8_t *status, uint8_t *out_kprime);
 /* PrivateKey::refund: proof, rng (n or #accepted)*128 -> refund n*128, status n.  As for act_issue_batch: a one-lane ACT_RNG_SEQUENTIAL
- * call needs its 128 bytes present whatever the verdict (the signature is computed beside the verification). */
+ * call needs its 128 bytes present whatever the verdict (the signature is computed beside the verification); generator-exact callers
+ * use act_verify_spend_batch + act_refund_sign_batch (src/lib.rs:842-846), or the wire-level calls with ACT_RNG_CALLBACK. */
 int act_refund_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *proof, const uint8_t *rng,
                      int rng_mode, uint8_t *out_refund, uint8_t *status);
 /* PreRefund::to_credit_token: prerefund n*96, proof, refund n*128, w 32 (host) -> token n*160, status n */
@@ -259,6 +267,7 @@ int act_issue_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], 
 int act_refund_sign_batch(act_ctx *ctx, size_t n, int mem, const uint8_t sk[64], const uint8_t *kprime, const uint8_t *status_in,
                           const uint8_t *rng, int rng_mode, uint8_t *out_refund, uint8_t *status);
 
+/* ======== row e: the GPUs of one node behind one handle (no collective) ========================================================= */
 /* Node-level dispatch: the GPUs of one node behind one handle.  act_node_create builds one context per
  * entry of devices[] (the same device may be listed more than once: each entry is its own context, stream set and
  * workspace).  Every act_node_*_batch call cuts its batch into contiguous pieces (one per context, shard k = lanes
@@ -318,6 +327,7 @@ int act_node_refund_batch(act_node *node, size_t n, const uint8_t sk[64], const 
 int act_node_refund_to_credit_token_batch(act_node *node, size_t n, const uint8_t *prerefund, const uint8_t *proof,
                                           const uint8_t *refund, const uint8_t w[32], uint8_t *out_token, uint8_t *status);
 
+/* ======== row f3: wire bytes -- the batch CBOR codec, wire -> verdict, wire -> wire ============================================= */
 /* Batch CBOR codec (src/cbor.rs: to_cbor / from_cbor of the nine wire and state types; deterministic RFC 8949
  * encoding, int-keyed maps, 32-byte byte strings).  `type` selects the struct; records are the raw layouts above.
  * Encoding writes n canonical messages of act_cbor_size(ctx, type) bytes each, back to back.  Decoding takes n
@@ -392,6 +402,7 @@ int act_node_refund_sign_cbor_batch(act_node *node, size_t n, const uint8_t sk[6
 int act_node_refund_cbor_batch(act_node *node, size_t n, const uint8_t sk[64], const uint8_t *cbor, const uint64_t *offsets,
                                const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
 
+/* ======== row f4: the nullifier set and the issuer's whole redemption step ====================================================== */
 /* Nullifier set: the double-spend database the crate leaves to the caller (src/lib.rs:741-745; `HashSet<Scalar>` with
  * "is_spent? reject : insert" per spend in src/tests.rs:29-50, examples/act.rs:10-30), as a hash set in one GPU's HBM.
  * act_nullifier_check_and_insert_batch has the meaning of that loop run over the batch in lane order: out_spent[i] = 1
@@ -468,6 +479,7 @@ int act_redeem_cbor_batch(act_ctx *ctx, act_nullifier_set *set, size_t n, int me
 int act_node_redeem_cbor_batch(act_node *node, act_node_nullifier_set *set, size_t n, const uint8_t sk[64], const uint8_t *cbor,
                                const uint64_t *offsets, const uint8_t *rng, int rng_mode, uint8_t *out_refund_cbor, uint8_t *status);
 
+/* ======== row d and test infrastructure: debug hooks, measurement knobs, kernel timing, roofline probes (nothing here is on the product's path) ==== */
 /* Debug / test hook: the exact "spend" transcript pre-images of the last act_verify_spend_batch /
  * act_refund_batch chunk (n_last * act_spend_transcript_bytes, copied to host memory). */
 int act_debug_last_spend_transcripts(act_ctx *ctx, size_t max_lanes, uint8_t *out, size_t *n_copied);

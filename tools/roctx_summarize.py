@@ -42,8 +42,10 @@ def main():
         print("no events found under", d)
         return
     ev.sort()
-    # the part of the trace that shows the pipeline: from the first spend.phaseA range on
-    first = next((i for i, x in enumerate(ev) if x[2] == "range " and x[3].startswith("spend.phaseA")), 0)
+    # the part of the trace that shows the pipeline in steady state: the LAST pass over the batch (the first one grows the pinned
+    # transcript buffers: hipHostMalloc inside hash_begin), i.e. from the last `spend.phaseA off=0` range on
+    starts = [i for i, x in enumerate(ev) if x[2] == "range " and x[3].startswith("spend.phaseA off=0 ")]
+    first = starts[-1] if starts else 0
     t0 = ev[first][0]
     counts = {}
     for _, _, kind, name in ev:
