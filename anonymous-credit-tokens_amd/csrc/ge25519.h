@@ -130,6 +130,19 @@ ACT_HD ge ge_sub(const ge& p, const ge& q) { return ge_add_cached(p, ge_cached_c
 
 // 2p with the T coordinate computed only when `with_t` (a wave-uniform flag): 4S + 3M or 4S + 4M
 ACT_HD ge ge_double_opt(const ge& p, bool with_t) {
+#if !defined(ACT_DBL_CARRY)
+  // ct = 2 Z^2 - (Y^2 - X^2) as (2 Z^2 + X^2) - Y^2 with the sum carried inside the squaring (fe_sqda_sq): {3} instead of {6}, so the
+  // doubling needs no carry pass; cx with a 3p offset (Y^2 + X^2 <= 3p limb-wise): {4}; products ct cx = 12, cy cz = 6, ct cz = 9, cy cx = 8
+  // (24 instructions fewer per doubling in the range kernel's build, 9 multiply-accumulates more; same-box A/B +0.25 % verifies/s:
+  // profiles/r06_ab_fused_doubling.txt.  -DACT_DBL_CARRY keeps rounds 3-5's form -- {6} carried to {1} -- for A/B)
+  fe xx, yy, w, xpy2;
+  fe_sq2(xx, yy, p.X, p.Y);
+  fe_sqda_sq(w, xpy2, p.Z, xx, fe_add(p.X, p.Y));
+  fe yypxx = fe_add(yy, xx);                  // cy {2}
+  fe yymxx = fe_sub(yy, xx);                  // cz {3}
+  fe cx = fe_sub3(xpy2, yypxx);               // {4}
+  fe ct = fe_sub(w, yy);                      // {3}
+#else
   fe xx, yy, zz, xpy2;
   fe_sq2(xx, yy, p.X, p.Y);
   fe_sq2(zz, xpy2, p.Z, fe_add(p.X, p.Y));
@@ -138,6 +151,7 @@ ACT_HD ge ge_double_opt(const ge& p, bool with_t) {
   fe yymxx = fe_sub(yy, xx);
   fe cx = fe_sub4(xpy2, yypxx);
   fe ct = fe_carry(fe_sub4(zz2, yymxx));      // operand sizes: ge_double below
+#endif
   ge r;
   fe_mul2(r.X, r.Y, ct, cx, yypxx, yymxx);
   r.T = fe_zero();

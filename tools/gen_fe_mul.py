@@ -42,6 +42,22 @@ def sq_terms(k):
             out.append((a, b))
     return out
 
+def sq_terms_dbl(k):
+    """the columns of 2 f^2: c f_i f_j with c = 2 * (1 or 2 for i != j) * (2 if needs2): 2 -> (2 f_i) f_i, 4 -> (2 f_i)(2 f_j), 8 -> (4 f_x)(2 f_y) with
+    x the one of i, j that is 1 mod 3 (it is whenever the radix doubles a squaring's cross term)"""
+    out = []
+    for i in range(9):
+        j = k - i
+        if i <= j < 9:
+            c = 2 * (1 if i == j else 2) * (2 if needs2(i, j) else 1)
+            if c == 2: out.append((f"f{i}_2", f"f{i}"))
+            elif c == 4: out.append((f"f{i}_2", f"f{j}_2"))
+            else:
+                x, y = (i, j) if i % 3 == 1 else (j, i)
+                assert x % 3 == 1
+                out.append((f"f{x}_4", f"f{y}_2"))
+    return out
+
 helpers = {}
 def blk(terms, first):
     """One column as ONE asm statement.  A term is (x, y): y a register name, or an int: -16..64 is an inline constant of the
@@ -102,8 +118,9 @@ mb, sb = body(mul_terms, mul_prep), body(sq_terms, sq_prep)
 # instruction; then l7, l8 and the wrap-around.
 TB = 244
 def pr(p): return f"v[{p[0]}:{p[1]}]"
-def one_asm_lines(terms_of, TB=TB, tag=""):
-    """the instruction list of one product: temporaries from register TB on, operands %[<name><tag>] (tag: the second product of a pair)"""
+def one_asm_lines(terms_of, TB=TB, tag="", addin=False):
+    """the instruction list of one product: temporaries from register TB on, operands %[<name><tag>] (tag: the second product of a pair).
+    addin: limb k of a tight element `a` joins low column k as one more multiply-accumulate (a_k * 1): the result is product + a, carried once"""
     HP = [(TB, TB + 1), (TB + 2, TB + 3)]
     LP = [(TB + 4, TB + 5), (TB + 6, TB + 7)]
     Q = (TB + 8, TB + 9)
@@ -117,7 +134,7 @@ def one_asm_lines(terms_of, TB=TB, tag=""):
         for x, y in terms:
             r.append(f"v_mad_u64_u32 {pr(dst)}, vcc, {x}, {y}, {add}"); add = pr(dst)
         return r
-    def prod(k): return [(R(a), R(b)) for a, b in terms_of(k)]
+    def prod(k): return [(R(a), R(b)) for a, b in terms_of(k)] + ([(R(f"a{k}"), "1")] if addin and k < 9 else [])
     h = HP[0]
     out += mads(h, prod(9), "0")
     for j in range(7):                                        # phase: h_{j+10} || l_j
@@ -182,6 +199,14 @@ def pair_asm(terms_of, doubled, inputs, second):
            ", ".join(f'[{n}b] "v"({second[n[0]]}.v[{n[1]}])' for n in inputs) + ", " + ", ".join(f'[{n}b] "v"({n}b)' for n in doubled) + ', [c304] "s"(304u)')
     return asm_stmt(lines, outs, ins, list(range(TB2, TB2 + 11)) + list(range(TB, TB + 11)))
 
+def pair_asm_mixed(terms_a, ops_a, addin_a, terms_b, ops_b):
+    """first product: operands ops_a = [(asm name, C expression)], result `h`; second: ops_b (asm names get the tag b), result `hb`"""
+    a, b = one_asm_lines(terms_a, TB, "", addin_a), one_asm_lines(terms_b, TB2, "b")
+    lines = [x for pair in zip(a, b) for x in pair] + a[len(b):] + b[len(a):]
+    outs = ", ".join(f'[o{i}] "=&v"(h.v[{i}])' for i in range(9)) + ", " + ", ".join(f'[o{i}b] "=&v"(hb.v[{i}])' for i in range(9))
+    ins = ", ".join(f'[{n}] "v"({e})' for n, e in ops_a) + ", " + ", ".join(f'[{n}b] "v"({e})' for n, e in ops_b) + ', [c304] "s"(304u)'
+    return asm_stmt(lines, outs, ins, list(range(TB2, TB2 + 11)) + list(range(TB, TB + 11)))
+
 mul_one, n_mul = one_asm(mul_terms, [f"f{i}_2" for i in (1, 4, 7)] + [f"g{i}_2" for i in (1, 4, 7)], [f"f{i}" for i in range(9)] + [f"g{i}" for i in range(9)])
 sq_one, n_sq = one_asm(sq_terms, [f"f{i}_2" for i in used], [f"f{i}" for i in range(9)])
 
@@ -207,6 +232,13 @@ print("#define ACT_FE_MUL2_ONE_ASM \\\n  const uint32_t " + ", ".join(f"f{i}_2 =
 print()
 print("#define ACT_FE_SQ2_ONE_ASM \\\n  const uint32_t " + ", ".join(f"f{i}_2 = 2u * f.v[{i}]" for i in used) + ", " + ", ".join(f"f{i}_2b = 2u * fb.v[{i}]" for i in used) + "; \\\n  " +
       pair_asm(sq_terms, [f"f{i}_2" for i in used], [f"f{i}" for i in range(9)], {"f": "fb"}))
+print()
+print("// h = 2 f^2 + a (one carry), hb = fb^2 in one statement (fe25519.h fe_sqda_sq: the doubling's 2 Z^2 + X^2 beside (X + Y)^2)")
+ops_a = ([(f"f{i}", f"f.v[{i}]") for i in range(9)] + [(f"f{i}_2", f"f{i}_2") for i in range(9)] + [(f"f{i}_4", f"f{i}_4") for i in (1, 4, 7)] +
+         [(f"a{i}", f"a.v[{i}]") for i in range(9)])
+ops_b = [(f"f{i}", f"fb.v[{i}]") for i in range(9)] + [(f"f{i}_2", f"f{i}_2b") for i in used]
+print("#define ACT_FE_SQDA_SQ_ONE_ASM \\\n  const uint32_t " + ", ".join(f"f{i}_2 = 2u * f.v[{i}]" for i in range(9)) + ", " + ", ".join(f"f{i}_4 = 4u * f.v[{i}]" for i in (1, 4, 7)) + ", " +
+      ", ".join(f"f{i}_2b = 2u * fb.v[{i}]" for i in used) + "; \\\n  " + pair_asm_mixed(sq_terms_dbl, ops_a, True, sq_terms, ops_b))
 import sys
 print(f"// one-statement forms: {n_mul} / {n_sq} instructions", file=sys.stderr)
 print(f"// multiply-accumulates: mul {sum(len(mul_terms(k)) for k in range(17)) + 16}, sq {sum(len(sq_terms(k)) for k in range(17)) + 16}; widths {W}", file=sys.stderr)
