@@ -221,7 +221,12 @@ int act_node_set_host_threads(act_node* nd, int per_gpu) {
 int act_node_set_fixed_base_bits(act_node* nd, int base, int bits) {
   if (!nd) return ACT_ERR_ARG;
   std::lock_guard<std::mutex> node_lock(nd->mu);
-  for (act_ctx* c : nd->ctx) { int rc = act_ctx_set_fixed_base_bits(c, base, bits); if (rc) { set_node_err(nd, act_last_error(c)); return rc; } }
+  // one thread per context, like act_node_create: a 24-bit table takes ~1 s to build and each GPU builds its own
+  std::vector<int> rcs(nd->ctx.size(), ACT_OK);
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < nd->ctx.size(); k++) th.emplace_back([&, k] { rcs[k] = act_ctx_set_fixed_base_bits(nd->ctx[k], base, bits); });
+  for (std::thread& t : th) t.join();
+  for (size_t k = 0; k < nd->ctx.size(); k++) if (rcs[k]) { set_node_err(nd, act_last_error(nd->ctx[k])); return rcs[k]; }
   return ACT_OK;
 }
 int act_node_set_balance(act_node* nd, int weighted, int tail_64ths) {
