@@ -136,15 +136,17 @@ def scalar_to_u128(s: bytes):
     return int.from_bytes(s[:16], "little") if not any(s[16:]) else None
 
 
-def _draw_accepting(rng, n_lanes: int, run):
-    """issue/refund draw 128 rng bytes per ACCEPTED lane, in lane order (src/lib.rs:638-643, 842-846).
-    With a peekable rng the unused bytes stay in the stream, like a sequential loop over one generator."""
-    if hasattr(rng, "peek"):
-        st, out = run(rng.peek(128 * n_lanes), capi.RNG_SEQUENTIAL)
-        rng.advance(128 * sum(1 for s in st if s == 0))
-    else:
-        st, out = run(rng.fill_bytes(128 * n_lanes), capi.RNG_SEQUENTIAL)
-    return st, out
+def _check_then_sign(rng, check, sign):
+    """issue / refund draw e, alpha only AFTER the checks have passed (src/lib.rs:638-643, 842-846): a rejected item leaves the caller's
+    generator untouched.  So: `check()` -> (statuses, whatever the signature needs); exactly 128 bytes per ACCEPTED lane are drawn, in
+    lane order, with ONE fill_bytes call; `sign(state, statuses, bytes)` -> (statuses, records).  Two library calls, the crate's contract
+    for ANY generator (round 5 drew 128 bytes per lane up front unless the generator could peek)."""
+    st, state = check()
+    accepted = sum(1 for s in st if s == 0)
+    drawn = rng.fill_bytes(128 * accepted) if accepted else b""
+    if len(drawn) != 128 * accepted:
+        raise ValueError("generator returned %d bytes, %d asked" % (len(drawn), 128 * accepted))
+    return sign(state, st, drawn + b"\0")          # (+ one byte: never an empty buffer at the C boundary)
 
 
 class Params:
@@ -205,7 +207,8 @@ class PrivateKey(_Cbor):
     def issue_batch(self, params: Params, requests: Sequence["IssuanceRequest"], cs: Sequence, rng) -> List["IssuanceResponse"]:
         e = params.engine()
         req = b"".join(r.record for r in requests); cc = b"".join(scalar(c) for c in cs)
-        st, out = _draw_accepting(rng, len(requests), lambda rb, mode: e.issue(self.record, req, cc, rb, mode))
+        st, out = _check_then_sign(rng, lambda: (e.issue_check(req), None),
+                                   lambda _s, st, rb: e.issue_sign(self.record, req, cc, st, rb, capi.RNG_SEQUENTIAL))
         res = [IssuanceResponse(out[160 * i:160 * i + 160]) if st[i] == 0 else Error(st[i]) for i in range(len(requests))]
         if len(res) == 1 and isinstance(res[0], Error):
             raise res[0]
@@ -218,7 +221,8 @@ class PrivateKey(_Cbor):
         nbits = proofs[0].nbits if proofs else L
         e = params.engine(nbits)
         pb = b"".join(p.record for p in proofs)
-        st, out = _draw_accepting(rng, len(proofs), lambda rb, mode: e.refund(self.record, pb, rb, mode))
+        st, out = _check_then_sign(rng, lambda: e.verify_spend(self.record, pb, True),
+                                   lambda kp, st, rb: e.refund_sign(self.record, kp, st, rb, capi.RNG_SEQUENTIAL))
         res = [Refund(out[128 * i:128 * i + 128]) if st[i] == 0 else Error(st[i]) for i in range(len(proofs))]
         if len(res) == 1 and isinstance(res[0], Error):
             raise res[0]
@@ -230,7 +234,7 @@ class PrivateKey(_Cbor):
         nbits = proofs[0].nbits if proofs else L
         e = params.engine(nbits)
         pb = b"".join(p.record for p in proofs)
-        st, out = _draw_accepting(rng, len(proofs), lambda rb, mode: e.redeem(db.set, self.record, pb, rb, mode))
+        st, out = _draw_signed(rng, len(proofs), lambda src, mode: e.redeem(db.set, self.record, pb, src, mode))      # the generator itself: drawn once, after the nullifier step, for the lanes that are signed
         return [Refund(out[128 * i:128 * i + 128]) if st[i] == 0 else Error(st[i]) for i in range(len(proofs))]
 
     # ---- wire bytes in, wire bytes out (rust/src/mi355x.rs refund_cbor_batch / redeem_cbor_batch) ----------

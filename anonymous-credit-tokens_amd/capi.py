@@ -527,6 +527,23 @@ class Engine:
         self._ck(self.lib.act_redeem_batch(self.ctx, nullifier_set.h, n, MEM_HOST, ps, p0, p1, rng_mode, out.ctypes.data, st.ctypes.data))
         return st.tobytes(), out.tobytes()
 
+    # the halves of issue / refund around the point where the crate draws its rng (src/lib.rs:643, 846): check, then sign what was accepted
+    def issue_check(self, req: bytes) -> bytes:
+        n = len(req) // 128; st = np.zeros(n, np.uint8); p0, k0 = _in(req, 128 * n)
+        self._ck(self.lib.act_issue_check_batch(self.ctx, n, MEM_HOST, p0, st.ctypes.data)); return st.tobytes()
+
+    def issue_sign(self, sk: bytes, req: bytes, c: bytes, status_in: bytes, rng: bytes, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(status_in); out = np.zeros(160 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(req, 128 * n); p1, k1 = _in(c, 32 * n); p2, k2 = _in(status_in, n); p3, k3 = _in(rng)
+        self._ck(self.lib.act_issue_sign_batch(self.ctx, n, MEM_HOST, ps, p0, p1, p2, p3, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
+    def refund_sign(self, sk: bytes, kprime: bytes, status_in: bytes, rng: bytes, rng_mode: int = RNG_SEQUENTIAL):
+        n = len(status_in); out = np.zeros(128 * n, np.uint8); st = np.zeros(n, np.uint8)
+        ps, ks = _in(sk, 64); p0, k0 = _in(kprime, 32 * n); p1, k1 = _in(status_in, n); p2, k2 = _in(rng)
+        self._ck(self.lib.act_refund_sign_batch(self.ctx, n, MEM_HOST, ps, p0, p1, p2, rng_mode, out.ctypes.data, st.ctypes.data))
+        return st.tobytes(), out.tobytes()
+
     def redeem_dev(self, nullifier_set, sk: bytes, n: int, d_proofs: int, d_rng: int, rng_mode: int, d_out: int, d_status: int):
         ps, ks = _in(sk, 64)
         self._ck(self.lib.act_redeem_batch(self.ctx, nullifier_set.h, n, MEM_DEVICE, ps, d_proofs, d_rng, rng_mode, d_out, d_status))

@@ -145,6 +145,41 @@ def test_sequential_rng_is_consumed_only_by_accepted_lanes(env):   # src/lib.rs:
     assert stream.pos == pos + 2 * 128                     # two accepted lanes drew 2 scalars each
 
 
+def test_a_rejected_item_leaves_any_generator_untouched(env):   # VERDICT r5 #1b; src/lib.rs:638-643, :842-846
+    """The crate draws e, alpha only after its checks have passed, so `issue` / `refund` of a REJECTED item never call the generator --
+    whatever kind of generator it is (round 5's mirror drew 128 bytes up front unless the generator could peek, and the Rust
+    binding's `*_eager` methods did the same).  A generator that only counts its calls: none for a rejected item, ONE fill_bytes(128 k)
+    for the k accepted lanes of a batch, single-item calls included."""
+    api, params, rng, sk = env
+
+    class Counting:
+        def __init__(self):
+            self.calls = []
+
+        def fill_bytes(self, n):
+            self.calls.append(n)
+            return os.urandom(n)
+
+    pre = api.PreIssuance.random(rng, params)
+    req = pre.request(params, rng)
+    bad = bytearray(req.record); bad[70] ^= 1
+    g = Counting()
+    with pytest.raises(api.Error):
+        sk.issue(params, api.IssuanceRequest(bytes(bad)), 9, g)
+    assert g.calls == []
+    resp = sk.issue(params, req, 9, g)
+    assert g.calls == [128]
+    tok = pre.to_credit_token(params, sk.public(), req, resp)
+    proof, _ = tok.prove_spend(params, 4, rng)
+    tampered = bytearray(proof.record); tampered[40] ^= 1
+    g = Counting()
+    with pytest.raises(api.Error):
+        sk.refund(params, api.SpendProof(bytes(tampered), proof.nbits), g)
+    assert g.calls == []
+    out = sk.refund_batch(params, [api.SpendProof(bytes(tampered), proof.nbits), proof], g)
+    assert isinstance(out[0], api.Error) and not isinstance(out[1], api.Error) and g.calls == [128]
+
+
 def test_cbor_round_trips_of_every_type(env):             # src/tests.rs:1450-1496, 1776-1860, 2216-2233
     """prop_cbor_round_trip_* and prop_cbor_encoding_canonical, restated: to_cbor / from_cbor of the nine wire and state types
     through the API mirror; encoding twice and re-encoding the decoded value give the same bytes; CborError on broken input."""

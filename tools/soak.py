@@ -121,5 +121,5 @@ for L in [int(x) for x in os.environ.get("ACT_SOAK_L", "128,64").split(",")]:
         tiny_note = "; %d refunds of 1 - 64 proofs (signature beside the verification; pageable / pinned-in-place / sequential one-proof) == the batch answers" % calls
     hist = {}
     for s_ in st_o: hist[s_] = hist.get(s_, 0) + 1
-    print("L=%d: %d proofs, statuses %s: engine == oracle (both transcript modes, refunds sampled)%s" % (L, n, dict(sorted(hist.items())), ("; %d merged small calls from %d threads == the batch answers" % (len(cuts), T) if T else "") + tiny_note))
+    print("L=%d: %d proofs, statuses %s: engine == oracle (both transcript modes, refunds sampled)%s" % (L, n, dict(sorted(hist.items())), ("; %d concurrent small calls from %d threads == the batch answers" % (len(cuts), T) if T else "") + tiny_note))
     eng.close()
