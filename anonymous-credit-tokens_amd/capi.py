@@ -195,7 +195,7 @@ def load() -> C.CDLL:
 # The library reads no ACT_* tuning variable itself (act_tuning_set is the only way in): tools/, tests/ and bench.py keep their
 # environment-variable interface HERE, in the binding they all go through.  ACT_<NAME>=v -> act_tuning_set("<name>", v).
 TUNING_ENV = ("NO_MAPPED_READS", "NO_STREAM_PROBE", "NO_FUSED_TINY", "NO_TAPER", "NO_WIDE_CLIENT", "NO_WIDE_PROVE", "NO_WIDE_SIGN", "NO_LDS_ISOLATION",
-              "SMALL_NORMAL_PRIO", "SMALL_TRACE", "SMALL_IN_FLIGHT", "SMALL_SUB", "STAGGER", "HOST_CHUNK", "CBOR_CHUNK_MSGS", "UBENCH_ITERS")
+              "SMALL_NORMAL_PRIO", "SMALL_TRACE", "SMALL_IN_FLIGHT", "SMALL_SUB", "STAGGER", "HARD_STAGGER", "HOST_CHUNK", "CBOR_CHUNK_MSGS", "UBENCH_ITERS")
 
 
 def forward_tuning_env(lib=None):

@@ -95,6 +95,8 @@ struct Slot {
   uint8_t* h_cst = nullptr; size_t h_cst_cap = 0;      // pinned: a codec chunk's statuses on their way to the host reader (cbor_impl.inc)
   hipEvent_t h_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // one per returned piece (HASH_PIECES)
   hipEvent_t bits_ev = nullptr;        // recorded after this slot's k_spend_bits (staggering, spend_stage1)
+  uint32_t* bits_sig = nullptr;        // signal memory: workgroups this slot's k_spend_bits launches have finished in the running call
+  uint32_t bits_wgs = 0;               // ... and have launched
   hipEvent_t cp_in_ev = nullptr, cp_out_ev = nullptr;   // after this slot's copy in / copy out of a codec chunk (cbor_impl.inc: the two slots take turns on each link direction)
   std::vector<PendingProf> pending;
   size_t last_spend_lanes = 0;
@@ -155,6 +157,8 @@ struct act_ctx {
   std::atomic<size_t> small_max{8192}; // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
+  uint32_t* last_bits_sig = nullptr; uint32_t last_bits_release = 0;      // ... its slot's counter and the count at which its last round is running
+  bool wait_value = false;             // the device supports hipStreamWaitValue32 (act_ctx_create)
   double trace_wait_s = 0, trace_hash_s = 0; size_t trace_msgs = 0;      // ACT_TRACE accumulators
   double host_wait_s = 0, host_hash_s = 0; uint64_t host_hash_bytes = 0; // act_ctx_host_hash_stats: the calling thread's time in hash_end since the last reset
   // tiny calls (at most TINY_MAX lanes: the crate's one-item call shape): one pinned + one device buffer, one copy each way, one kernel
@@ -395,80 +399,8 @@ int set_pubkey(act_ctx* c, const uint8_t w[32]) {
 }
 
 
-// ---- fixed-base tables shared between the contexts of one device --------------------------------------------------
-// A table is a pure function of (base, window width): contexts with the same Params on the same GPU (the entries of a node
-// handle that list a device twice, a verifier context beside a prover context) use one copy.  At 24-bit windows that is
-// 23.6 GB and 0.9 s of construction per base saved for every context after the first.  Reference counted; the last context
-// to go frees it.  One lock per device, held across construction, so contexts on different GPUs build concurrently and a
-// second context on the same GPU waits for the first's table instead of building its own.
-struct SharedTable { uint8_t enc[32]; int bits; uint32_t* p; int refs; };
-struct DeviceTables { std::mutex mu; std::vector<SharedTable> tabs; };
-DeviceTables g_tables[64];
+#include "workspace_impl.inc"     // fixed-base tables shared between the contexts of one device (reference counted); workspace_alloc
 
-// returns the table (building it on `s` from the decoded base at d_ext if no context of this device has it yet); nullptr =
-// the allocation failed (the caller falls back to a narrower width)
-uint32_t* table_acquire(int device, const uint8_t enc[32], int bits, const uint32_t* d_ext, hipStream_t s, bool* built) {
-  DeviceTables& dt = g_tables[device & 63];
-  std::lock_guard<std::mutex> lk(dt.mu);
-  for (SharedTable& t : dt.tabs)
-    if (t.bits == bits && memcmp(t.enc, enc, 32) == 0) { t.refs++; if (built) *built = false; return t.p; }
-  uint32_t* p = nullptr;
-  if (hipMalloc(&p, fb_table_words((uint32_t)bits) * 4) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  launch_build_table(d_ext, p, (uint32_t)bits, s);
-  if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
-  SharedTable t{}; memcpy(t.enc, enc, 32); t.bits = bits; t.p = p; t.refs = 1;
-  dt.tabs.push_back(t);
-  if (built) *built = true;
-  return p;
-}
-void table_release(int device, uint32_t* p) {
-  if (!p) return;
-  DeviceTables& dt = g_tables[device & 63];
-  std::lock_guard<std::mutex> lk(dt.mu);
-  for (size_t i = 0; i < dt.tabs.size(); i++)
-    if (dt.tabs[i].p == p) {
-      if (--dt.tabs[i].refs == 0) { (void)hipFree(p); dt.tabs.erase(dt.tabs.begin() + i); }
-      return;
-    }
-}
-bool table_cached(int device, const uint8_t enc[32], int bits) {
-  DeviceTables& dt = g_tables[device & 63];
-  std::lock_guard<std::mutex> lk(dt.mu);
-  for (SharedTable& t : dt.tabs) if (t.bits == bits && memcmp(t.enc, enc, 32) == 0) return true;
-  return false;
-}
-
-int workspace_alloc(act_ctx* c) {
-  const SpendTranscript st{c->L};
-  size_t B = c->max_batch;
-  HIPCK(c, hipMalloc(&c->d_group_ctr, GROUP_CTR_WORDS * 4));
-  HIPCK(c, hipMemset(c->d_group_ctr, 0, GROUP_CTR_WORDS * 4));
-  HIPCK(c, hipMalloc(&c->d_tiny_tr, TINY_MAX * SMALL_TR_STRIDE));
-  HIPCK(c, hipDeviceSynchronize());
-  for (Slot& sl : c->slots) {
-    HIPCK(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
-    HIPCK(c, hipMalloc(&sl.d_tr, B * st.stride()));
-    HIPCK(c, hipMalloc(&sl.d_coords, B * (size_t)c->L * NIELS_WORDS * 4));
-    HIPCK(c, hipMalloc(&sl.d_d01, B * 3 * GE_WORDS * 4));
-    HIPCK(c, hipMalloc(&sl.d_buckets, B * (size_t)std::max(c->L, PREP_BUCKET_SETS) * BUCKET_WORDS * 4));   // >= 3 bucket sets per proof for the per-proof kernels
-    HIPCK(c, hipMalloc(&sl.d_xa, B * GE_WORDS * 4));
-    HIPCK(c, hipMalloc(&sl.d_flags, B * 4));
-    HIPCK(c, hipMalloc(&sl.d_xof, B * 64));
-    HIPCK(c, hipMalloc(&sl.d_status, B));
-    HIPCK(c, hipMalloc(&sl.d_trs, B * SMALL_TR_STRIDE));
-    HIPCK(c, hipMalloc(&sl.d_state, B * 24 * 4));
-    HIPCK(c, hipMalloc(&sl.d_slot, B * 4));
-    HIPCK(c, hipMalloc(&sl.d_naf, B * NAF_WORDS * 4));
-    HIPCK(c, hipMalloc(&sl.d_dig, B * (size_t)c->L * 8 * 4));
-    HIPCK(c, hipMemsetAsync(sl.d_trs, 0, B * SMALL_TR_STRIDE, sl.stream));
-    // the secret-bearing buffers start clean (the allocator may hand back another context's freed memory) and are
-    // returned to that state by every call (finish_call)
-    HIPCK(c, hipMemsetAsync(sl.d_state, 0, B * 24 * 4, sl.stream));
-    HIPCK(c, hipMemsetAsync(sl.d_d01, 0, B * 3 * GE_WORDS * 4, sl.stream));
-    HIPCK(c, hipMemsetAsync(sl.d_buckets, 0, B * PREP_BUCKET_SETS * BUCKET_WORDS * 4, sl.stream));
-  }
-  return ACT_OK;
-}
 // Do the two slots' streams run side by side?  HIP multiplexes the streams of a process onto GPU_MAX_HW_QUEUES hardware queues per
 // device and priority (default 4); a process that holds several contexts next to the streams of its framework (measured: bench.py's
 // engine + a node handle + torch) runs out, both streams of a context land on one queue, and its two-chunk pipeline silently
@@ -675,9 +607,23 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
   // running: rocprofv3 --memory-copy-trace showed 38 ms of PCIe per 290 ms of compute fully exposed for host-memory
   // callers.  When a call moves data over PCIe, every range kernel therefore waits for the previous chunk's (one of them
   // fills the GPU anyway): chunk i's encodes, tail, copies and host hashing then run under chunk i+1's range kernel.
-  if (ch.stagger && c->last_bits_ev) HIPCK(c, hipStreamWaitEvent(sl.stream, c->last_bits_ev, 0));
+  // "Waits for the previous chunk's" = for the START OF ITS LAST ROUND of workgroups, not for its end: a range kernel drains for half a
+  // round on average (waves of one round end up to ~1 ms apart; a round is ~2 ms, a 16 384-proof chunk 16 of them), and the other
+  // chunk's kernel is what can fill those CUs.  k_spend_bits counts finished workgroups in the slot's signal word and the next
+  // launch sits behind a hipStreamWaitValue32 for "all but the resident ones have finished" (every workgroup of the earlier kernel
+  // is then placed; the later one gets what frees up).  tools/soft_gate_probe.hip is the mechanism alone; measured on the bench
+  // workload in profiles/r06_ab_soft_stagger.txt.  Only an ordering hint: no result depends on it.  Without the device attribute
+  // (or with the hard_stagger knob) the wait is the previous kernel's completion event.
+  const bool soft = ch.stagger && c->wait_value && sl.bits_sig && !tune(T_HARD_STAGGER);
+  if (soft) { if (c->last_bits_sig) HIPCK(c, hipStreamWaitValue32(sl.stream, c->last_bits_sig, c->last_bits_release, hipStreamWaitValueGte, 0xFFFFFFFFu)); }
+  else if (ch.stagger && c->last_bits_ev) HIPCK(c, hipStreamWaitEvent(sl.stream, c->last_bits_ev, 0));
+  a.progress = soft ? sl.bits_sig : nullptr;
   if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)ch.m * c->L, [&] { launch_spend_bits(a, sl.stream); }))) return rc;
-  if (ch.stagger) {
+  if (soft) {
+    const uint32_t wgs = (uint32_t)(((uint64_t)ch.m * c->L + 255) / 256), resident = 2u * device_cus(), before = sl.bits_wgs;
+    sl.bits_wgs += wgs;
+    c->last_bits_sig = sl.bits_sig; c->last_bits_release = wgs > resident ? sl.bits_wgs - resident : before + 1;
+  } else if (ch.stagger) {
     if (!sl.bits_ev) HIPCK(c, hipEventCreateWithFlags(&sl.bits_ev, hipEventDisableTiming));
     HIPCK(c, hipEventRecord(sl.bits_ev, sl.stream));
     c->last_bits_ev = sl.bits_ev;
@@ -801,6 +747,7 @@ void act_ctx_destroy(act_ctx* c) {
     if (sl.h_cst) (void)hipHostFree(sl.h_cst);
     for (hipEvent_t& e : sl.h_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (sl.bits_ev) (void)hipEventDestroy(sl.bits_ev);
+    if (sl.bits_sig) (void)hipFree(sl.bits_sig);
     if (sl.cp_in_ev) (void)hipEventDestroy(sl.cp_in_ev);
     if (sl.cp_out_ev) (void)hipEventDestroy(sl.cp_out_ev);
     if (sl.stream) (void)hipStreamDestroy(sl.stream);
@@ -1211,7 +1158,7 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
     const bool taper_off = tune(T_NO_TAPER) != 0;
     std::vector<size_t> head, tail;
     size_t left = n;
-    if (stagger && !taper_off && chunk_len >= 4096 && n >= 4 * chunk_len) {
+    if (stagger && !taper_off && chunk_len >= 4096 && n >= 4 * chunk_len) {      // (a tail halved further, down to a sixteenth: 2^17 proofs 486 k/s against 500 k, profiles/r06_ab_tail_taper.txt)
       head = {chunk_len / 4, chunk_len / 2}; tail = {chunk_len / 2, chunk_len / 4};
       left -= chunk_len / 4 * 2 + chunk_len / 2 * 2;
     }
@@ -1231,7 +1178,8 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
   SpendChunk chunks[2];
   size_t cursor = 0;
   const size_t depth = (size_t)c->depth;
-  c->last_bits_ev = nullptr;
+  c->last_bits_ev = nullptr; c->last_bits_sig = nullptr;
+  for (Slot& sl : c->slots) if (sl.bits_sig) { *(volatile uint32_t*)sl.bits_sig = 0; sl.bits_wgs = 0; }      // nothing of an earlier call is in flight (sync_all)
   auto stage1 = [&](size_t i) -> int {
     Slot& sl = c->slots[i % depth]; SpendChunk& ch = chunks[i % depth];
     ch = SpendChunk{}; ch.off = sched[i].first; ch.m = (uint32_t)sched[i].second;

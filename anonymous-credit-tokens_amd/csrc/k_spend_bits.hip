@@ -24,6 +24,8 @@ template <bool UNIFORM>
 __global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
   __shared__ uint32_t u_lds[(ACT_BITS_BLOCK / 64) * 2 * GE_LDS_WORDS_PER_WAVE];            // 18 KiB per wavefront
   spend_bits_lane<UNIFORM>(a, blockIdx.x * ACT_BITS_BLOCK + threadIdx.x, u_lds + (threadIdx.x >> 6) * 2 * GE_LDS_WORDS_PER_WAVE);
+  // one count per workgroup (its first wavefront's end stands for the workgroup's): what engine.hip's hipStreamWaitValue32 gate reads
+  if (threadIdx.x == 0 && a.progress) __hip_atomic_fetch_add(a.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 void launch_spend_bits(const SpendArgs& a, hipStream_t s) {

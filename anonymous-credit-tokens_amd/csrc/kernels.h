@@ -22,7 +22,7 @@
 namespace act {
 enum TuneKey {
   T_NO_MAPPED_READS, T_NO_STREAM_PROBE, T_NO_FUSED_TINY, T_NO_TAPER, T_NO_WIDE_CLIENT, T_NO_WIDE_PROVE, T_NO_WIDE_SIGN, T_NO_LDS_ISOLATION,
-  T_SMALL_NORMAL_PRIO, T_SMALL_TRACE, T_SMALL_IN_FLIGHT, T_SMALL_SUB, T_STAGGER, T_HOST_CHUNK, T_CBOR_CHUNK_MSGS, T_UBENCH_ITERS, T_COUNT
+  T_SMALL_NORMAL_PRIO, T_SMALL_TRACE, T_SMALL_IN_FLIGHT, T_SMALL_SUB, T_STAGGER, T_HARD_STAGGER, T_HOST_CHUNK, T_CBOR_CHUNK_MSGS, T_UBENCH_ITERS, T_COUNT
 };
 extern std::atomic<long> g_tune[T_COUNT];
 inline long tune(TuneKey k) { return g_tune[k].load(std::memory_order_relaxed); }
@@ -117,6 +117,8 @@ struct SpendArgs {
                              // Large batches: = buckets (prep, bits, tail run one after the other).  Small-batch schedule: an area of
                              // its own, because those kernels then run NEXT TO k_spend_bits (spend_lanes.h)
   uint32_t* part;            // small-batch schedule only: n * 4 * GE_WORDS partial sums of A1 / A2 (spend_lanes.h PART_POINTS)
+  uint32_t* progress;        // nullable: k_spend_bits counts its finished workgroups here (engine.hip spend_stage1: the next chunk's range kernel
+                             // is released when this one's LAST ROUND of workgroups is running, not when it has drained)
 };
 
 struct SignArgs {

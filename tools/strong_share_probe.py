@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What one GPU does with its share of ONE 2^20 batch at N = 1, 2, 4, 8 GPUs (bench.py's strong scaling: 2^20 / N proofs per rank and
 step, HBM-resident, host transcripts), for host-transcript chunk sizes ACT_HOST_CHUNK (read once per process: this script re-runs
-itself per setting).  Predicts the shape of the strong-scaling curve from one GPU.  Usage: python tools/strong_share_probe.py"""
+itself per setting; --one = the environment as it is, one row).  Predicts the shape of the strong-scaling curve from one GPU.
+Usage: python tools/strong_share_probe.py [--one]"""
 import json
 import os
 import subprocess
@@ -45,7 +46,8 @@ def child():
 
 def main():
     rows = {}
-    for name, env in [("default", {})] + [("ACT_HOST_CHUNK=%d" % c, {"ACT_HOST_CHUNK": str(c)}) for c in (16384, 32768, 65536)]:
+    settings = [("default", {})] + ([] if "--one" in sys.argv else [("ACT_HOST_CHUNK=%d" % c, {"ACT_HOST_CHUNK": str(c)}) for c in (16384, 32768, 65536)])
+    for name, env in settings:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, **env), capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
         rows[name] = json.loads(line[0]) if line else {"error": r.stderr[-400:]}
