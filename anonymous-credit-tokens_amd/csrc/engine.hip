@@ -620,7 +620,7 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
   a.progress = soft ? sl.bits_sig : nullptr;
   if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)ch.m * c->L, [&] { launch_spend_bits(a, sl.stream); }))) return rc;
   if (soft) {
-    const uint32_t wgs = (uint32_t)(((uint64_t)ch.m * c->L + 255) / 256), resident = 2u * device_cus(), before = sl.bits_wgs;
+    const uint32_t wgs = spend_bits_workgroups(a), resident = 2u * device_cus(), before = sl.bits_wgs;
     sl.bits_wgs += wgs;
     c->last_bits_sig = sl.bits_sig; c->last_bits_release = wgs > resident ? sl.bits_wgs - resident : before + 1;
   } else if (ch.stagger) {

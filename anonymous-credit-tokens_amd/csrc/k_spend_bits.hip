@@ -28,10 +28,10 @@ __global__ void __launch_bounds__(ACT_BITS_BLOCK, 2) k_spend_bits(SpendArgs a) {
   if (threadIdx.x == 0 && a.progress) __hip_atomic_fetch_add(a.progress, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+unsigned spend_bits_workgroups(const SpendArgs& a) { return (unsigned)(((size_t)a.n * a.P.L + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK); }
 void launch_spend_bits(const SpendArgs& a, hipStream_t s) {
   if (!a.n) return;
-  size_t lanes = (size_t)a.n * a.P.L;
-  const dim3 grid((unsigned)((lanes + ACT_BITS_BLOCK - 1) / ACT_BITS_BLOCK));
+  const dim3 grid(spend_bits_workgroups(a));
   if (a.P.L % 64 == 0) hipLaunchKernelGGL(k_spend_bits<true>, grid, dim3(ACT_BITS_BLOCK), isolate_bits(grid.x), s, a);
   else hipLaunchKernelGGL(k_spend_bits<false>, grid, dim3(ACT_BITS_BLOCK), isolate_bits(grid.x), s, a);
 }

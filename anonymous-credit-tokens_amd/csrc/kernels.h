@@ -262,6 +262,7 @@ void launch_spend_prep_role(const SpendArgs& a, int role /* 0 A, 1 B, 2 C, 3 joi
 void launch_spend_enc_small(const SpendArgs& a, hipStream_t s);
 void launch_spend_coords(const SpendArgs& a, hipStream_t s);
 void launch_spend_bits(const SpendArgs& a, hipStream_t s);
+unsigned spend_bits_workgroups(const SpendArgs& a);      // the grid launch_spend_bits uses = what a.progress reaches
 void launch_spend_enc(const SpendArgs& a, hipStream_t s);
 // Launches that leave most of the chip empty (a call of a few hundred proofs, a one-item call's role blocks beside other kernels)
 // want every wavefront on a SIMD of its own: their lanes are dependent chains, and two workgroups that the dispatcher happens to put
