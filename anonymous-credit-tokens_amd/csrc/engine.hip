@@ -1143,9 +1143,13 @@ static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64
   // of which only overlaps with compute if there are other chunks to compute: long batches use full-size chunks (the
   // kernels' best size), short ones are cut finer so that there is something to pipeline
   // (measured per share of a 2^20 batch, profiles/r06_strong_share.txt: 2^19 and 2^18 proofs are fastest in full-size chunks -- 525 k
-  // and 517 k/s against 501 k in 16 384s at 2^18 --, 2^17 in half-size ones -- 501 k against 493 k --, below that 16 384)
+  // and 517 k/s against 501 k in 16 384s at 2^18 --, 2^17 in half-size ones -- 501 k against 493 k --, below that 16 384; a call
+  // of at most 20 480 proofs goes in two halves of at least 8 192: 16 384 proofs 38.9 ms against 41.1 as one chunk, 12 288 30.4 against
+  // 32.5; finer is worse -- two chunks in flight cannot cover a chunk's ~10 ms of per-proof kernels, copies and hashing with range
+  // kernels of 4 ms each: profiles/r06_midsize_host_chunks.txt)
+  const size_t halves = n <= 20480 ? std::max<size_t>(8192, (n / 2 + 1023) / 1024 * 1024) : (size_t)16384;
   const size_t host_chunk = host_chunk_env ? host_chunk_env
-                                           : (n >= 4 * c->max_batch ? c->max_batch : n >= 2 * c->max_batch ? std::max<size_t>(c->max_batch / 2, 16384) : (size_t)16384);
+                                           : (n >= 4 * c->max_batch ? c->max_batch : n >= 2 * c->max_batch ? std::max<size_t>(c->max_batch / 2, 16384) : halves);
   const size_t chunk_len = c->tr_mode == ACT_TRANSCRIPT_HOST ? std::min<size_t>(c->max_batch, host_chunk) : c->max_batch;
   const int stagger_env = (int)tune(T_STAGGER);      // measurement knob: force on / off (-1 = decide)
   const bool stagger = stagger_env >= 0 ? stagger_env != 0 : (in_host || c->tr_mode == ACT_TRANSCRIPT_HOST);
