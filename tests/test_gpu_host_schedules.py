@@ -83,3 +83,41 @@ def test_host_and_device_memory_calls_agree_at_sizes_that_split(engine_factory, 
     got = h_tok2.numpy()[:, 128:136].copy().view("<u8").reshape(-1)
     assert np.array_equal(got[exp == 0], want[exp == 0].astype(np.uint64))
     assert eng.secret_residue() == 0
+
+
+@pytest.mark.parametrize("L,N,max_batch", [(128, 6000, 2000), (8, 40000, 4096)])      # range kernels of 1 000 workgroups (more than the 512 resident) / of 128
+def test_the_release_point_of_the_next_range_kernel_changes_no_byte(bench_params, monkeypatch, L, N, max_batch):
+    """Host-transcript callers run their chunks' range kernels one behind the other; the later one is released by a
+    hipStreamWaitValue32 on the earlier one's finished-workgroup counter (engine.hip spend_stage1), or -- knob `hard_stagger`, and on a
+    device without the attribute -- by its completion event.  An ordering hint: statuses and K' must not know which."""
+    import numpy as np
+    import torch
+    from act_amd import capi
+    D = 50
+    outs = []
+    for hard in (0, 1):
+        monkeypatch.setenv("ACT_HARD_STAGGER", str(hard))      # capi.Engine forwards the ACT_* knobs as they stand (act_tuning_set)
+        try:
+            eng = capi.Engine(bench_params, L, max_batch=max_batch, transcript=capi.TRANSCRIPT_HOST)
+            sk = eng.private_key_random(shake("rp-sk", 64))
+            pre = eng.pre_issuance_random(shake("rp-pre", 128 * D)); req = eng.request(pre, shake("rp-rq", 128 * D))
+            st, resp = eng.issue(sk, req, b"".join(scb(200 + i) for i in range(D)), shake("rp-ir", 128 * D))
+            st, tok = eng.issuance_to_credit_token(pre, sk[32:], req, resp)
+            st, proofs, _ = eng.prove_spend(tok, b"".join(scb(i) for i in range(D)), shake("rp-pr", eng.prove_rng_bytes * D))
+            assert st == bytes(D)
+            pb = eng.proof_bytes
+            rec = np.tile(np.frombuffer(proofs, np.uint8).reshape(D, pb), ((N + D - 1) // D, 1))[:N].copy()
+            bad = np.arange(3, N, 61); rec[bad, 40] ^= 1
+            d_proof = torch.from_numpy(rec).cuda()
+            d_st = torch.full((N,), 9, dtype=torch.uint8, device="cuda"); d_kp = torch.zeros((N, 32), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(2):
+                eng.verify_spend_dev(sk, N, d_proof.data_ptr(), d_st.data_ptr(), d_kp.data_ptr())
+            torch.cuda.synchronize()
+            exp = np.zeros(N, np.uint8); exp[bad] = 7
+            assert np.array_equal(d_st.cpu().numpy(), exp)
+            outs.append(d_kp.cpu())
+            eng.close()
+        finally:
+            monkeypatch.delenv("ACT_HARD_STAGGER"); capi.forward_tuning_env()
+    assert torch.equal(outs[0], outs[1]) and bool(outs[0][torch.from_numpy(exp == 0)].any(dim=1).all())
