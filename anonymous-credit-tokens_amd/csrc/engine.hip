@@ -155,6 +155,8 @@ struct act_ctx {
   std::vector<hipEvent_t> sm_ev;       // SM_EVENTS per sub-chunk, created on first use, kept
   uint32_t* d_small = nullptr; size_t d_small_cap = 0, d_small_dirty = 0;      // bytes
   std::atomic<size_t> small_max{8192}; // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
+  std::atomic<bool> small_max_set{false};   // ... the caller's figure; otherwise device-transcript calls take it up to twice the default
+                                            // (9 216 proofs 442 k/s against 407 k, 16 384: 469 k against 464 k, beyond that the pipelined chunks win; host transcripts: 8 192. profiles/r06_midsize_small_limit.txt)
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
   uint32_t* last_bits_sig = nullptr; uint32_t last_bits_release = 0;      // ... its slot's counter and the count at which its last round is running
@@ -818,7 +820,7 @@ int act_build_has_ct_secret_tables(void) {
   return 0;
 #endif
 }
-int act_ctx_set_small_batch_max(act_ctx* c, size_t n) { if (!c) return ACT_ERR_ARG; c->small_max.store(n); return ACT_OK; }
+int act_ctx_set_small_batch_max(act_ctx* c, size_t n) { if (!c) return ACT_ERR_ARG; c->small_max.store(n); c->small_max_set.store(true); return ACT_OK; }
 int act_ctx_set_tiny_calls(act_ctx* c, int on) { if (!c) return ACT_ERR_ARG; c->tiny_on.store(on != 0); return ACT_OK; }
 int act_debug_set_slowdown(act_ctx* c, uint32_t ns_per_lane) { if (!c) return ACT_ERR_ARG; c->debug_ns_per_lane.store(ns_per_lane); return ACT_OK; }
 int act_ctx_set_pipeline_depth(act_ctx* c, int depth) { if (!c || depth < 1 || depth > 2) return ACT_ERR_ARG; c->depth = depth; return ACT_OK; }
@@ -1128,7 +1130,7 @@ static int copy_chain_record(act_ctx* c, Slot& sl, bool out);
 static int spend_batch_locked(act_ctx* c, size_t n, int mem, const uint8_t sk[64], const uint8_t* proof, bool sign, const uint8_t* rng,
                               int rng_mode, uint8_t* out_refund, uint8_t* status, uint8_t* out_kprime, const WireSrc* wire = nullptr) {
   int rc = set_key(c, sk); if (rc) return rc;
-  if (n && n <= c->small_max.load() && n <= c->max_batch) {
+  if (n && n <= c->small_max.load() * ((c->tr_mode == ACT_TRANSCRIPT_DEVICE && !c->small_max_set.load()) ? 2u : 1u) && n <= c->max_batch) {
     if (!wire) return spend_small_locked(c, n, mem, proof, sign, rng, rng_mode, out_refund, status, out_kprime);
     // wire bytes: all n messages are unframed on slot 0's stream, the small-batch schedule starts from those records
     const uint8_t* d_records = nullptr;

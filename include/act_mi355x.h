@@ -166,7 +166,7 @@ int act_ctx_streams_overlap(const act_ctx *ctx);
  * must not overlap) */
 int act_ctx_set_pipeline_depth(act_ctx *ctx, int depth);
 /* The crate's entry points take ONE proof per call (src/lib.rs:781-786).  Verify / refund calls of at most `n` proofs (default
- * 8192; 0 = never) run the small-batch schedule: one chunk, the per-proof kernels next to the range kernel on streams of their own (five in all) instead of
+ * 8192, and 16384 while the context hashes its transcripts on the device; 0 = never) run the small-batch schedule: one chunk, the per-proof kernels next to the range kernel on streams of their own (five in all) instead of
  * in front of and behind it -- the same lane code and bytes, 2-3 x shorter for one proof and ~1.5 x the rate at 4 096 proofs; larger
  * calls pipeline 65 536-proof chunks as before (one lane per proof is the faster form once a launch fills the chip).
  * Threads with a context each may make such calls at the same time; two of them run on a device at once, the others wait their

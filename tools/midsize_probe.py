@@ -21,6 +21,7 @@ h = capi.params_new("bench-org", "bench-service", "bench-env", "2024-01-01")
 MB = int(os.environ.get("MAX_BATCH", "65536"))
 tr = capi.TRANSCRIPT_HOST if os.environ.get("HOST_TR") else capi.TRANSCRIPT_DEVICE
 eng = capi.Engine(h, 128, max_batch=MB, transcript=tr)
+if os.environ.get("SMALL_MAX"): eng.set_small_batch_max(int(os.environ["SMALL_MAX"]))      # where the small-batch schedule ends (library default 8 192)
 eng.set_wide_range_tables(24)      # as bench.py: 24-bit windows on h1 / h3 where the device has the room (act_ctx_create itself never widens)
 N = 64
 sk = eng.private_key_random(sh("ms-sk", 64))
