@@ -12,7 +12,8 @@ from conftest import shake, scb
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N", [20100, 5000])    # above the small-batch limit (8 192): the pipelined schedule; below: the small-batch one,
+@pytest.mark.parametrize("N", [20100, 12000, 5000])    # 20 100: the pipelined schedule; 12 000: two halves under host transcripts, the small-batch schedule
+                                                       # under device transcripts (its limit there is 16 384); 5 000: the small-batch one in both modes,
 @pytest.mark.parametrize("mode", [0, 1])        # whose copy-in and range kernel go in two halves.  mode: ACT_TRANSCRIPT_HOST, _DEVICE
 def test_host_and_device_memory_calls_agree_at_sizes_that_split(engine_factory, bench_params, mode, N):
     import numpy as np
