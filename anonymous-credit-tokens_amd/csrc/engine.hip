@@ -155,8 +155,9 @@ struct act_ctx {
   std::vector<hipEvent_t> sm_ev;       // SM_EVENTS per sub-chunk, created on first use, kept
   uint32_t* d_small = nullptr; size_t d_small_cap = 0, d_small_dirty = 0;      // bytes
   std::atomic<size_t> small_max{8192}; // calls of at most this many proofs take the small-batch schedule (act_ctx_set_small_batch_max; 0 = never)
-  std::atomic<bool> small_max_set{false};   // ... the caller's figure; otherwise device-transcript calls take it up to twice the default
-                                            // (9 216 proofs 442 k/s against 407 k, 16 384: 469 k against 464 k, beyond that the pipelined chunks win; host transcripts: 8 192. profiles/r06_midsize_small_limit.txt)
+  // ... the caller's figure; otherwise device-transcript calls take that schedule up to twice the default (9 216 proofs 442 k/s against
+  // 407 k, 16 384: 469 k against 464 k, beyond that the pipelined chunks win; host transcripts: 8 192. profiles/r06_midsize_small_limit.txt)
+  std::atomic<bool> small_max_set{false};
   int last_spend_slot = 0;
   hipEvent_t last_bits_ev = nullptr;   // the most recently launched k_spend_bits of the running call
   uint32_t* last_bits_sig = nullptr; uint32_t last_bits_release = 0;      // ... its slot's counter and the count at which its last round is running
