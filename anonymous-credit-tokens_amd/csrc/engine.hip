@@ -618,18 +618,24 @@ int spend_stage1(act_ctx* c, Slot& sl, SpendChunk& ch) {
   // workload in profiles/r06_ab_soft_stagger.txt.  Only an ordering hint: no result depends on it.  Without the device attribute
   // (or with the hard_stagger knob) the wait is the previous kernel's completion event.
   const bool soft = ch.stagger && c->wait_value && sl.bits_sig && !tune(T_HARD_STAGGER);
-  if (soft) { if (c->last_bits_sig) HIPCK(c, hipStreamWaitValue32(sl.stream, c->last_bits_sig, c->last_bits_release, hipStreamWaitValueGte, 0xFFFFFFFFu)); }
-  else if (ch.stagger && c->last_bits_ev) HIPCK(c, hipStreamWaitEvent(sl.stream, c->last_bits_ev, 0));
+  bool gated = false;
+  if (soft && c->last_bits_sig) {
+    if (hipStreamWaitValue32(sl.stream, c->last_bits_sig, c->last_bits_release, hipStreamWaitValueGte, 0xFFFFFFFFu) == hipSuccess) gated = true;
+    else { (void)hipGetLastError(); c->wait_value = false; }      // refused after all (never seen): this context orders by events from here on
+  }
+  if (ch.stagger && !gated && c->last_bits_ev) HIPCK(c, hipStreamWaitEvent(sl.stream, c->last_bits_ev, 0));
   a.progress = soft ? sl.bits_sig : nullptr;
   if ((rc = prof_launch(c, sl, PK_SPEND_BITS, (uint64_t)ch.m * c->L, [&] { launch_spend_bits(a, sl.stream); }))) return rc;
+  if (ch.stagger) {                            // the completion event is recorded in either case: it is what a refused wait falls back to
+    if (!sl.bits_ev) HIPCK(c, hipEventCreateWithFlags(&sl.bits_ev, hipEventDisableTiming));
+    HIPCK(c, hipEventRecord(sl.bits_ev, sl.stream));
+    c->last_bits_ev = sl.bits_ev;
+  }
+  c->last_bits_sig = nullptr;
   if (soft) {
     const uint32_t wgs = spend_bits_workgroups(a), resident = 2u * device_cus(), before = sl.bits_wgs;
     sl.bits_wgs += wgs;
     c->last_bits_sig = sl.bits_sig; c->last_bits_release = wgs > resident ? sl.bits_wgs - resident : before + 1;
-  } else if (ch.stagger) {
-    if (!sl.bits_ev) HIPCK(c, hipEventCreateWithFlags(&sl.bits_ev, hipEventDisableTiming));
-    HIPCK(c, hipEventRecord(sl.bits_ev, sl.stream));
-    c->last_bits_ev = sl.bits_ev;
   }
   if ((rc = prof_launch(c, sl, PK_SPEND_ENC, (uint64_t)ch.m * c->L * 2, [&] { launch_spend_enc(a, sl.stream); }))) return rc;
   if ((rc = prof_launch(c, sl, PK_SPEND_TAIL, ch.m, [&] { launch_spend_tail(a, sl.stream); }))) return rc;
